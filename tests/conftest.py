@@ -1,0 +1,36 @@
+import gzip
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    with gzip.open(os.path.join(GOLDEN, name + ".json.gz"), "rt") as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def port():
+    from oracle.pyoracle import Port, build
+    build()
+    return Port()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    from oracle.pyoracle import Ref, have_ref
+    if not have_ref():
+        pytest.skip("oracle/_ref/falcon_ref.so not built (needs /root/reference)")
+    return Ref()
