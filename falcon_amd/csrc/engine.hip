@@ -1,0 +1,699 @@
+// engine.hip -- host side of the batch ABI (include/falcon_amd.h section 2):
+// staging, HBM layout, stage scheduling on one HIP stream, result fetch.
+//
+// Replaces the per-pile driver generate_consensus() (src/c/falcon.c:562-666) and
+// the process pool around it (falcon_kit/mains/consensus.py:264-274): instead of
+// one C call per pile per worker process, all piles of a batch go through each
+// stage together.
+#include "../../include/falcon_amd.h"
+#include "fa_internal.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+
+static void set_err(const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+#define HIP_OK(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            set_err("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,   \
+                    __LINE__);                                                         \
+            return -1;                                                                 \
+        }                                                                              \
+    } while (0)
+
+#define HIP_OK_P(call)                                                                 \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            set_err("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,   \
+                    __LINE__);                                                         \
+            return nullptr;                                                            \
+        }                                                                              \
+    } while (0)
+
+struct fa_ctx {
+    int device = 0;
+    int n_cu = 0;
+    size_t total_mem = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    // alignment work-slot arena (grow only)
+    FaAlignArena arena = {};
+    size_t arena_cells_bytes = 0, arena_rows_bytes = 0;
+};
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            set_err("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+            p = nullptr;
+            return -1;
+        }
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+struct fa_batch {
+    fa_ctx *ctx = nullptr;
+    int n_pile = 0, n_seq = 0;
+    bool pair_mode = false;   // fa_align_pairs: ranges are forced, no k-mer stages
+    int band = FA_BAND;
+    std::vector<FaSeq> seq;
+    std::vector<FaPile> pile;
+    std::vector<int> order;
+    std::vector<u64> ascii_off, bin_off, script_off;
+    u64 n_words = 0, ascii_bytes = 0, bin_words = 0, script_words = 0;
+    int max_read_len = 0, max_seed_len = 0, max_rows = 0;
+    long long sum_len = 0, sum_seed = 0;
+
+    DevBuf<uint8_t> d_ascii;
+    DevBuf<u64> d_ascii_off, d_bin_off, d_script_off;
+    DevBuf<u32> d_words, d_kidx, d_kpos, d_bins, d_script;
+    DevBuf<FaSeq> d_seq;
+    DevBuf<FaPile> d_pile;
+    DevBuf<int> d_order;
+    DevBuf<FaRange> d_range;
+    DevBuf<FaAln> d_aln;
+    DevBuf<FaNode> d_nodes;
+    DevBuf<char> d_out_seq;
+    DevBuf<int> d_out_eqv;
+    DevBuf<FaPileOut> d_pile_out;
+
+    std::vector<FaRange> h_range;
+    std::vector<FaAln> h_aln;
+    std::vector<FaPileOut> h_pile_out;
+    std::vector<char> h_out_seq;
+    std::vector<int> h_out_eqv;
+    std::vector<std::string> h_result;
+    bool have_range = false, have_aln = false, fetched = false, fetched_eqv = false;
+    u64 out_slots = 0;
+    fa_stats stats = {};
+
+    FaBatchDev dev() const {
+        FaBatchDev b;
+        b.ascii = d_ascii.p; b.ascii_off = d_ascii_off.p; b.words = d_words.p;
+        b.seq = d_seq.p; b.pile = d_pile.p; b.n_seq = n_seq; b.n_pile = n_pile;
+        b.n_words = n_words; b.kidx = d_kidx.p; b.kpos = d_kpos.p; b.order = d_order.p;
+        b.bins = d_bins.p; b.bin_off = d_bin_off.p; b.range = d_range.p; b.aln = d_aln.p;
+        b.script = d_script.p; b.script_off = d_script_off.p; b.nodes = d_nodes.p;
+        b.out_seq = d_out_seq.p; b.out_eqv = d_out_eqv.p; b.pile_out = d_pile_out.p;
+        return b;
+    }
+};
+
+extern "C" const char *fa_last_error(void) { return g_err.c_str(); }
+
+extern "C" int fa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" fa_ctx *fa_create(int device) {
+    int n = fa_device_count();
+    if (n <= 0) {
+        set_err("falcon_amd: no HIP device visible -- this library has no CPU fallback");
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        set_err("falcon_amd: device %d out of range (%d visible)", device, n);
+        return nullptr;
+    }
+    HIP_OK_P(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_OK_P(hipGetDeviceProperties(&prop, device));
+    fa_ctx *c = new fa_ctx();
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount;
+    c->total_mem = prop.totalGlobalMem;
+    HIP_OK_P(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto &e : c->ev) HIP_OK_P(hipEventCreate(&e));
+    HIP_OK_P(hipMalloc((void **)&c->arena.counter, sizeof(int)));
+    return c;
+}
+
+extern "C" void fa_destroy(fa_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->arena.cells) (void)hipFree(c->arena.cells);
+    if (c->arena.rows) (void)hipFree(c->arena.rows);
+    if (c->arena.counter) (void)hipFree(c->arena.counter);
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// rows an alignment of this read can use: max_d = (int)(0.3*(dq+dt))
+// (DW_banded.c:149) with dq <= len, dt <= T and, past the sanity filter of
+// falcon.c:613-619, |dq-dt| <= 0.05*(dq+dt)  =>  dq+dt <= 2.106*len.
+static int rows_bound(int len, int T, bool filtered) {
+    double s = (double)len + (double)T;
+    if (filtered) s = std::min(s, 2.106 * (double)len + 2.0);
+    return (int)(0.3 * s) + 2;
+}
+
+static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
+                             const char *const *seqs, const int *seq_len, bool pair_mode,
+                             int band) {
+    if (!ctx) {
+        set_err("falcon_amd: null context");
+        return nullptr;
+    }
+    HIP_OK_P(hipSetDevice(ctx->device));
+    fa_batch *b = new fa_batch();
+    b->ctx = ctx;
+    b->n_pile = n_pile;
+    b->pair_mode = pair_mode;
+    b->band = band;
+    int g = 0;
+    u64 woff = 0, aoff = 0, kpos = 0, out = 0;
+    b->pile.resize(n_pile);
+    for (int p = 0; p < n_pile; p++) {
+        FaPile &pm = b->pile[p];
+        memset(&pm, 0, sizeof(pm));
+        pm.first = g;
+        pm.n_seq = pile_n_seq[p];
+        if (pm.n_seq < 1) {
+            set_err("falcon_amd: pile %d has no seed", p);
+            delete b;
+            return nullptr;
+        }
+        for (int j = 0; j < pm.n_seq; j++, g++) {
+            int len = seq_len ? seq_len[g] : (int)strlen(seqs[g]);
+            if (len < 0 || len >= 100000 * 10) {
+                set_err("falcon_amd: sequence %d has unsupported length %d", g, len);
+                delete b;
+                return nullptr;
+            }
+            FaSeq s;
+            s.woff = (u32)woff;
+            s.len = len;
+            s.pile = p;
+            s.idx = j;
+            b->seq.push_back(s);
+            b->ascii_off.push_back(aoff);
+            u64 nw = (u64)((len + 15) / 16) + 2;
+            nw = (nw + 3) & ~(u64)3;
+            woff += nw;
+            aoff += (((u64)len + 15) & ~(u64)15) + 16;
+            b->sum_len += len;
+            if (j == 0) {
+                pm.seed_len = len;
+                b->sum_seed += len;
+                b->max_seed_len = std::max(b->max_seed_len, len);
+            } else {
+                b->max_read_len = std::max(b->max_read_len, len);
+            }
+        }
+        // the reference asserts t_len < 100000 (falcon.c:343)
+        if (!pair_mode && pm.seed_len >= 100000) {
+            set_err("falcon_amd: seed of pile %d is %d bp; the reference asserts < 100000", p,
+                    pm.seed_len);
+            delete b;
+            return nullptr;
+        }
+        pm.kidx_off = (u64)p * FA_IDX_STRIDE;
+        pm.kpos_off = kpos;
+        kpos += (u64)pm.seed_len + 4;
+        pm.out_off = out;
+        out += 2 * (u64)pm.seed_len + 4;
+    }
+    if (woff >= 0xffffffffull) {
+        set_err("falcon_amd: batch too large (%llu packed words)", (unsigned long long)woff);
+        delete b;
+        return nullptr;
+    }
+    b->n_seq = g;
+    b->n_words = woff;
+    b->ascii_bytes = aoff + 16;
+    b->out_slots = out;
+    // per-sequence scratch extents
+    b->bin_off.resize(g);
+    b->script_off.resize(g);
+    u64 bo = 0, so = 0;
+    int max_rows = 4;
+    for (int i = 0; i < g; i++) {
+        const FaSeq &s = b->seq[i];
+        int T = b->pile[s.pile].seed_len;
+        b->bin_off[i] = bo;
+        b->script_off[i] = so;
+        if (s.idx == 0) continue;
+        bo += (u64)((s.len + T) / (FA_K * 6) + 4);
+        int rb = rows_bound(s.len, T, !pair_mode);
+        so += (u64)rb;
+        max_rows = std::max(max_rows, rb);
+    }
+    b->bin_words = bo;
+    b->script_words = so;
+    b->max_rows = max_rows;
+    // longest reads first: the lanes of a k_chain wave and the tail of the
+    // k_align work queue then see similar work
+    b->order.resize(g);
+    std::iota(b->order.begin(), b->order.end(), 0);
+    std::stable_sort(b->order.begin(), b->order.end(), [&](int x, int y) {
+        int lx = b->seq[x].idx == 0 ? -1 : b->seq[x].len;
+        int ly = b->seq[y].idx == 0 ? -1 : b->seq[y].len;
+        return lx > ly;
+    });
+
+    // stage ASCII through pinned memory
+    uint8_t *h_ascii = nullptr;
+    if (hipHostMalloc((void **)&h_ascii, b->ascii_bytes, hipHostMallocDefault) != hipSuccess) {
+        set_err("falcon_amd: hipHostMalloc(%llu) failed", (unsigned long long)b->ascii_bytes);
+        delete b;
+        return nullptr;
+    }
+    for (int i = 0; i < g; i++) memcpy(h_ascii + b->ascii_off[i], seqs[i], (size_t)b->seq[i].len);
+
+    int rc = 0;
+    rc |= b->d_ascii.alloc(b->ascii_bytes);
+    rc |= b->d_ascii_off.alloc(g);
+    rc |= b->d_words.alloc(b->n_words + 8);
+    rc |= b->d_seq.alloc(g);
+    rc |= b->d_pile.alloc(n_pile);
+    rc |= b->d_order.alloc(g);
+    rc |= b->d_range.alloc(g);
+    rc |= b->d_aln.alloc(g);
+    rc |= b->d_script_off.alloc(g);
+    rc |= b->d_script.alloc(b->script_words + 8);
+    if (!pair_mode) {
+        rc |= b->d_kidx.alloc((u64)n_pile * FA_IDX_STRIDE);
+        rc |= b->d_kpos.alloc(kpos + 8);
+        rc |= b->d_bin_off.alloc(g);
+        rc |= b->d_bins.alloc(b->bin_words + 8);
+        rc |= b->d_out_seq.alloc(b->out_slots + 8);
+        rc |= b->d_out_eqv.alloc(b->out_slots + 8);
+        rc |= b->d_pile_out.alloc(n_pile);
+    }
+    if (rc) {
+        (void)hipHostFree(h_ascii);
+        delete b;
+        return nullptr;
+    }
+    hipStream_t s = ctx->stream;
+    bool ok = true;
+    ok &= hipMemcpyAsync(b->d_ascii.p, h_ascii, b->ascii_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
+    ok &= hipMemcpyAsync(b->d_ascii_off.p, b->ascii_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
+    ok &= hipMemcpyAsync(b->d_seq.p, b->seq.data(), g * sizeof(FaSeq), hipMemcpyHostToDevice, s) == hipSuccess;
+    ok &= hipMemcpyAsync(b->d_pile.p, b->pile.data(), n_pile * sizeof(FaPile), hipMemcpyHostToDevice, s) == hipSuccess;
+    ok &= hipMemcpyAsync(b->d_order.p, b->order.data(), g * sizeof(int), hipMemcpyHostToDevice, s) == hipSuccess;
+    ok &= hipMemcpyAsync(b->d_script_off.p, b->script_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
+    if (!pair_mode)
+        ok &= hipMemcpyAsync(b->d_bin_off.p, b->bin_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
+    if (ok) {
+        fa_launch_pack(b->dev(), s);
+        ok &= hipGetLastError() == hipSuccess;
+        ok &= hipStreamSynchronize(s) == hipSuccess;
+    }
+    (void)hipHostFree(h_ascii);
+    b->d_ascii.release();  // only the packed form stays resident
+    if (!ok) {
+        set_err("falcon_amd: staging the batch failed: %s", hipGetErrorString(hipGetLastError()));
+        delete b;
+        return nullptr;
+    }
+    b->stats.L = b->sum_len;
+    b->stats.T = b->sum_seed;
+    b->stats.n_piles = n_pile;
+    b->stats.n_seqs = g;
+    return b;
+}
+
+extern "C" fa_batch *fa_batch_create(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
+                                     const char *const *seqs, const int *seq_len) {
+    return batch_build(ctx, n_pile, pile_n_seq, seqs, seq_len, false, FA_BAND);
+}
+
+extern "C" void fa_batch_free(fa_batch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    b->d_ascii.release(); b->d_ascii_off.release(); b->d_bin_off.release();
+    b->d_script_off.release(); b->d_words.release(); b->d_kidx.release(); b->d_kpos.release();
+    b->d_bins.release(); b->d_script.release(); b->d_seq.release(); b->d_pile.release();
+    b->d_order.release(); b->d_range.release(); b->d_aln.release(); b->d_nodes.release();
+    b->d_out_seq.release(); b->d_out_eqv.release(); b->d_pile_out.release();
+    delete b;
+}
+
+// Size the alignment arena: one slot per resident wavefront.
+static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes) {
+    int per_cu = fa_align_blocks_per_cu(lds_bytes);
+    per_cu = std::max(1, std::min(per_cu, 16));
+    int n_slot = c->n_cu * per_cu;
+    n_slot = std::max(1, std::min(n_slot, b->n_seq));
+    u64 rows = (u64)b->max_rows;
+    u64 cells = rows * (u64)(b->band + 1);
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    // never take more than half of what is free for the transient trace arena
+    u64 per_slot = cells * 4 + rows * sizeof(FaRowRec);
+    u64 have = (u64)c->arena_cells_bytes + (u64)c->arena_rows_bytes;
+    u64 budget = (u64)free_b / 2 + have;
+    if ((u64)n_slot * per_slot > budget) n_slot = (int)std::max<u64>(1, budget / per_slot);
+    size_t need_cells = (size_t)n_slot * cells * 4, need_rows = (size_t)n_slot * rows * sizeof(FaRowRec);
+    if (need_cells > c->arena_cells_bytes) {
+        if (c->arena.cells) (void)hipFree(c->arena.cells);
+        c->arena.cells = nullptr;
+        c->arena_cells_bytes = 0;
+        HIP_OK(hipMalloc((void **)&c->arena.cells, need_cells));
+        c->arena_cells_bytes = need_cells;
+    }
+    if (need_rows > c->arena_rows_bytes) {
+        if (c->arena.rows) (void)hipFree(c->arena.rows);
+        c->arena.rows = nullptr;
+        c->arena_rows_bytes = 0;
+        HIP_OK(hipMalloc((void **)&c->arena.rows, need_rows));
+        c->arena_rows_bytes = need_rows;
+    }
+    c->arena.cells_per_slot = cells;
+    c->arena.rows_per_slot = rows;
+    c->arena.n_slot = n_slot;
+    return 0;
+}
+
+static int fetch_aln(fa_batch *b) {
+    b->h_aln.resize(b->n_seq);
+    HIP_OK(hipMemcpyAsync(b->h_aln.data(), b->d_aln.p, (size_t)b->n_seq * sizeof(FaAln),
+                          hipMemcpyDeviceToHost, b->ctx->stream));
+    HIP_OK(hipStreamSynchronize(b->ctx->stream));
+    b->have_aln = true;
+    for (int g = 0; g < b->n_seq; g++) {
+        if (b->h_aln[g].err) {
+            set_err("falcon_amd: alignment of sequence %d overflowed its work slot", g);
+            return -2;
+        }
+    }
+    return 0;
+}
+
+extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double min_idt) {
+    if (!b || b->pair_mode) {
+        set_err("falcon_amd: fa_batch_run on an invalid batch");
+        return -1;
+    }
+    if (K != FA_K) {
+        set_err("falcon_amd: K=%u unsupported (the falcon_sense path hard-wires K=8, "
+                "falcon_kit/mains/consensus.py:270)", K);
+        return -1;
+    }
+    fa_ctx *c = b->ctx;
+    HIP_OK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    b->fetched = b->fetched_eqv = false;
+    b->have_range = b->have_aln = false;
+    const double max_diff = 1.0 - min_idt;  // falcon.c:580
+    size_t lds = fa_align_lds_bytes(b->max_read_len, b->max_seed_len);
+    if (ensure_arena(c, b, lds)) return -1;
+    FaBatchDev d = b->dev();
+
+    HIP_OK(hipEventRecord(c->ev[0], s));
+    fa_launch_index(d, s);
+    HIP_OK(hipEventRecord(c->ev[1], s));
+    fa_launch_chain(d, s);
+    HIP_OK(hipEventRecord(c->ev[2], s));
+    fa_launch_align(d, c->arena, b->max_read_len, b->max_seed_len, max_diff, s);
+    HIP_OK(hipEventRecord(c->ev[3], s));
+    HIP_OK(hipGetLastError());
+    // alignment summaries bound the MSA node pools (levels <= seed + insertions)
+    if (int rc = fetch_aln(b)) return rc;
+    u64 node_off = 0;
+    long long sC = 0, sD = 0, sA = 0, nal = 0;
+    for (int p = 0; p < b->n_pile; p++) {
+        FaPile &pm = b->pile[p];
+        u64 levels = (u64)pm.seed_len + 2;
+        for (int j = 1; j < pm.n_seq; j++) {
+            const FaAln &al = b->h_aln[pm.first + j];
+            sC += al.cells;
+            if (al.accept) {
+                levels += (u64)al.n_ins;
+                sD += al.dist;
+                sA += al.size;
+                nal++;
+            }
+        }
+        pm.node_off = node_off;
+        pm.node_cap = levels * 5;
+        node_off += pm.node_cap;
+    }
+    if (b->d_nodes.n < node_off + 8) {
+        if (b->d_nodes.alloc(node_off + 8)) return -1;
+    }
+    HIP_OK(hipMemcpyAsync(b->d_pile.p, b->pile.data(), (size_t)b->n_pile * sizeof(FaPile),
+                          hipMemcpyHostToDevice, s));
+    d = b->dev();
+    HIP_OK(hipEventRecord(c->ev[4], s));
+    fa_launch_consensus(d, min_cov, s);
+    HIP_OK(hipEventRecord(c->ev[5], s));
+    HIP_OK(hipGetLastError());
+    b->h_pile_out.resize(b->n_pile);
+    HIP_OK(hipMemcpyAsync(b->h_pile_out.data(), b->d_pile_out.p,
+                          (size_t)b->n_pile * sizeof(FaPileOut), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipEventRecord(c->ev[6], s));
+    HIP_OK(hipStreamSynchronize(s));
+    long long sO = 0;
+    for (int p = 0; p < b->n_pile; p++) {
+        if (b->h_pile_out[p].err) {
+            set_err("falcon_amd: consensus of pile %d failed (code %d: %s)", p, b->h_pile_out[p].err,
+                    b->h_pile_out[p].err == 2 ? "more than 512 usable reads" : "node pool overflow");
+            return -3;
+        }
+        sO += b->h_pile_out[p].len;
+    }
+    fa_stats &st = b->stats;
+    st.C = sC; st.D = sD; st.A = sA; st.O = sO; st.n_aligned = nal;
+    st.align_slots = c->arena.n_slot;
+    (void)hipEventElapsedTime(&st.ms_index, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&st.ms_chain, c->ev[1], c->ev[2]);
+    (void)hipEventElapsedTime(&st.ms_align, c->ev[2], c->ev[3]);
+    (void)hipEventElapsedTime(&st.ms_consensus, c->ev[4], c->ev[5]);
+    (void)hipEventElapsedTime(&st.ms_total, c->ev[0], c->ev[6]);
+    return 0;
+}
+
+extern "C" int fa_batch_fetch(fa_batch *b, int want_eqv) {
+    if (!b || b->pair_mode || b->h_pile_out.empty()) {
+        set_err("falcon_amd: fa_batch_fetch before fa_batch_run");
+        return -1;
+    }
+    fa_ctx *c = b->ctx;
+    HIP_OK(hipSetDevice(c->device));
+    b->h_out_seq.resize(b->out_slots + 8);
+    HIP_OK(hipMemcpyAsync(b->h_out_seq.data(), b->d_out_seq.p, b->out_slots, hipMemcpyDeviceToHost,
+                          c->stream));
+    if (want_eqv) {
+        b->h_out_eqv.resize(b->out_slots + 8);
+        HIP_OK(hipMemcpyAsync(b->h_out_eqv.data(), b->d_out_eqv.p, b->out_slots * sizeof(int),
+                              hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_OK(hipStreamSynchronize(c->stream));
+    b->h_result.assign(b->n_pile, std::string());
+    for (int p = 0; p < b->n_pile; p++) {
+        const FaPileOut &po = b->h_pile_out[p];
+        b->h_result[p].assign(b->h_out_seq.data() + b->pile[p].out_off + po.start, (size_t)po.len);
+    }
+    b->fetched = true;
+    b->fetched_eqv = want_eqv != 0;
+    return 0;
+}
+
+extern "C" int fa_batch_result(fa_batch *b, int p, const char **seq, int *len, const int **eqv) {
+    if (!b || !b->fetched || p < 0 || p >= b->n_pile) {
+        set_err("falcon_amd: fa_batch_result: no fetched result for pile %d", p);
+        return -1;
+    }
+    if (seq) *seq = b->h_result[p].c_str();
+    if (len) *len = (int)b->h_result[p].size();
+    if (eqv) {
+        if (!b->fetched_eqv) {
+            set_err("falcon_amd: eqv was not fetched");
+            return -1;
+        }
+        *eqv = b->h_out_eqv.data() + b->pile[p].out_off + b->h_pile_out[p].start;
+    }
+    return 0;
+}
+
+extern "C" int fa_batch_stats(fa_batch *b, fa_stats *out) {
+    if (!b || !out) return -1;
+    *out = b->stats;
+    return 0;
+}
+
+extern "C" int fa_batch_range(fa_batch *b, int g, int *s1, int *e1, int *s2, int *e2,
+                              long long *score, int *ok, int *n_hit) {
+    if (!b || g < 0 || g >= b->n_seq) return -1;
+    if (!b->have_range) {
+        b->h_range.resize(b->n_seq);
+        HIP_OK(hipSetDevice(b->ctx->device));
+        HIP_OK(hipMemcpy(b->h_range.data(), b->d_range.p, (size_t)b->n_seq * sizeof(FaRange),
+                         hipMemcpyDeviceToHost));
+        b->have_range = true;
+    }
+    const FaRange &r = b->h_range[g];
+    if (s1) *s1 = r.s1;
+    if (e1) *e1 = r.e1;
+    if (s2) *s2 = r.s2;
+    if (e2) *e2 = r.e2;
+    if (score) *score = r.score;
+    if (ok) *ok = r.ok;
+    if (n_hit) *n_hit = r.n_hit;
+    return 0;
+}
+
+extern "C" int fa_batch_alignment(fa_batch *b, int g, int *dist, int *q_e, int *t_e, int *size,
+                                  int *accept, long long *cells) {
+    if (!b || g < 0 || g >= b->n_seq || !b->have_aln) return -1;
+    const FaAln &a = b->h_aln[g];
+    if (dist) *dist = a.dist;
+    if (q_e) *q_e = a.q_e;
+    if (t_e) *t_e = a.t_e;
+    if (size) *size = a.size;
+    if (accept) *accept = a.accept;
+    if (cells) *cells = a.cells;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Pairwise alignment (legacy align(), DW_banded.c:115-330): every pair is a
+// two-sequence "pile" (target, query) whose window is forced to the full
+// strings; only the alignment stage runs.  The gapped strings are expanded on
+// the host from the device edit script (formatting of a device result).
+// ---------------------------------------------------------------------------
+extern "C" int fa_align_pairs(fa_ctx *ctx, int n, const char *const *q, const int *q_len,
+                              const char *const *t, const int *t_len, int band_tolerance,
+                              int get_aln_str, alignment **out) {
+    if (n <= 0) return 0;
+    if (band_tolerance < 0 || band_tolerance + 1 > 64 * FA_ALIGN_MAXCH - 1) {
+        set_err("falcon_amd: band_tolerance %d unsupported by the GPU alignment kernel (max %d)",
+                band_tolerance, 64 * FA_ALIGN_MAXCH - 2);
+        return -1;
+    }
+    std::vector<const char *> seqs(2 * (size_t)n);
+    std::vector<int> lens(2 * (size_t)n), pn((size_t)n, 2);
+    for (int i = 0; i < n; i++) {
+        seqs[2 * i] = t[i];
+        lens[2 * i] = t_len[i];
+        seqs[2 * i + 1] = q[i];
+        lens[2 * i + 1] = q_len[i];
+    }
+    fa_batch *b = batch_build(ctx, n, pn.data(), seqs.data(), lens.data(), true, band_tolerance);
+    if (!b) return -1;
+    int rc = 0;
+    fa_ctx *c = ctx;
+    hipStream_t s = c->stream;
+    std::vector<FaRange> rg(b->n_seq);
+    int max_q = 0, max_t = 0;
+    for (int i = 0; i < n; i++) {
+        FaRange z;
+        memset(&z, 0, sizeof(z));
+        rg[2 * i] = z;
+        z.e1 = q_len[i];
+        z.e2 = t_len[i];
+        z.ok = 1;
+        rg[2 * i + 1] = z;
+        max_q = std::max(max_q, q_len[i]);
+        max_t = std::max(max_t, t_len[i]);
+    }
+    auto fail = [&](int code) {
+        fa_batch_free(b);
+        return code;
+    };
+    if (hipMemcpyAsync(b->d_range.p, rg.data(), rg.size() * sizeof(FaRange), hipMemcpyHostToDevice,
+                       s) != hipSuccess) {
+        set_err("falcon_amd: range upload failed");
+        return fail(-1);
+    }
+    size_t lds = fa_align_lds_bytes(max_q, max_t);
+    if (lds > 160 * 1024) {
+        set_err("falcon_amd: sequences too long for the LDS-staged alignment kernel");
+        return fail(-1);
+    }
+    if (ensure_arena(c, b, lds)) return fail(-1);
+    FaBatchDev d = b->dev();
+    FaAlignArena ar = c->arena;
+    fa_launch_align_band(d, ar, max_q, max_t, 2.0, band_tolerance, s);
+    if (hipGetLastError() != hipSuccess) {
+        set_err("falcon_amd: k_align launch failed");
+        return fail(-1);
+    }
+    if ((rc = fetch_aln(b))) return fail(rc);
+    std::vector<u32> script;
+    if (get_aln_str > 0) {
+        script.resize(b->script_words + 8);
+        if (hipMemcpy(script.data(), b->d_script.p, b->script_words * sizeof(u32),
+                      hipMemcpyDeviceToHost) != hipSuccess) {
+            set_err("falcon_amd: script download failed");
+            return fail(-1);
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        const FaAln &a = b->h_aln[2 * i + 1];
+        alignment *r = (alignment *)calloc(1, sizeof(alignment));
+        size_t cap = (size_t)q_len[i] + (size_t)t_len[i] + 1;
+        r->q_aln_str = (char *)calloc(cap, 1);
+        r->t_aln_str = (char *)calloc(cap, 1);
+        if (a.aligned) {
+            r->aln_str_size = a.size;
+            r->dist = a.dist;
+            r->aln_q_e = a.q_e;
+            r->aln_t_e = a.t_e;
+            if (get_aln_str > 0) {
+                const u32 *sc = script.data() + b->script_off[2 * i + 1];
+                int x = 0, y = 0;
+                size_t pos = 0;
+                for (int dd = 0; dd <= a.dist; dd++) {
+                    u32 e = sc[dd];
+                    if (dd > 0) {
+                        if (e & 1u) {
+                            r->q_aln_str[pos] = '-';
+                            r->t_aln_str[pos] = t[i][y++];
+                        } else {
+                            r->q_aln_str[pos] = q[i][x++];
+                            r->t_aln_str[pos] = '-';
+                        }
+                        pos++;
+                    }
+                    for (u32 m = e >> 1; m > 0; m--) {
+                        r->q_aln_str[pos] = q[i][x++];
+                        r->t_aln_str[pos] = t[i][y++];
+                        pos++;
+                    }
+                }
+                r->aln_str_size = (int)pos;
+            }
+        }
+        out[i] = r;
+    }
+    fa_batch_free(b);
+    return 0;
+}

@@ -1,0 +1,136 @@
+// fa_internal.h -- structures shared by the HIP kernels and the host batch engine.
+//
+// Device data layout of one batch (everything stays resident in HBM between
+// stages; see DESIGN.md "Data layout in HBM"):
+//
+//   words[]      2-bit packed bases, 16 per u32, base i at bits 2*(i%16);
+//                every sequence starts on a 16-byte boundary and is followed by
+//                >= 2 zero words so 64-bit window reads never leave the buffer.
+//   seq[g]       per sequence: word offset, length, pile id, index inside pile
+//                (index 0 = the seed/target, reference falcon.c:593).
+//   pile[p]      per pile: first sequence, count, CSR k-mer table offsets,
+//                node-arena and output offsets.
+//   kidx[]       per pile 65537 u32: CSR bucket bounds of the seed's 8-mers
+//   kpos[]       per pile: seed positions grouped by 8-mer, ascending
+//   range[g]     k-mer chain window (s1,e1,s2,e2) + sanity-filter verdict
+//   aln[g]       alignment summary (dist, ends, columns, accept verdict)
+//   script[]     per accepted alignment: one u32 per edit row d:
+//                (snake_length << 1) | from_above
+//   nodes[]      per pile: MSA nodes, 5 per (t_pos,delta) level
+//   out_seq/out_eqv  per pile: consensus written right-aligned in 2*T slots
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define FA_K 8                 // k-mer size (consensus.py:270 hard-wires 8)
+#define FA_NKMER 65536         // 4^8
+#define FA_IDX_STRIDE 65540    // u32 per pile for the CSR table (65537 used, padded)
+#define FA_BAND 150            // falcon.c:624 INDEL_ALLOWENCE_2
+#define FA_ALIGN_MAXCH 3       // 64-lane chunks per band row (<= 191 diagonals)
+#define FA_CNS_MAX_ALN 512     // accepted alignments per pile handled on the GPU
+
+struct FaSeq {
+    u32 woff;   // offset into words[]
+    int len;    // bases
+    int pile;   // pile id
+    int idx;    // index in pile, 0 = seed
+};
+
+struct FaPile {
+    int first;      // global index of the seed
+    int n_seq;
+    int seed_len;
+    int pad0;
+    u64 kidx_off;   // u32 offset of this pile's CSR table
+    u64 kpos_off;   // u32 offset of this pile's position list
+    u64 node_off;   // node offset in nodes[] (set after the alignment stage)
+    u64 node_cap;   // nodes available (multiple of 5)
+    u64 out_off;    // char/int offset into out_seq / out_eqv (2*T+2 slots)
+};
+
+struct FaRange {
+    int s1, e1, s2, e2;
+    int ok;         // 1 = passed the falcon.c:613-619 sanity filter
+    int n_hit;      // diagnostic: k-mer hits
+    long long score;
+};
+
+struct FaAln {
+    int dist;
+    int q_e, t_e;
+    int size;       // alignment columns (aln_str_size)
+    int accept;     // falcon.c:629 verdict
+    int n_ins;      // query-only edit rows (bounds the number of MSA levels)
+    int aligned;    // 1 = the O(ND) search reached a sequence end
+    int err;        // 1 = resource overflow (must not happen; checked on host)
+    long long cells;// (d,k) cells evaluated
+};
+
+struct FaRowRec {   // one per edit row d of an alignment in flight (32 B)
+    u32 off;        // first cell of the row in the slot's cell arena
+    int min_k;
+    u64 dir[FA_ALIGN_MAXCH];  // from_above bit per cell
+};
+
+struct FaNode {     // 8 B
+    int score_h;    // score in half units; -2 = the reference's -1 floor
+    int link;       // (best_prev_node + 1) << 1 | upper ; prev -1 = alignment start
+};
+
+struct FaPileOut {
+    int len;        // consensus length
+    int start;      // first character inside the pile's output slots
+    int n_aligned;
+    int err;
+    long long g_best_h;
+};
+
+// ---- launcher prototypes (each .hip file owns its kernels) ----
+struct FaBatchDev {
+    // inputs
+    const uint8_t *ascii;  // staged ASCII, each sequence 16-byte aligned
+    const u64 *ascii_off;  // [n_seq]
+    u32 *words;
+    FaSeq *seq;
+    FaPile *pile;
+    int n_seq;
+    int n_pile;
+    u64 n_words;
+    // stage buffers
+    u32 *kidx;
+    u32 *kpos;
+    const int *order;      // sequence indices, longest first
+    u32 *bins;             // k_chain histogram scratch
+    const u64 *bin_off;    // [n_seq]
+    FaRange *range;
+    FaAln *aln;
+    u32 *script;
+    const u64 *script_off; // [n_seq]
+    FaNode *nodes;
+    char *out_seq;
+    int *out_eqv;
+    FaPileOut *pile_out;
+};
+
+struct FaAlignArena {
+    u32 *cells;        // n_slot * cells_per_slot
+    FaRowRec *rows;    // n_slot * rows_per_slot
+    u64 cells_per_slot;
+    u64 rows_per_slot;
+    int n_slot;
+    int *counter;      // work-queue head
+};
+
+void fa_launch_pack(const FaBatchDev &b, hipStream_t s);
+void fa_launch_index(const FaBatchDev &b, hipStream_t s);
+void fa_launch_chain(const FaBatchDev &b, hipStream_t s);
+void fa_launch_align(const FaBatchDev &b, const FaAlignArena &a, int max_q_len, int max_t_len,
+                     double max_diff, hipStream_t s);
+void fa_launch_align_band(const FaBatchDev &b, const FaAlignArena &a, int max_q_len,
+                          int max_t_len, double max_diff, int band, hipStream_t s);
+void fa_launch_consensus(const FaBatchDev &b, unsigned min_cov, hipStream_t s);
+size_t fa_align_lds_bytes(int max_q_len, int max_t_len);
+int fa_align_blocks_per_cu(size_t lds_bytes);

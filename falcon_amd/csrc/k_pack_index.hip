@@ -1,0 +1,151 @@
+// k_pack_index.hip -- (1) ASCII -> 2-bit packing, (2) per-pile seed 8-mer index.
+//
+// Replaces, for one whole batch of piles at once:
+//   * the per-call ASCII->code loops of the reference
+//     (src/c/kmer_lookup.c:159-171, :236-249), and
+//   * add_sequence() (src/c/kmer_lookup.c:140-192): instead of the start/last
+//     table plus a "next occurrence" chain we build a CSR table
+//     kidx[kmer] .. kidx[kmer+1] of ascending seed positions, which enumerates
+//     the same list in the same order (positions 0 .. seed_len-K-1, :174).
+//
+// Both kernels are HBM streaming work (byte in / quarter-byte out; 65537-entry
+// table per pile); no MFMA.
+#include "fa_device.h"
+
+// --------------------------------------------------------------------------
+// pack: one thread produces one u32 (16 bases) from one aligned 16-byte load.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack(const uint8_t *__restrict__ ascii,
+                                              const u64 *__restrict__ ascii_off,
+                                              const FaSeq *__restrict__ seq, int n_seq,
+                                              u32 *__restrict__ words, u64 n_words) {
+    u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    // which sequence owns word w: last g with seq[g].woff <= w
+    int lo = 0, hi = n_seq - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if ((u64)seq[mid].woff <= w) lo = mid; else hi = mid - 1;
+    }
+    const FaSeq s = seq[lo];
+    u32 wi = (u32)(w - s.woff);
+    int base0 = (int)wi * 16;
+    u32 out = 0;
+    if (base0 < s.len) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(ascii + ascii_off[lo] + (u64)base0);
+        const u32 q[4] = {v.x, v.y, v.z, v.w};
+        int valid = min(16, s.len - base0);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            u32 c = (q[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+            // 'A'->0 'C'->1 'G'->2 'T'->3 (also lower case)
+            u32 code = ((c >> 1) ^ (c >> 2)) & 3u;
+            if (j < valid) out |= code << (2 * j);
+        }
+    }
+    words[w] = out;
+}
+
+void fa_launch_pack(const FaBatchDev &b, hipStream_t s) {
+    if (b.n_words == 0) return;
+    unsigned grid = (unsigned)((b.n_words + 255) / 256);
+    hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, s, b.ascii, b.ascii_off, b.seq, b.n_seq,
+                       b.words, b.n_words);
+}
+
+// --------------------------------------------------------------------------
+// seed index: one 256-thread workgroup per pile.
+//   phase A  zero the table
+//   phase B  histogram of the seed's 8-mers (global atomics, L2)
+//   phase C  exclusive scan (tile of 1024 entries per step, LDS carry)
+//   phase D  ordered fill by wave 0: 64 positions per step in ascending order;
+//            lanes holding the same 8-mer are found with 16 ballots, ranked by
+//            lane id, and the group leader reserves the slots with one atomic,
+//            so every bucket ends up in ascending position order
+//            (== the reference chain order) without any sort.
+// After phase D, T[k+1] (the bucket cursor) equals the bucket end, and T[0]=0,
+// so bucket(k) = [T[k], T[k+1]).
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_seed_index(const u32 *__restrict__ words,
+                                                    const FaSeq *__restrict__ seq,
+                                                    const FaPile *__restrict__ pile,
+                                                    u32 *__restrict__ kidx,
+                                                    u32 *__restrict__ kpos) {
+    const FaPile pm = pile[blockIdx.x];
+    const FaSeq sd = seq[pm.first];
+    const u32 *w = words + sd.woff;
+    u32 *T = kidx + pm.kidx_off;   // 65537 entries used
+    u32 *P = kpos + pm.kpos_off;
+    const int tid = threadIdx.x;
+    const int n_pos = max(0, sd.len - FA_K);
+
+    for (int i = tid; i < FA_NKMER + 1; i += 256) T[i] = 0;
+    __syncthreads();
+
+    for (int i = tid; i < n_pos; i += 256) atomicAdd(&T[fa_kmer8(w, i) + 1], 1u);
+    __syncthreads();
+
+    // exclusive scan of T[1..65536] in place
+    __shared__ u32 s_part[256];
+    __shared__ u32 s_carry;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int tile = 0; tile < FA_NKMER; tile += 1024) {
+        u32 v[4];
+        // T+1 is only 4-byte aligned, so read scalars
+        v[0] = T[1 + tile + tid * 4 + 0];
+        v[1] = T[1 + tile + tid * 4 + 1];
+        v[2] = T[1 + tile + tid * 4 + 2];
+        v[3] = T[1 + tile + tid * 4 + 3];
+        u32 sum = v[0] + v[1] + v[2] + v[3];
+        s_part[tid] = sum;
+        __syncthreads();
+        // Hillis-Steele inclusive scan over 256 partials
+        for (int off = 1; off < 256; off <<= 1) {
+            u32 add = (tid >= off) ? s_part[tid - off] : 0;
+            __syncthreads();
+            s_part[tid] += add;
+            __syncthreads();
+        }
+        u32 excl = s_part[tid] - sum + s_carry;
+        T[1 + tile + tid * 4 + 0] = excl;
+        T[1 + tile + tid * 4 + 1] = excl + v[0];
+        T[1 + tile + tid * 4 + 2] = excl + v[0] + v[1];
+        T[1 + tile + tid * 4 + 3] = excl + v[0] + v[1] + v[2];
+        __syncthreads();
+        if (tid == 255) s_carry += s_part[255];
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    if (tid >= 64) return;
+    const int lane = tid;
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int i0 = 0; i0 < n_pos; i0 += 64) {
+        const int i = i0 + lane;
+        const bool valid = i < n_pos;
+        const u32 km = valid ? fa_kmer8(w, i) : 0u;
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 16; bit++) {
+            const bool one = (km >> bit) & 1u;
+            const u64 bal = __ballot(one);
+            peers &= one ? bal : ~bal;
+        }
+        if (!valid) peers = 0;
+        const int rank = __popcll(peers & lt_mask);
+        const int cnt = __popcll(peers);
+        const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+        u32 base = 0;
+        if (valid && lane == leader) base = atomicAdd(&T[km + 1], (u32)cnt);
+        base = __shfl(base, leader);
+        if (valid) P[base + rank] = (u32)i;
+    }
+}
+
+void fa_launch_index(const FaBatchDev &b, hipStream_t s) {
+    if (b.n_pile == 0) return;
+    hipLaunchKernelGGL(k_seed_index, dim3(b.n_pile), dim3(256), 0, s, b.words, b.seq, b.pile,
+                       b.kidx, b.kpos);
+}

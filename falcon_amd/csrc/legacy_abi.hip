@@ -1,0 +1,337 @@
+// legacy_abi.hip -- the 19 symbols falcon_kit/falcon_kit.py:54-122 binds, so this
+// library can stand in for the reference's ext_falcon shared object.
+//
+//  * generate_consensus / align run on the GPU through the batch engine
+//    (a batch of one); there is no CPU implementation of either in this library
+//    and both abort() loudly (like the reference's my_calloc/abort discipline,
+//    DW_banded.c:100-113) when no HIP device is usable.
+//  * the kup table functions (allocate_* / add_sequence / mask_k_mer /
+//    find_kmer_pos_for_seq / find_best_aln_range[2]) operate on caller-owned
+//    host structs whose layout the ABI fixes (common.h:95-120); they exist for
+//    ABI completeness of the --trim and graph_to_contig callers (SURVEY.md 8f-1,
+//    8f-3) and are NOT on the falcon_sense hot path: the hot path never builds
+//    these host tables (its equivalents are k_seed_index / k_chain on the GPU).
+#include "../../include/falcon_amd.h"
+
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+static fa_ctx *g_ctx = nullptr;
+static std::mutex g_mu;
+
+static fa_ctx *default_ctx() {
+    if (!g_ctx) {
+        int dev = 0;
+        if (const char *e = getenv("FALCON_AMD_DEVICE")) dev = atoi(e);
+        g_ctx = fa_create(dev);
+        if (!g_ctx) {
+            fprintf(stderr, "CRITICAL ERROR: falcon_amd: %s\n", fa_last_error());
+            abort();
+        }
+    }
+    return g_ctx;
+}
+
+static void die(const char *what) {
+    fprintf(stderr, "CRITICAL ERROR: falcon_amd %s: %s\n", what, fa_last_error());
+    abort();
+}
+
+// ---- falcon.c:562-666 ------------------------------------------------------
+extern "C" consensus_data *generate_consensus(char **input_seq, unsigned int n_seq,
+                                              unsigned min_cov, unsigned K, double min_idt) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    fa_ctx *c = default_ctx();
+    int n = (int)n_seq;
+    fa_batch *b = fa_batch_create(c, 1, &n, (const char *const *)input_seq, nullptr);
+    if (!b) die("generate_consensus(stage)");
+    if (fa_batch_run(b, min_cov, K, min_idt)) die("generate_consensus(run)");
+    if (fa_batch_fetch(b, 1)) die("generate_consensus(fetch)");
+    const char *s = nullptr;
+    const int *e = nullptr;
+    int len = 0;
+    if (fa_batch_result(b, 0, &s, &len, &e)) die("generate_consensus(result)");
+    consensus_data *r = (consensus_data *)calloc(1, sizeof(consensus_data));
+    r->sequence = (char *)calloc((size_t)len + 1, 1);
+    r->eqv = (int *)calloc((size_t)len + 1, sizeof(int));
+    memcpy(r->sequence, s, (size_t)len);
+    memcpy(r->eqv, e, (size_t)len * sizeof(int));
+    fa_batch_free(b);
+    return r;
+}
+
+extern "C" void free_consensus_data(consensus_data *c) {  // falcon.c:776
+    if (!c) return;
+    free(c->sequence);
+    free(c->eqv);
+    free(c);
+}
+
+// ---- DW_banded.c:115-337 ---------------------------------------------------
+extern "C" alignment *align(char *query_seq, seq_coor_t q_len, char *target_seq, seq_coor_t t_len,
+                            seq_coor_t band_tolerance, int get_aln_str) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    fa_ctx *c = default_ctx();
+    const char *q = query_seq, *t = target_seq;
+    alignment *out = nullptr;
+    if (fa_align_pairs(c, 1, &q, &q_len, &t, &t_len, band_tolerance, get_aln_str, &out))
+        die("align");
+    return out;
+}
+
+extern "C" void free_alignment(alignment *a) {
+    if (!a) return;
+    free(a->q_aln_str);
+    free(a->t_aln_str);
+    free(a);
+}
+
+// ---- host-struct table functions (kmer_lookup.c) ---------------------------
+extern "C" void init_kmer_lookup(kmer_lookup *kl, seq_coor_t size) {  // :80-88
+    for (seq_coor_t i = 0; i < size; i++) {
+        kl[i].start = INT_MAX;
+        kl[i].last = INT_MAX;
+        kl[i].count = 0;
+    }
+}
+
+extern "C" kmer_lookup *allocate_kmer_lookup(seq_coor_t size) {  // :71-78
+    kmer_lookup *kl = (kmer_lookup *)malloc((size_t)size * sizeof(kmer_lookup));
+    init_kmer_lookup(kl, size);
+    return kl;
+}
+
+extern "C" void free_kmer_lookup(kmer_lookup *kl) { free(kl); }
+
+extern "C" void init_seq_array(seq_array sa, seq_coor_t size) { memset(sa, 0xff, (size_t)size); }
+
+extern "C" seq_array allocate_seq(seq_coor_t size) {  // :95-107
+    seq_array sa = (seq_array)malloc((size_t)size);
+    init_seq_array(sa, size);
+    return sa;
+}
+
+extern "C" void free_seq_array(seq_array sa) { free(sa); }
+
+extern "C" seq_addr_array allocate_seq_addr(seq_coor_t size) {  // :113
+    return (seq_addr_array)calloc((size_t)size, sizeof(seq_addr));
+}
+
+extern "C" void free_seq_addr_array(seq_addr_array sda) { free(sda); }
+
+static inline int code_of(char c, int *ok) {
+    switch (c) {
+    case 'A': *ok = 1; return 0;
+    case 'C': *ok = 1; return 1;
+    case 'G': *ok = 1; return 2;
+    case 'T': *ok = 1; return 3;
+    default: *ok = 0; return 0;
+    }
+}
+
+// Table form of the seed index (:140-192): first/last occurrence + count per
+// k-mer, sda[] links each occurrence to the next one of the same k-mer.
+extern "C" void add_sequence(seq_coor_t start, unsigned int K, char *seq, seq_coor_t seq_len,
+                             seq_addr_array sda, seq_array sa, kmer_lookup *lk) {
+    for (seq_coor_t i = 0; i < seq_len; i++) {
+        int ok;
+        int c = code_of(seq[i], &ok);
+        if (ok) sa[start + i] = (base)c;
+    }
+    if (seq_len <= (seq_coor_t)K) return;
+    const unsigned mask = (K >= 16) ? 0xffffffffu : ((1u << (2 * K)) - 1u);
+    unsigned km = 0;
+    for (unsigned j = 0; j < K; j++) km = (km << 2) | (sa[start + j] & 3u);
+    for (seq_coor_t i = 0; i < seq_len - (seq_coor_t)K; i++) {
+        kmer_lookup *e = &lk[km];
+        const seq_coor_t pos = start + i;
+        if (e->start == INT_MAX) {
+            e->start = pos;
+        } else {
+            sda[e->last] = pos;
+        }
+        e->last = pos;
+        e->count += 1;
+        km = ((km << 2) | sa[start + i + K]) & mask;
+    }
+}
+
+extern "C" void mask_k_mer(seq_coor_t size, kmer_lookup *kl, seq_coor_t threshold) {  // :195-204
+    for (seq_coor_t i = 0; i < size; i++) {
+        if (kl[i].count > threshold) kl[i].start = kl[i].last = INT_MAX;
+    }
+}
+
+extern "C" kmer_match *find_kmer_pos_for_seq(char *seq, seq_coor_t seq_len, unsigned int K,
+                                             seq_addr_array sda, kmer_lookup *lk) {  // :207-286
+    std::vector<seq_coor_t> qv, tv;
+    std::vector<unsigned char> code((size_t)std::max(seq_len, 1), 0);
+    for (seq_coor_t i = 0; i < seq_len; i++) {
+        int ok;
+        code[i] = (unsigned char)code_of(seq[i], &ok);
+    }
+    const seq_coor_t step = (seq_coor_t)(K >> 1);
+    for (seq_coor_t i = 0; i < seq_len - (seq_coor_t)K; i += step) {
+        unsigned km = 0;
+        for (unsigned j = 0; j < K; j++) km = (km << 2) | code[i + j];
+        seq_coor_t pos = lk[km].start;
+        if (pos == INT_MAX) continue;
+        for (;;) {
+            qv.push_back(i);
+            tv.push_back(pos);
+            const seq_coor_t nx = sda[pos];
+            if (nx <= pos) break;
+            pos = nx;
+        }
+    }
+    kmer_match *m = (kmer_match *)malloc(sizeof(kmer_match));
+    m->count = (seq_coor_t)qv.size();
+    m->query_pos = (seq_coor_t *)calloc(qv.size() + 1, sizeof(seq_coor_t));
+    m->target_pos = (seq_coor_t *)calloc(tv.size() + 1, sizeof(seq_coor_t));
+    if (!qv.empty()) {
+        memcpy(m->query_pos, qv.data(), qv.size() * sizeof(seq_coor_t));
+        memcpy(m->target_pos, tv.data(), tv.size() * sizeof(seq_coor_t));
+    }
+    return m;
+}
+
+extern "C" void free_kmer_match(kmer_match *m) {
+    if (!m) return;
+    free(m->query_pos);
+    free(m->target_pos);
+    free(m);
+}
+
+extern "C" aln_range *find_best_aln_range(kmer_match *km, seq_coor_t K, seq_coor_t bin_size,
+                                          seq_coor_t count_th) {  // :294-427
+    (void)K;
+    aln_range *r = (aln_range *)calloc(1, sizeof(aln_range));
+    const int n = km->count;
+    if (n <= 0) return r;
+    long lo = LONG_MAX, hi = LONG_MIN;
+    for (int i = 0; i < n; i++) {
+        long d = (long)km->query_pos[i] - (long)km->target_pos[i];
+        lo = std::min(lo, d);
+        hi = std::max(hi, d);
+    }
+    std::vector<int> cnt((size_t)((hi - lo) / bin_size + 1), 0);
+    auto bin_of = [&](int i) {
+        return ((long)km->query_pos[i] - (long)km->target_pos[i] - lo) / (long)bin_size;
+    };
+    for (int i = 0; i < n; i++) cnt[bin_of(i)]++;
+    long top = -1, top_n = 0;
+    for (int i = 0; i < n; i++) {
+        long b = bin_of(i);
+        if (cnt[b] > top_n) {
+            top_n = cnt[b];
+            top = b;
+        }
+    }
+    if (top < 0 || top_n <= count_th) return r;
+    bool have_first = false, have_two = false;
+    int prev_q = 0, start_q = 0, start_t = 0;
+    long run = 0, best = 0;
+    aln_range out = *r;
+    for (int i = 0; i < n; i++) {
+        long b = bin_of(i);
+        if (labs(b - top) > 5 || cnt[b] <= count_th) continue;
+        const int q = km->query_pos[i], t = km->target_pos[i];
+        if (!have_first) {
+            have_first = true;
+            out.s1 = out.e1 = start_q = q;
+            out.s2 = out.e2 = start_t = t;
+        } else {
+            have_two = true;
+            run += 32 - (q - prev_q);
+            if (run < 0) {
+                run = 0;
+                start_q = q;
+                start_t = t;
+            } else if (run > best) {
+                best = run;
+                out.s1 = start_q;
+                out.s2 = start_t;
+                out.e1 = q;
+                out.e2 = t;
+                out.score = best;
+            }
+        }
+        prev_q = q;
+    }
+    if (have_two) *r = out;
+    return r;
+}
+
+extern "C" aln_range *find_best_aln_range2(kmer_match *km, seq_coor_t K, seq_coor_t bin_width,
+                                           seq_coor_t count_th) {  // :429-585
+    (void)K; (void)bin_width; (void)count_th;  // unused by the reference as well
+    aln_range *r = (aln_range *)calloc(1, sizeof(aln_range));
+    const int n = km->count;
+    if (n <= 0) return r;
+    std::vector<int> ds((size_t)n);
+    int max_q = -1, max_t = -1;
+    for (int i = 0; i < n; i++) {
+        ds[i] = km->query_pos[i] - km->target_pos[i];
+        max_q = std::max(max_q, km->query_pos[i]);
+        max_t = (max_t > km->target_pos[i]) ? max_q : km->target_pos[i];  // sic, :458
+    }
+    std::sort(ds.begin(), ds.end());
+    const int delta = (int)(long)(0.05 * (max_q + max_t));
+    int s = 0, e = 0, bs = -1, be = -1, span = -1;
+    for (;;) {
+        const int d_s = ds[s];
+        int d_e = ds[e];
+        while (d_e < d_s + delta && e < n - 1) d_e = ds[++e];
+        if (span == -1 || e - s > span) {
+            span = e - s;
+            bs = s;
+            be = e;
+        }
+        if (++s == n || e == n) break;
+    }
+    if (bs == -1 || be == -1 || be - bs < 32) return r;
+    const int lo = ds[bs], hi = ds[be];
+    std::vector<int> prev((size_t)n, -1), score((size_t)n, 0), links((size_t)n, 0);
+    int top = -1, top_score = 0, top_links = 0;
+    for (int i = 0; i < n; i++) {
+        const int cx = km->query_pos[i], cy = km->target_pos[i];
+        if (cx - cy < lo || cx - cy > hi) continue;
+        int cand = -1, gap = 65535;
+        for (int j = i - 1; j >= 0; j--) {
+            const int px = km->query_pos[j], py = km->target_pos[j];
+            if (px - py < lo || px - py > hi) continue;
+            if (cx - px > 320) break;
+            if (cy > py && cx - px + cy - py < gap && cy - py <= 320) {
+                gap = cx - px + cy - py;
+                cand = j;
+            }
+        }
+        if (cand != -1) {
+            prev[i] = cand;
+            score[i] = score[cand] + (64 - gap);
+            links[i] = links[cand] + 1;
+            if (score[i] < 0) score[i] = links[i] = 0;
+        }
+        if (score[i] > top_score) {
+            top_score = score[i];
+            top_links = links[i];
+            top = i;
+        }
+    }
+    if (top == -1) return r;
+    r->score = top_links + 1;
+    r->e1 = km->query_pos[top];
+    r->e2 = km->target_pos[top];
+    int i = top;
+    while (prev[i] != -1) i = prev[i];
+    r->s1 = km->query_pos[i];
+    r->s2 = km->target_pos[i];
+    return r;
+}
+
+extern "C" void free_aln_range(aln_range *r) { free(r); }

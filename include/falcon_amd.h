@@ -1,0 +1,171 @@
+/*
+ * falcon_amd.h -- C ABI of libfalcon_amd.so, the MI355X (gfx950) implementation of
+ * FALCON's pre-assembly consensus ("falcon_sense") hot path.
+ *
+ * Two surfaces:
+ *
+ *  (1) LEGACY ABI -- exactly the symbols the reference binds through ctypes in
+ *      falcon_kit/falcon_kit.py:54-122 (one CDLL for kup / DWA / falcon), with the
+ *      struct layouts of src/c/common.h:57-126.  Loading this library in place of
+ *      the reference's ext_falcon .so keeps `import falcon_kit` and
+ *      falcon_kit/mains/consensus.py working unchanged.  generate_consensus and
+ *      align execute on the GPU (a batch of one); see (2) for the fast path.
+ *
+ *  (2) BATCH ABI (additive) -- submit many piles at once; sequences are packed
+ *      to 2 bits per base in HBM and every stage (k-mer index, k-mer chaining,
+ *      banded O(ND) alignment + trace-back, MSA sweep + back-trace) runs as HIP
+ *      kernels over the whole batch.  Results are bit-identical to the legacy
+ *      entry points.
+ *
+ * All pointers are plain host pointers; there are no torch / HIP types in any
+ * signature.  Functions returning int return 0 on success and a negative code
+ * on failure; fa_last_error() describes the last failure of the calling thread.
+ * If no usable HIP device is present every entry point fails loudly -- there is
+ * no CPU fallback.
+ */
+#ifndef FALCON_AMD_H
+#define FALCON_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* (1) Legacy ABI -- replaces /root/reference/src/c/common.h:57-177           */
+/* ------------------------------------------------------------------------- */
+typedef int seq_coor_t;                       /* common.h:57 */
+
+typedef struct {                              /* common.h:59-69 */
+    seq_coor_t aln_str_size;
+    seq_coor_t dist;
+    seq_coor_t aln_q_s;
+    seq_coor_t aln_q_e;
+    seq_coor_t aln_t_s;
+    seq_coor_t aln_t_e;
+    char *q_aln_str;
+    char *t_aln_str;
+} alignment;
+
+typedef struct {                              /* common.h:95-99 */
+    seq_coor_t start;
+    seq_coor_t last;
+    seq_coor_t count;
+} kmer_lookup;
+
+typedef unsigned char base;                   /* common.h:101-104 */
+typedef base *seq_array;
+typedef seq_coor_t seq_addr;
+typedef seq_addr *seq_addr_array;
+
+typedef struct {                              /* common.h:107-111 */
+    seq_coor_t count;
+    seq_coor_t *query_pos;
+    seq_coor_t *target_pos;
+} kmer_match;
+
+typedef struct {                              /* common.h:114-120 */
+    seq_coor_t s1;
+    seq_coor_t e1;
+    seq_coor_t s2;
+    seq_coor_t e2;
+    long int score;
+} aln_range;
+
+typedef struct {                              /* common.h:123-126 */
+    char *sequence;
+    int *eqv;
+} consensus_data;
+
+/* kmer_lookup.c:71-119 -- table/array owners (falcon_kit.py:54-66) */
+kmer_lookup *allocate_kmer_lookup(seq_coor_t size);
+void init_kmer_lookup(kmer_lookup *kl, seq_coor_t size);
+void free_kmer_lookup(kmer_lookup *kl);
+seq_array allocate_seq(seq_coor_t size);
+void init_seq_array(seq_array sa, seq_coor_t size);
+void free_seq_array(seq_array sa);
+seq_addr_array allocate_seq_addr(seq_coor_t size);
+void free_seq_addr_array(seq_addr_array sda);
+
+/* kmer_lookup.c:140-192, :195-204, :207-286, :288 (falcon_kit.py:68-75) */
+void add_sequence(seq_coor_t start, unsigned int K, char *seq, seq_coor_t seq_len,
+                  seq_addr_array sda, seq_array sa, kmer_lookup *lk);
+void mask_k_mer(seq_coor_t size, kmer_lookup *kl, seq_coor_t threshold);
+kmer_match *find_kmer_pos_for_seq(char *seq, seq_coor_t seq_len, unsigned int K,
+                                  seq_addr_array sda, kmer_lookup *lk);
+void free_kmer_match(kmer_match *ptr);
+
+/* kmer_lookup.c:294-427, :429-585, :587 (falcon_kit.py:78-84) */
+aln_range *find_best_aln_range(kmer_match *km, seq_coor_t K, seq_coor_t bin_size,
+                               seq_coor_t count_th);
+aln_range *find_best_aln_range2(kmer_match *km, seq_coor_t K, seq_coor_t bin_width,
+                                seq_coor_t count_th);
+void free_aln_range(aln_range *r);
+
+/* DW_banded.c:115-337 (falcon_kit.py:111-114) */
+alignment *align(char *query_seq, seq_coor_t q_len, char *target_seq, seq_coor_t t_len,
+                 seq_coor_t band_tolerance, int get_aln_str);
+void free_alignment(alignment *aln);
+
+/* falcon.c:562-666, :776 (falcon_kit.py:119-122, consensus.py:20-23) */
+consensus_data *generate_consensus(char **input_seq, unsigned int n_seq, unsigned min_cov,
+                                   unsigned K, double min_idt);
+void free_consensus_data(consensus_data *c);
+
+/* ------------------------------------------------------------------------- */
+/* (2) Batch ABI -- replaces the multiprocessing.Pool.imap over piles of       */
+/*     falcon_kit/mains/consensus.py:264-274 and falcon_kit/multiproc.py:28-36 */
+/* ------------------------------------------------------------------------- */
+typedef struct fa_ctx fa_ctx;     /* one per process and GPU */
+typedef struct fa_batch fa_batch; /* a set of piles resident in HBM */
+
+typedef struct {
+    /* B_alg = L/4 + 4C + 8D + 16A + 12T + 5O bytes */
+    long long L;  /* input bases (all sequences)                          */
+    long long C;  /* (d,k) cells evaluated by the banded alignments        */
+    long long D;  /* sum of edit distance over accepted alignments         */
+    long long A;  /* sum of alignment columns over accepted alignments     */
+    long long T;  /* sum of seed lengths                                    */
+    long long O;  /* sum of consensus lengths                               */
+    long long n_piles, n_seqs, n_aligned;
+    /* stage times of the last fa_batch_run, HIP events on the engine stream */
+    float ms_index, ms_chain, ms_align, ms_consensus, ms_total;
+    int align_slots; /* resident alignment work slots (wavefronts) */
+} fa_stats;
+
+const char *fa_last_error(void);
+int fa_device_count(void);
+fa_ctx *fa_create(int device);
+void fa_destroy(fa_ctx *ctx);
+
+/* Stage a batch: n_pile piles, pile p owns pile_n_seq[p] consecutive entries of
+ * seqs[]/seq_len[] (first entry = seed).  seq_len may be NULL (strlen is used).
+ * Copies the ASCII bases to HBM and packs them to 2 bits per base.  The host
+ * strings are not referenced after the call returns. */
+fa_batch *fa_batch_create(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
+                          const char *const *seqs, const int *seq_len);
+/* Run the whole path on the resident batch (may be called repeatedly). */
+int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double min_idt);
+/* Copy results to the host (want_eqv != 0 also copies the eqv arrays). */
+int fa_batch_fetch(fa_batch *b, int want_eqv);
+/* Consensus of pile p: *seq is NUL terminated and owned by the batch. */
+int fa_batch_result(fa_batch *b, int pile, const char **seq, int *len, const int **eqv);
+int fa_batch_stats(fa_batch *b, fa_stats *out);
+void fa_batch_free(fa_batch *b);
+
+/* Diagnostics used by the parity tests: per-sequence stage outputs.
+ * g = index into the flattened seqs[] of fa_batch_create. */
+int fa_batch_range(fa_batch *b, int g, int *s1, int *e1, int *s2, int *e2, long long *score,
+                   int *ok, int *n_hit);
+int fa_batch_alignment(fa_batch *b, int g, int *dist, int *q_e, int *t_e, int *size, int *accept,
+                       long long *cells);
+
+/* Pairwise banded alignment of n independent (query, target) pairs in one
+ * launch; out[i] receives a malloc'ed `alignment` (free with free_alignment). */
+int fa_align_pairs(fa_ctx *ctx, int n, const char *const *q, const int *q_len,
+                   const char *const *t, const int *t_len, int band_tolerance, int get_aln_str,
+                   alignment **out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

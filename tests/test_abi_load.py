@@ -1,0 +1,71 @@
+"""CPU-side checks of the product library: it builds, loads, and exports every
+symbol include/falcon_amd.h declares.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "falcon_amd", "libfalcon_amd.so")
+HDR = os.path.join(ROOT, "include", "falcon_amd.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(SO):
+        import __graft_entry__
+        __graft_entry__.build()
+    return ctypes.CDLL(SO)
+
+
+def declared_functions():
+    src = open(HDR).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b([a-zA-Z_][a-zA-Z0-9_]*)\s*\([^;{]*\)\s*;", src)
+    return sorted(set(n for n in names if n not in ("defined",)))
+
+
+def test_header_declares_the_legacy_abi():
+    from oracle.pyoracle import LEGACY_SYMBOLS
+    names = declared_functions()
+    for s in LEGACY_SYMBOLS:
+        assert s in names, s
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_functions()
+    assert len(names) >= 19 + 10
+    for n in names:
+        assert hasattr(lib, n), "libfalcon_amd.so does not export %s" % n
+
+
+def test_no_gpu_means_loud_failure(lib):
+    """Without a HIP device the engine must refuse, not fall back."""
+    lib.fa_device_count.restype = ctypes.c_int
+    if lib.fa_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    lib.fa_create.restype = ctypes.c_void_p
+    lib.fa_last_error.restype = ctypes.c_char_p
+    assert not lib.fa_create(0)
+    assert b"no CPU fallback" in lib.fa_last_error()
+
+
+def test_product_does_not_link_the_oracle():
+    import subprocess
+    out = subprocess.run(["ldd", SO], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "falcon_ref" not in out
+    syms = subprocess.run(["nm", "-D", SO], capture_output=True, text=True).stdout
+    assert " fo_" not in syms
+
+
+def test_legacy_table_functions_match_golden(lib):
+    """The host-struct kup functions of the legacy ABI (not on the GPU hot path)."""
+    from conftest import load_golden
+    from helpers import check_hits_case
+    from oracle.pyoracle import LegacyABI
+    impl = LegacyABI(SO)
+    for c in load_golden("f1_f2_hits_ranges")["cases"]:
+        check_hits_case(impl, c)
+    for c in load_golden("f2_ranges_extra")["cases"]:
+        assert list(impl.best_range(c["q"], c["t"], c["bin"], c["th"])) == c["range"]

@@ -1,0 +1,163 @@
+"""GPU parity tests: the HIP path, called through the C ABI of
+include/falcon_amd.h, against (a) the golden vectors generated from the compiled
+reference and (b) the CPU oracle on seeded synthetic piles.  Bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from helpers import check_align_case, check_pile_case, sha_ints
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "falcon_amd", "libfalcon_amd.so")
+
+F1 = load_golden("f1_f2_hits_ranges")["cases"]
+F3 = load_golden("f3_align")["cases"]
+F4 = load_golden("f4_piles")["cases"]
+
+
+@pytest.fixture(scope="module")
+def legacy():
+    from oracle.pyoracle import LegacyABI
+    return LegacyABI(SO)
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from falcon_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def test_native_library_is_loaded(engine):
+    maps = open("/proc/self/maps").read()
+    assert "libfalcon_amd.so" in maps
+
+
+@pytest.mark.parametrize("case", [c for c in F3 if c["band"] <= 190],
+                         ids=[c["name"] for c in F3 if c["band"] <= 190])
+def test_align_golden_legacy_abi(legacy, case):
+    check_align_case(legacy, case)
+
+
+def test_align_golden_one_launch(engine):
+    cases = [c for c in F3 if c["band"] == 150 and c["want_str"]]
+    res = engine.align_pairs([(c["q"], c["t"]) for c in cases], band=150, want_str=True)
+    for c, r in zip(cases, res):
+        for k, v in c["expect"].items():
+            assert r[k] == v, (c["name"], k)
+
+
+def test_wide_band_is_refused_loudly(engine):
+    from falcon_amd.lib import FalconAmdError
+    with pytest.raises(FalconAmdError):
+        engine.align_pairs([("ACGT" * 10, "ACGT" * 10)], band=1500)
+
+
+def test_chain_ranges_golden(engine):
+    """k_seed_index + k_chain vs find_kmer_pos_for_seq + find_best_aln_range."""
+    cases = [c for c in F1 if c["mask"] < 0]
+    b = engine.batch([[c["seed"], c["query"]] for c in cases])
+    b.run(4, 8, 0.70)
+    for i, c in enumerate(cases):
+        r = b.range(2 * i + 1)
+        assert r["n_hit"] == c["count"], c["name"]
+        assert [r["s1"], r["e1"], r["s2"], r["e2"], r["score"]] == c["range_48_5"], c["name"]
+    b.free()
+
+
+@pytest.mark.parametrize("case", F4, ids=[c["name"] for c in F4])
+def test_piles_golden_legacy_abi(legacy, case):
+    check_pile_case(legacy, case)
+
+
+def test_piles_golden_one_batch(engine):
+    by_cfg = {}
+    for c in F4:
+        by_cfg.setdefault((c["min_cov"], c["min_idt"]), []).append(c)
+    for (min_cov, min_idt), cases in by_cfg.items():
+        res = engine.consensus([c["seqs"] for c in cases], min_cov, 8, min_idt, want_eqv=True)
+        for c, (seq, eqv) in zip(cases, res):
+            assert seq == c["sequence"], c["name"]
+            assert sha_ints(eqv) == c["eqv_sha"], c["name"]
+
+
+def _synthetic(seed, **kw):
+    from falcon_amd.synth import codes_to_str, make_pile, pile_to_seqs
+    s, rd = make_pile(seed, **kw)
+    return [codes_to_str(x) for x in pile_to_seqs(s, rd, kw.get("max_n_read", 200))]
+
+
+def test_synthetic_piles_vs_oracle(engine, port):
+    piles = [
+        _synthetic(31, S=3000, coverage=12, min_read=500, mean_read=1500, sd_read=500),
+        _synthetic(32, S=8000, coverage=25, min_read=1000, mean_read=5000, sd_read=2000),
+        _synthetic(33, S=8000, coverage=30, het=0.005, min_read=1000, mean_read=5000, sd_read=2000),
+        _synthetic(34, S=6000, coverage=20, e=0.20, min_read=1000, mean_read=4000, sd_read=1500),
+        _synthetic(35, S=6000, coverage=20, e=0.02, min_read=1000, mean_read=4000, sd_read=1500),
+    ]
+    for min_cov, idt in ((4, 0.70), (0, 0.80), (8, 0.70)):
+        got = engine.consensus(piles, min_cov, 8, idt, want_eqv=True)
+        for p, (seq, eqv) in zip(piles, got):
+            eseq, eeqv = port.generate_consensus(p, min_cov, 8, idt)
+            assert seq == eseq
+            assert eqv == eeqv
+
+
+def test_stage_outputs_vs_oracle(engine, port):
+    """Per-read stage outputs (range, alignment summary, cell counts) and the
+    B_alg work statistics agree with the oracle."""
+    pile = _synthetic(41, S=5000, coverage=15, min_read=800, mean_read=3000, sd_read=1000)
+    b = engine.batch([pile])
+    b.run(4, 8, 0.70)
+    _seq, _eqv, st = port.generate_consensus(pile, 4, 8, 0.70, want_stats=True)
+    gs = b.stats()
+    assert (gs.L, gs.C, gs.D, gs.A, gs.T, gs.O, gs.n_aligned) == \
+        (st["L"], st["C"], st["D"], st["A"], st["T"], st["O"], st["n_aligned"])
+    for g in range(1, len(pile)):
+        hq, ht = port.find_hits(pile[0], pile[g])
+        r = b.range(g)
+        assert [r["s1"], r["e1"], r["s2"], r["e2"], r["score"]] == list(port.best_range(hq, ht))
+        if r["ok"]:
+            a = port.align(pile[g][r["s1"]:r["e1"]], pile[0][r["s2"]:r["e2"]], 150, 1)
+            ga = b.alignment(g)
+            assert (ga["dist"], ga["q_e"], ga["t_e"], ga["size"], ga["cells"]) == \
+                (a["dist"], a["aln_q_e"], a["aln_t_e"], a["aln_str_size"], a["cells"])
+    b.free()
+
+
+def test_ecoli_scale_pile_vs_oracle(engine, port):
+    """BASELINE config 2 shape: ~20 kb seed x 40x."""
+    pile = _synthetic(7, S=20000, coverage=40)
+    (seq, eqv), = engine.consensus([pile], 4, 8, 0.70, want_eqv=True)
+    eseq, eeqv = port.generate_consensus(pile, 4, 8, 0.70)
+    assert len(seq) > 19000
+    assert seq == eseq and eqv == eeqv
+
+
+def test_many_reads_pile_uses_wide_chunks(engine, port):
+    """> 64 and > 128 accepted alignments exercise the 2- and 4-chunk sweeps."""
+    for seed, cov in ((51, 90), (52, 170)):
+        pile = _synthetic(seed, S=3000, coverage=cov, min_read=1500, mean_read=2500,
+                          sd_read=300, max_n_read=500)
+        (seq, eqv), = engine.consensus([pile], 4, 8, 0.70, want_eqv=True)
+        eseq, eeqv, st = port.generate_consensus(pile, 4, 8, 0.70, want_stats=True)
+        assert st["n_aligned"] > (64 if cov == 90 else 128)
+        assert seq == eseq and eqv == eeqv
+
+
+def test_batch_is_order_preserving_and_rerunnable(engine):
+    piles = [_synthetic(60 + i, S=2500, coverage=12, min_read=500, mean_read=1500, sd_read=400)
+             for i in range(6)]
+    a = engine.consensus(piles, 4, 8, 0.70)
+    b = engine.consensus(list(reversed(piles)), 4, 8, 0.70)
+    assert a == list(reversed(b))
+    bt = engine.batch(piles)
+    r1 = [bt.run(4, 8, 0.70).fetch().result(i) for i in range(len(piles))]
+    r2 = [bt.run(4, 8, 0.70).fetch().result(i) for i in range(len(piles))]
+    assert r1 == r2 == a
+    bt.free()
