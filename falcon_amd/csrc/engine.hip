@@ -19,6 +19,19 @@
 
 static thread_local std::string g_err;
 
+// FALCON_AMD_TRACE=1: synchronise and report after every stage (debugging aid)
+static bool trace_on() {
+    static int v = -1;
+    if (v < 0) v = getenv("FALCON_AMD_TRACE") ? 1 : 0;
+    return v == 1;
+}
+static void trace_stage(hipStream_t s, const char *name) {
+    if (!trace_on()) return;
+    hipError_t e = hipStreamSynchronize(s);
+    fprintf(stderr, "[falcon_amd] stage %-10s %s\n", name, hipGetErrorString(e));
+    fflush(stderr);
+}
+
 static void set_err(const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -330,11 +343,13 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
     ok &= hipMemcpyAsync(b->d_script_off.p, b->script_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
     if (!pair_mode)
         ok &= hipMemcpyAsync(b->d_bin_off.p, b->bin_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
+    trace_stage(s, "upload");
     if (ok) {
         fa_launch_pack(b->dev(), s);
         ok &= hipGetLastError() == hipSuccess;
         ok &= hipStreamSynchronize(s) == hipSuccess;
     }
+    trace_stage(s, "pack");
     (void)hipHostFree(h_ascii);
     b->d_ascii.release();  // only the packed form stays resident
     if (!ok) {
@@ -371,6 +386,7 @@ static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes) {
     per_cu = std::max(1, std::min(per_cu, 16));
     int n_slot = c->n_cu * per_cu;
     n_slot = std::max(1, std::min(n_slot, b->n_seq));
+    if (const char *e = getenv("FALCON_AMD_SLOTS")) n_slot = std::max(1, std::min(n_slot, atoi(e)));
     u64 rows = (u64)b->max_rows;
     u64 cells = rows * (u64)(b->band + 1);
     size_t free_b = 0, total_b = 0;
@@ -439,10 +455,13 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     HIP_OK(hipEventRecord(c->ev[0], s));
     fa_launch_index(d, s);
     HIP_OK(hipEventRecord(c->ev[1], s));
+    trace_stage(s, "index");
     fa_launch_chain(d, s);
     HIP_OK(hipEventRecord(c->ev[2], s));
+    trace_stage(s, "chain");
     fa_launch_align(d, c->arena, b->max_read_len, b->max_seed_len, max_diff, s);
     HIP_OK(hipEventRecord(c->ev[3], s));
+    trace_stage(s, "align");
     HIP_OK(hipGetLastError());
     // alignment summaries bound the MSA node pools (levels <= seed + insertions)
     if (int rc = fetch_aln(b)) return rc;
@@ -474,6 +493,7 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     HIP_OK(hipEventRecord(c->ev[4], s));
     fa_launch_consensus(d, min_cov, s);
     HIP_OK(hipEventRecord(c->ev[5], s));
+    trace_stage(s, "consensus");
     HIP_OK(hipGetLastError());
     b->h_pile_out.resize(b->n_pile);
     HIP_OK(hipMemcpyAsync(b->h_pile_out.data(), b->d_pile_out.p,
@@ -638,10 +658,13 @@ extern "C" int fa_align_pairs(fa_ctx *ctx, int n, const char *const *q, const in
         set_err("falcon_amd: sequences too long for the LDS-staged alignment kernel");
         return fail(-1);
     }
+    trace_stage(s, "pair-range");
     if (ensure_arena(c, b, lds)) return fail(-1);
+    trace_stage(s, "pair-arena");
     FaBatchDev d = b->dev();
     FaAlignArena ar = c->arena;
     fa_launch_align_band(d, ar, max_q, max_t, 2.0, band_tolerance, s);
+    trace_stage(s, "pair-align");
     if (hipGetLastError() != hipSuccess) {
         set_err("falcon_amd: k_align launch failed");
         return fail(-1);
@@ -658,6 +681,13 @@ extern "C" int fa_align_pairs(fa_ctx *ctx, int n, const char *const *q, const in
     }
     for (int i = 0; i < n; i++) {
         const FaAln &a = b->h_aln[2 * i + 1];
+        if (trace_on()) {
+            fprintf(stderr, "[falcon_amd] pair %d: aligned %d dist %d q_e %d t_e %d size %d cells %lld err %d",
+                    i, a.aligned, a.dist, a.q_e, a.t_e, a.size, a.cells, a.err);
+            if (get_aln_str > 0)
+                for (int k = 0; k < 4; k++) fprintf(stderr, " s[%d]=%u", k, script[b->script_off[2 * i + 1] + k]);
+            fprintf(stderr, "\n");
+        }
         alignment *r = (alignment *)calloc(1, sizeof(alignment));
         size_t cap = (size_t)q_len[i] + (size_t)t_len[i] + 1;
         r->q_aln_str = (char *)calloc(cap, 1);

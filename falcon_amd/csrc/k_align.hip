@@ -33,6 +33,12 @@
 
 #define RING 256  // V entries per parity; live band <= 191 diagonals
 
+#ifdef FA_TRACE_KERNEL
+#define KTRACE(...) do { if (lane == 0) printf(__VA_ARGS__); } while (0)
+#else
+#define KTRACE(...) do { } while (0)
+#endif
+
 struct AlignArgs {
     const u32 *words;
     const FaSeq *seq;
@@ -67,12 +73,13 @@ __device__ void align_one(const AlignArgs &A, int g, const u32 *qL, int qb, int 
     const int max_d = (int)(0.3 * (double)(q_len + t_len));  // DW_banded.c:149
     if ((u64)max_d > A.rows_per_slot) {  // host sized the slot from the same formula
         res.err = 1;
-        if (lane == 0) A.aln[g] = res;
+        A.aln[g] = res;
         return;
     }
     // zero the ring (reference: calloc'ed V, :153)
     for (int i = lane; i < 2 * RING; i += 64) Vring[i] = 0;
 
+    KTRACE("align g=%d q_len=%d t_len=%d max_d=%d qb=%d tb=%d\n", g, q_len, t_len, max_d, qb, tb);
     int best_m = -1, min_k = 0, max_k = 0;
     u32 row_off = 0;
     int fin_d = -1, fin_k = 0, fin_x = 0, fin_y = 0;
@@ -139,6 +146,7 @@ __device__ void align_one(const AlignArgs &A, int g, const u32 *qL, int qb, int 
             rr.dir[2] = dirw[2];
             rows[d] = rr;
         }
+        KTRACE(" row d=%d min_k=%d max_k=%d n=%d fin=%d\n", d, min_k, max_k, n, (int)finished);
         if (finished) break;
         row_off += (u32)n;
         best_m = max(best_m, fa_wave_max(row_max));
@@ -168,9 +176,10 @@ __device__ void align_one(const AlignArgs &A, int g, const u32 *qL, int qb, int 
 
     if (fin_d < 0) {  // unaligned: aln_str_size stays 0 (:171,:184-186)
         res.cells = row_off;
-        if (lane == 0) A.aln[g] = res;
+        A.aln[g] = res;
         return;
     }
+    KTRACE(" forward done fin_d=%d fin_k=%d x=%d y=%d\n", fin_d, fin_k, fin_x, fin_y);
     res.aligned = 1;
     res.dist = fin_d;
     res.q_e = fin_x;
@@ -236,10 +245,11 @@ __device__ void align_one(const AlignArgs &A, int g, const u32 *qL, int qb, int 
         if (hi < 63) break;
         // k_cur now is the diagonal of row hi-63 (lane 63's row): restart there
     }
+    KTRACE(" trace done n_ins=%d\n", n_ins);
     res.n_ins = n_ins;
     res.accept = (res.size > 500) &&
                  ((double)res.dist / (double)res.size < A.max_diff);  // falcon.c:629
-    if (lane == 0) A.aln[g] = res;
+    A.aln[g] = res;  // every lane stores the same record
 }
 
 __global__ __launch_bounds__(64) void k_align(AlignArgs A) {
@@ -253,48 +263,53 @@ __global__ __launch_bounds__(64) void k_align(AlignArgs A) {
     FaRowRec *rows = A.rows + (u64)slot * A.rows_per_slot;
 
     for (;;) {
-        int wi = 0;
-        if (lane == 0) wi = atomicAdd(A.counter, 1);
+        // One work item per trip.  Everything that steers control flow is forced
+        // into SGPRs (readfirstlane) so the trip is provably wave-uniform.
+        // (no `if (lane == 0)` around the atomic or the result stores of this
+        // loop: hipcc 7.2 jump-threads such blocks across the back edge and
+        // folds the readfirstlane on the lane != 0 path, which livelocks)
+        int wi = atomicAdd(A.counter, lane == 0 ? 1 : 0);
         wi = __builtin_amdgcn_readfirstlane(wi);
+        KTRACE("block %d got wi=%d of %d\n", (int)blockIdx.x, wi, A.n_work);
         if (wi >= A.n_work) break;
-        const int g = A.order[wi];
-        const FaSeq sq = A.seq[g];
-        const FaRange rg = A.range[g];
-        if (sq.idx == 0 || !rg.ok) {
-            if (lane == 0) {
-                FaAln z;
-                z.dist = 0; z.q_e = 0; z.t_e = 0; z.size = 0; z.accept = 0; z.n_ins = 0;
-                z.aligned = 0; z.err = 0; z.cells = 0;
-                A.aln[g] = z;
-            }
-            continue;
-        }
-        const FaPile pm = A.pile[sq.pile];
-        const FaSeq sd = A.seq[pm.first];
-        const int q_len = rg.e1 - rg.s1, t_len = rg.e2 - rg.s2;  // falcon.c:626-627
+        const int g = __builtin_amdgcn_readfirstlane(A.order[wi]);
+        const int q_idx = __builtin_amdgcn_readfirstlane(A.seq[g].idx);
+        const int q_slen = __builtin_amdgcn_readfirstlane(A.seq[g].len);
+        const u32 q_woff = (u32)__builtin_amdgcn_readfirstlane((int)A.seq[g].woff);
+        const int pile_id = __builtin_amdgcn_readfirstlane(A.seq[g].pile);
+        const int s1 = __builtin_amdgcn_readfirstlane(A.range[g].s1);
+        const int e1 = __builtin_amdgcn_readfirstlane(A.range[g].e1);
+        const int s2 = __builtin_amdgcn_readfirstlane(A.range[g].s2);
+        const int e2 = __builtin_amdgcn_readfirstlane(A.range[g].e2);
+        const int rg_ok = __builtin_amdgcn_readfirstlane(A.range[g].ok);
+        const int seed_g = __builtin_amdgcn_readfirstlane(A.pile[pile_id].first);
+        const int t_slen = __builtin_amdgcn_readfirstlane(A.seq[seed_g].len);
+        const u32 t_woff = (u32)__builtin_amdgcn_readfirstlane((int)A.seq[seed_g].woff);
+
+        const int q_len = e1 - s1, t_len = e2 - s2;  // falcon.c:626-627
         // stage the two windows: words [s/16, (s+len)/16 + 2]
-        const int qw0 = rg.s1 >> 4, tw0 = rg.s2 >> 4;
-        const int qn = ((rg.s1 + q_len) >> 4) - qw0 + 3;
-        const int tn = ((rg.s2 + t_len) >> 4) - tw0 + 3;
-        if (qn > A.lds_q_words || tn > A.lds_t_words) {
-            if (lane == 0) {
-                FaAln z;
-                z.dist = 0; z.q_e = 0; z.t_e = 0; z.size = 0; z.accept = 0; z.n_ins = 0;
-                z.aligned = 0; z.err = 1; z.cells = 0;
-                A.aln[g] = z;
-            }
-            continue;
+        const int qw0 = s1 >> 4, tw0 = s2 >> 4;
+        const int qn = ((s1 + q_len) >> 4) - qw0 + 3;
+        const int tn = ((s2 + t_len) >> 4) - tw0 + 3;
+        const bool skip = (q_idx == 0) || !rg_ok;
+        const bool too_big = !skip && (qn > A.lds_q_words || tn > A.lds_t_words);
+        if (skip || too_big) {
+            FaAln z;
+            z.dist = 0; z.q_e = 0; z.t_e = 0; z.size = 0; z.accept = 0; z.n_ins = 0;
+            z.aligned = 0; z.err = too_big ? 1 : 0; z.cells = 0;
+            A.aln[g] = z;  // every lane stores the same record
+        } else {
+            const u32 *qg = A.words + q_woff + qw0;
+            const u32 *tg = A.words + t_woff + tw0;
+            // the sequence's own words end at ceil(len/16)+2 (zero padded by pack)
+            const int qavail = ((q_slen + 15) >> 4) + 2 - qw0;
+            const int tavail = ((t_slen + 15) >> 4) + 2 - tw0;
+            for (int i = lane; i < qn; i += 64) qL[i] = (i < qavail) ? qg[i] : 0u;
+            for (int i = lane; i < tn; i += 64) tL[i] = (i < tavail) ? tg[i] : 0u;
+            __syncthreads();
+            align_one(A, g, qL, s1 & 15, q_len, tL, s2 & 15, t_len, Vring, cells, rows, lane);
+            __syncthreads();
         }
-        const u32 *qg = A.words + sq.woff + qw0;
-        const u32 *tg = A.words + sd.woff + tw0;
-        // the sequence's own words end at ceil(len/16)+2 (zero padded by pack)
-        const int qavail = ((sq.len + 15) >> 4) + 2 - qw0;
-        const int tavail = ((sd.len + 15) >> 4) + 2 - tw0;
-        for (int i = lane; i < qn; i += 64) qL[i] = (i < qavail) ? qg[i] : 0u;
-        for (int i = lane; i < tn; i += 64) tL[i] = (i < tavail) ? tg[i] : 0u;
-        __syncthreads();
-        align_one(A, g, qL, rg.s1 & 15, q_len, tL, rg.s2 & 15, t_len, Vring, cells, rows, lane);
-        __syncthreads();
     }
 }
 
