@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- FALCON pre-assembly consensus hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the whole hot path (seed k-mer index -> k-mer chaining ->
+banded O(ND) alignment + trace-back -> MSA sweep + consensus back-trace) over one
+resident batch of synthetic LA4Falcon-style piles, BASELINE.json configs[1]:
+E. coli-like ~20 kb seeds x 40x coverage, flags of examples/fc_run_ecoli.cfg:33
+(--min-cov 4 --min-idt 0.70 --max-n-read 200).  Inputs are 2-bit packed and resident
+in HBM before the timed region starts; every rank owns its own piles (piles are
+independent: no collective on the data path, weak scaling).
+
+Prints ONE JSON line (rank 0): metric = consensus bases/s over all GPUs, plus
+  roofline     -- dominant kernel, algorithmic bytes / HIP-event time
+  cpu_baseline -- the reference C path (oracle/_ref, else our restatement) timed on the
+                  host cores on a bounded sample of the same piles (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+MIN_COV, K, MIN_IDT, MAX_N_READ = 4, 8, 0.70, 200
+
+
+def _gen_pile(seed):
+    from falcon_amd.synth import codes_to_str, make_pile, pile_to_seqs
+    s, rd = make_pile(seed, S=20000, coverage=40.0)
+    return [codes_to_str(x).encode("ascii") for x in pile_to_seqs(s, rd, MAX_N_READ)]
+
+
+def gen_piles(seeds, procs):
+    if procs <= 1 or len(seeds) < 4:
+        return [_gen_pile(s) for s in seeds]
+    ctx = mp.get_context("fork")
+    with ctx.Pool(procs) as pool:
+        return pool.map(_gen_pile, seeds, chunksize=4)
+
+
+# ---- CPU baseline workers (own processes: the reference C is not re-entrant,
+# ---- falcon.c:338, and pays a one-off 0.9 GB workspace per process) ----------
+def _cpu_worker(args):
+    kind, piles = args
+    from oracle.pyoracle import Port, Ref
+    impl = Ref() if kind == "reference" else Port()
+    impl.generate_consensus(piles[0], MIN_COV, K, MIN_IDT)  # warm-up, untimed
+    t0 = time.perf_counter()
+    bases = 0
+    for p in piles[1:]:
+        bases += len(impl.generate_consensus(p, MIN_COV, K, MIN_IDT)[0])
+    return bases, len(piles) - 1, time.perf_counter() - t0
+
+
+def cpu_baseline(piles):
+    from oracle.pyoracle import build, have_ref
+    try:
+        build()
+    except Exception:
+        pass
+    kind = "reference" if have_ref() else "port"
+    cores = max(1, min(os.cpu_count() or 1, 16, len(piles) // 3))
+    per = max(2, min(4, len(piles) // cores))
+    jobs = [(kind, piles[i * per:(i + 1) * per]) for i in range(cores)]
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - t0
+    bases = sum(r[0] for r in res)
+    n = sum(r[1] for r in res)
+    busy = max(r[2] for r in res)  # workers run concurrently: timed span of the slowest
+    return {
+        "value": round(bases / busy, 1), "unit": "bases/s", "cores": cores, "kind": kind,
+        "piles_per_sec": round(n / busy, 3),
+        "per_core_bases_per_sec": round(bases / sum(r[2] for r in res), 1),
+        "sample": "%d piles of this workload (+1 untimed warm-up pile per worker process), "
+                  "%d worker processes, %.1f s wall incl. warm-up" % (n, cores, wall),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--piles", type=int, default=int(os.environ.get("FALCON_BENCH_PILES", "768")),
+                    help="piles per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    # synthetic input first (forks worker processes; no GPU state exists yet)
+    ncpu = os.cpu_count() or 1
+    procs = max(1, min(32, ncpu // max(1, world)))
+    seeds = [1000003 * (rank + 1) + i for i in range(args.piles)]
+    t_gen = time.perf_counter()
+    piles = gen_piles(seeds, procs)
+    t_gen = time.perf_counter() - t_gen
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from falcon_amd.engine import Engine
+
+    eng = Engine(local_rank)
+    t_up = time.perf_counter()
+    batch = eng.batch(piles)  # ASCII -> HBM, packed to 2 bits/base on the GPU
+    t_up = time.perf_counter() - t_up
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        batch.run(MIN_COV, K, MIN_IDT)
+    sync()
+    t0 = time.perf_counter()
+    ms_align = ms_cns = ms_chain = ms_index = 0.0
+    for _ in range(args.steps):
+        batch.run(MIN_COV, K, MIN_IDT)  # returns after the stream drained
+        st = batch.stats()
+        ms_align += st.ms_align
+        ms_cns += st.ms_consensus
+        ms_chain += st.ms_chain
+        ms_index += st.ms_index
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    st = batch.stats()
+    bases_step = st.O
+    tot = torch.tensor([float(bases_step), float(st.n_piles), elapsed], dtype=torch.float64,
+                       device="cuda")
+    if world > 1:
+        tmax = tot[2:3].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot[0:2], op=dist.ReduceOp.SUM)
+        elapsed = float(tmax.item())
+    bases_all, piles_all = float(tot[0].item()), float(tot[1].item())
+
+    if rank == 0:
+        k = max(1, args.steps)
+        stage_ms = {"index": ms_index / k, "chain": ms_chain / k, "align": ms_align / k,
+                    "consensus": ms_cns / k}
+        # algorithmic bytes per launch
+        alg = {
+            "index": st.T // 4 + 8 * st.T + 2 * 4 * 65537 * st.n_piles,
+            "chain": st.L // 4,
+            "align": st.L // 4 + 4 * st.C + 8 * st.D,
+            "consensus": 16 * st.A + 12 * st.T + 5 * st.O,
+        }
+        dom = max(stage_ms, key=lambda s: stage_ms[s])
+        ach = alg[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+        out = {
+            "metric": "consensus_bases_per_sec",
+            "value": round(bases_all * args.steps / elapsed, 1),
+            "unit": "bases/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/int32 (2-bit packed bases, integer DP)",
+            "data": "synthetic",
+            "config": {
+                "workload": "E. coli-like piles: ~20 kb seed x 40x coverage, e=0.13 "
+                            "(BASELINE.json configs[1]; falcon_amd/synth.py, SURVEY.md 8d)",
+                "piles_per_step_per_gpu": args.piles,
+                "flags": "--min-cov 4 --min-idt 0.70 --max-n-read 200 (K=8)",
+                "sequences_per_step_per_gpu": int(st.n_seqs),
+                "accepted_alignments_per_step_per_gpu": int(st.n_aligned),
+            },
+            "piles_per_sec": round(piles_all * args.steps / elapsed, 2),
+            "roofline": {
+                "bound": "hbm", "kernel": "k_" + dom,
+                "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5),
+                "algorithmic_bytes_per_launch": int(alg[dom]),
+                "avg_launch_ms": round(stage_ms[dom], 4),
+                "traffic": None,
+            },
+            "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},
+            "path_b_alg_bytes_per_step": int(st.b_alg()),
+            "path_frac_of_hbm_roofline": round(
+                st.b_alg() * world * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),
+            "setup_s": {"generate": round(t_gen, 2), "stage_to_hbm_incl_pcie": round(t_up, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(piles[:64])
+            except Exception as e:  # the baseline is informative; never lose the GPU line
+                out["cpu_baseline"] = {"value": None, "unit": "bases/s", "cores": 0,
+                                       "kind": "unavailable", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    batch.free()
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

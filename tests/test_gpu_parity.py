@@ -86,10 +86,10 @@ def test_piles_golden_one_batch(engine):
             assert sha_ints(eqv) == c["eqv_sha"], c["name"]
 
 
-def _synthetic(seed, **kw):
+def _synthetic(seed, max_n_read=200, **kw):
     from falcon_amd.synth import codes_to_str, make_pile, pile_to_seqs
     s, rd = make_pile(seed, **kw)
-    return [codes_to_str(x) for x in pile_to_seqs(s, rd, kw.get("max_n_read", 200))]
+    return [codes_to_str(x) for x in pile_to_seqs(s, rd, max_n_read)]
 
 
 def test_synthetic_piles_vs_oracle(engine, port):
