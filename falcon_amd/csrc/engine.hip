@@ -103,14 +103,14 @@ struct fa_batch {
     std::vector<FaSeq> seq;
     std::vector<FaPile> pile;
     std::vector<int> order;
-    std::vector<u64> ascii_off, bin_off, script_off;
-    u64 n_words = 0, ascii_bytes = 0, bin_words = 0, script_words = 0;
-    int max_read_len = 0, max_seed_len = 0, max_rows = 0;
+    std::vector<u64> ascii_off, script_off;
+    u64 n_words = 0, ascii_bytes = 0, script_words = 0;
+    int max_read_len = 0, max_seed_len = 0, max_rows = 0, max_bins = 4;
     long long sum_len = 0, sum_seed = 0;
 
     DevBuf<uint8_t> d_ascii;
-    DevBuf<u64> d_ascii_off, d_bin_off, d_script_off;
-    DevBuf<u32> d_words, d_kidx, d_kpos, d_bins, d_script;
+    DevBuf<u64> d_ascii_off, d_script_off;
+    DevBuf<u32> d_words, d_kidx, d_kpos, d_script;
     DevBuf<FaSeq> d_seq;
     DevBuf<FaPile> d_pile;
     DevBuf<int> d_order;
@@ -136,7 +136,7 @@ struct fa_batch {
         b.ascii = d_ascii.p; b.ascii_off = d_ascii_off.p; b.words = d_words.p;
         b.seq = d_seq.p; b.pile = d_pile.p; b.n_seq = n_seq; b.n_pile = n_pile;
         b.n_words = n_words; b.kidx = d_kidx.p; b.kpos = d_kpos.p; b.order = d_order.p;
-        b.bins = d_bins.p; b.bin_off = d_bin_off.p; b.range = d_range.p; b.aln = d_aln.p;
+        b.range = d_range.p; b.aln = d_aln.p;
         b.script = d_script.p; b.script_off = d_script_off.p; b.nodes = d_nodes.p;
         b.out_seq = d_out_seq.p; b.out_eqv = d_out_eqv.p; b.pile_out = d_pile_out.p;
         return b;
@@ -271,22 +271,20 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
     b->ascii_bytes = aoff + 16;
     b->out_slots = out;
     // per-sequence scratch extents
-    b->bin_off.resize(g);
     b->script_off.resize(g);
-    u64 bo = 0, so = 0;
+    u64 so = 0;
     int max_rows = 4;
     for (int i = 0; i < g; i++) {
         const FaSeq &s = b->seq[i];
         int T = b->pile[s.pile].seed_len;
-        b->bin_off[i] = bo;
         b->script_off[i] = so;
         if (s.idx == 0) continue;
-        bo += (u64)((s.len + T) / (FA_K * 6) + 4);
+        // diagonals q-t span at most len+T, binned by K*6 (kmer_lookup.c:350-355)
+        b->max_bins = std::max(b->max_bins, (s.len + T) / (FA_K * 6) + 4);
         int rb = rows_bound(s.len, T, !pair_mode);
-        so += (u64)rb;
+        so += (u64)((rb + 3) & ~3);
         max_rows = std::max(max_rows, rb);
     }
-    b->bin_words = bo;
     b->script_words = so;
     b->max_rows = max_rows;
     // longest reads first: the lanes of a k_chain wave and the tail of the
@@ -322,8 +320,6 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
     if (!pair_mode) {
         rc |= b->d_kidx.alloc((u64)n_pile * FA_IDX_STRIDE);
         rc |= b->d_kpos.alloc(kpos + 8);
-        rc |= b->d_bin_off.alloc(g);
-        rc |= b->d_bins.alloc(b->bin_words + 8);
         rc |= b->d_out_seq.alloc(b->out_slots + 8);
         rc |= b->d_out_eqv.alloc(b->out_slots + 8);
         rc |= b->d_pile_out.alloc(n_pile);
@@ -341,8 +337,6 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
     ok &= hipMemcpyAsync(b->d_pile.p, b->pile.data(), n_pile * sizeof(FaPile), hipMemcpyHostToDevice, s) == hipSuccess;
     ok &= hipMemcpyAsync(b->d_order.p, b->order.data(), g * sizeof(int), hipMemcpyHostToDevice, s) == hipSuccess;
     ok &= hipMemcpyAsync(b->d_script_off.p, b->script_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
-    if (!pair_mode)
-        ok &= hipMemcpyAsync(b->d_bin_off.p, b->bin_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
     trace_stage(s, "upload");
     if (ok) {
         fa_launch_pack(b->dev(), s);
@@ -372,9 +366,9 @@ extern "C" fa_batch *fa_batch_create(fa_ctx *ctx, int n_pile, const int *pile_n_
 extern "C" void fa_batch_free(fa_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
-    b->d_ascii.release(); b->d_ascii_off.release(); b->d_bin_off.release();
+    b->d_ascii.release(); b->d_ascii_off.release();
     b->d_script_off.release(); b->d_words.release(); b->d_kidx.release(); b->d_kpos.release();
-    b->d_bins.release(); b->d_script.release(); b->d_seq.release(); b->d_pile.release();
+    b->d_script.release(); b->d_seq.release(); b->d_pile.release();
     b->d_order.release(); b->d_range.release(); b->d_aln.release(); b->d_nodes.release();
     b->d_out_seq.release(); b->d_out_eqv.release(); b->d_pile_out.release();
     delete b;
@@ -456,7 +450,7 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     fa_launch_index(d, s);
     HIP_OK(hipEventRecord(c->ev[1], s));
     trace_stage(s, "index");
-    fa_launch_chain(d, s);
+    fa_launch_chain(d, b->max_bins, s);
     HIP_OK(hipEventRecord(c->ev[2], s));
     trace_stage(s, "chain");
     fa_launch_align(d, c->arena, b->max_read_len, b->max_seed_len, max_diff, s);

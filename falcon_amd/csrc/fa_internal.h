@@ -103,8 +103,6 @@ struct FaBatchDev {
     u32 *kidx;
     u32 *kpos;
     const int *order;      // sequence indices, longest first
-    u32 *bins;             // k_chain histogram scratch
-    const u64 *bin_off;    // [n_seq]
     FaRange *range;
     FaAln *aln;
     u32 *script;
@@ -126,7 +124,7 @@ struct FaAlignArena {
 
 void fa_launch_pack(const FaBatchDev &b, hipStream_t s);
 void fa_launch_index(const FaBatchDev &b, hipStream_t s);
-void fa_launch_chain(const FaBatchDev &b, hipStream_t s);
+void fa_launch_chain(const FaBatchDev &b, int max_bins, hipStream_t s);
 void fa_launch_align(const FaBatchDev &b, const FaAlignArena &a, int max_q_len, int max_t_len,
                      double max_diff, hipStream_t s);
 void fa_launch_align_band(const FaBatchDev &b, const FaAlignArena &a, int max_q_len,

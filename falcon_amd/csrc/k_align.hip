@@ -345,9 +345,9 @@ void fa_launch_align_band(const FaBatchDev &b, const FaAlignArena &a, int max_q_
     A.lds_t_words = (int)tw;
     A.max_diff = max_diff;
     size_t lds = fa_align_lds_bytes(max_q_len, max_t_len);
-    hipMemsetAsync(a.counter, 0, sizeof(int), s);
+    (void)hipMemsetAsync(a.counter, 0, sizeof(int), s);
     if (lds > 48 * 1024)
-        hipFuncSetAttribute((const void *)k_align, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)k_align, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
     int grid = a.n_slot < b.n_seq ? a.n_slot : b.n_seq;
     hipLaunchKernelGGL(k_align, dim3(grid), dim3(64), lds, s, A);

@@ -9,131 +9,254 @@
 //       first-fullest bin, +-5 bin filter, reset-at-negative running score;
 //   the range sanity filter of generate_consensus (src/c/falcon.c:613-619).
 //
-// Round-1 mapping: one thread per read (reads are scheduled longest-first so
-// the lanes of a wave have similar trip counts); the batch supplies >= 10^5
-// independent reads, which is what hides the L2 latency of the CSR walks.
-// Integer work, L2/HBM-latency bound; no MFMA.
+// Mapping: one wavefront per read, lane <-> probe (query offsets 0,4,8,..).
+//   pass A  bucket bounds of every probe -> diagonal extent (wave min/max)
+//   pass B  diagonal histogram in LDS (ds atomics) + per bin the order key of
+//           its first hit, so "first fullest bin in hit order" (:360-366) is a
+//           reduction over bins instead of a second walk over the hits
+//   pass C  wave reduction over the bins
+//   pass D  the reference's sequential scan (:385-411) as a wave prefix scan:
+//           all kept hits of one probe share q, so a probe is one element
+//           r -> max(c, r + a + c)  with a = 32 - (q - q_prev), c = 32*(kept-1);
+//           these maps are closed under composition, which gives every probe
+//           its entering score; the first strict maximum and the last reset
+//           before it are wave reductions.
+// Integer work on L2-resident tables (the CSR index is 262 KB per pile);
+// HBM traffic is the packed reads (L/4 bytes); no MFMA.
 #include "fa_device.h"
 
-__global__ __launch_bounds__(256) void k_chain(const u32 *__restrict__ words,
-                                               const FaSeq *__restrict__ seq,
-                                               const FaPile *__restrict__ pile,
-                                               const u32 *__restrict__ kidx,
-                                               const u32 *__restrict__ kpos,
-                                               const int *__restrict__ order,
-                                               u32 *__restrict__ bins,
-                                               const u64 *__restrict__ bin_off, int n_seq,
-                                               FaRange *__restrict__ out) {
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= n_seq) return;
-    const int g = order[slot];
-    const FaSeq sq = seq[g];
+#define CH_BIN (FA_K * 6)  // falcon.c:602-604
+#define CH_TH 5
+
+struct ChainArgs {
+    const u32 *words;
+    const FaSeq *seq;
+    const FaPile *pile;
+    const u32 *kidx;
+    const u32 *kpos;
+    const int *order;
+    int n_seq;
+    int lds_bins;
+    FaRange *out;
+};
+
+typedef long long i64;
+
+// inclusive wave scan of the maps r -> max(u, r + v), composed left to right
+__device__ __forceinline__ void scan_maps(i64 &u, i64 &v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const i64 pu = __shfl_up(u, off);
+        const i64 pv = __shfl_up(v, off);
+        if (lane >= off) {  // (pu,pv) then (u,v)
+            u = max(u, pu + v);
+            v = pv + v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
+    extern __shared__ __attribute__((aligned(16))) u32 smem[];
+    u32 *bin_cnt = smem;
+    u32 *bin_key = smem + A.lds_bins;
+    const int lane = fa_lane();
+    const int g = A.order[blockIdx.x];
+    const FaSeq sq = A.seq[g];
     FaRange r;
     r.s1 = r.e1 = r.s2 = r.e2 = 0;
     r.ok = 0;
     r.n_hit = 0;
     r.score = 0;
     if (sq.idx == 0) {  // the seed itself is the target, not a query
-        out[g] = r;
+        A.out[g] = r;
         return;
     }
-    const FaPile pm = pile[sq.pile];
-    const u32 *w = words + sq.woff;
-    const u32 *T = kidx + pm.kidx_off;
-    const u32 *P = kpos + pm.kpos_off;
-    const int n_probe_end = sq.len - FA_K;  // probes at i = 0,4,8,.. while i < len-K (:251-252)
-    const int BIN = FA_K * 6;               // falcon.c:602-604
-    const int TH = 5;
+    const FaPile pm = A.pile[sq.pile];
+    const u32 *w = A.words + sq.woff;
+    const u32 *T = A.kidx + pm.kidx_off;
+    const u32 *P = A.kpos + pm.kpos_off;
+    const int n_probe = (sq.len > FA_K) ? (sq.len - FA_K + 3) / 4 : 0;  // i = 4p < len-K
 
-    // pass 1: diagonal extent.  Buckets are ascending, so the extreme
-    // diagonals of a probe come from its first and last entry.
-    long long d_min = 0x7fffffffffffffffLL, d_max = -0x7fffffffffffffffLL - 1;
+    // ---- pass A: diagonal extent and hit count
+    int d_min = 0x7fffffff, d_max = -0x7fffffff;
     int n_hit = 0;
-    for (int i = 0; i < n_probe_end; i += FA_K / 2) {
-        const u32 km = fa_kmer8(w, i);
-        const u32 lo = T[km], hi = T[km + 1];
-        if (lo == hi) continue;
-        n_hit += (int)(hi - lo);
-        const long long dl = (long long)i - (long long)P[hi - 1];
-        const long long dh = (long long)i - (long long)P[lo];
-        if (dl < d_min) d_min = dl;
-        if (dh > d_max) d_max = dh;
+    for (int p0 = 0; p0 < n_probe; p0 += 64) {
+        const int p = p0 + lane;
+        if (p < n_probe) {
+            const int i = 4 * p;
+            const u32 km = fa_kmer8(w, i);
+            const u32 lo = T[km], hi = T[km + 1];
+            if (hi > lo) {
+                n_hit += (int)(hi - lo);
+                d_min = min(d_min, i - (int)P[hi - 1]);  // buckets are ascending
+                d_max = max(d_max, i - (int)P[lo]);
+            }
+        }
+    }
+    d_min = fa_wave_min(d_min);
+    d_max = fa_wave_max(d_max);
+    {   // wave sum
+        int s = n_hit;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        n_hit = s;
     }
     r.n_hit = n_hit;
     if (n_hit == 0) {
-        out[g] = r;
+        A.out[g] = r;
         return;
     }
-    const int n_bin = (int)((d_max - d_min) / BIN) + 1;
-    u32 *bc = bins + bin_off[g];
-    for (int b = 0; b < n_bin; b++) bc[b] = 0;
+    const int n_bin = (d_max - d_min) / CH_BIN + 1;
+    if (n_bin > A.lds_bins) {  // host sizes the LDS from the same bound
+        r.ok = -1;
+        A.out[g] = r;
+        return;
+    }
+    for (int b = lane; b < n_bin; b += 64) {
+        bin_cnt[b] = 0;
+        bin_key[b] = 0xffffffffu;
+    }
+    __syncthreads();
 
-    // pass 2: histogram of diagonals (:350-355)
-    for (int i = 0; i < n_probe_end; i += FA_K / 2) {
-        const u32 km = fa_kmer8(w, i);
-        const u32 lo = T[km], hi = T[km + 1];
-        for (u32 p = lo; p < hi; p++) {
-            const long long d = (long long)i - (long long)P[p];
-            bc[(int)((d - d_min) / BIN)]++;
-        }
-    }
-    // pass 3: fullest bin, first maximum in hit order (:360-366)
-    long long top_count = 0;
-    int top_bin = -1;
-    for (int i = 0; i < n_probe_end; i += FA_K / 2) {
-        const u32 km = fa_kmer8(w, i);
-        const u32 lo = T[km], hi = T[km + 1];
-        for (u32 p = lo; p < hi; p++) {
-            const long long d = (long long)i - (long long)P[p];
-            const int b = (int)((d - d_min) / BIN);
-            if ((long long)bc[b] > top_count) {
-                top_count = bc[b];
-                top_bin = b;
-            }
-        }
-    }
-    // pass 4: filter (:369-383) fused with the running-score scan (:385-411)
-    int kept = 0;
-    if (top_bin >= 0 && top_count > TH) {
-        long long run = 0, best = 0;
-        int prev_q = 0, start_q = 0, start_t = 0;
-        for (int i = 0; i < n_probe_end; i += FA_K / 2) {
+    // ---- pass B: histogram + first-hit order key per bin (:350-366)
+    for (int p0 = 0; p0 < n_probe; p0 += 64) {
+        const int p = p0 + lane;
+        if (p < n_probe) {
+            const int i = 4 * p;
             const u32 km = fa_kmer8(w, i);
             const u32 lo = T[km], hi = T[km + 1];
-            for (u32 p = lo; p < hi; p++) {
-                const int t = (int)P[p];
-                const long long d = (long long)i - (long long)t;
-                const int b = (int)((d - d_min) / BIN);
-                int db = b - top_bin;
-                if (db < 0) db = -db;
-                if (db > 5) continue;
-                if ((int)bc[b] <= TH) continue;
-                if (kept == 0) {
-                    r.s1 = r.e1 = i;
-                    r.s2 = r.e2 = t;
-                    start_q = i;
-                    start_t = t;
-                } else {
-                    run += 32 - (i - prev_q);
-                    if (run < 0) {
-                        run = 0;
-                        start_q = i;
-                        start_t = t;
-                    } else if (run > best) {
-                        best = run;
-                        r.s1 = start_q;
-                        r.s2 = start_t;
-                        r.e1 = i;
-                        r.e2 = t;
-                        r.score = best;
-                    }
-                }
-                prev_q = i;
-                kept++;
+            for (u32 k = lo; k < hi; k++) {
+                const int b = (i - (int)P[k] - d_min) / CH_BIN;
+                atomicAdd(&bin_cnt[b], 1u);
+                atomicMin(&bin_key[b], ((u32)p << 17) | (k - lo));
             }
         }
     }
-    if (kept <= 1) {  // :413-419
+    __syncthreads();
+
+    // ---- pass C: fullest bin, ties broken by the earliest first hit
+    u32 best_cnt = 0, best_key = 0xffffffffu;
+    int top_bin = -1;
+    for (int b = lane; b < n_bin; b += 64) {
+        const u32 c = bin_cnt[b], k = bin_key[b];
+        if (c > best_cnt || (c == best_cnt && c > 0 && k < best_key)) {
+            best_cnt = c;
+            best_key = k;
+            top_bin = b;
+        }
+    }
+    {
+        const u32 wc = (u32)fa_wave_max((int)best_cnt);
+        u32 k = (best_cnt == wc && top_bin >= 0) ? best_key : 0xffffffffu;
+        // min over lanes of an unsigned key: flip to a signed max
+        const u32 wk = ~(u32)(fa_wave_max((int)((~k) ^ 0x80000000u)) ^ 0x80000000u);
+        const u64 who = __ballot(best_cnt == wc && top_bin >= 0 && best_key == wk);
+        const int src = who ? (__ffsll((long long)who) - 1) : 0;
+        top_bin = __shfl(top_bin, src);
+        best_cnt = wc;
+        if (!who) top_bin = -1;
+    }
+
+    // ---- pass D: filter (:369-383) + running-score scan (:385-411)
+    int kept_total = 0;
+    if (top_bin >= 0 && (int)best_cnt > CH_TH) {
+        i64 carry_run = 0, best = 0;
+        int carry_prev_q = -1;             // q of the last kept group so far (-1: none yet)
+        int carry_start_q = 0, carry_start_t = 0;
+        for (int p0 = 0; p0 < n_probe; p0 += 64) {
+            const int p = p0 + lane;
+            int m = 0, t_first = 0, t_last = 0;
+            const int q = 4 * p;
+            if (p < n_probe) {
+                const u32 km = fa_kmer8(w, q);
+                const u32 lo = T[km], hi = T[km + 1];
+                for (u32 k = lo; k < hi; k++) {
+                    const int t = (int)P[k];
+                    const int b = (q - t - d_min) / CH_BIN;
+                    int db = b - top_bin;
+                    if (db < 0) db = -db;
+                    if (db > 5 || (int)bin_cnt[b] <= CH_TH) continue;
+                    if (m == 0) t_first = t;
+                    t_last = t;
+                    m++;
+                }
+            }
+            const bool has = m > 0;
+            const u64 hm = __ballot(has);
+            if (!hm) continue;
+            // q of the previous kept group
+            const u64 below = hm & ((lane == 0) ? 0ull : (~0ull >> (64 - lane)));
+            int prev_q = below ? (4 * (p0 + 63 - __clzll((long long)below))) : carry_prev_q;
+            const bool first_ever = has && prev_q < 0;
+            // map of this group: r -> max(c, r + a + c)
+            const i64 c = 32ll * (m - 1);
+            const i64 a = first_ever ? 0 : (i64)(32 - (q - prev_q));
+            i64 u = has ? c : (i64)(-(1ll << 60));
+            i64 v = has ? (a + c) : 0;
+            const i64 my_v_only = v;
+            scan_maps(u, v, lane);
+            const i64 r_out = max(u, carry_run + v);       // score after my group
+            const i64 r_in = r_out - my_v_only;            // tentative: r_in + a + c
+            // entering score of my group = leaving score of the previous kept group
+            i64 r_prev = __shfl_up(r_out, 1);
+            {   // propagate over lanes without a group
+                // (r_out of a lane without a group equals that of the last group before it)
+                if (lane == 0) r_prev = carry_run;
+            }
+            (void)r_in;
+            const bool reset = has && (first_ever || (r_prev + a < 0));
+            // best so far: first strict maximum in order (:402)
+            i64 cand = has ? r_out : (i64)(-(1ll << 60));
+            // wave max of a 64-bit value
+            i64 wmax = cand;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, (i64)__shfl_xor(wmax, off));
+            if (wmax > best) {
+                const u64 at = __ballot(has && cand == wmax);
+                const int L = __ffsll((long long)at) - 1;
+                best = wmax;
+                const u64 rs = __ballot(reset) & ((L == 63) ? ~0ull : ((1ull << (L + 1)) - 1));
+                int sq_, st_;
+                if (rs) {
+                    const int R = 63 - __clzll((long long)rs);
+                    sq_ = 4 * (p0 + R);
+                    st_ = __shfl(t_first, R);
+                } else {
+                    sq_ = carry_start_q;
+                    st_ = carry_start_t;
+                }
+                r.s1 = sq_;
+                r.s2 = st_;
+                r.e1 = 4 * (p0 + L);
+                r.e2 = __shfl(t_last, L);
+                r.score = best;
+            }
+            // carries for the next chunk
+            const int last = 63 - __clzll((long long)hm);
+            if (carry_prev_q < 0) {  // the very first kept hit initialises the range (:386-390)
+                const int F = __ffsll((long long)hm) - 1;
+                if (r.score == 0 && best == 0) {
+                    r.s1 = r.e1 = 4 * (p0 + F);
+                    r.s2 = r.e2 = __shfl(t_first, F);
+                }
+            }
+            carry_run = __shfl(r_out, last);
+            carry_prev_q = 4 * (p0 + last);
+            const u64 rsall = __ballot(reset);
+            if (rsall) {
+                const int R = 63 - __clzll((long long)rsall);
+                carry_start_q = 4 * (p0 + R);
+                carry_start_t = __shfl(t_first, R);
+            }
+            {
+                int s = m;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+                kept_total += s;
+            }
+        }
+    }
+    if (kept_total <= 1) {  // :413-419
         r.s1 = r.e1 = r.s2 = r.e2 = 0;
         r.score = 0;
     }
@@ -144,12 +267,18 @@ __global__ __launch_bounds__(256) void k_chain(const u32 *__restrict__ words,
     if (diff < 0) diff = -diff;
     const int tol = (int)(0.5 * 0.10 * (double)(dq + dt));
     r.ok = !(dq < 100 || dt < 100 || diff > tol);
-    out[g] = r;
+    A.out[g] = r;
 }
 
-void fa_launch_chain(const FaBatchDev &b, hipStream_t s) {
+void fa_launch_chain(const FaBatchDev &b, int max_bins, hipStream_t s) {
     if (b.n_seq == 0) return;
-    unsigned grid = (unsigned)((b.n_seq + 255) / 256);
-    hipLaunchKernelGGL(k_chain, dim3(grid), dim3(256), 0, s, b.words, b.seq, b.pile, b.kidx,
-                       b.kpos, b.order, b.bins, b.bin_off, b.n_seq, b.range);
+    ChainArgs A;
+    A.words = b.words; A.seq = b.seq; A.pile = b.pile; A.kidx = b.kidx; A.kpos = b.kpos;
+    A.order = b.order; A.n_seq = b.n_seq; A.out = b.range;
+    A.lds_bins = (max_bins + 3) & ~3;
+    size_t lds = (size_t)A.lds_bins * 2 * sizeof(u32);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    hipLaunchKernelGGL(k_chain, dim3(b.n_seq), dim3(64), lds, s, A);
 }
