@@ -102,7 +102,7 @@ struct fa_batch {
     int band = FA_BAND;
     std::vector<FaSeq> seq;
     std::vector<FaPile> pile;
-    std::vector<int> order;
+    std::vector<int> order, cns_list;
     std::vector<u64> ascii_off, script_off;
     u64 n_words = 0, ascii_bytes = 0, script_words = 0;
     int max_read_len = 0, max_seed_len = 0, max_rows = 0, max_bins = 4;
@@ -113,7 +113,7 @@ struct fa_batch {
     DevBuf<u32> d_words, d_kidx, d_kpos, d_script;
     DevBuf<FaSeq> d_seq;
     DevBuf<FaPile> d_pile;
-    DevBuf<int> d_order;
+    DevBuf<int> d_order, d_cns_list;
     DevBuf<FaRange> d_range;
     DevBuf<FaAln> d_aln;
     DevBuf<FaNode> d_nodes;
@@ -369,7 +369,7 @@ extern "C" void fa_batch_free(fa_batch *b) {
     b->d_ascii.release(); b->d_ascii_off.release();
     b->d_script_off.release(); b->d_words.release(); b->d_kidx.release(); b->d_kpos.release();
     b->d_script.release(); b->d_seq.release(); b->d_pile.release();
-    b->d_order.release(); b->d_range.release(); b->d_aln.release(); b->d_nodes.release();
+    b->d_order.release(); b->d_cns_list.release(); b->d_range.release(); b->d_aln.release(); b->d_nodes.release();
     b->d_out_seq.release(); b->d_out_eqv.release(); b->d_pile_out.release();
     delete b;
 }
@@ -461,9 +461,12 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     if (int rc = fetch_aln(b)) return rc;
     u64 node_off = 0;
     long long sC = 0, sD = 0, sA = 0, nal = 0;
+    // piles are swept by kernels specialised for 64/128/256/512 accepted alignments
+    std::vector<int> cls[4];
     for (int p = 0; p < b->n_pile; p++) {
         FaPile &pm = b->pile[p];
         u64 levels = (u64)pm.seed_len + 2;
+        int n_acc = 0;
         for (int j = 1; j < pm.n_seq; j++) {
             const FaAln &al = b->h_aln[pm.first + j];
             sC += al.cells;
@@ -471,13 +474,27 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
                 levels += (u64)al.n_ins;
                 sD += al.dist;
                 sA += al.size;
-                nal++;
+                n_acc++;
             }
         }
+        nal += n_acc;
         pm.node_off = node_off;
         pm.node_cap = levels * 5;
         node_off += pm.node_cap;
+        cls[n_acc <= 64 ? 0 : (n_acc <= 128 ? 1 : (n_acc <= 256 ? 2 : 3))].push_back(p);
     }
+    b->cns_list.clear();
+    int n_list[4];
+    const int *d_list[4];
+    if (b->d_cns_list.n < (size_t)b->n_pile && b->d_cns_list.alloc((size_t)b->n_pile)) return -1;
+    for (int k = 0, at = 0; k < 4; k++) {
+        n_list[k] = (int)cls[k].size();
+        d_list[k] = b->d_cns_list.p + at;
+        b->cns_list.insert(b->cns_list.end(), cls[k].begin(), cls[k].end());
+        at += n_list[k];
+    }
+    HIP_OK(hipMemcpyAsync(b->d_cns_list.p, b->cns_list.data(), (size_t)b->n_pile * sizeof(int),
+                          hipMemcpyHostToDevice, s));
     if (b->d_nodes.n < node_off + 8) {
         if (b->d_nodes.alloc(node_off + 8)) return -1;
     }
@@ -485,7 +502,7 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
                           hipMemcpyHostToDevice, s));
     d = b->dev();
     HIP_OK(hipEventRecord(c->ev[4], s));
-    fa_launch_consensus(d, min_cov, s);
+    fa_launch_consensus(d, min_cov, d_list, n_list, s);
     HIP_OK(hipEventRecord(c->ev[5], s));
     trace_stage(s, "consensus");
     HIP_OK(hipGetLastError());

@@ -129,6 +129,7 @@ void fa_launch_align(const FaBatchDev &b, const FaAlignArena &a, int max_q_len, 
                      double max_diff, hipStream_t s);
 void fa_launch_align_band(const FaBatchDev &b, const FaAlignArena &a, int max_q_len,
                           int max_t_len, double max_diff, int band, hipStream_t s);
-void fa_launch_consensus(const FaBatchDev &b, unsigned min_cov, hipStream_t s);
+void fa_launch_consensus(const FaBatchDev &b, unsigned min_cov, const int *const d_list[4],
+                         const int n_list[4], hipStream_t s);
 size_t fa_align_lds_bytes(int max_q_len, int max_t_len);
 int fa_align_blocks_per_cu(size_t lds_bytes);

@@ -7,9 +7,12 @@
 // MSA workspace (:338-341):
 //
 //   * lane a of the wave owns accepted alignment a of the pile (accepted
-//     alignments in read order; 64 per register "chunk", up to 8 chunks) and
-//     walks its edit script ((snake << 1) | from_above per row, produced by
-//     k_align) column by column;
+//     alignments in read order; 64 per register "chunk", NCH chunks, the kernel
+//     is instantiated for NCH = 1,2,4,8 and the host sorts piles into classes)
+//     and walks its edit script ((snake << 1) | from_above per row, produced by
+//     k_align) column by column.  The script and the read's packed bases are
+//     per-lane streams: both are double-buffered in registers (16-byte script
+//     quads, 16-base words) so no load sits on the critical path of a column;
 //   * the sweep visits target positions t in ascending order and, inside one t,
 //     the insertion levels delta = 0,1,2,..  -- the order of the reference's
 //     scoring loops (:405-407).  At one (t, delta) level every participating
@@ -25,8 +28,10 @@
 //     which is all the "graph" the forward pass needs;
 //   * the global best node (first strict maximum in (t,delta,base) order,
 //     :464-469) and the link index of its best link (Q2) are tracked in scalars;
-//   * the back-trace (:494-528) walks the 8-byte node records and writes the
-//     consensus right-aligned, so no reversal pass (:531-539) is needed.
+//   * the back-trace (:494-528) walks the 8-byte node records through a
+//     64-level window staged in LDS (back pointers reach only a few levels
+//     back) and writes the consensus right-aligned, 64 characters per store,
+//     so no reversal pass (:531-539) is needed.
 //
 // Per-column reduction over aligned bases; integer only, no MFMA.  The forward
 // sweep is a dependent chain over t (like the reference), so throughput comes
@@ -45,12 +50,21 @@ struct CnsArgs {
     char *out_seq;
     int *out_eqv;
     FaPileOut *pile_out;
+    const int *pile_list;  // piles of this NCH class
+    int n_list;
     unsigned min_cov;
 };
 
+#define BT_WIN 64  // levels per back-trace window
+
+// entry j of a lane's script through the two resident quads
+__device__ __forceinline__ u32 quad_get(const uint4 &q, int k) {
+    return k == 0 ? q.x : (k == 1 ? q.y : (k == 2 ? q.z : q.w));
+}
+
 template <int NCH>
 __device__ void consensus_pile(const CnsArgs &A, const FaPile pm, int p, int n_acc,
-                               const int *acc, int lane) {
+                               const int *acc, u32 *win, int lane) {
     const int T = pm.seed_len;
     const u32 *seedw = A.words + A.seq[pm.first].woff;
     FaNode *nodes = A.nodes + pm.node_off;
@@ -59,8 +73,14 @@ __device__ void consensus_pile(const CnsArgs &A, const FaPile pm, int p, int n_a
     bool valid[NCH], started[NCH], finished[NCH];
     int s2[NCH], dist[NCH], sp[NCH], mrem[NCH], qpos[NCH], pnode[NCH], pscore[NCH];
     u32 nxt[NCH];
-    const u32 *scr[NCH];
+    // script stream: quads [qb, qb+4) and [qb+4, qb+8)
+    const uint4 *scr4[NCH];
+    uint4 q0[NCH], q1[NCH];
+    int qb[NCH];
+    // read stream: words wb and wb+1
     const u32 *rw[NCH];
+    u32 r0[NCH], r1[NCH];
+    int wb[NCH];
 
     int t0 = 0x7fffffff;
 #pragma unroll
@@ -70,23 +90,62 @@ __device__ void consensus_pile(const CnsArgs &A, const FaPile pm, int p, int n_a
         started[c] = false;
         finished[c] = !valid[c];
         s2[c] = 0x7fffffff; dist[c] = 0; sp[c] = 0; mrem[c] = 0; qpos[c] = 0;
-        pnode[c] = -1; pscore[c] = 0; nxt[c] = 0; scr[c] = A.script; rw[c] = A.words;
+        pnode[c] = -1; pscore[c] = 0; nxt[c] = 0;
+        scr4[c] = reinterpret_cast<const uint4 *>(A.script);
+        rw[c] = A.words;
+        q0[c] = make_uint4(0, 0, 0, 0); q1[c] = q0[c]; qb[c] = 0;
+        r0[c] = r1[c] = 0; wb[c] = 0;
         if (valid[c]) {
             const int g = acc[a];
             const FaRange rg = A.range[g];
             const FaAln al = A.aln[g];
-            scr[c] = A.script + A.script_off[g];
+            scr4[c] = reinterpret_cast<const uint4 *>(A.script + A.script_off[g]);
             rw[c] = A.words + A.seq[g].woff;
             dist[c] = al.dist;
-            mrem[c] = (int)(scr[c][0] >> 1);
-            nxt[c] = (al.dist > 0) ? scr[c][1] : 0u;
+            q0[c] = scr4[c][0];
+            if (al.dist >= 4) q1[c] = scr4[c][1];
+            mrem[c] = (int)(q0[c].x >> 1);
+            nxt[c] = (al.dist > 0) ? q0[c].y : 0u;
             qpos[c] = rg.s1;   // falcon.c:119 (i = s1-1 before the first column)
             s2[c] = rg.s2;     // falcon.c:120
+            wb[c] = rg.s1 >> 4;
+            r0[c] = rw[c][wb[c]];
+            r1[c] = rw[c][wb[c] + 1];
             if (mrem[c] == 0 && al.dist == 0) finished[c] = true;
         }
         t0 = min(t0, s2[c]);
     }
     t0 = fa_wave_min(t0);
+
+    // consume one script row for chunk c (the lane is at row sp, moves to sp+1)
+#define ADVANCE_ROW(c)                                                            \
+    do {                                                                          \
+        sp[c]++;                                                                  \
+        mrem[c] = (int)(nxt[c] >> 1);                                             \
+        const int j_ = sp[c] + 1;                                                 \
+        if (j_ <= dist[c]) {                                                      \
+            if (j_ >= qb[c] + 4) { /* slide the window; prefetch the next quad */ \
+                q0[c] = q1[c];                                                    \
+                qb[c] += 4;                                                       \
+                if (qb[c] + 4 <= dist[c]) q1[c] = scr4[c][(qb[c] >> 2) + 1];      \
+            }                                                                     \
+            nxt[c] = quad_get(q0[c], j_ - qb[c]);                                 \
+        } else {                                                                  \
+            nxt[c] = 0u;                                                          \
+        }                                                                         \
+        finished[c] = (mrem[c] == 0 && sp[c] == dist[c]);                         \
+    } while (0)
+
+    // consume one query base for chunk c
+#define ADVANCE_QUERY(c)                                                          \
+    do {                                                                          \
+        qpos[c]++;                                                                \
+        if ((qpos[c] >> 4) != wb[c]) {                                            \
+            wb[c]++;                                                              \
+            r0[c] = r1[c];                                                        \
+            r1[c] = rw[c][wb[c] + 1];                                             \
+        }                                                                         \
+    } while (0)
 
     int lvl = 0;
     int g_h = -2, g_node = -1, g_ck = 0;
@@ -106,7 +165,7 @@ __device__ void consensus_pile(const CnsArgs &A, const FaPile pm, int p, int n_a
     int seed_word_idx = -1;
     while (t < T && !overflow) {
         bool part[NCH];
-        int base[NCH];
+        int key[NCH];  // (previous node + 1) * 8 + base: one link per distinct key
         int cov = 0;
         bool any_open = false;
 #pragma unroll
@@ -137,19 +196,19 @@ __device__ void consensus_pile(const CnsArgs &A, const FaPile pm, int p, int n_a
         // ---- level delta = 0: every participating alignment consumes target base t
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-            base[c] = 0;
+            key[c] = 0;
             if (part[c]) {
+                int base;
                 if (mrem[c] > 0) {  // match column
-                    base[c] = sbase;
+                    base = sbase;
                     mrem[c]--;
-                    qpos[c]++;
+                    ADVANCE_QUERY(c);
+                    finished[c] = (mrem[c] == 0 && sp[c] == dist[c]);
                 } else {            // target-only edit: query shows '-'
-                    base[c] = 4;
-                    sp[c]++;
-                    mrem[c] = (int)(nxt[c] >> 1);
-                    nxt[c] = (sp[c] < dist[c]) ? scr[c][sp[c] + 1] : 0u;
+                    base = 4;
+                    ADVANCE_ROW(c);
                 }
-                finished[c] = (mrem[c] == 0 && sp[c] == dist[c]);
+                key[c] = ((pnode[c] + 1) << 3) | base;
             }
         }
         int delta = 0;
@@ -169,23 +228,23 @@ __device__ void consensus_pile(const CnsArgs &A, const FaPile pm, int p, int n_a
                 for (int c = NCH - 1; c >= 0; c--)
                     if (rem[c]) c0 = c;
                 if (c0 < 0) break;
-                int kb = 0, kp = 0, ks = 0;
+                int kk = 0, ks = 0;
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
                     if (c == c0) {
                         const int l0 = __ffsll((long long)rem[c]) - 1;
-                        kb = __builtin_amdgcn_readlane(base[c], l0);
-                        kp = __builtin_amdgcn_readlane(pnode[c], l0);
+                        kk = __builtin_amdgcn_readlane(key[c], l0);
                         ks = __builtin_amdgcn_readlane(pscore[c], l0);
                     }
                 }
                 int cnt = 0;
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
-                    const u64 m = __ballot(part[c] && base[c] == kb && pnode[c] == kp);
+                    const u64 m = __ballot(part[c] && key[c] == kk);
                     cnt += __popcll(m);
                     rem[c] &= ~m;
                 }
+                const int kb = kk & 7, kp = (kk >> 3) - 1;
                 const int h = ((kp < 0) ? 0 : ks) + 2 * cnt - cov;  // falcon.c:440-445
                 if (lane == kb) {
                     if (h > nb_h) {  // strict, first maximum in link order (:447)
@@ -197,12 +256,22 @@ __device__ void consensus_pile(const CnsArgs &A, const FaPile pm, int p, int n_a
                 }
             }
             const int node0 = lvl * 5;
+            int hs[5];
+#pragma unroll
+            for (int b = 0; b < 5; b++) {
+                hs[b] = __builtin_amdgcn_readlane(nb_h, b);
+                if (hs[b] > g_h) {  // :464-469
+                    g_h = hs[b];
+                    g_node = node0 + b;
+                    g_ck = __builtin_amdgcn_readlane(nb_ck, b);
+                }
+            }
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
-                const int sc = __shfl(nb_h, base[c]);
                 if (part[c]) {
-                    pscore[c] = sc;
-                    pnode[c] = node0 + base[c];
+                    const int b = key[c] & 7;
+                    pscore[c] = b == 0 ? hs[0] : (b == 1 ? hs[1] : (b == 2 ? hs[2] : (b == 3 ? hs[3] : hs[4])));
+                    pnode[c] = node0 + b;
                 }
             }
             if (lane < 5) {
@@ -210,15 +279,6 @@ __device__ void consensus_pile(const CnsArgs &A, const FaPile pm, int p, int n_a
                 nd.score_h = nb_h;
                 nd.link = ((nb_prev + 1) << 1) | upper;
                 nodes[node0 + lane] = nd;
-            }
-#pragma unroll
-            for (int b = 0; b < 5; b++) {
-                const int hb = __builtin_amdgcn_readlane(nb_h, b);
-                if (hb > g_h) {  // :464-469
-                    g_h = hb;
-                    g_node = node0 + b;
-                    g_ck = __builtin_amdgcn_readlane(nb_ck, b);
-                }
             }
             lvl++;
 
@@ -241,17 +301,17 @@ __device__ void consensus_pile(const CnsArgs &A, const FaPile pm, int p, int n_a
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
                 if (part[c]) {
-                    base[c] = (int)fa_base_at(rw[c], qpos[c]);
-                    qpos[c]++;
-                    sp[c]++;
-                    mrem[c] = (int)(nxt[c] >> 1);
-                    nxt[c] = (sp[c] < dist[c]) ? scr[c][sp[c] + 1] : 0u;
-                    finished[c] = (mrem[c] == 0 && sp[c] == dist[c]);
+                    const int base = (int)((r0[c] >> ((qpos[c] & 15) * 2)) & 3u);
+                    ADVANCE_QUERY(c);
+                    ADVANCE_ROW(c);
+                    key[c] = ((pnode[c] + 1) << 3) | base;
                 }
             }
         }
         t++;
     }
+#undef ADVANCE_ROW
+#undef ADVANCE_QUERY
 
     // ---- back-trace (falcon.c:494-528), uniform across the wave -------------
     __threadfence_block();
@@ -265,7 +325,30 @@ __device__ void consensus_pile(const CnsArgs &A, const FaPile pm, int p, int n_a
         unsigned index = 0;
         int ck = g_ck;
         char bb = '$';
-        FaNode rec = nodes[g_node];
+        int win_lo = -1, win_hi = -2;  // node-id range [win_lo, win_hi] resident in LDS
+        auto fetch = [&](int node) -> FaNode {
+            if (node < win_lo || node > win_hi) {
+                const int lvl_hi = node / 5;
+                const int lvl_lo = max(0, lvl_hi - (BT_WIN - 1));
+                win_lo = lvl_lo * 5;
+                win_hi = lvl_hi * 5 + 4;
+                const int n_rec = win_hi - win_lo + 1;
+                __syncthreads();
+                const uint2 *src = reinterpret_cast<const uint2 *>(nodes + win_lo);
+                for (int i = lane; i < n_rec; i += 64) {
+                    const uint2 v = src[i];
+                    win[2 * i] = v.x;
+                    win[2 * i + 1] = v.y;
+                }
+                __syncthreads();
+            }
+            FaNode r;
+            r.score_h = (int)win[2 * (node - win_lo)];
+            r.link = (int)win[2 * (node - win_lo) + 1];
+            return r;
+        };
+        FaNode rec = fetch(g_node);
+        int out_c = 0, out_e = 0;  // lane (index & 63) holds character `index`
         for (;;) {
             const int up = rec.link & 1;
             switch (ck) {
@@ -280,63 +363,78 @@ __device__ void consensus_pile(const CnsArgs &A, const FaPile pm, int p, int n_a
             const int prev = (rec.link >> 1) - 1;
             if (prev == -1 || index >= lim) break;  // :517-519 (Q1)
             ck = prev % 5;
-            rec = nodes[prev];
+            rec = fetch(prev);
             if (bb != '-') {
-                const unsigned pos = lim - 1u - index;
-                if (lane == 0) {
-                    oseq[pos] = bb;
-                    oeqv[pos] = score0 / 2 - rec.score_h / 2;  // (int) truncations (Q6)
+                if (lane == (int)(index & 63u)) {
+                    out_c = bb;
+                    out_e = score0 / 2 - rec.score_h / 2;  // (int) truncations (Q6)
                 }
                 index++;
+                if ((index & 63u) == 0u) {  // 64 characters ready: one coalesced store
+                    const unsigned pos = lim - 1u - (index - 64u + (unsigned)lane);
+                    oseq[pos] = (char)out_c;
+                    oeqv[pos] = out_e;
+                }
             }
+        }
+        if ((index & 63u) != 0u && lane < (int)(index & 63u)) {
+            const unsigned pos = lim - 1u - ((index & ~63u) + (unsigned)lane);
+            oseq[pos] = (char)out_c;
+            oeqv[pos] = out_e;
         }
         po.len = (int)index;
         po.start = (int)(lim - index);
     }
-    if (lane == 0) A.pile_out[p] = po;
+    A.pile_out[p] = po;  // every lane stores the same record
 }
 
-__global__ __launch_bounds__(64) void k_consensus(CnsArgs A, int n_pile) {
-    __shared__ int acc[FA_CNS_MAX_ALN];
-    const int p = blockIdx.x;
-    if (p >= n_pile) return;
+// second launch-bound = waves per SIMD the register allocator must allow: the
+// 1-chunk sweep fits 6, wider ones take what their state needs
+template <int NCH>
+__global__ __launch_bounds__(64, (NCH == 1 ? 6 : 1)) void k_consensus(CnsArgs A) {
+    __shared__ int acc[NCH * 64];
+    __shared__ u32 win[2 * 5 * BT_WIN];
     const int lane = fa_lane();
+    const int p = __builtin_amdgcn_readfirstlane(A.pile_list[blockIdx.x]);
     const FaPile pm = A.pile[p];
     // accepted alignments in read order (falcon.c:597,:630-636)
     int n_acc = 0;
-    bool too_many = false;
     for (int j0 = 1; j0 < pm.n_seq; j0 += 64) {
         const int j = j0 + lane;
         const bool ok = (j < pm.n_seq) && A.aln[pm.first + j].accept;
         const u64 m = __ballot(ok);
         const int rank = __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-        if (ok && n_acc + rank < FA_CNS_MAX_ALN) acc[n_acc + rank] = pm.first + j;
+        if (ok && n_acc + rank < NCH * 64) acc[n_acc + rank] = pm.first + j;
         n_acc += __popcll(m);
-        if (n_acc > FA_CNS_MAX_ALN) too_many = true;
     }
     __syncthreads();
-    if (too_many || n_acc == 0) {
-        if (lane == 0) {
-            FaPileOut po;
-            po.len = 0; po.start = 2 * pm.seed_len; po.n_aligned = n_acc;
-            po.err = too_many ? 2 : 0;
-            po.g_best_h = -2;
-            A.pile_out[p] = po;
-        }
+    if (n_acc == 0 || n_acc > NCH * 64) {
+        FaPileOut po;
+        po.len = 0; po.start = 2 * pm.seed_len; po.n_aligned = n_acc;
+        po.err = (n_acc > NCH * 64) ? 2 : 0;
+        po.g_best_h = -2;
+        A.pile_out[p] = po;
         return;
     }
-    if (n_acc <= 64) consensus_pile<1>(A, pm, p, n_acc, acc, lane);
-    else if (n_acc <= 128) consensus_pile<2>(A, pm, p, n_acc, acc, lane);
-    else if (n_acc <= 256) consensus_pile<4>(A, pm, p, n_acc, acc, lane);
-    else consensus_pile<8>(A, pm, p, n_acc, acc, lane);
+    consensus_pile<NCH>(A, pm, p, n_acc, acc, win, lane);
 }
 
-void fa_launch_consensus(const FaBatchDev &b, unsigned min_cov, hipStream_t s) {
-    if (b.n_pile == 0) return;
+void fa_launch_consensus(const FaBatchDev &b, unsigned min_cov, const int *const d_list[4],
+                         const int n_list[4], hipStream_t s) {
     CnsArgs A;
     A.words = b.words; A.seq = b.seq; A.pile = b.pile; A.range = b.range; A.aln = b.aln;
     A.script = b.script; A.script_off = b.script_off; A.nodes = b.nodes;
     A.out_seq = b.out_seq; A.out_eqv = b.out_eqv; A.pile_out = b.pile_out;
     A.min_cov = min_cov;
-    hipLaunchKernelGGL(k_consensus, dim3(b.n_pile), dim3(64), 0, s, A, b.n_pile);
+    for (int k = 0; k < 4; k++) {
+        if (n_list[k] == 0) continue;
+        A.pile_list = d_list[k];
+        A.n_list = n_list[k];
+        switch (k) {
+        case 0: hipLaunchKernelGGL(k_consensus<1>, dim3(n_list[k]), dim3(64), 0, s, A); break;
+        case 1: hipLaunchKernelGGL(k_consensus<2>, dim3(n_list[k]), dim3(64), 0, s, A); break;
+        case 2: hipLaunchKernelGGL(k_consensus<4>, dim3(n_list[k]), dim3(64), 0, s, A); break;
+        default: hipLaunchKernelGGL(k_consensus<8>, dim3(n_list[k]), dim3(64), 0, s, A); break;
+        }
+    }
 }
