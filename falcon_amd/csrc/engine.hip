@@ -69,7 +69,7 @@ struct fa_ctx {
     hipEvent_t ev[8] = {};
     // alignment work-slot arena (grow only)
     FaAlignArena arena = {};
-    size_t arena_cells_bytes = 0, arena_rows_bytes = 0;
+    size_t arena_cells_bytes = 0, arena_rows_bytes = 0;  // rows and rowx have equal size
 };
 
 template <class T>
@@ -171,6 +171,8 @@ extern "C" fa_ctx *fa_create(int device) {
     HIP_OK_P(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &e : c->ev) HIP_OK_P(hipEventCreate(&e));
     HIP_OK_P(hipMalloc((void **)&c->arena.counter, sizeof(int)));
+    HIP_OK_P(hipMalloc((void **)&c->arena.prof, 8 * sizeof(u64)));
+    HIP_OK_P(hipMemset(c->arena.prof, 0, 8 * sizeof(u64)));
     return c;
 }
 
@@ -179,6 +181,7 @@ extern "C" void fa_destroy(fa_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->arena.cells) (void)hipFree(c->arena.cells);
     if (c->arena.rows) (void)hipFree(c->arena.rows);
+    if (c->arena.rowx) (void)hipFree(c->arena.rowx);
     if (c->arena.counter) (void)hipFree(c->arena.counter);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -377,7 +380,7 @@ extern "C" void fa_batch_free(fa_batch *b) {
 // Size the alignment arena: one slot per resident wavefront.
 static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes) {
     int per_cu = fa_align_blocks_per_cu(lds_bytes);
-    per_cu = std::max(1, std::min(per_cu, 16));
+    per_cu = std::max(1, std::min(per_cu, 32));
     int n_slot = c->n_cu * per_cu;
     n_slot = std::max(1, std::min(n_slot, b->n_seq));
     if (const char *e = getenv("FALCON_AMD_SLOTS")) n_slot = std::max(1, std::min(n_slot, atoi(e)));
@@ -386,8 +389,8 @@ static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes) {
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     // never take more than half of what is free for the transient trace arena
-    u64 per_slot = cells * 4 + rows * sizeof(FaRowRec);
-    u64 have = (u64)c->arena_cells_bytes + (u64)c->arena_rows_bytes;
+    u64 per_slot = cells * 4 + rows * (sizeof(FaRowRec) + sizeof(FaRowExt));
+    u64 have = (u64)c->arena_cells_bytes + 2 * (u64)c->arena_rows_bytes;
     u64 budget = (u64)free_b / 2 + have;
     if ((u64)n_slot * per_slot > budget) n_slot = (int)std::max<u64>(1, budget / per_slot);
     size_t need_cells = (size_t)n_slot * cells * 4, need_rows = (size_t)n_slot * rows * sizeof(FaRowRec);
@@ -400,9 +403,12 @@ static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes) {
     }
     if (need_rows > c->arena_rows_bytes) {
         if (c->arena.rows) (void)hipFree(c->arena.rows);
+        if (c->arena.rowx) (void)hipFree(c->arena.rowx);
         c->arena.rows = nullptr;
+        c->arena.rowx = nullptr;
         c->arena_rows_bytes = 0;
         HIP_OK(hipMalloc((void **)&c->arena.rows, need_rows));
+        HIP_OK(hipMalloc((void **)&c->arena.rowx, need_rows));
         c->arena_rows_bytes = need_rows;
     }
     c->arena.cells_per_slot = cells;
@@ -456,6 +462,15 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     fa_launch_align(d, c->arena, b->max_read_len, b->max_seed_len, max_diff, s);
     HIP_OK(hipEventRecord(c->ev[3], s));
     trace_stage(s, "align");
+    if (getenv("FALCON_AMD_PROF")) {  // only meaningful in -DFA_ALIGN_PROF builds
+        u64 pf[8];
+        HIP_OK(hipStreamSynchronize(s));
+        HIP_OK(hipMemcpy(pf, c->arena.prof, sizeof(pf), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemset(c->arena.prof, 0, sizeof(pf)));
+        fprintf(stderr, "[falcon_amd] k_align section ticks:");
+        for (int i = 0; i < 8; i++) fprintf(stderr, " %llu", (unsigned long long)pf[i]);
+        fprintf(stderr, "\n");
+    }
     HIP_OK(hipGetLastError());
     // alignment summaries bound the MSA node pools (levels <= seed + insertions)
     if (int rc = fetch_aln(b)) return rc;

@@ -38,3 +38,18 @@ __device__ __forceinline__ int fa_wave_max(int v) {
 }
 
 __device__ __forceinline__ int fa_wave_min(int v) { return -fa_wave_max(-v); }
+
+// Force a wave-uniform value into SGPRs.  Arguments of out-of-line device
+// functions arrive in VGPRs and the compiler must treat them as divergent;
+// readfirstlane makes the uniformity explicit so branches on them stay scalar.
+__device__ __forceinline__ int fa_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ u32 fa_uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 fa_uni(u64 v) {
+    const u32 lo = fa_uni((u32)v), hi = fa_uni((u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ double fa_uni(double v) {
+    return __longlong_as_double((long long)fa_uni((u64)__double_as_longlong(v)));
+}
+template <class T>
+__device__ __forceinline__ T *fa_uni(T *p) { return (T *)fa_uni((u64)p); }

@@ -69,10 +69,14 @@ struct FaAln {
     long long cells;// (d,k) cells evaluated
 };
 
-struct FaRowRec {   // one per edit row d of an alignment in flight (32 B)
+struct FaRowRec {   // one per edit row d of an alignment in flight (16 B)
     u32 off;        // first cell of the row in the slot's cell arena
     int min_k;
-    u64 dir[FA_ALIGN_MAXCH];  // from_above bit per cell
+    u32 dlo, dhi;   // from_above bit of cells 0..63
+};
+
+struct FaRowExt {   // rows wider than 64 cells only: from_above bits of cells 64..191
+    u64 d1, d2;
 };
 
 struct FaNode {     // 8 B
@@ -116,10 +120,12 @@ struct FaBatchDev {
 struct FaAlignArena {
     u32 *cells;        // n_slot * cells_per_slot
     FaRowRec *rows;    // n_slot * rows_per_slot
+    FaRowExt *rowx;    // n_slot * rows_per_slot
     u64 cells_per_slot;
     u64 rows_per_slot;
     int n_slot;
     int *counter;      // work-queue head
+    u64 *prof;         // 8 debug counters (FA_ALIGN_PROF builds)
 };
 
 void fa_launch_pack(const FaBatchDev &b, hipStream_t s);

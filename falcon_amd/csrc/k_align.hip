@@ -30,8 +30,21 @@
 //
 // Integer / LDS / HBM-write bound (4 B per DP cell); no MFMA.
 #include "fa_device.h"
+#include <cstdlib>
+#include <type_traits>
 
 #define RING 256  // V entries per parity; live band <= 191 diagonals
+
+// FA_ALIGN_PROF: per-section s_memtime accounting of the row loop (debug builds only)
+#ifdef FA_ALIGN_PROF
+#define PROF_DECL u64 pf_t = __builtin_amdgcn_s_memtime(), pf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF(i) do { const u64 n_ = __builtin_amdgcn_s_memtime(); pf_acc[i] += n_ - pf_t; pf_t = n_; } while (0)
+#define PROF_FLUSH(p) do { if (lane == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd((unsigned long long *)(p) + i_, (unsigned long long)pf_acc[i_]); } while (0)
+#else
+#define PROF_DECL
+#define PROF(i) do { } while (0)
+#define PROF_FLUSH(p) do { } while (0)
+#endif
 
 #ifdef FA_TRACE_KERNEL
 #define KTRACE(...) do { if (lane == 0) printf(__VA_ARGS__); } while (0)
@@ -49,6 +62,7 @@ struct AlignArgs {
     int *counter;
     u32 *cells;
     FaRowRec *rows;
+    FaRowExt *rowx;
     u64 cells_per_slot;
     u64 rows_per_slot;
     u32 *script;
@@ -58,125 +72,317 @@ struct AlignArgs {
     int lds_q_words;
     int lds_t_words;
     double max_diff;
+    u64 *prof;  // FA_ALIGN_PROF builds: 8 section counters
 };
 
+// Snake (DW_banded.c:203-206): extend (x,y) while bases match, 16 bases per
+// step: two packed words per sequence funnel-shifted (v_alignbit) into one
+// 16-base window, xor, find-first-set.  ffbl(0) = -1 turns into a huge count
+// that the min() against the remaining lengths clamps.
+template <class QP, class TP>
+__device__ __forceinline__ u32 snake_step(QP qL, TP tL, int qa, int ta, u32 lim) {
+    const u32 qw = __builtin_amdgcn_alignbit(qL[(qa >> 4) + 1], qL[qa >> 4], (u32)(qa & 15) * 2u);
+    const u32 tw = __builtin_amdgcn_alignbit(tL[(ta >> 4) + 1], tL[ta >> 4], (u32)(ta & 15) * 2u);
+    return min(((u32)(__ffs((int)(qw ^ tw)) - 1)) >> 1, lim);
+}
+
+template <class QP, class TP>
+__device__ __forceinline__ void snake16(QP qL, TP tL, int qb, int tb, int q_len, int t_len,
+                                        bool act, int &x, int &y) {
+    bool go = act && x < q_len && y < t_len;
+    {   // first step: every lane, predicated by selects (idle lanes probe offset 0)
+        const int xs = go ? x : 0, ys = go ? y : 0;
+        const u32 lim = min(16u, (u32)min(q_len - xs, t_len - ys));
+        u32 m = snake_step(qL, tL, qb + xs, tb + ys, lim);
+        const bool full = (m == lim);
+        m = go ? m : 0u;
+        x += (int)m;
+        y += (int)m;
+        go = go && full && x < q_len && y < t_len;
+    }
+    while (__ballot(go)) {  // only lanes inside a run of >= 16 matches get here
+        if (go) {
+            const u32 lim = min(16u, (u32)min(q_len - x, t_len - y));
+            const u32 m = snake_step(qL, tL, qb + x, tb + y, lim);
+            x += (int)m;
+            y += (int)m;
+            go = (m == lim) && x < q_len && y < t_len;
+        }
+    }
+}
+
 // One alignment.  qL/tL: LDS windows (word aligned), qb/tb: base offset of
-// window position 0 inside the first staged word.
-__device__ void align_one(const AlignArgs &A, int g, const u32 *qL, int qb, int q_len,
-                          const u32 *tL, int tb, int t_len, int *Vring, u32 *cells, FaRowRec *rows,
-                          int lane) {
+// window position 0 inside the first staged word.  Vring: 2 x RING ints.
+// (kept out of line: inlined into the persistent work loop, hipcc 7.2 fuses the
+// row loop with the work loop into one state machine and the per-row scalar
+// overhead triples)
+// LDS is addressed through the kernel's dynamic __shared__ array plus word
+// offsets, never through generic pointers (those would compile to flat_load).
+//
+// SEQ_LDS = true : the read/seed windows were staged in LDS (q_off/t_off are
+//                  word offsets into the dynamic __shared__ array);
+// SEQ_LDS = false: the snake reads the packed words straight from HBM through
+//                  the vector L1 (qg_/tg_ point at the first window word); LDS
+//                  then only holds the 2 KB V ring, which is what lets 24+
+//                  wavefronts share a CU -- the row loop is a dependent chain,
+//                  so resident waves, not instruction count, set the pace.
+template <bool SEQ_LDS>
+__device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double max_diff_v,
+                                       u32 *script_v, FaAln *aln_out_v, int q_off_v, int qb_v,
+                                       int q_len_v, int t_off_v, int tb_v, int t_len_v, int v_off_v,
+                                       u32 *cells_v, FaRowRec *rows_v, FaRowExt *rowx_v,
+                                       const u32 *qg_v, const u32 *tg_v, u64 *prof_v) {
+    // every argument is wave-uniform; pin them in SGPRs (see fa_uni)
+    const int band = fa_uni(band_v), q_off = fa_uni(q_off_v), qb = fa_uni(qb_v);
+    const int q_len = fa_uni(q_len_v), t_off = fa_uni(t_off_v), tb = fa_uni(tb_v);
+    const int t_len = fa_uni(t_len_v), v_off = fa_uni(v_off_v);
+    const u64 rows_per_slot = fa_uni(rows_per_slot_v);
+    const double max_diff = fa_uni(max_diff_v);
+    u32 *script_ = fa_uni(script_v);
+    FaAln *aln_out_ = fa_uni(aln_out_v);
+    u32 *cells_ = fa_uni(cells_v);
+    FaRowRec *rows_ = fa_uni(rows_v);
+    FaRowExt *rowx_ = fa_uni(rowx_v);
+    const u32 *qg_ = fa_uni(qg_v), *tg_ = fa_uni(tg_v);
+    u64 *prof_ = fa_uni(prof_v);
+    (void)prof_;
+    extern __shared__ __attribute__((aligned(16))) u32 smem[];
+    typedef const __attribute__((address_space(1))) u32 *gcu32p;
+    typedef typename std::conditional<SEQ_LDS, const u32 *, gcu32p>::type seqp;
+    seqp qL, tL;
+    if constexpr (SEQ_LDS) {
+        qL = smem + q_off;
+        tL = smem + t_off;
+    } else {
+        qL = (gcu32p)qg_;
+        tL = (gcu32p)tg_;
+    }
+    int *Vring = (int *)(smem + v_off);
+    // arena / output pointers are global memory: say so, or they become flat_*
+    // (records are moved as clang vector types: struct assignment is only
+    // defined for the generic address space)
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(1))) u32 g_u32;
+    typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+    typedef __attribute__((address_space(1))) u32x2 g_u32x2;
+    static_assert(sizeof(FaRowRec) == 16 && sizeof(FaRowExt) == 16 && sizeof(FaAln) == 40, "layout");
+    g_u32 *cells = (g_u32 *)cells_;
+    g_u32 *script = (g_u32 *)script_;
+    g_u32x4 *rows = (g_u32x4 *)rows_;    // {off, min_k, dlo, dhi}
+    g_u32x4 *rowx = (g_u32x4 *)rowx_;    // {d1.lo, d1.hi, d2.lo, d2.hi}
+    auto store_result = [&](const FaAln &r) {
+        g_u32x4 *o4 = (g_u32x4 *)aln_out_;
+        u32x4 a = {(u32)r.dist, (u32)r.q_e, (u32)r.t_e, (u32)r.size};
+        u32x4 b = {(u32)r.accept, (u32)r.n_ins, (u32)r.aligned, (u32)r.err};
+        u32x2 c = {(u32)(u64)r.cells, (u32)((u64)r.cells >> 32)};
+        o4[0] = a;
+        o4[1] = b;
+        ((g_u32x2 *)aln_out_)[4] = c;
+    };
+    const int lane = fa_lane();
     FaAln res;
     res.dist = 0; res.q_e = 0; res.t_e = 0; res.size = 0; res.accept = 0; res.n_ins = 0;
     res.aligned = 0; res.err = 0; res.cells = 0;
 
-    const int band = A.band;
     const int max_d = (int)(0.3 * (double)(q_len + t_len));  // DW_banded.c:149
-    if ((u64)max_d > A.rows_per_slot) {  // host sized the slot from the same formula
+    if ((u64)max_d > rows_per_slot) {  // host sized the slot from the same formula
         res.err = 1;
-        A.aln[g] = res;
+        store_result(res);
         return;
     }
     // zero the ring (reference: calloc'ed V, :153)
     for (int i = lane; i < 2 * RING; i += 64) Vring[i] = 0;
+    KTRACE("align q_len=%d t_len=%d max_d=%d qb=%d tb=%d\n", q_len, t_len, max_d, qb, tb);
 
-    KTRACE("align g=%d q_len=%d t_len=%d max_d=%d qb=%d tb=%d\n", g, q_len, t_len, max_d, qb, tb);
-    int best_m = -1, min_k = 0, max_k = 0;
+    int best_m = -1, min_k = 0, n = 1;  // n = cells of the row, max_k = min_k + 2(n-1)
     u32 row_off = 0;
     int fin_d = -1, fin_k = 0, fin_x = 0, fin_y = 0;
+    // the last <= 64 row records live in registers, lane (d & 63) holds row d;
+    // they are flushed to the arena 64 at a time with one coalesced 16-byte store
+    u32 rc_off = 0, rc_mink = 0, rc_dlo = 0, rc_dhi = 0;
+#define PUT_ROW_RECORD(dir0_, finished_)                                          \
+    do {                                                                          \
+        const int slot_ = d & 63;                                                 \
+        const bool mine_ = lane == slot_;                                         \
+        rc_off = mine_ ? row_off : rc_off;                                        \
+        rc_mink = mine_ ? (u32)min_k : rc_mink;                                   \
+        rc_dlo = mine_ ? (u32)(dir0_) : rc_dlo;                                   \
+        rc_dhi = mine_ ? (u32)((dir0_) >> 32) : rc_dhi;                           \
+        if (slot_ == 63 || (finished_)) {                                         \
+            if (lane <= slot_) {                                                  \
+                const u32x4 rr_ = {rc_off, rc_mink, rc_dlo, rc_dhi};              \
+                rows[d - slot_ + lane] = rr_;                                     \
+            }                                                                     \
+        }                                                                         \
+    } while (0)
 
-    for (int d = 0; d < max_d; d++) {
-        if (max_k - min_k > 2 * band) break;  // :184
-        const int n = ((max_k - min_k) >> 1) + 1;
-        int *Vcur = Vring + (d & 1) * RING;
-        const int *Vprev = Vring + ((d & 1) ^ 1) * RING;
-        int ureg[FA_ALIGN_MAXCH];
-        u64 dirw[FA_ALIGN_MAXCH];
-        int row_max = -1;
-        bool finished = false;
+    // Register mode (rows of <= REG_MAX_N diagonals, i.e. nearly all of them):
+    // lane l owns diagonal kbase + 2l + (d & 1) for as long as the band stays
+    // inside the wave, and vreg holds the previous row's x on the lane's
+    // diagonal of the *other* parity.  The two neighbours a = V[k-1], b = V[k+1]
+    // (DW_banded.c:190-196) are then the lane's own register and ONE DPP wave
+    // shift -- no LDS traffic for V at all.  Wider rows fall back to the LDS
+    // ring (ring mode) until the band narrows again.  The two modes are two
+    // plain loops (the row loop must stay a simple loop: the scalar unit is the
+    // bottleneck of this kernel).
+    const int REG_MAX_N = 60;
+    int kbase = -62;       // diagonal 0 sits on lane 31
+    int lo = 31;           // lane of min_k in register mode
+    int vreg = 0;          // reference: calloc'ed V (:153)
+    int d = 0;
+    bool done = false, dead = false;
+    PROF_DECL;
+    while (!done && !dead) {
+        // ================= register-mode rows =================
+        for (;;) {
+            if (d >= max_d || n - 1 > band) { dead = true; break; }  // :183-184
+            if (n > REG_MAX_N) break;
+            const int par = d & 1;
+            int hi = lo + n - 1;
+            if (lo < 1 || hi > 62) {  // re-centre the band inside the wave
+                const int nlo = (64 - n) >> 1;
+                const int sh = lo - nlo;  // new lane l takes old lane l + sh
+                vreg = __shfl(vreg, lane + sh);
+                kbase += 2 * sh;
+                lo = nlo;
+                hi = lo + n - 1;
+            }
+            PROF(0);
+            const bool act = lane >= lo && lane <= hi;
+            const int k = kbase + 2 * lane + par;
+            // a = V[k-1], b = V[k+1]: own register and one wave shift
+            const int sh_dn = __builtin_amdgcn_update_dpp(vreg, vreg, 0x138, 0xf, 0xf, false);  // lane-1
+            const int sh_up = __builtin_amdgcn_update_dpp(vreg, vreg, 0x130, 0xf, 0xf, false);  // lane+1
+            const int a = par ? vreg : sh_dn;
+            const int b = par ? sh_up : vreg;
+            const bool from_above = (lane == lo) || ((lane != hi) && (a < b));  // :190
+            int x = from_above ? b : a + 1;
+            int y = x - k;
+            PROF(1);
+            snake16(qL, tL, qb, tb, q_len, t_len, act, x, y);
+            PROF(2);
+            vreg = x;
+            g_u32 *rowp = cells + row_off - lo;
+            if (act) rowp[lane] = ((u32)x << 1) | (from_above ? 1u : 0u);
+            const u64 dir0 = __ballot(act && from_above) >> lo;
+            const u64 fin = __ballot(act && (x >= q_len || y >= t_len));  // :220
+            PROF(3);
+            if (fin) {
+                const int fl = __ffsll((long long)fin) - 1;
+                fin_d = d;
+                fin_k = kbase + 2 * fl + par;
+                fin_x = __builtin_amdgcn_readlane(x, fl);
+                fin_y = __builtin_amdgcn_readlane(y, fl);
+                res.cells = (long long)row_off + (fl - lo) + 1;
+                PUT_ROW_RECORD(dir0, true);
+                done = true;
+                break;
+            }
+            const int u = act ? x + y : -1;
+            best_m = max(best_m, fa_wave_max(u));
+            const u64 in = __ballot(u >= best_m - band && u >= 0);  // :228-243
+            PROF(4);
+            PUT_ROW_RECORD(dir0, false);
+            // `in` is never empty: best_m is attained inside the row
+            const int llo = __ffsll((long long)in) - 1;   // absolute lanes
+            const int lhi = 63 - __clzll((long long)in);
+            row_off += (u32)n;
+            min_k = min_k + 2 * (llo - lo) - 1;
+            n = lhi - llo + 2;
+            lo = par ? llo : llo - 1;  // even row -> odd row moves one lane down
+            d++;
+            PROF(5);
+        }
+        if (done || dead) break;
+        // ================= ring-mode rows (61..191 diagonals) =================
+        {   // spill the previous row into the ring: k_prev = kbase + 2l + (par^1)
+            const int par = d & 1;
+            const int kp = kbase + 2 * lane + (par ^ 1);
+            Vring[(par ^ 1) * RING + ((kp >> 1) & (RING - 1))] = vreg;
+        }
+        for (;;) {
+            if (d >= max_d || n - 1 > band) { dead = true; break; }
+            if (n <= REG_MAX_N - 12) break;
+            const int par = d & 1;
+            const int max_k = min_k + 2 * (n - 1);
+            int *Vcur = Vring + par * RING;
+            const int *Vprev = Vring + (par ^ 1) * RING;
+            g_u32 *rowp = cells + row_off;
+            u64 dirw[FA_ALIGN_MAXCH] = {0, 0, 0};
+            int row_max = -1;
+            bool finished = false;
 #pragma unroll
-        for (int c = 0; c < FA_ALIGN_MAXCH; c++) {
-            ureg[c] = -1;
-            dirw[c] = 0;
-            if (c * 64 < n && !finished) {
-                const int j = c * 64 + lane;
-                const bool act = j < n;
-                const int k = min_k + 2 * j;
-                const int a = Vprev[((k - 1) >> 1) & (RING - 1)];
-                const int b = Vprev[((k + 1) >> 1) & (RING - 1)];
-                const bool from_above = (k == min_k) || ((k != max_k) && (a < b));  // :190
-                int x = from_above ? b : a + 1;
-                int y = x - k;
-                if (act) {
-                    // snake (:203-206), up to 32 bases per step
-                    while (x < q_len && y < t_len) {
-                        const int qa = qb + x, ta = tb + y;
-                        const u64 diff = fa_window64(qL, qa) ^ fa_window64(tL, ta);
-                        int lim = min(32 - (qa & 15), 32 - (ta & 15));
-                        lim = min(lim, min(q_len - x, t_len - y));
-                        int m = diff ? (__builtin_ctzll(diff) >> 1) : 32;
-                        m = min(m, lim);
-                        x += m;
-                        y += m;
-                        if (m < lim) break;
+            for (int c = 0; c < FA_ALIGN_MAXCH; c++) {
+                if (c * 64 < n && !finished) {
+                    const int j = c * 64 + lane;
+                    const bool act = j < n;
+                    const int k = min_k + 2 * j;
+                    const int a = Vprev[((k - 1) >> 1) & (RING - 1)];
+                    const int b = Vprev[((k + 1) >> 1) & (RING - 1)];
+                    const bool from_above = (j == 0) || ((k != max_k) && (a < b));
+                    int x = from_above ? b : a + 1;
+                    int y = x - k;
+                    snake16(qL, tL, qb, tb, q_len, t_len, act, x, y);
+                    if (act) {
+                        Vcur[(k >> 1) & (RING - 1)] = x;
+                        rowp[j] = ((u32)x << 1) | (from_above ? 1u : 0u);
+                        row_max = max(row_max, x + y);
                     }
-                    Vcur[(k >> 1) & (RING - 1)] = x;
-                    cells[row_off + j] = ((u32)x << 1) | (from_above ? 1u : 0u);
-                    ureg[c] = x + y;
+                    dirw[c] = __ballot(act && from_above);
+                    const u64 fin = __ballot(act && (x >= q_len || y >= t_len));
+                    if (fin) {
+                        const int fl = __ffsll((long long)fin) - 1;
+                        fin_d = d;
+                        fin_k = min_k + 2 * (c * 64 + fl);
+                        fin_x = __builtin_amdgcn_readlane(x, fl);
+                        fin_y = __builtin_amdgcn_readlane(y, fl);
+                        res.cells = (long long)row_off + c * 64 + fl + 1;
+                        finished = true;
+                    }
                 }
-                dirw[c] = __ballot(act && from_above);
-                const u64 fin = __ballot(act && (x >= q_len || y >= t_len));  // :220
-                if (fin) {
-                    const int fl = __ffsll((long long)fin) - 1;
-                    fin_d = d;
-                    fin_k = min_k + 2 * (c * 64 + fl);
-                    fin_x = __builtin_amdgcn_readlane(x, fl);
-                    fin_y = __builtin_amdgcn_readlane(y, fl);
-                    res.cells = (long long)row_off + c * 64 + fl + 1;
-                    finished = true;
-                }
-                row_max = max(row_max, ureg[c]);
             }
-        }
-        if (lane == 0) {
-            FaRowRec rr;
-            rr.off = row_off;
-            rr.min_k = min_k;
-            rr.dir[0] = dirw[0];
-            rr.dir[1] = dirw[1];
-            rr.dir[2] = dirw[2];
-            rows[d] = rr;
-        }
-        KTRACE(" row d=%d min_k=%d max_k=%d n=%d fin=%d\n", d, min_k, max_k, n, (int)finished);
-        if (finished) break;
-        row_off += (u32)n;
-        best_m = max(best_m, fa_wave_max(row_max));
-        // band for the next row (:228-243)
-        int jlo = 0x7fffffff, jhi = -1;
+            if (n > 64) {   // the two extra direction words of a wide row
+                const u32x4 ex = {(u32)dirw[1], (u32)(dirw[1] >> 32), (u32)dirw[2],
+                                  (u32)(dirw[2] >> 32)};
+                rowx[d] = ex;  // every lane stores the same record
+            }
+            PUT_ROW_RECORD(dirw[0], finished);
+            if (finished) { done = true; break; }
+            best_m = max(best_m, fa_wave_max(row_max));
+            int jlo = -1, jhi = -1;
 #pragma unroll
-        for (int c = 0; c < FA_ALIGN_MAXCH; c++) {
-            if (c * 64 < n) {
-                const u64 in = __ballot(ureg[c] >= 0 && ureg[c] >= best_m - band);
-                if (in) {
-                    jlo = min(jlo, c * 64 + __ffsll((long long)in) - 1);
-                    jhi = max(jhi, c * 64 + 63 - __clzll((long long)in));
+            for (int c = 0; c < FA_ALIGN_MAXCH; c++) {
+                if (c * 64 < n) {
+                    const int j = c * 64 + lane;
+                    const int k = min_k + 2 * j;
+                    const int x = Vcur[(k >> 1) & (RING - 1)];
+                    const u64 in = __ballot(j < n && (2 * x - k) >= best_m - band);
+                    if (in) {
+                        if (jlo < 0) jlo = c * 64 + __ffsll((long long)in) - 1;
+                        jhi = c * 64 + 63 - __clzll((long long)in);
+                    }
                 }
             }
+            row_off += (u32)n;
+            min_k = min_k + 2 * jlo - 1;  // jlo >= 0: best_m is attained inside the row
+            n = jhi - jlo + 2;
+            d++;
         }
-        int new_min, new_max;
-        if (jhi < 0) {  // unreachable (best_m is attained in the row); reference init values
-            new_min = max_k;
-            new_max = min_k;
-        } else {
-            new_min = min_k + 2 * jlo;
-            new_max = min_k + 2 * jhi;
+        if (done || dead) break;
+        {   // reload into registers: put min_k on lane (64-n)/2
+            const int par = d & 1;
+            lo = (64 - n) >> 1;
+            kbase = min_k - par - 2 * lo;
+            const int kp = kbase + 2 * lane + (par ^ 1);
+            vreg = Vring[(par ^ 1) * RING + ((kp >> 1) & (RING - 1))];
         }
-        max_k = new_max + 1;
-        min_k = new_min - 1;
     }
+#undef PUT_ROW_RECORD
 
-    if (fin_d < 0) {  // unaligned: aln_str_size stays 0 (:171,:184-186)
+    if (!done) {  // unaligned: aln_str_size stays 0 (:171,:184-186)
         res.cells = row_off;
-        A.aln[g] = res;
+        store_result(res);
         return;
     }
     KTRACE(" forward done fin_d=%d fin_k=%d x=%d y=%d\n", fin_d, fin_k, fin_x, fin_y);
@@ -186,10 +392,13 @@ __device__ void align_one(const AlignArgs &A, int g, const u32 *qL, int qb, int 
     res.t_e = fin_y;
     res.size = (fin_x + fin_y + fin_d) / 2;  // :248
 
-    // ---- trace-back -------------------------------------------------------
-    // make this wave's row records / cells visible to its own loads
+    // ---- trace-back (DW_banded.c:264-319) -----------------------------------
+    // 64 rows per block: lane l loads the record of row hi-l and parks
+    // {min_k, dlo, dhi} in LDS; the diagonal chain k_d is then resolved on the
+    // VALU from broadcast LDS reads (the scalar unit is the busy one), after
+    // which all 64 rows gather their cell and emit one script word each.
     __threadfence_block();
-    u32 *script = A.script + A.script_off[g];
+    u32 *tb_rec = (u32 *)Vring;  // 64 x 4 words, the ring is free now
     int k_cur = fin_k;
     int n_ins = 0;
     for (int hi = fin_d; hi >= 0; hi -= 63) {
@@ -197,37 +406,34 @@ __device__ void align_one(const AlignArgs &A, int g, const u32 *qL, int qb, int 
         // is look-ahead only and is re-done by the next block.
         const int r = hi - lane;
         const bool have = r >= 0;
-        FaRowRec rr;
-        rr.off = 0; rr.min_k = 0; rr.dir[0] = rr.dir[1] = rr.dir[2] = 0;
-        if (have) rr = rows[r];
+        u32x4 rv = {0u, 0u, 0u, 0u};
+        if (have) rv = rows[r];
+        tb_rec[4 * lane + 0] = rv.y;  // min_k
+        tb_rec[4 * lane + 1] = rv.z;  // dlo
+        tb_rec[4 * lane + 2] = rv.w;  // dhi
         const int n_rows = min(64, hi + 1);
         int my_k = 0, my_dir = 0;
+        int kv = k_cur;  // the chain lives in a VGPR (same value in every lane)
         for (int l = 0; l < n_rows; l++) {
-            const int mk = __builtin_amdgcn_readlane(rr.min_k, l);
-            const int j = (k_cur - mk) >> 1;
-            const int wsel = j >> 6;
-            u32 lo32, hi32;
-            if (wsel == 0) {
-                lo32 = __builtin_amdgcn_readlane((int)(u32)rr.dir[0], l);
-                hi32 = __builtin_amdgcn_readlane((int)(u32)(rr.dir[0] >> 32), l);
-            } else if (wsel == 1) {
-                lo32 = __builtin_amdgcn_readlane((int)(u32)rr.dir[1], l);
-                hi32 = __builtin_amdgcn_readlane((int)(u32)(rr.dir[1] >> 32), l);
-            } else {
-                lo32 = __builtin_amdgcn_readlane((int)(u32)rr.dir[2], l);
-                hi32 = __builtin_amdgcn_readlane((int)(u32)(rr.dir[2] >> 32), l);
+            const int mk = (int)tb_rec[4 * l + 0];
+            const u32 dlo = tb_rec[4 * l + 1], dhi = tb_rec[4 * l + 2];
+            const int j = (kv - mk) >> 1;
+            u64 wbits = ((u64)dhi << 32) | dlo;
+            if (j >= 64) {  // wide row: fetch the extra words (rare)
+                const u32x4 ex = rowx[hi - l];
+                wbits = (j < 128) ? (((u64)ex.y << 32) | ex.x) : (((u64)ex.w << 32) | ex.z);
             }
-            const u64 wbits = ((u64)hi32 << 32) | lo32;
             const int bit = (int)((wbits >> (j & 63)) & 1ull);
             if (lane == l) {
-                my_k = k_cur;
+                my_k = kv;
                 my_dir = bit;
             }
-            if (l < 63 || hi < 63) k_cur += bit ? 1 : -1;  // lane 63's row is redone next block
+            if (l < 63 || hi < 63) kv += 2 * bit - 1;  // lane 63's row is redone next block
         }
+        k_cur = __builtin_amdgcn_readfirstlane(kv);
         // x2 of my row on the path
         int x2 = 0;
-        if (have) x2 = (int)(cells[rr.off + (u32)((my_k - rr.min_k) >> 1)] >> 1);
+        if (have) x2 = (int)(cells[rv.x + (u32)((my_k - (int)rv.y) >> 1)] >> 1);
         int x2_prev = __shfl_down(x2, 1);  // row r-1 sits in lane+1
         const bool emit = have && (lane < 63 || hi < 63);
         if (emit) {
@@ -245,22 +451,25 @@ __device__ void align_one(const AlignArgs &A, int g, const u32 *qL, int qb, int 
         if (hi < 63) break;
         // k_cur now is the diagonal of row hi-63 (lane 63's row): restart there
     }
+    PROF(6);
+    PROF_FLUSH(prof_);
     KTRACE(" trace done n_ins=%d\n", n_ins);
     res.n_ins = n_ins;
     res.accept = (res.size > 500) &&
-                 ((double)res.dist / (double)res.size < A.max_diff);  // falcon.c:629
-    A.aln[g] = res;  // every lane stores the same record
+                 ((double)res.dist / (double)res.size < max_diff);  // falcon.c:629
+    store_result(res);  // every lane stores the same record
 }
 
-__global__ __launch_bounds__(64) void k_align(AlignArgs A) {
+template <bool SEQ_LDS>
+__global__ __launch_bounds__(64, (SEQ_LDS ? 3 : 6)) void k_align(AlignArgs A) {
     extern __shared__ __attribute__((aligned(16))) u32 smem[];
     u32 *qL = smem;
     u32 *tL = qL + A.lds_q_words;
-    int *Vring = (int *)(tL + A.lds_t_words);
     const int lane = fa_lane();
     const int slot = blockIdx.x;
     u32 *cells = A.cells + (u64)slot * A.cells_per_slot;
     FaRowRec *rows = A.rows + (u64)slot * A.rows_per_slot;
+    FaRowExt *rowx = A.rowx + (u64)slot * A.rows_per_slot;
 
     for (;;) {
         // One work item per trip.  Everything that steers control flow is forced
@@ -292,7 +501,7 @@ __global__ __launch_bounds__(64) void k_align(AlignArgs A) {
         const int qn = ((s1 + q_len) >> 4) - qw0 + 3;
         const int tn = ((s2 + t_len) >> 4) - tw0 + 3;
         const bool skip = (q_idx == 0) || !rg_ok;
-        const bool too_big = !skip && (qn > A.lds_q_words || tn > A.lds_t_words);
+        const bool too_big = SEQ_LDS && !skip && (qn > A.lds_q_words || tn > A.lds_t_words);
         if (skip || too_big) {
             FaAln z;
             z.dist = 0; z.q_e = 0; z.t_e = 0; z.size = 0; z.accept = 0; z.n_ins = 0;
@@ -304,16 +513,32 @@ __global__ __launch_bounds__(64) void k_align(AlignArgs A) {
             // the sequence's own words end at ceil(len/16)+2 (zero padded by pack)
             const int qavail = ((q_slen + 15) >> 4) + 2 - qw0;
             const int tavail = ((t_slen + 15) >> 4) + 2 - tw0;
-            for (int i = lane; i < qn; i += 64) qL[i] = (i < qavail) ? qg[i] : 0u;
-            for (int i = lane; i < tn; i += 64) tL[i] = (i < tavail) ? tg[i] : 0u;
-            __syncthreads();
-            align_one(A, g, qL, s1 & 15, q_len, tL, s2 & 15, t_len, Vring, cells, rows, lane);
+            if constexpr (SEQ_LDS) {
+                for (int i = lane; i < qn; i += 64) qL[i] = (i < qavail) ? qg[i] : 0u;
+                for (int i = lane; i < tn; i += 64) tL[i] = (i < tavail) ? tg[i] : 0u;
+                __syncthreads();
+                align_one<true>(A.band, A.rows_per_slot, A.max_diff, A.script + A.script_off[g],
+                                A.aln + g, 0, s1 & 15, q_len, A.lds_q_words, s2 & 15, t_len,
+                                A.lds_q_words + A.lds_t_words, cells, rows, rowx, qg, tg, A.prof);
+            } else {
+                (void)qavail; (void)tavail;
+                align_one<false>(A.band, A.rows_per_slot, A.max_diff, A.script + A.script_off[g],
+                                 A.aln + g, 0, s1 & 15, q_len, 0, s2 & 15, t_len, 0, cells, rows,
+                                 rowx, qg, tg, A.prof);
+            }
             __syncthreads();
         }
     }
 }
 
+static bool seq_in_lds() {
+    static int v = -1;
+    if (v < 0) v = getenv("FALCON_AMD_ALIGN_LDS") ? 1 : 0;  // A/B switch; default: L1 path
+    return v == 1;
+}
+
 size_t fa_align_lds_bytes(int max_q_len, int max_t_len) {
+    if (!seq_in_lds()) return 2 * RING * sizeof(u32);
     size_t qw = (size_t)(max_q_len >> 4) + 4, tw = (size_t)(max_t_len >> 4) + 4;
     qw = (qw + 3) & ~(size_t)3;
     tw = (tw + 3) & ~(size_t)3;
@@ -322,7 +547,9 @@ size_t fa_align_lds_bytes(int max_q_len, int max_t_len) {
 
 int fa_align_blocks_per_cu(size_t lds_bytes) {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_align, 64, lds_bytes);
+    hipError_t e = seq_in_lds()
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_align<true>, 64, lds_bytes)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_align<false>, 64, lds_bytes);
     if (e != hipSuccess || nb <= 0) nb = 8;
     return nb;
 }
@@ -334,23 +561,28 @@ void fa_launch_align_band(const FaBatchDev &b, const FaAlignArena &a, int max_q_
     A.words = b.words; A.seq = b.seq; A.pile = b.pile; A.range = b.range; A.order = b.order;
     A.n_work = b.n_seq;
     A.counter = a.counter;
-    A.cells = a.cells; A.rows = a.rows;
+    A.cells = a.cells; A.rows = a.rows; A.rowx = a.rowx;
     A.cells_per_slot = a.cells_per_slot; A.rows_per_slot = a.rows_per_slot;
     A.script = b.script; A.script_off = b.script_off; A.aln = b.aln;
     A.band = band;
     size_t qw = (size_t)(max_q_len >> 4) + 4, tw = (size_t)(max_t_len >> 4) + 4;
     qw = (qw + 3) & ~(size_t)3;
     tw = (tw + 3) & ~(size_t)3;
+    A.prof = a.prof;
     A.lds_q_words = (int)qw;
     A.lds_t_words = (int)tw;
     A.max_diff = max_diff;
     size_t lds = fa_align_lds_bytes(max_q_len, max_t_len);
     (void)hipMemsetAsync(a.counter, 0, sizeof(int), s);
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)k_align, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
     int grid = a.n_slot < b.n_seq ? a.n_slot : b.n_seq;
-    hipLaunchKernelGGL(k_align, dim3(grid), dim3(64), lds, s, A);
+    if (seq_in_lds()) {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)k_align<true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_align<true>, dim3(grid), dim3(64), lds, s, A);
+    } else {
+        hipLaunchKernelGGL(k_align<false>, dim3(grid), dim3(64), lds, s, A);
+    }
 }
 
 void fa_launch_align(const FaBatchDev &b, const FaAlignArena &a, int max_q_len, int max_t_len,
