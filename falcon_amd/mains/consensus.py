@@ -1,0 +1,336 @@
+"""falcon_sense on MI355X: drop-in for ``python -m falcon_kit.mains.consensus``.
+
+Same flags, same stdin grammar and the same stdout bytes as the reference worker
+(/root/reference/falcon_kit/mains/consensus.py), so the pipe that fc_run writes,
+
+    LA4Falcon -H$CUTOFF -fo db las | python -m falcon_kit.mains.consensus <opts> > cns.fasta
+
+(falcon_kit/mains/consensus_task.py:90) keeps working unchanged.  What differs is
+what sits between the parser and the printer: the reference hands one pile at a
+time to a pool of worker processes (consensus.py:264-274); here piles are gathered
+into batches, staged in HBM once, and every stage of generate_consensus runs as HIP
+kernels over the whole batch (falcon_amd/csrc).  Records are printed in input
+order, like ``Pool.imap``.
+
+There is no CPU fallback: without libfalcon_amd.so and a HIP device the command
+fails.
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import multiprocessing
+import os
+import re
+import sys
+import threading
+from collections import namedtuple
+
+LOG = logging.getLogger("falcon_amd.consensus")
+
+KMER = 8              # consensus.py:270 hard-wires K = 8
+MAX_SEQ_LEN = 100000  # consensus.py:162: longer sequences are cut to MAX_SEQ_LEN - 1
+
+# (flag, type, default, help) -- names, types and defaults of consensus.py:219-250
+_OPTIONS = (
+    ("--n-core", int, 24, "worker count requested by the caller (accepted for compatibility; "
+                          "the GPU path does not fork workers)"),
+    ("--min-cov", int, 6, "positions covered by at most this many reads are lower-cased and "
+                          "split the output"),
+    ("--min-cov-aln", int, 10, "skip seeds whose pile has less than this average depth"),
+    ("--max-cov-aln", int, 0, "if > 0, stop adding (longest-first) reads past this average depth"),
+    ("--min-len-aln", int, 0, "ignore sequences shorter than this"),
+    ("--min-n-read", int, 10, "skip seeds with fewer sequences than this (seed copy included)"),
+    ("--max-n-read", int, 500, "use at most this many sequences per seed (seed included)"),
+    ("--min-idt", float, 0.70, "minimum identity of an alignment used for correction"),
+    ("--edge-tolerance", int, 1000, "--trim: drop reads whose unaligned ends exceed this"),
+    ("--trim-size", int, 50, "--trim: bases cut from both ends of the mapped window"),
+)
+_SWITCHES = (
+    ("--trim", "window every read to its chained k-mer span before the consensus"),
+    ("--output-full", "print the raw consensus, lower-case regions included"),
+    ("--output-multi", "print every well-covered region of >= 500 bp (at most 10)"),
+)
+
+Settings = namedtuple("Settings", "min_cov K max_n_read min_idt edge_tolerance trim_size "
+                                  "min_cov_aln max_cov_aln")
+
+
+def parse_args(argv):
+    ap = argparse.ArgumentParser(
+        prog=os.path.basename(argv[0]) if argv else None,
+        description="pre-assembly consensus (falcon_sense) on AMD MI355X GPUs",
+        formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    for flag, typ, default, text in _OPTIONS:
+        ap.add_argument(flag, type=typ, default=default, help=text)
+    for flag, text in _SWITCHES:
+        ap.add_argument(flag, action="store_true", default=False, help=text)
+    ap.add_argument("-v", "--verbose-level", type=float, default=2.0,
+                    help="logging level = 10 * value (1 DEBUG, 2 INFO, 3 WARNING)")
+    return ap.parse_args(argv[1:])
+
+
+def settings_from(args) -> Settings:
+    return Settings(args.min_cov, KMER, args.max_n_read, args.min_idt, args.edge_tolerance,
+                    args.trim_size, args.min_cov_aln, args.max_cov_aln)
+
+
+# --------------------------------------------------------------------------
+# pile selection and stream parsing (behaviour of consensus.py:26-45, :161-209)
+# --------------------------------------------------------------------------
+def select_reads(pile, max_n_read, max_cov_aln, presorted=False):
+    """Seed first, then the longest reads.
+
+    The sort is stable on descending length (ties keep stream order).  The result
+    holds at most ``max_n_read`` sequences; with ``max_cov_aln`` > 0 reads are only
+    added while (bases so far) // seed_len has not exceeded it."""
+    seed, rest = pile[:1], pile[1:]
+    if not presorted:
+        rest = sorted(rest, key=len, reverse=True)  # python's sort is stable, also reversed
+    keep = max_n_read
+    if max_cov_aln > 0:
+        seed_len = len(seed[0])
+        depth_bases = 0
+        keep = 1
+        for r in rest:
+            if depth_bases // seed_len > max_cov_aln:
+                break
+            keep += 1
+            depth_bases += len(r)
+        keep = min(keep, max_n_read)
+    return (seed + rest)[:keep]
+
+
+class PileReader:
+    """Iterates over the admitted piles of an LA4Falcon ``-fo`` text stream.
+
+    Grammar: ``<id> <bases>`` lines; ``+ +`` ends a pile, ``* *`` ends and discards
+    it, ``- -`` ends the stream; lines that do not split into exactly two tokens are
+    skipped.  The first sequence of a pile is the seed; it is stored as the target
+    and -- unless its id shows up again -- once more as an ordinary read, exactly
+    like the reference.  A pile is admitted when it holds at least ``min_n_read``
+    sequences and its read bases cover the seed ``min_cov_aln`` times."""
+
+    def __init__(self, stream, cfg: Settings, min_n_read: int, min_len_aln: int):
+        self.stream, self.cfg = stream, cfg
+        self.min_n_read, self.min_len_aln = min_n_read, min_len_aln
+
+    def __iter__(self):
+        pile, ids, bases, seed_id = [], set(), 0, None
+        for line in self.stream:
+            tok = line.split()
+            if len(tok) != 2:
+                continue
+            name, seq = tok
+            if len(seq) > MAX_SEQ_LEN:
+                seq = seq[:MAX_SEQ_LEN - 1]
+            if name in ("+", "*", "-"):
+                if name == "-":
+                    return
+                if name == "+" and pile and len(pile) >= self.min_n_read and \
+                        bases // len(pile[0]) >= self.cfg.min_cov_aln:
+                    yield seed_id, select_reads(pile, self.cfg.max_n_read, self.cfg.max_cov_aln)
+                pile, ids, bases, seed_id = [], set(), 0, None
+                continue
+            if len(seq) < self.min_len_aln:
+                continue
+            if not pile:
+                pile.append(seq)
+                seed_id = name
+            if name not in ids:
+                ids.add(name)
+                pile.append(seq)
+                bases += len(seq)
+
+
+# --------------------------------------------------------------------------
+# --trim (behaviour of consensus.py:48-99 and :123-146) on the legacy table ABI
+# --------------------------------------------------------------------------
+def mapped_window(kup, read, seed, edge_tolerance):
+    """Chained k-mer span of ``read`` on ``seed``: (q_start, q_end, score) or None."""
+    from ctypes import c_char_p
+    rb, sb = read.encode("ascii"), seed.encode("ascii")
+    table = kup.allocate_kmer_lookup(1 << (2 * KMER))
+    codes = kup.allocate_seq(len(sb))
+    chain = kup.allocate_seq_addr(len(sb))
+    try:
+        kup.add_sequence(0, KMER, c_char_p(sb), len(sb), chain, codes, table)
+        kup.mask_k_mer(1 << (2 * KMER), table, 16)
+        hits = kup.find_kmer_pos_for_seq(c_char_p(rb), len(rb), KMER, chain, table)
+        rng = kup.find_best_aln_range2(hits, KMER, KMER * 50, 25)
+        q0, q1, t0, t1, score = rng[0].s1, rng[0].e1, rng[0].s2, rng[0].e2, rng[0].score
+        kup.free_kmer_match(hits)
+        kup.free_aln_range(rng)
+    finally:
+        kup.free_seq_addr_array(chain)
+        kup.free_seq_array(codes)
+        kup.free_kmer_lookup(table)
+    pad = KMER + KMER // 2
+    q1 = min(q1 + pad, len(read))
+    t1 = min(t1 + pad, len(seed))
+    if q0 > edge_tolerance and t0 > edge_tolerance:
+        return None
+    if len(read) - q1 > edge_tolerance and len(seed) - t1 > edge_tolerance:
+        return None
+    if q1 - q0 <= 500:
+        return None
+    return q0, q1, int(score * 48)
+
+
+def trimmed_pile(kup, pile, cfg: Settings):
+    seed = pile[0]
+    windows = []
+    for read in pile[1:]:
+        w = mapped_window(kup, read, seed, cfg.edge_tolerance)
+        if w is None:
+            continue
+        q0, q1, score = w
+        if score > 1000:
+            q0 += cfg.trim_size
+            q1 -= cfg.trim_size
+            windows.append((q1 - q0, read[q0:q1]))
+    windows.sort(key=lambda w: -w[0])  # longest window first, stable
+    out = [seed] + [w[1] for w in windows]
+    if len(out) - 1 > cfg.max_n_read:
+        out = select_reads(out, cfg.max_n_read, cfg.max_cov_aln, presorted=True)
+    return out
+
+
+# --------------------------------------------------------------------------
+# batching over one or more GPUs
+# --------------------------------------------------------------------------
+class GpuConsensus:
+    """Ordered map over piles on the visible GPU(s).
+
+    Piles are cut into batches; a batch is split into contiguous shards, one per
+    device, each handled by its own engine on its own thread (independent work
+    queues -- piles never interact, so there is no collective)."""
+
+    def __init__(self, min_cov, min_idt, devices=None, batch_bases=400_000_000):
+        from falcon_amd.engine import Engine
+        from falcon_amd.lib import load
+        n_dev = load().fa_device_count()
+        if n_dev <= 0:
+            raise RuntimeError("falcon_amd: no HIP device visible (there is no CPU fallback)")
+        if devices is None:
+            env = os.environ.get("FALCON_AMD_DEVICES")
+            devices = [int(x) for x in env.split(",")] if env else list(range(n_dev))
+        self.engines = [Engine(d) for d in devices]
+        self.min_cov, self.min_idt = min_cov, min_idt
+        self.batch_bases = batch_bases
+
+    def imap(self, piles):
+        batch, bases = [], 0
+        for p in piles:
+            batch.append(p)
+            bases += sum(map(len, p))
+            if bases >= self.batch_bases * len(self.engines):
+                yield from self._run_batch(batch)
+                batch, bases = [], 0
+        if batch:
+            yield from self._run_batch(batch)
+
+    def _run_batch(self, batch):
+        n = len(self.engines)
+        if n == 1 or len(batch) < 2 * n:
+            return self.engines[0].consensus(batch, self.min_cov, KMER, self.min_idt)
+        step = -(-len(batch) // n)
+        shards = [batch[i:i + step] for i in range(0, len(batch), step)]
+        results, errors = [None] * len(shards), []
+
+        def work(i):
+            try:
+                results[i] = self.engines[i].consensus(shards[i], self.min_cov, KMER, self.min_idt)
+            except Exception as exc:  # surfaced below, in the caller's thread
+                errors.append(exc)
+
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(shards))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return [c for shard in results for c in shard]
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+
+# --------------------------------------------------------------------------
+# output (behaviour of consensus.py:275-299)
+# --------------------------------------------------------------------------
+_SOLID = re.compile("[ACGT]+")
+
+
+def fasta_records(seed_id, cns, output_full, output_multi):
+    """The FASTA text the reference prints for one consensus string."""
+    if len(cns) < 500:
+        return ""
+    if output_full:
+        return ">%s_f\n%s\n" % (seed_id, cns)
+    solid = _SOLID.findall(cns)
+    if not solid:
+        return ""
+    if not output_multi:
+        best = solid[0]
+        for s in solid[1:]:  # the last of the longest, like sort()[-1]
+            if len(s) >= len(best):
+                best = s
+        return ">%s\n%s\n" % (seed_id, best)
+    text, k = [], 0
+    for s in solid:
+        if len(s) < 500:
+            continue
+        if k == 10:
+            break
+        text.append(">prolog/%s%01d/%d_%d\n" % (seed_id, k, 0, len(s)))
+        text.extend(s[i:i + 80] + "\n" for i in range(0, len(s), 80))
+        k += 1
+    return "".join(text)
+
+
+def run(args, stdin=None, stdout=None, consensus_map=None):
+    """``consensus_map`` (tests) replaces the GPU map: iterable of piles -> iterable of
+    consensus strings."""
+    stdin = sys.stdin if stdin is None else stdin
+    stdout = sys.stdout if stdout is None else stdout
+    logging.basicConfig(level=int(round(10 * args.verbose_level)))
+    # the reference refuses more workers than cores (consensus.py:258); callers
+    # (consensus_task.py:44-54) clamp --n-core accordingly, so keep the contract
+    assert args.n_core <= multiprocessing.cpu_count(), \
+        'Requested n_core={} > cpu_count={}'.format(args.n_core, multiprocessing.cpu_count())
+    cfg = settings_from(args)
+    kup = None
+    if args.trim:
+        from falcon_amd import falcon_kit as fk
+        kup = fk.kup
+    gpu = None
+    if consensus_map is None:
+        gpu = GpuConsensus(args.min_cov, args.min_idt)
+        consensus_map = gpu.imap
+        LOG.info("falcon_amd consensus on %d GPU(s)", len(gpu.engines))
+
+    seed_ids = []
+
+    def piles():
+        for seed_id, pile in PileReader(stdin, cfg, args.min_n_read, args.min_len_aln):
+            seed_ids.append(seed_id)
+            yield trimmed_pile(kup, pile, cfg) if args.trim else pile
+
+    try:
+        for i, cns in enumerate(consensus_map(piles())):
+            stdout.write(fasta_records(seed_ids[i], cns, args.output_full, args.output_multi))
+    finally:
+        if gpu is not None:
+            gpu.close()
+    stdout.flush()
+
+
+def main(argv=None):
+    run(parse_args(sys.argv if argv is None else argv))
+
+
+if __name__ == "__main__":
+    main(sys.argv)

@@ -1,0 +1,72 @@
+"""The fc_consensus command line: parser, pile admission/selection and FASTA
+formatting against the CLI golden vectors produced by the reference's own
+driver.  The consensus calls themselves are served by the CPU oracle here (this
+is a test harness; the product CLI only ever uses the GPU engine)."""
+import io
+
+import pytest
+
+from conftest import load_golden
+from falcon_amd.mains import consensus as cli
+
+F5 = load_golden("f5_cli")
+F6 = load_golden("f6_cli_trim")
+
+
+def oracle_map(port, min_cov, min_idt):
+    def run(piles):
+        for p in piles:
+            yield port.generate_consensus(p, min_cov, 8, min_idt)[0]
+    return run
+
+
+def run_cli(argv, stdin_text, cmap):
+    args = cli.parse_args(["fc_consensus"] + argv + ["--n-core", "0"])
+    out = io.StringIO()
+    cli.run(args, stdin=io.StringIO(stdin_text), stdout=out, consensus_map=cmap)
+    return out.getvalue()
+
+
+@pytest.mark.parametrize("case", F5["runs"], ids=[" ".join(r["argv"]) or "defaults" for r in F5["runs"]])
+def test_cli_matches_reference_driver(port, case):
+    args = cli.parse_args(["x"] + case["argv"])
+    got = run_cli(case["argv"], F5["stdin"], oracle_map(port, args.min_cov, args.min_idt))
+    assert got == case["stdout"]
+
+
+@pytest.mark.parametrize("case", F6["runs"], ids=[" ".join(r["argv"]) for r in F6["runs"]])
+def test_cli_trim_matches_reference_driver(port, case):
+    args = cli.parse_args(["x"] + case["argv"])
+    got = run_cli(case["argv"], F5["stdin"], oracle_map(port, args.min_cov, args.min_idt))
+    assert got == case["stdout"]
+
+
+def test_flags_and_defaults_match_the_reference_cli():
+    a = cli.parse_args(["x"])
+    assert (a.n_core, a.min_cov, a.min_cov_aln, a.max_cov_aln, a.min_len_aln, a.min_n_read,
+            a.max_n_read, a.min_idt, a.edge_tolerance, a.trim_size, a.verbose_level) == \
+        (24, 6, 10, 0, 0, 10, 500, 0.70, 1000, 50, 2.0)
+    assert not (a.trim or a.output_full or a.output_multi)
+    b = cli.parse_args("x --output-multi --min-idt 0.70 --min-cov 4 --max-n-read 200 --n-core 6".split())
+    assert b.output_multi and b.min_cov == 4 and b.max_n_read == 200 and b.n_core == 6
+
+
+def test_help_exits_cleanly():
+    with pytest.raises(SystemExit) as e:
+        cli.parse_args(["prog", "--help"])   # reference test/test_consensus.py:5-9
+    assert e.value.code == 0
+
+
+def test_select_reads_is_stable_and_capped():
+    pile = ["S" * 10, "a" * 5, "b" * 7, "c" * 7, "d" * 3]
+    assert cli.select_reads(pile, 4, 0) == ["S" * 10, "b" * 7, "c" * 7, "a" * 5]
+    # coverage cap: stop once bases // seed_len exceeds the cap
+    assert cli.select_reads(pile, 500, 1) == ["S" * 10, "b" * 7, "c" * 7, "a" * 5, "d" * 3][:5]
+    assert len(cli.select_reads(["S" * 4] + ["r" * 4] * 9, 500, 1)) == 3
+
+
+def test_pile_reader_grammar():
+    text = "s1 ACGT\nr1 AAAA\nr1 CCCC\nthree tokens here\nr2 GG\n+ +\nx TTTT\n* *\ns2 AC\n- -\nz AAAA\n+ +\n"
+    cfg = cli.Settings(4, 8, 500, 0.7, 1000, 50, 0, 0)
+    piles = list(cli.PileReader(io.StringIO(text), cfg, 1, 0))
+    assert piles == [("s1", ["ACGT", "ACGT", "AAAA", "GG"])]
