@@ -145,15 +145,10 @@ def main():
     elapsed = time.perf_counter() - t0
 
     st = batch.stats()
-    bases_step = st.O
-    tot = torch.tensor([float(bases_step), float(st.n_piles), elapsed], dtype=torch.float64,
-                       device="cuda")
-    if world > 1:
-        tmax = tot[2:3].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot[0:2], op=dist.ReduceOp.SUM)
-        elapsed = float(tmax.item())
-    bases_all, piles_all = float(tot[0].item()), float(tot[1].item())
+    # whole-job aggregate: units summed over ranks, time = slowest rank
+    from falcon_amd.multigpu import reduce_measurement
+    bases_all, piles_all, elapsed = reduce_measurement(float(st.O), float(st.n_piles), elapsed,
+                                                       device="cuda")
 
     if rank == 0:
         k = max(1, args.steps)
