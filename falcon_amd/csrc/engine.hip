@@ -102,7 +102,7 @@ struct fa_batch {
     int band = FA_BAND;
     std::vector<FaSeq> seq;
     std::vector<FaPile> pile;
-    std::vector<int> order, cns_list;
+    std::vector<int> order;
     std::vector<u64> ascii_off, script_off;
     u64 n_words = 0, ascii_bytes = 0, script_words = 0;
     int max_read_len = 0, max_seed_len = 0, max_rows = 0, max_bins = 4;
@@ -113,7 +113,16 @@ struct fa_batch {
     DevBuf<u32> d_words, d_kidx, d_kpos, d_script;
     DevBuf<FaSeq> d_seq;
     DevBuf<FaPile> d_pile;
-    DevBuf<int> d_order, d_cns_list;
+    DevBuf<int> d_order;
+    // MSA stage (k_msa.hip)
+    DevBuf<FaTagAln> d_ta;
+    DevBuf<u32> d_acc_first, d_desc, d_links;
+    DevBuf<int> d_tcov, d_tarr, d_score_ovf, d_seg_pile, d_seg_t0, d_wide;
+    DevBuf<uint8_t> d_insb;
+    DevBuf<u64> d_t_off, d_link_off, d_link_cap;
+    DevBuf<FaTInfo> d_tinfo;
+    DevBuf<uint16_t> d_lvl_nlink;
+    DevBuf<FaScoreOut> d_score_out;
     DevBuf<FaRange> d_range;
     DevBuf<FaAln> d_aln;
     DevBuf<FaNode> d_nodes;
@@ -372,7 +381,11 @@ extern "C" void fa_batch_free(fa_batch *b) {
     b->d_ascii.release(); b->d_ascii_off.release();
     b->d_script_off.release(); b->d_words.release(); b->d_kidx.release(); b->d_kpos.release();
     b->d_script.release(); b->d_seq.release(); b->d_pile.release();
-    b->d_order.release(); b->d_cns_list.release(); b->d_range.release(); b->d_aln.release(); b->d_nodes.release();
+    b->d_order.release(); b->d_range.release();
+    b->d_ta.release(); b->d_acc_first.release(); b->d_desc.release(); b->d_links.release();
+    b->d_tcov.release(); b->d_tarr.release(); b->d_score_ovf.release(); b->d_seg_pile.release();
+    b->d_seg_t0.release(); b->d_wide.release(); b->d_insb.release(); b->d_t_off.release(); b->d_link_off.release();
+    b->d_link_cap.release(); b->d_tinfo.release(); b->d_lvl_nlink.release(); b->d_score_out.release(); b->d_aln.release(); b->d_nodes.release();
     b->d_out_seq.release(); b->d_out_eqv.release(); b->d_pile_out.release();
     delete b;
 }
@@ -474,50 +487,124 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     HIP_OK(hipGetLastError());
     // alignment summaries bound the MSA node pools (levels <= seed + insertions)
     if (int rc = fetch_aln(b)) return rc;
-    u64 node_off = 0;
+    // ---- plan the MSA stage from the alignment summaries (host, O(#reads))
+    u64 node_off = 0, desc_tot = 0, ins_tot = 0, t_tot = 0, link_tot = 0;
     long long sC = 0, sD = 0, sA = 0, nal = 0;
-    // piles are swept by kernels specialised for 64/128/256/512 accepted alignments
-    std::vector<int> cls[4];
+    std::vector<FaTagAln> ta;
+    std::vector<u32> acc_first(b->n_pile + 1, 0);
+    std::vector<u64> t_off(b->n_pile), link_off(b->n_pile), link_cap(b->n_pile);
+    std::vector<int> seg_pile, seg_t0;
+    const int TSEG = 128;  // must match k_msa.hip
     for (int p = 0; p < b->n_pile; p++) {
         FaPile &pm = b->pile[p];
-        u64 levels = (u64)pm.seed_len + 2;
+        u64 levels = (u64)pm.seed_len + 2, cols = 8;
+        acc_first[p] = (u32)ta.size();
         int n_acc = 0;
         for (int j = 1; j < pm.n_seq; j++) {
-            const FaAln &al = b->h_aln[pm.first + j];
+            const int g = pm.first + j;
+            const FaAln &al = b->h_aln[g];
             sC += al.cells;
-            if (al.accept) {
-                levels += (u64)al.n_ins;
-                sD += al.dist;
-                sA += al.size;
-                n_acc++;
-            }
+            if (!al.accept) continue;
+            levels += (u64)al.n_ins;
+            cols += (u64)al.size;
+            sD += al.dist;
+            sA += al.size;
+            n_acc++;
+            FaTagAln x;
+            x.desc_off = desc_tot;
+            x.ins_off = (u32)ins_tot;
+            x.s2 = 0;  // filled on the device side from range[g] (k_tags reads it); kept for k_links
+            x.g = g;
+            x.pile = p;
+            x.pad = 0;
+            ta.push_back(x);
+            desc_tot += (u64)al.t_e + 2;
+            ins_tot += (u64)al.n_ins + 4;
+        }
+        if (n_acc > FA_CNS_MAX_ALN) {
+            set_err("falcon_amd: pile %d has %d usable reads; at most %d are supported", p, n_acc,
+                    FA_CNS_MAX_ALN);
+            return -3;
         }
         nal += n_acc;
         pm.node_off = node_off;
         pm.node_cap = levels * 5;
         node_off += pm.node_cap;
-        cls[n_acc <= 64 ? 0 : (n_acc <= 128 ? 1 : (n_acc <= 256 ? 2 : 3))].push_back(p);
+        t_off[p] = t_tot;
+        t_tot += (u64)pm.seed_len;
+        link_off[p] = link_tot;
+        link_cap[p] = cols;
+        link_tot += cols;
+        for (int t0 = 0; t0 < pm.seed_len; t0 += TSEG) {
+            seg_pile.push_back(p);
+            seg_t0.push_back(t0);
+        }
     }
-    b->cns_list.clear();
-    int n_list[4];
-    const int *d_list[4];
-    if (b->d_cns_list.n < (size_t)b->n_pile && b->d_cns_list.alloc((size_t)b->n_pile)) return -1;
-    for (int k = 0, at = 0; k < 4; k++) {
-        n_list[k] = (int)cls[k].size();
-        d_list[k] = b->d_cns_list.p + at;
-        b->cns_list.insert(b->cns_list.end(), cls[k].begin(), cls[k].end());
-        at += n_list[k];
+    acc_first[b->n_pile] = (u32)ta.size();
+    if (ins_tot >= 0xffffffffull || link_tot >= 0xffffffffull * 4) {
+        set_err("falcon_amd: batch too large for the MSA stage");
+        return -1;
     }
-    HIP_OK(hipMemcpyAsync(b->d_cns_list.p, b->cns_list.data(), (size_t)b->n_pile * sizeof(int),
-                          hipMemcpyHostToDevice, s));
-    if (b->d_nodes.n < node_off + 8) {
-        if (b->d_nodes.alloc(node_off + 8)) return -1;
+    // s2 of every accepted alignment comes from the chain stage
+    {
+        b->h_range.resize(b->n_seq);
+        HIP_OK(hipMemcpyAsync(b->h_range.data(), b->d_range.p, (size_t)b->n_seq * sizeof(FaRange),
+                              hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        b->have_range = true;
+        for (auto &x : ta) x.s2 = b->h_range[x.g].s2;
     }
-    HIP_OK(hipMemcpyAsync(b->d_pile.p, b->pile.data(), (size_t)b->n_pile * sizeof(FaPile),
-                          hipMemcpyHostToDevice, s));
+    const size_t n_ta = ta.size();
+    const size_t tarr_ints = 3 * (size_t)(t_tot + (u64)b->n_pile);
+    auto need = [&](auto &buf, size_t n) { return (buf.n < n) ? buf.alloc(n) : 0; };
+    int rc2 = 0;
+    rc2 |= need(b->d_ta, n_ta + 1);
+    rc2 |= need(b->d_acc_first, (size_t)b->n_pile + 1);
+    rc2 |= need(b->d_tcov, n_ta + 1);
+    rc2 |= need(b->d_desc, 2 * (size_t)desc_tot + 8);
+    rc2 |= need(b->d_insb, (size_t)ins_tot + 8);
+    rc2 |= need(b->d_tarr, tarr_ints + 8);
+    rc2 |= need(b->d_t_off, (size_t)b->n_pile);
+    rc2 |= need(b->d_tinfo, (size_t)t_tot + 8);
+    rc2 |= need(b->d_links, (size_t)link_tot + 8);
+    rc2 |= need(b->d_link_off, (size_t)b->n_pile);
+    rc2 |= need(b->d_link_cap, (size_t)b->n_pile);
+    rc2 |= need(b->d_lvl_nlink, (size_t)(node_off / 5) + 8);
+    rc2 |= need(b->d_score_ovf, (size_t)b->n_pile * 2 * 256 * 5);
+    rc2 |= need(b->d_score_out, (size_t)b->n_pile);
+    rc2 |= need(b->d_seg_pile, seg_pile.size() + 1);
+    rc2 |= need(b->d_seg_t0, seg_t0.size() + 1);
+    rc2 |= need(b->d_wide, seg_t0.size() + 2);
+    rc2 |= need(b->d_nodes, (size_t)node_off + 8);
+    if (rc2) return -1;
+    auto up = [&](void *dst, const void *src, size_t bytes) {
+        return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s) == hipSuccess;
+    };
+    bool okc = true;
+    okc &= up(b->d_ta.p, ta.data(), n_ta * sizeof(FaTagAln));
+    okc &= up(b->d_acc_first.p, acc_first.data(), acc_first.size() * sizeof(u32));
+    okc &= up(b->d_t_off.p, t_off.data(), t_off.size() * sizeof(u64));
+    okc &= up(b->d_link_off.p, link_off.data(), link_off.size() * sizeof(u64));
+    okc &= up(b->d_link_cap.p, link_cap.data(), link_cap.size() * sizeof(u64));
+    okc &= up(b->d_seg_pile.p, seg_pile.data(), seg_pile.size() * sizeof(int));
+    okc &= up(b->d_seg_t0.p, seg_t0.data(), seg_t0.size() * sizeof(int));
+    okc &= up(b->d_pile.p, b->pile.data(), (size_t)b->n_pile * sizeof(FaPile));
+    if (!okc) {
+        set_err("falcon_amd: uploading the MSA plan failed");
+        return -1;
+    }
+    FaMsaDev md;
+    md.ta = b->d_ta.p; md.acc_first = b->d_acc_first.p; md.n_acc_total = (int)n_ta;
+    md.tcov = b->d_tcov.p; md.desc = b->d_desc.p; md.insb = b->d_insb.p; md.tarr = b->d_tarr.p;
+    md.tarr_bytes = tarr_ints * sizeof(int); md.t_off = b->d_t_off.p; md.tinfo = b->d_tinfo.p;
+    md.links = b->d_links.p; md.link_off = b->d_link_off.p; md.link_cap = b->d_link_cap.p;
+    md.lvl_nlink16 = b->d_lvl_nlink.p; md.score_ovf = b->d_score_ovf.p;
+    md.score_out = b->d_score_out.p; md.seg_pile = b->d_seg_pile.p; md.seg_t0 = b->d_seg_t0.p;
+    md.n_seg = (int)seg_pile.size();
+    md.wide_count = b->d_wide.p; md.wide_list = b->d_wide.p + 1;
     d = b->dev();
     HIP_OK(hipEventRecord(c->ev[4], s));
-    fa_launch_consensus(d, min_cov, d_list, n_list, s);
+    fa_launch_msa(d, md, min_cov, s);
     HIP_OK(hipEventRecord(c->ev[5], s));
     trace_stage(s, "consensus");
     HIP_OK(hipGetLastError());
@@ -530,7 +617,7 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     for (int p = 0; p < b->n_pile; p++) {
         if (b->h_pile_out[p].err) {
             set_err("falcon_amd: consensus of pile %d failed (code %d: %s)", p, b->h_pile_out[p].err,
-                    b->h_pile_out[p].err == 2 ? "more than 512 usable reads" : "node pool overflow");
+                    b->h_pile_out[p].err == 2 ? "more than 512 usable reads" : "MSA pool overflow");
             return -3;
         }
         sO += b->h_pile_out[p].len;

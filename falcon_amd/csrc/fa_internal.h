@@ -24,6 +24,7 @@
 
 typedef uint32_t u32;
 typedef uint64_t u64;
+typedef uint16_t u16;
 
 #define FA_K 8                 // k-mer size (consensus.py:270 hard-wires 8)
 #define FA_NKMER 65536         // 4^8
@@ -92,6 +93,29 @@ struct FaPileOut {
     long long g_best_h;
 };
 
+struct FaTagAln {   // one per accepted alignment, grouped by pile in read order (host-built)
+    u64 desc_off;   // offset of its tag words (2 x u32 per covered target position)
+    u32 ins_off;    // offset of its inserted-base bytes
+    int s2;         // first covered target position
+    int g;          // sequence index
+    int pile;
+    int pad;
+};
+
+struct FaTInfo {    // per target position of a pile (k_tscan)
+    u32 lvl_start;  // first level slot of the position (node id = slot * 5 + base)
+    u32 link_start; // first link word of the position
+    u16 cov;        // alignments covering it (falcon.c:357-360)
+    u16 nlev;       // 1 + deepest insertion level
+};
+
+struct FaScoreOut { // per pile
+    int g_node, g_ck, g_h;   // global best node, link index of its best link, its score
+    int n_levels;
+    int n_links;
+    int err;
+};
+
 // ---- launcher prototypes (each .hip file owns its kernels) ----
 struct FaBatchDev {
     // inputs
@@ -135,7 +159,29 @@ void fa_launch_align(const FaBatchDev &b, const FaAlignArena &a, int max_q_len, 
                      double max_diff, hipStream_t s);
 void fa_launch_align_band(const FaBatchDev &b, const FaAlignArena &a, int max_q_len,
                           int max_t_len, double max_diff, int band, hipStream_t s);
-void fa_launch_consensus(const FaBatchDev &b, unsigned min_cov, const int *const d_list[4],
-                         const int n_list[4], hipStream_t s);
+struct FaMsaDev {
+    const FaTagAln *ta;
+    const u32 *acc_first;
+    int n_acc_total;
+    int *tcov;
+    u32 *desc;
+    uint8_t *insb;
+    int *tarr;
+    size_t tarr_bytes;
+    const u64 *t_off;
+    FaTInfo *tinfo;
+    u32 *links;
+    const u64 *link_off;
+    const u64 *link_cap;
+    uint16_t *lvl_nlink16;
+    int *score_ovf;
+    FaScoreOut *score_out;
+    const int *seg_pile;
+    const int *seg_t0;
+    int n_seg;
+    int *wide_count;
+    int *wide_list;
+};
+void fa_launch_msa(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov, hipStream_t s);
 size_t fa_align_lds_bytes(int max_q_len, int max_t_len);
 int fa_align_blocks_per_cu(size_t lds_bytes);

@@ -1,0 +1,738 @@
+// k_msa.hip -- alignment tags -> MSA graph -> best path -> consensus.
+//
+// Restates get_align_tags() (src/c/falcon.c:106-162) and
+// get_cns_from_align_tags() (src/c/falcon.c:308-558).  The reference builds the
+// graph by inserting tags one at a time into a pointer tree and then scores it;
+// both are serial per pile.  Here the graph construction -- the bulk of the
+// work, and independent of the scores -- is data-parallel over alignments and
+// over target positions; only the score recurrence itself stays sequential,
+// and it is a few operations per link:
+//
+//   k_tags      one wavefront per accepted alignment.  Prefix scans over the
+//               edit script turn it into position-major tags: one 8-byte word
+//               per covered target position {deleted?, insertion-run length,
+//               up to 16 inserted bases inline} (longer runs spill to a byte
+//               array).  Also accumulates, per target position, the coverage
+//               (difference array), the deepest insertion level and the number
+//               of tags.  This is SURVEY.md's "8 B packed tag written once".
+//   k_tscan     one wavefront per pile: prefix sums over target positions ->
+//               level slot and link slot of every position (deterministic
+//               layout, node ids ascend in (t, delta) order).
+//   k_links     one wavefront per (pile, segment of 128 target positions):
+//               lanes = alignments overlapping the segment (compacted, in read
+//               order).  For every (t, delta) level the lanes holding the same
+//               (base, previous node) are one link of the reference
+//               (update_col, falcon.c:232-263): grouped with __ballot, group
+//               size = link count, groups visited in lowest-lane order = the
+//               reference's first-insertion order (Q5).  Emits one u32 per link.
+//   k_score     one LANE per pile: the score recurrence (falcon.c:405-475) over
+//               the link words, -1 floor, strict '>', first maximum; scores of
+//               the previous and current target position live in lane-private
+//               LDS; writes the 8-byte node records and the global best.
+//   k_backtrace one wavefront per pile: walks the node records through a
+//               64-level LDS window and writes the consensus right-aligned,
+//               64 characters per store (falcon.c:494-528, no reversal pass).
+//
+// Integer only; per-column reduction over aligned bases; no MFMA.
+#include "fa_device.h"
+
+#define TSEG 128       // target positions per k_links wavefront
+#define MAXACT 512     // alignments overlapping one segment
+#define INL 16         // inserted bases stored inline in a tag
+#define SC_LCAP 16     // insertion levels whose scores are kept in LDS by k_score
+#define BT_WIN 64      // levels per back-trace window
+
+#define TAG_DEL 0x40000000u
+#define TAG_NINS_SHIFT 22
+
+struct MsaArgs {
+    const u32 *words;
+    const FaSeq *seq;
+    const FaPile *pile;
+    const FaRange *range;
+    const FaAln *aln;
+    const u32 *script;
+    const u64 *script_off;
+    const FaTagAln *ta;        // accepted alignments, grouped by pile, read order
+    const u32 *acc_first;      // [n_pile + 1]
+    int n_acc_total;
+    int n_pile;
+    int *tcov;                 // [n_acc_total] covered target positions (k_tags)
+    u32 *desc;                 // 2 x u32 per covered target position
+    uint8_t *insb;             // inserted bases of runs longer than INL (and all others)
+    int *tarr;                 // per pile 3 x (T+1): cov diff, max ins, sum ins
+    const u64 *t_off;          // [n_pile] position offset of the pile's per-t arrays
+    FaTInfo *tinfo;            // per target position
+    u32 *links;                // link words
+    const u64 *link_off;       // [n_pile]
+    const u64 *link_cap;       // [n_pile]
+    uint8_t *lvl_nlink;        // per level slot: number of links (capped at 255 -> see k_links)
+    u16 *lvl_nlink16;          // same, 16 bit (the one that is read)
+    FaNode *nodes;
+    int *score_ovf;            // per pile 2 x 256 x 5 ints: scores of levels >= SC_LCAP
+    FaScoreOut *score_out;     // per pile
+    char *out_seq;
+    int *out_eqv;
+    FaPileOut *pile_out;
+    const int *seg_pile;       // k_links work list
+    const int *seg_t0;
+    int n_seg;
+    int *wide_count;           // k_links<1> -> k_links<8> hand-over
+    int *wide_list;
+    unsigned min_cov;
+};
+
+// ---------------------------------------------------------------------------
+// wave scans
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int wave_incl_sum(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_incl_max(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(v, off);
+        if (lane >= off) v = max(v, t);
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// k_tags
+// ---------------------------------------------------------------------------
+// Insertion depth (delta) of every row of a 64-row chunk.  Row d is an insertion
+// column iff its edit bit is 0; it continues the run of the previous column iff
+// row d-1 is an insertion with an empty snake.  carry_open = depth of the last
+// row of the previous chunk (0 if that row is not an insertion).
+__device__ __forceinline__ int chunk_delta(const u32 *scr, int d, int d0, bool is_ins, int lane,
+                                           int carry_open, bool &cont) {
+    const u32 ep = (d >= 2) ? scr[d - 1] : 1u;
+    cont = is_ins && d >= 2 && (ep & 1u) == 0u && (ep >> 1) == 0u;
+    int start = (is_ins && !cont) ? d : -1;
+    start = wave_incl_max(start, lane);
+    if (!is_ins) return 0;
+    return (start >= d0) ? (d - start + 1) : (carry_open + (d - d0) + 1);
+}
+
+__global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
+    const int lane = fa_lane();
+    const int k = blockIdx.x;
+    if (k >= A.n_acc_total) return;
+    const FaTagAln ta = A.ta[k];
+    const int g = ta.g;
+    const FaAln al = A.aln[g];
+    const FaRange rg = A.range[g];
+    const u32 *scr = A.script + A.script_off[g];
+    const u32 *rw = A.words + A.seq[g].woff;
+    u32 *desc = A.desc + 2 * ta.desc_off;
+    uint8_t *insb = A.insb + ta.ins_off;
+    int *tarr = A.tarr + 3 * (A.t_off[ta.pile] + (u64)ta.pile);  // (T+1) entries per array
+    const int T1 = A.pile[ta.pile].seed_len + 1;
+    int *a_cov = tarr, *a_max = tarr + T1, *a_sum = tarr + 2 * T1;
+    const int dist = al.dist, te = al.t_e;
+
+    for (int u = lane; u < 2 * te; u += 64) desc[u] = 0u;
+
+    // pre-pass: tagging stops at the first column whose insertion depth reaches
+    // 255 (falcon.c:138-152); dcut = that row (dist + 1 if none)
+    int dcut = dist + 1;
+    {
+        int carry_open = 0, first_bad = 0x7fffffff;
+        for (int d0 = 0; d0 <= dist; d0 += 64) {
+            const int d = d0 + lane;
+            const bool have = d <= dist;
+            const u32 e = have ? scr[d] : 1u;
+            const bool is_ins = have && d >= 1 && (e & 1u) == 0u;
+            bool cont;
+            const int delta = chunk_delta(scr, d, d0, is_ins, lane, carry_open, cont);
+            if (delta >= 255) first_bad = min(first_bad, d);
+            carry_open = __shfl(delta, 63);
+        }
+        first_bad = fa_wave_min(first_bad);
+        if (first_bad <= dist) dcut = first_bad;
+    }
+    __threadfence_block();
+
+    // main pass over rows 0 .. dlast
+    const int dlast = min(dist, dcut - 1);
+    int carry_t = 0, carry_q = rg.s1, carry_i = 0, carry_open = 0, carry_run_i = 0;
+    for (int d0 = 0; d0 <= dlast; d0 += 64) {
+        const int d = d0 + lane;
+        const bool have = d <= dlast;
+        const u32 e = have ? scr[d] : 1u;
+        const int m = have ? (int)(e >> 1) : 0;
+        const bool is_edit = have && d >= 1;
+        const bool is_del = is_edit && (e & 1u) != 0u;
+        const bool is_ins = is_edit && (e & 1u) == 0u;
+        const int tc = (is_del ? 1 : 0) + m, qc = (is_ins ? 1 : 0) + m;
+        const int ts = wave_incl_sum(tc, lane), qs = wave_incl_sum(qc, lane);
+        const int is = wave_incl_sum(is_ins ? 1 : 0, lane);
+        const int tpos = carry_t + ts - tc;     // target index of this row's edit
+        const int qpos = carry_q + qs - qc;     // query index of this row's inserted base
+        const int iidx = carry_i + is - (is_ins ? 1 : 0);
+        bool cont;
+        const int delta = chunk_delta(scr, d, d0, is_ins, lane, carry_open, cont);
+        // index (in the alignment's insertion list) of the first base of my run
+        const int run_i = is_ins ? ((delta - 1 <= d - d0) ? iidx - (delta - 1) : carry_run_i) : 0;
+        // the run ends here unless the next row continues it
+        const u32 en = (d + 1 <= dlast) ? scr[d + 1] : 1u;
+        const bool ends = is_ins && (m > 0 || (en & 1u) != 0u);
+        if (is_del) atomicOr(&desc[2 * tpos + 1], TAG_DEL);
+        if (is_ins) {
+            const int us = tpos - 1;  // the target position the run hangs off
+            const u32 b = fa_base_at(rw, qpos);
+            insb[iidx] = (uint8_t)b;
+            if (delta <= INL) atomicOr(&desc[2 * us], b << (2 * (delta - 1)));
+            if (!cont) atomicOr(&desc[2 * us + 1], (u32)run_i & 0x3fffffu);
+            if (ends) {
+                atomicOr(&desc[2 * us + 1], (u32)delta << TAG_NINS_SHIFT);
+                atomicMax(&a_max[rg.s2 + us], delta);
+                atomicAdd(&a_sum[rg.s2 + us], delta);
+            }
+        }
+        carry_t += __shfl(ts, 63);
+        carry_q += __shfl(qs, 63);
+        carry_i += __shfl(is, 63);
+        carry_open = __shfl(delta, 63);
+        carry_run_i = __shfl(run_i, 63);
+    }
+    // rows >= dcut are dropped: the alignment covers only what the kept rows consumed
+    const int t_cov = (dcut <= dist) ? carry_t : te;
+    if (lane == 0) {
+        A.tcov[k] = t_cov;
+        atomicAdd(&a_cov[rg.s2], 1);
+        atomicAdd(&a_cov[rg.s2 + t_cov], -1);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_tscan: per pile prefix sums over target positions
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_tscan(MsaArgs A) {
+    const int lane = fa_lane();
+    const int p = blockIdx.x;
+    if (p >= A.n_pile) return;
+    const FaPile pm = A.pile[p];
+    const int T = pm.seed_len, T1 = T + 1;
+    const int *tarr = A.tarr + 3 * (A.t_off[p] + (u64)p);
+    const int *a_cov = tarr, *a_max = tarr + T1, *a_sum = tarr + 2 * T1;
+    FaTInfo *ti = A.tinfo + A.t_off[p];
+    int c_cov = 0;
+    u32 c_lvl = 0, c_link = 0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        const bool have = t < T;
+        const int cd = have ? a_cov[t] : 0;
+        const int cov = c_cov + wave_incl_sum(cd, lane);
+        int nlev = 0, parts = 0;
+        if (have) {
+            nlev = cov > 0 ? 1 + a_max[t] : (t == 0 ? 1 : 0);  // slot 0 is always (t=0, delta=0)
+            parts = cov > 0 ? cov + a_sum[t] : 0;
+        }
+        const int ls = wave_incl_sum(nlev, lane), ps = wave_incl_sum(parts, lane);
+        if (have) {
+            FaTInfo x;
+            x.lvl_start = c_lvl + (u32)(ls - nlev);
+            x.link_start = c_link + (u32)(ps - parts);
+            x.cov = (u16)min(cov, 65535);
+            x.nlev = (u16)nlev;
+            ti[t] = x;
+        }
+        c_cov = __shfl(cov, 63);
+        c_lvl += (u32)__shfl(ls, 63);
+        c_link += (u32)__shfl(ps, 63);
+    }
+    FaScoreOut so;
+    so.g_node = -1; so.g_ck = 0; so.g_h = -2;
+    so.n_levels = (int)c_lvl;
+    so.n_links = (int)c_link;
+    so.err = ((u64)c_lvl * 5 > pm.node_cap || (u64)c_link > A.link_cap[p]) ? 1 : 0;
+    A.score_out[p] = so;  // every lane stores the same record
+}
+
+// ---------------------------------------------------------------------------
+// k_links
+// ---------------------------------------------------------------------------
+// tag word accessors
+__device__ __forceinline__ int tag_nins(u32 hi) { return (int)((hi >> TAG_NINS_SHIFT) & 0xffu); }
+__device__ __forceinline__ int tag_ins_base(const MsaArgs &A, const FaTagAln &ta, u32 lo, u32 hi,
+                                            int delta /* 1-based */) {
+    if (delta <= INL) return (int)((lo >> (2 * (delta - 1))) & 3u);
+    return (int)A.insb[ta.ins_off + (hi & 0x3fffffu) + (u32)(delta - 1)];
+}
+
+// NCHT = 1: segments overlapped by <= 64 alignments (the normal case below 64x
+// coverage); wider segments put themselves on a to-do list that the NCHT = 8
+// instance works off in a second launch (no host round trip).
+template <int NCHT>
+__global__ __launch_bounds__(64) void k_links(MsaArgs A) {
+    __shared__ int act[MAXACT];
+    const int lane = fa_lane();
+    int sidx = blockIdx.x;
+    if (NCHT > 1) {
+        if (sidx >= A.wide_count[0]) return;
+        sidx = A.wide_list[sidx];
+    }
+    if (sidx >= A.n_seg) return;
+    const int p = __builtin_amdgcn_readfirstlane(A.seg_pile[sidx]);
+    const int t_lo = __builtin_amdgcn_readfirstlane(A.seg_t0[sidx]);
+    const FaPile pm = A.pile[p];
+    const int T = pm.seed_len;
+    const int t_hi = min(T, t_lo + TSEG);
+    const u32 *seedw = A.words + A.seq[pm.first].woff;
+    const FaTInfo *ti = A.tinfo + A.t_off[p];
+    u32 *links = A.links + A.link_off[p];
+    u16 *nlk = A.lvl_nlink16 + pm.node_off / 5;
+    if (A.score_out[p].err) return;
+
+    // alignments of the pile overlapping [t_lo, t_hi), compacted in read order
+    const u32 a0 = A.acc_first[p], a1 = A.acc_first[p + 1];
+    int n_act = 0;
+    for (u32 i0 = a0; i0 < a1; i0 += 64) {
+        const u32 i = i0 + lane;
+        bool ov = false;
+        if (i < a1) {
+            const int s2 = A.ta[i].s2, tc = A.tcov[i];
+            ov = s2 < t_hi && s2 + tc > t_lo;
+        }
+        const u64 m = __ballot(ov);
+        const int rank = __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+        if (ov && n_act + rank < MAXACT) act[n_act + rank] = (int)i;
+        n_act += __popcll(m);
+    }
+    __syncthreads();
+    if (n_act > MAXACT) {  // cannot happen: <= 512 accepted alignments per pile
+        if (lane == 0) A.score_out[p].err = 2;
+        return;
+    }
+    const int nch = (n_act + 63) >> 6;
+    if (nch > NCHT) {  // too wide for this instance: defer
+        if (lane == 0) A.wide_list[atomicAdd(A.wide_count, 1)] = sidx;
+        return;
+    }
+
+    // per-chunk lane state
+    int s2v[NCHT], tcv[NCHT];
+    const u32 *dptr[NCHT];
+    FaTagAln tav[NCHT];
+#pragma unroll
+    for (int c = 0; c < NCHT; c++) {
+        s2v[c] = 0x7fffffff; tcv[c] = 0; dptr[c] = A.desc;
+        tav[c].desc_off = 0; tav[c].ins_off = 0; tav[c].s2 = 0; tav[c].g = 0; tav[c].pile = 0;
+        tav[c].pad = 0;
+        const int a = c * 64 + lane;
+        if (c < nch && a < n_act) {
+            const int i = act[a];
+            tav[c] = A.ta[i];
+            s2v[c] = tav[c].s2;
+            tcv[c] = A.tcov[i];
+            dptr[c] = A.desc + 2 * tav[c].desc_off;
+        }
+    }
+
+    for (int t = t_lo; t < t_hi; t++) {
+        const FaTInfo x = ti[t];
+        if (x.cov == 0) continue;
+        const int sb = (int)fa_base_at(seedw, t);
+        const int sbp = t > 0 ? (int)fa_base_at(seedw, t - 1) : 0;
+        u32 out = x.link_start;
+        // tag words of the lanes covering t
+        bool covd[NCHT];
+        u32 wlo[NCHT], whi[NCHT];
+        int nins[NCHT], base0[NCHT];
+#pragma unroll
+        for (int c = 0; c < NCHT; c++) {
+            covd[c] = false; wlo[c] = 0; whi[c] = 0; nins[c] = 0; base0[c] = 0;
+            if (c < nch) {
+                const int u = t - s2v[c];
+                covd[c] = u >= 0 && u < tcv[c];
+                if (covd[c]) {
+                    wlo[c] = dptr[c][2 * u];
+                    whi[c] = dptr[c][2 * u + 1];
+                    nins[c] = tag_nins(whi[c]);
+                    base0[c] = (whi[c] & TAG_DEL) ? 4 : sb;
+                }
+            }
+        }
+        for (int dl = 0; dl < (int)x.nlev; dl++) {
+            // key of every participating lane: node base | prev base << 3 | prev delta << 6 | start << 14
+            bool part[NCHT];
+            int key[NCHT];
+#pragma unroll
+            for (int c = 0; c < NCHT; c++) {
+                part[c] = false; key[c] = 0;
+                if (c < nch) {
+                    if (dl == 0) {
+                        part[c] = covd[c];
+                        if (part[c]) {
+                            const int u = t - s2v[c];
+                            if (u == 0) {
+                                key[c] = base0[c] | (5 << 3) | (1 << 14);  // first column: no predecessor
+                            } else {
+                                const u32 plo = dptr[c][2 * (u - 1)], phi = dptr[c][2 * (u - 1) + 1];
+                                const int pn = tag_nins(phi);
+                                const int pb = pn > 0 ? tag_ins_base(A, tav[c], plo, phi, pn)
+                                                      : ((phi & TAG_DEL) ? 4 : sbp);
+                                key[c] = base0[c] | (pb << 3) | (pn << 6);
+                            }
+                        }
+                    } else {
+                        part[c] = covd[c] && nins[c] >= dl;
+                        if (part[c]) {
+                            const int b = tag_ins_base(A, tav[c], wlo[c], whi[c], dl);
+                            const int pb = dl == 1 ? base0[c]
+                                                   : tag_ins_base(A, tav[c], wlo[c], whi[c], dl - 1);
+                            key[c] = b | (pb << 3) | ((dl - 1) << 6);
+                        }
+                    }
+                }
+            }
+            u64 rem[NCHT];
+#pragma unroll
+            for (int c = 0; c < NCHT; c++) rem[c] = (c < nch) ? __ballot(part[c]) : 0ull;
+            int n_link = 0;
+            u32 myw = 0;            // lane i keeps link i of the level (first 64)
+            bool spilled = false;   // more than 64 links: written in visiting order
+            for (;;) {
+                int c0 = -1;
+#pragma unroll
+                for (int c = NCHT - 1; c >= 0; c--)
+                    if (rem[c]) c0 = c;
+                if (c0 < 0) break;
+                int kk = 0;
+#pragma unroll
+                for (int c = 0; c < NCHT; c++)
+                    if (c == c0) kk = __builtin_amdgcn_readlane(key[c], __ffsll((long long)rem[c]) - 1);
+                int cnt = 0;
+#pragma unroll
+                for (int c = 0; c < NCHT; c++) {
+                    if (c < nch) {
+                        const u64 m = __ballot(part[c] && key[c] == kk);
+                        cnt += __popcll(m);
+                        rem[c] &= ~m;
+                    }
+                }
+                // link word: count | node base << 10 | prev score index (delta*5+base) << 13 | start << 24
+                const u32 pidx = (u32)((kk >> 6) & 0xff) * 5u + (u32)((kk >> 3) & 7);
+                const bool st = (kk >> 14) & 1;
+                const u32 w = (u32)cnt | ((u32)(kk & 7) << 10) | ((st ? 0u : pidx) << 13) |
+                              ((u32)(st ? 1 : 0) << 24);
+                if (n_link < 64) {
+                    if (lane == n_link) myw = w;
+                } else {
+                    if (!spilled) {  // flush the 64 collected links unsorted
+                        links[out + (u32)lane] = myw;
+                        spilled = true;
+                    }
+                    links[out + (u32)n_link] = w;  // every lane stores the same word
+                }
+                n_link++;
+            }
+            if (!spilled) {
+                // stable node-major order + head flags: k_score reduces every node of the
+                // level with one segmented scan (links of a node stay in visiting order)
+                const bool have = lane < n_link;
+                const int nbv = have ? (int)((myw >> 10) & 7u) : 7;
+                int pos = 0, base_off = 0;
+                bool head = false;
+#pragma unroll
+                for (int b = 0; b < 5; b++) {
+                    const u64 mb = __ballot(nbv == b);
+                    if (nbv == b) {
+                        const u64 below = mb & ((lane == 0) ? 0ull : (~0ull >> (64 - lane)));
+                        pos = base_off + __popcll(below);
+                        head = below == 0ull;
+                    }
+                    base_off += __popcll(mb);
+                }
+                if (have) links[out + (u32)pos] = myw | (head ? (1u << 25) : 0u);
+            }
+            out += (u32)n_link;
+            nlk[x.lvl_start + (u32)dl] = (u16)(n_link | (spilled ? 0x8000 : 0));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_score: one wavefront per pile.  Blocks of target positions are staged in
+// LDS (position records, link counts, link words: three coalesced bursts), then
+// every (t, delta) level is scored with lanes = links: one LDS gather for the
+// previous-node scores, the per-node maximum resolved over the node's lanes in
+// link order (strict '>', first maximum, falcon.c:447).
+// ---------------------------------------------------------------------------
+#define SC_TB 64          // target positions per block
+#define SC_LINKS 2048     // link words staged per block
+#define SC_LEVELS 160     // levels (link counts in, node records out) staged per block
+
+__global__ __launch_bounds__(64) void k_score(MsaArgs A) {
+    __shared__ u32 s_links[SC_LINKS];
+    __shared__ u16 s_nlk[SC_LEVELS];
+    __shared__ FaTInfo s_ti[SC_TB];
+    __shared__ int s_sc[2][256 * 5];   // node scores of the previous / current target position
+    __shared__ uint2 s_node[SC_LEVELS * 5];  // node records of the block, flushed coalesced
+    const int lane = fa_lane();
+    const int p = blockIdx.x;
+    if (p >= A.n_pile) return;
+    const FaPile pm = A.pile[p];
+    FaScoreOut so = A.score_out[p];
+    if (so.err) return;
+    const int T = pm.seed_len;
+    const FaTInfo *ti = A.tinfo + A.t_off[p];
+    const u32 *links = A.links + A.link_off[p];
+    const u16 *nlk = A.lvl_nlink16 + pm.node_off / 5;
+    FaNode *nodes = A.nodes + pm.node_off;
+    const int min_cov = (int)A.min_cov;
+
+    int g_h = -2, g_node = -1, g_ck = 0;
+    int cur = 0;        // which half of s_sc holds the position being scored
+    int prev_t = -2;    // last scored target position
+    u32 prev_lvl = 0;   // its first level slot
+    if (ti[0].cov == 0 && lane < 5) {
+        // slot 0 = (t 0, delta 0): absent nodes, target of the zero back pointer (Q4)
+        FaNode nd;
+        nd.score_h = -2;
+        nd.link = (0 + 1) << 1;
+        nodes[lane] = nd;
+    }
+    int t0 = 0;
+    while (t0 < T) {
+        // ---- stage a block of positions: as many (<= 63) as fit the LDS budgets.
+        // Lane j holds position t0+j; a block of length j ends where position t0+j
+        // starts (or at the pile totals), so lane j can judge whether length j fits.
+        __syncthreads();
+        const int tl = t0 + lane;
+        FaTInfo x;
+        x.lvl_start = 0; x.link_start = 0; x.cov = 0; x.nlev = 0;
+        if (tl < T) x = ti[tl];
+        s_ti[lane] = x;
+        const u32 lvl0 = (u32)__shfl((int)x.lvl_start, 0), lnk0 = (u32)__shfl((int)x.link_start, 0);
+        const u32 end_l = (tl < T) ? x.lvl_start : (u32)so.n_levels;
+        const u32 end_k = (tl < T) ? x.link_start : (u32)so.n_links;
+        const bool fits = lane >= 1 && tl <= T && (end_l - lvl0) <= SC_LEVELS &&
+                          (end_k - lnk0) <= SC_LINKS;
+        int nb = __popcll(__ballot(fits));  // prefix sums are monotone, so is `fits`
+        const bool bulk = nb > 0;
+        if (!bulk) nb = 1;  // one oversized position: read it straight from HBM
+        if (bulk) {
+            const u32 n_l = (u32)__shfl((int)end_l, nb) - lvl0, n_k = (u32)__shfl((int)end_k, nb) - lnk0;
+            for (u32 i = lane; i < n_l; i += 64) s_nlk[i] = nlk[lvl0 + i];
+            for (u32 i = lane; i < n_k; i += 64) s_links[i] = links[lnk0 + i];
+            // slot 0 of an uncovered position 0 stays "absent" (it is flushed with the block)
+            if (t0 == 0 && lane < 5 && (u32)__shfl((int)x.cov, 0) == 0u)
+                s_node[lane] = make_uint2((u32)-2, (u32)((0 + 1) << 1));
+        }
+        __syncthreads();
+
+        for (int j = 0; j < nb; j++) {
+            const int t = t0 + j;
+            const FaTInfo y = s_ti[j];
+            if (y.cov == 0) continue;
+            const int cov = (int)y.cov;
+            const int upper = cov > min_cov ? 1 : 0;  // falcon.c:498 (Q7)
+            const bool adjacent = (prev_t == t - 1);
+            cur ^= 1;
+            u32 lk = y.link_start;
+            for (int dl = 0; dl < (int)y.nlev; dl++) {
+                const u32 slot = y.lvl_start + (u32)dl;
+                int nl_raw;
+                if (bulk) nl_raw = (int)s_nlk[slot - lvl0]; else nl_raw = (int)nlk[slot];
+                const int n_link = nl_raw & 0x7fff;
+                const bool sorted = (nl_raw & 0x8000) == 0;
+                const u32 plvl5 = (dl == 0 ? prev_lvl : y.lvl_start) * 5u;  // node id = plvl5 + pidx
+                // lanes 0..4 are the accumulators of the five nodes of the level
+                int acc_h = -2, acc_p = 0, acc_n = 0, acc_k = 0;
+                for (int c0 = 0; c0 < n_link; c0 += 64) {
+                    const int i = c0 + lane;
+                    const bool have = i < n_link;
+                    u32 w = 0;
+                    if (have) { if (bulk) w = s_links[lk - lnk0 + (u32)i]; else w = links[lk + (u32)i]; }
+                    const int cnt = (int)(w & 0x3ffu), nbase = (int)((w >> 10) & 7u);
+                    const int pidx = (int)((w >> 13) & 0x7ffu);
+                    const bool start = (w >> 24) & 1u;
+                    int ph = 0, pid = -1;
+                    if (have && !start) {
+                        const int which = (dl == 0) ? (cur ^ 1) : cur;
+                        ph = s_sc[which][pidx];
+                        if (dl == 0 && !adjacent) ph = -2;
+                        pid = (int)(plvl5 + (u32)pidx);
+                    }
+                    const int h = ph + 2 * cnt - cov;  // falcon.c:440-445, half units
+                    // the links in visiting order; node nb's accumulator lives in lane nb
+                    const int n_here = min(64, n_link - c0);
+                    for (int l = 0; l < n_here; l++) {
+                        const int nb_l = __builtin_amdgcn_readlane(nbase, l);
+                        const int h_l = __builtin_amdgcn_readlane(h, l);
+                        const int p_l = __builtin_amdgcn_readlane(pid, l);
+                        const bool mine = lane == nb_l;
+                        const bool better = mine && h_l > acc_h;  // strict: first maximum (:447)
+                        acc_h = better ? h_l : acc_h;
+                        acc_p = better ? p_l : acc_p;
+                        acc_k = better ? acc_n : acc_k;
+                        acc_n += mine ? 1 : 0;
+                    }
+                }
+                (void)sorted;
+                lk += (u32)n_link;
+                // publish the five nodes of the level
+                if (lane < 5) {
+                    s_sc[cur][dl * 5 + lane] = acc_h;
+                    const uint2 rec = make_uint2((u32)acc_h, (u32)(((acc_p + 1) << 1) | upper));
+                    if (bulk) {
+                        s_node[(slot - lvl0) * 5u + (u32)lane] = rec;
+                    } else {
+                        FaNode nd;
+                        nd.score_h = (int)rec.x;
+                        nd.link = (int)rec.y;
+                        nodes[slot * 5u + (u32)lane] = nd;
+                    }
+                }
+                if (__ballot(lane < 5 && acc_h > g_h)) {  // falcon.c:464-469, nodes in base order
+#pragma unroll
+                    for (int bq = 0; bq < 5; bq++) {
+                        const int hv = __builtin_amdgcn_readlane(acc_h, bq);
+                        if (hv > g_h) {
+                            g_h = hv;
+                            g_node = (int)(slot * 5u + (u32)bq);
+                            g_ck = __builtin_amdgcn_readlane(acc_k, bq);
+                        }
+                    }
+                }
+                // scores of this level are read by the next one: one wave, LDS is in order;
+                // only stop the compiler from moving LDS traffic across (a __syncthreads()
+                // here would also wait for the node stores, ~1 us per level)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            prev_t = t;
+            prev_lvl = y.lvl_start;
+        }
+        if (bulk) {  // one coalesced burst for the node records of the block
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const u32 n_rec = ((u32)__shfl((int)end_l, nb) - lvl0) * 5u;
+            uint2 *dst = reinterpret_cast<uint2 *>(nodes + (u64)lvl0 * 5u);
+            for (u32 i = lane; i < n_rec; i += 64) dst[i] = s_node[i];
+        }
+        t0 += nb;
+    }
+    so.g_h = g_h;
+    so.g_node = g_node;
+    so.g_ck = g_ck;
+    A.score_out[p] = so;  // every lane stores the same record
+}
+
+// ---------------------------------------------------------------------------
+// k_backtrace: one wavefront per pile (falcon.c:494-528)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_backtrace(MsaArgs A) {
+    __shared__ u32 win[2 * 5 * BT_WIN];
+    const int lane = fa_lane();
+    const int p = blockIdx.x;
+    if (p >= A.n_pile) return;
+    const FaPile pm = A.pile[p];
+    const FaScoreOut so = A.score_out[p];
+    const int T = pm.seed_len;
+    const FaNode *nodes = A.nodes + pm.node_off;
+    FaPileOut po;
+    po.len = 0; po.start = 2 * T;
+    po.n_aligned = (int)(A.acc_first[p + 1] - A.acc_first[p]);
+    po.err = so.err;
+    po.g_best_h = so.g_h;
+    if (!so.err && so.g_node >= 0 && po.n_aligned > 0) {
+        char *oseq = A.out_seq + pm.out_off;
+        int *oeqv = A.out_eqv + pm.out_off;
+        const unsigned lim = (unsigned)T * 2u;
+        unsigned index = 0;
+        int ck = so.g_ck;
+        char bb = '$';
+        int win_lo = -1, win_hi = -2;  // node-id range [win_lo, win_hi] resident in LDS
+        auto fetch = [&](int node) -> FaNode {
+            if (node < win_lo || node > win_hi) {
+                const int lvl_hi = node / 5;
+                const int lvl_lo = max(0, lvl_hi - (BT_WIN - 1));
+                win_lo = lvl_lo * 5;
+                win_hi = lvl_hi * 5 + 4;
+                const int n_rec = win_hi - win_lo + 1;
+                __syncthreads();
+                const uint2 *src = reinterpret_cast<const uint2 *>(nodes + win_lo);
+                for (int i = lane; i < n_rec; i += 64) {
+                    const uint2 v = src[i];
+                    win[2 * i] = v.x;
+                    win[2 * i + 1] = v.y;
+                }
+                __syncthreads();
+            }
+            FaNode r;
+            r.score_h = (int)win[2 * (node - win_lo)];
+            r.link = (int)win[2 * (node - win_lo) + 1];
+            return r;
+        };
+        FaNode rec = fetch(so.g_node);
+        int out_c = 0, out_e = 0;  // lane (index & 63) holds character `index`
+        for (;;) {
+            const int up = rec.link & 1;
+            switch (ck) {
+            case 0: bb = up ? 'A' : 'a'; break;
+            case 1: bb = up ? 'C' : 'c'; break;
+            case 2: bb = up ? 'G' : 'g'; break;
+            case 3: bb = up ? 'T' : 't'; break;
+            case 4: bb = '-'; break;
+            default: break;  // a link index >= 5 keeps the previous character (Q2)
+            }
+            const int score0 = rec.score_h;
+            const int prev = (rec.link >> 1) - 1;
+            if (prev == -1 || index >= lim) break;  // :517-519 (Q1)
+            ck = prev % 5;
+            rec = fetch(prev);
+            if (bb != '-') {
+                if (lane == (int)(index & 63u)) {
+                    out_c = bb;
+                    out_e = score0 / 2 - rec.score_h / 2;  // (int) truncations (Q6)
+                }
+                index++;
+                if ((index & 63u) == 0u) {  // 64 characters ready: one coalesced store
+                    const unsigned pos = lim - 1u - (index - 64u + (unsigned)lane);
+                    oseq[pos] = (char)out_c;
+                    oeqv[pos] = out_e;
+                }
+            }
+        }
+        if ((index & 63u) != 0u && lane < (int)(index & 63u)) {
+            const unsigned pos = lim - 1u - ((index & ~63u) + (unsigned)lane);
+            oseq[pos] = (char)out_c;
+            oeqv[pos] = out_e;
+        }
+        po.len = (int)index;
+        po.start = (int)(lim - index);
+    }
+    A.pile_out[p] = po;  // every lane stores the same record
+}
+
+// ---------------------------------------------------------------------------
+void fa_launch_msa(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov, hipStream_t s) {
+    if (b.n_pile == 0) return;
+    MsaArgs A;
+    A.words = b.words; A.seq = b.seq; A.pile = b.pile; A.range = b.range; A.aln = b.aln;
+    A.script = b.script; A.script_off = b.script_off;
+    A.ta = m.ta; A.acc_first = m.acc_first; A.n_acc_total = m.n_acc_total; A.n_pile = b.n_pile;
+    A.tcov = m.tcov; A.desc = m.desc; A.insb = m.insb; A.tarr = m.tarr; A.t_off = m.t_off;
+    A.tinfo = m.tinfo; A.links = m.links; A.link_off = m.link_off; A.link_cap = m.link_cap;
+    A.lvl_nlink = nullptr; A.lvl_nlink16 = m.lvl_nlink16; A.nodes = b.nodes;
+    A.score_ovf = m.score_ovf; A.score_out = m.score_out;
+    A.out_seq = b.out_seq; A.out_eqv = b.out_eqv; A.pile_out = b.pile_out;
+    A.seg_pile = m.seg_pile; A.seg_t0 = m.seg_t0; A.n_seg = m.n_seg; A.min_cov = min_cov;
+    A.wide_count = m.wide_count; A.wide_list = m.wide_list;
+    (void)hipMemsetAsync(m.tarr, 0, m.tarr_bytes, s);
+    if (m.n_acc_total > 0) hipLaunchKernelGGL(k_tags, dim3(m.n_acc_total), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(k_tscan, dim3(b.n_pile), dim3(64), 0, s, A);
+    if (m.n_seg > 0) {
+        (void)hipMemsetAsync(m.wide_count, 0, sizeof(int), s);
+        hipLaunchKernelGGL(k_links<1>, dim3(m.n_seg), dim3(64), 0, s, A);
+        hipLaunchKernelGGL(k_links<8>, dim3(m.n_seg), dim3(64), 0, s, A);
+    }
+    hipLaunchKernelGGL(k_score, dim3(b.n_pile), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(k_backtrace, dim3(b.n_pile), dim3(64), 0, s, A);
+}
