@@ -85,20 +85,28 @@ struct MsaArgs {
 // ---------------------------------------------------------------------------
 // wave scans
 // ---------------------------------------------------------------------------
+// DPP inclusive scans over the 64 lanes: Kogge-Stone inside each row of 16
+// (row_shr 1,2,4,8), then row_bcast15 / row_bcast31 carry the row totals across
+// (gfx9 DPP controls).  ~12 VALU, no LDS crossbar traffic.
 __device__ __forceinline__ int wave_incl_sum(int v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(v, off);
-        if (lane >= off) v += t;
-    }
+    (void)lane;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
     return v;
 }
 __device__ __forceinline__ int wave_incl_max(int v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(v, off);
-        if (lane >= off) v = max(v, t);
-    }
+    (void)lane;
+    const int lowest = -0x7fffffff - 1;
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(lowest, v, 0x143, 0xc, 0xf, false));
     return v;
 }
 
@@ -466,14 +474,15 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
 // link order (strict '>', first maximum, falcon.c:447).
 // ---------------------------------------------------------------------------
 #define SC_TB 64          // target positions per block
-#define SC_LINKS 2048     // link words staged per block
-#define SC_LEVELS 160     // levels (link counts in, node records out) staged per block
+#define SC_LINKS 1280     // link words staged per block
+#define SC_LEVELS 128     // levels (link counts in, node records out) staged per block
+#define SC_RES 32         // insertion levels per position whose scores stay in LDS
 
 __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
     __shared__ u32 s_links[SC_LINKS];
     __shared__ u16 s_nlk[SC_LEVELS];
     __shared__ FaTInfo s_ti[SC_TB];
-    __shared__ int s_sc[2][256 * 5];   // node scores of the previous / current target position
+    __shared__ int s_sc[2][SC_RES * 5];  // node scores of the previous / current target position
     __shared__ uint2 s_node[SC_LEVELS * 5];  // node records of the block, flushed coalesced
     const int lane = fa_lane();
     const int p = blockIdx.x;
@@ -487,8 +496,11 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
     const u16 *nlk = A.lvl_nlink16 + pm.node_off / 5;
     FaNode *nodes = A.nodes + pm.node_off;
     const int min_cov = (int)A.min_cov;
+    int *ovf = A.score_ovf + (u64)p * (2 * 256 * 5);  // scores of levels >= SC_RES (rare)
 
-    int g_h = -2, g_node = -1, g_ck = 0;
+    // every node lane (0..4) tracks the best node it has produced; the five are
+    // merged at the end in (level, base) order, which is the reference's scan order
+    int gl_h = -2, gl_slot = 0, gl_ck = 0;
     int cur = 0;        // which half of s_sc holds the position being scored
     int prev_t = -2;    // last scored target position
     u32 prev_lvl = 0;   // its first level slot
@@ -557,7 +569,8 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                     int ph = 0, pid = -1;
                     if (have && !start) {
                         const int which = (dl == 0) ? (cur ^ 1) : cur;
-                        ph = s_sc[which][pidx];
+                        if (pidx < SC_RES * 5) ph = s_sc[which][pidx];
+                        else ph = ovf[which * 1280 + pidx];
                         if (dl == 0 && !adjacent) ph = -2;
                         pid = (int)(plvl5 + (u32)pidx);
                     }
@@ -580,7 +593,13 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                 lk += (u32)n_link;
                 // publish the five nodes of the level
                 if (lane < 5) {
-                    s_sc[cur][dl * 5 + lane] = acc_h;
+                    if (dl < SC_RES) s_sc[cur][dl * 5 + lane] = acc_h;
+                    else { ovf[cur * 1280 + dl * 5 + lane] = acc_h; __threadfence_block(); }
+                    if (acc_h > gl_h) {  // strict: the lane's first maximum
+                        gl_h = acc_h;
+                        gl_slot = (int)slot;
+                        gl_ck = acc_k;
+                    }
                     const uint2 rec = make_uint2((u32)acc_h, (u32)(((acc_p + 1) << 1) | upper));
                     if (bulk) {
                         s_node[(slot - lvl0) * 5u + (u32)lane] = rec;
@@ -589,17 +608,6 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                         nd.score_h = (int)rec.x;
                         nd.link = (int)rec.y;
                         nodes[slot * 5u + (u32)lane] = nd;
-                    }
-                }
-                if (__ballot(lane < 5 && acc_h > g_h)) {  // falcon.c:464-469, nodes in base order
-#pragma unroll
-                    for (int bq = 0; bq < 5; bq++) {
-                        const int hv = __builtin_amdgcn_readlane(acc_h, bq);
-                        if (hv > g_h) {
-                            g_h = hv;
-                            g_node = (int)(slot * 5u + (u32)bq);
-                            g_ck = __builtin_amdgcn_readlane(acc_k, bq);
-                        }
                     }
                 }
                 // scores of this level are read by the next one: one wave, LDS is in order;
@@ -617,6 +625,20 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
             for (u32 i = lane; i < n_rec; i += 64) dst[i] = s_node[i];
         }
         t0 += nb;
+    }
+    // global best = first strict maximum in (t, delta, base) order (falcon.c:464-469):
+    // the highest score; among equals the lowest level slot, then the lowest base
+    int g_h = -2, g_node = -1, g_ck = 0, g_slot = 0x7fffffff;
+#pragma unroll
+    for (int bq = 0; bq < 5; bq++) {
+        const int hv = __builtin_amdgcn_readlane(gl_h, bq);
+        const int sv = __builtin_amdgcn_readlane(gl_slot, bq);
+        if (hv > g_h || (hv == g_h && hv > -2 && sv < g_slot)) {
+            g_h = hv;
+            g_slot = sv;
+            g_node = sv * 5 + bq;
+            g_ck = __builtin_amdgcn_readlane(gl_ck, bq);
+        }
     }
     so.g_h = g_h;
     so.g_node = g_node;
