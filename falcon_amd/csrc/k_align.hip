@@ -227,6 +227,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
     // plain loops (the row loop must stay a simple loop: the scalar unit is the
     // bottleneck of this kernel).
     const int REG_MAX_N = 60;
+    const int nmax = min(REG_MAX_N, band + 1);
     int kbase = -62;       // diagonal 0 sits on lane 31
     int lo = 31;           // lane of min_k in register mode
     int vreg = 0;          // reference: calloc'ed V (:153)
@@ -236,18 +237,19 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
     while (!done && !dead) {
         // ================= register-mode rows =================
         for (;;) {
-            if (d >= max_d || n - 1 > band) { dead = true; break; }  // :183-184
-            if (n > REG_MAX_N) break;
-            const int par = d & 1;
-            int hi = lo + n - 1;
-            if (lo < 1 || hi > 62) {  // re-centre the band inside the wave
-                const int nlo = (64 - n) >> 1;
-                const int sh = lo - nlo;  // new lane l takes old lane l + sh
+            // one sign test covers the four rare events: rows exhausted (:183), band too
+            // wide (:184), row too wide for register mode, band drifting out of the wave
+            if (((max_d - 1 - d) | (nmax - n) | (lo - 1) | (63 - lo - n)) < 0) {
+                if (d >= max_d || n - 1 > band) { dead = true; break; }
+                if (n > REG_MAX_N) break;
+                const int nlo = (64 - n) >> 1;  // re-centre the band inside the wave
+                const int sh = lo - nlo;        // new lane l takes old lane l + sh
                 vreg = __shfl(vreg, lane + sh);
                 kbase += 2 * sh;
                 lo = nlo;
-                hi = lo + n - 1;
             }
+            const int par = d & 1;
+            const int hi = lo + n - 1;
             PROF(0);
             const bool act = lane >= lo && lane <= hi;
             const int k = kbase + 2 * lane + par;
@@ -279,6 +281,8 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
                 done = true;
                 break;
             }
+            // (an LDS ds_max on one word instead of the DPP reduction was measured 2x
+            // slower: 64 same-address atomics serialise)
             const int u = act ? x + y : -1;
             best_m = max(best_m, fa_wave_max(u));
             const u64 in = __ballot(u >= best_m - band && u >= 0);  // :228-243
@@ -538,11 +542,11 @@ static bool seq_in_lds() {
 }
 
 size_t fa_align_lds_bytes(int max_q_len, int max_t_len) {
-    if (!seq_in_lds()) return 2 * RING * sizeof(u32);
+    if (!seq_in_lds()) return (2 * RING + 4) * sizeof(u32);
     size_t qw = (size_t)(max_q_len >> 4) + 4, tw = (size_t)(max_t_len >> 4) + 4;
     qw = (qw + 3) & ~(size_t)3;
     tw = (tw + 3) & ~(size_t)3;
-    return (qw + tw + 2 * RING) * sizeof(u32);
+    return (qw + tw + 2 * RING + 4) * sizeof(u32);
 }
 
 int fa_align_blocks_per_cu(size_t lds_bytes) {

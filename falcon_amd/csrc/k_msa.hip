@@ -118,11 +118,12 @@ __device__ __forceinline__ int wave_incl_max(int v, int lane) {
 // row d-1 is an insertion with an empty snake.  carry_open = depth of the last
 // row of the previous chunk (0 if that row is not an insertion).
 __device__ __forceinline__ int chunk_delta(const u32 *scr, int d, int d0, bool is_ins, int lane,
-                                           int carry_open, bool &cont) {
+                                           int carry_open, bool &cont, int &start_row) {
     const u32 ep = (d >= 2) ? scr[d - 1] : 1u;
     cont = is_ins && d >= 2 && (ep & 1u) == 0u && (ep >> 1) == 0u;
     int start = (is_ins && !cont) ? d : -1;
     start = wave_incl_max(start, lane);
+    start_row = start;
     if (!is_ins) return 0;
     return (start >= d0) ? (d - start + 1) : (carry_open + (d - d0) + 1);
 }
@@ -157,7 +158,8 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
             const u32 e = have ? scr[d] : 1u;
             const bool is_ins = have && d >= 1 && (e & 1u) == 0u;
             bool cont;
-            const int delta = chunk_delta(scr, d, d0, is_ins, lane, carry_open, cont);
+            int sr;
+            const int delta = chunk_delta(scr, d, d0, is_ins, lane, carry_open, cont, sr);
             if (delta >= 255) first_bad = min(first_bad, d);
             carry_open = __shfl(delta, 63);
         }
@@ -169,6 +171,8 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
     // main pass over rows 0 .. dlast
     const int dlast = min(dist, dcut - 1);
     int carry_t = 0, carry_q = rg.s1, carry_i = 0, carry_open = 0, carry_run_i = 0;
+    int carry_start_row = 0;
+    u32 carry_inl = 0;
     for (int d0 = 0; d0 <= dlast; d0 += 64) {
         const int d = d0 + lane;
         const bool have = d <= dlast;
@@ -184,30 +188,51 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
         const int qpos = carry_q + qs - qc;     // query index of this row's inserted base
         const int iidx = carry_i + is - (is_ins ? 1 : 0);
         bool cont;
-        const int delta = chunk_delta(scr, d, d0, is_ins, lane, carry_open, cont);
+        int start_row = 0;
+        const int delta = chunk_delta(scr, d, d0, is_ins, lane, carry_open, cont, start_row);
+        const bool from_prev_chunk = is_ins && (delta - 1 > d - d0);
+        if (from_prev_chunk) start_row = carry_start_row;
         // index (in the alignment's insertion list) of the first base of my run
-        const int run_i = is_ins ? ((delta - 1 <= d - d0) ? iidx - (delta - 1) : carry_run_i) : 0;
+        const int run_i = is_ins ? (from_prev_chunk ? carry_run_i : iidx - (delta - 1)) : 0;
         // the run ends here unless the next row continues it
         const u32 en = (d + 1 <= dlast) ? scr[d + 1] : 1u;
         const bool ends = is_ins && (m > 0 || (en & 1u) != 0u);
-        if (is_del) atomicOr(&desc[2 * tpos + 1], TAG_DEL);
+        // inline bases of my run so far: OR of b << 2(delta-1) over the run's rows
+        u32 b = 0, inl = 0;
         if (is_ins) {
-            const int us = tpos - 1;  // the target position the run hangs off
-            const u32 b = fa_base_at(rw, qpos);
+            b = fa_base_at(rw, qpos);
             insb[iidx] = (uint8_t)b;
-            if (delta <= INL) atomicOr(&desc[2 * us], b << (2 * (delta - 1)));
-            if (!cont) atomicOr(&desc[2 * us + 1], (u32)run_i & 0x3fffffu);
-            if (ends) {
-                atomicOr(&desc[2 * us + 1], (u32)delta << TAG_NINS_SHIFT);
-                atomicMax(&a_max[rg.s2 + us], delta);
-                atomicAdd(&a_sum[rg.s2 + us], delta);
-            }
+            if (delta <= INL) inl = b << (2 * (delta - 1));
+        }
+#pragma unroll
+        for (int off = 1; off < INL; off <<= 1) {
+            const u32 o = (u32)__shfl_up((int)inl, off);
+            if (is_ins && delta - 1 >= off && lane >= off) inl |= o;
+        }
+        if (from_prev_chunk) inl |= carry_inl;
+        // Every tag word has exactly one writer (no atomics): a deletion writes its
+        // flag unless an insertion run hangs off the deleted base, in which case the
+        // run's last row writes the whole word.
+        if (is_del && !(m == 0 && d + 1 <= dlast && (en & 1u) == 0u)) {
+            desc[2 * tpos + 1] = TAG_DEL;
+        }
+        if (ends) {
+            const int us = tpos - 1;  // the target position the run hangs off
+            const u32 es = (start_row >= 2) ? scr[start_row - 1] : 0u;  // column before the run
+            const bool on_del = start_row >= 2 && (es & 1u) != 0u && (es >> 1) == 0u;
+            desc[2 * us] = inl;
+            desc[2 * us + 1] = ((u32)run_i & 0x3fffffu) | ((u32)delta << TAG_NINS_SHIFT) |
+                               (on_del ? TAG_DEL : 0u);
+            atomicMax(&a_max[rg.s2 + us], delta);
+            atomicAdd(&a_sum[rg.s2 + us], delta);
         }
         carry_t += __shfl(ts, 63);
         carry_q += __shfl(qs, 63);
         carry_i += __shfl(is, 63);
         carry_open = __shfl(delta, 63);
         carry_run_i = __shfl(run_i, 63);
+        carry_start_row = __shfl(start_row, 63);
+        carry_inl = (u32)__shfl((int)inl, 63);
     }
     // rows >= dcut are dropped: the alignment covers only what the kept rows consumed
     const int t_cov = (dcut <= dist) ? carry_t : te;
@@ -268,9 +293,11 @@ __global__ __launch_bounds__(64) void k_tscan(MsaArgs A) {
 // ---------------------------------------------------------------------------
 // tag word accessors
 __device__ __forceinline__ int tag_nins(u32 hi) { return (int)((hi >> TAG_NINS_SHIFT) & 0xffu); }
+// base `delta` (1-based) of the insertion run of a tag: runs of up to INL bases are
+// inline in the low word, longer runs live entirely in the byte array
 __device__ __forceinline__ int tag_ins_base(const MsaArgs &A, const FaTagAln &ta, u32 lo, u32 hi,
-                                            int delta /* 1-based */) {
-    if (delta <= INL) return (int)((lo >> (2 * (delta - 1))) & 3u);
+                                            int delta) {
+    if (tag_nins(hi) <= INL) return (int)((lo >> (2 * (delta - 1))) & 3u);
     return (int)A.insb[ta.ins_off + (hi & 0x3fffffu) + (u32)(delta - 1)];
 }
 
