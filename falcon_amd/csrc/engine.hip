@@ -103,13 +103,13 @@ struct fa_batch {
     std::vector<FaSeq> seq;
     std::vector<FaPile> pile;
     std::vector<int> order;
-    std::vector<u64> ascii_off, script_off;
-    u64 n_words = 0, ascii_bytes = 0, script_words = 0;
+    std::vector<u64> ascii_off, script_off, probe_off;
+    u64 n_words = 0, ascii_bytes = 0, script_words = 0, probe_words = 0;
     int max_read_len = 0, max_seed_len = 0, max_rows = 0, max_bins = 4;
     long long sum_len = 0, sum_seed = 0;
 
     DevBuf<uint8_t> d_ascii;
-    DevBuf<u64> d_ascii_off, d_script_off;
+    DevBuf<u64> d_ascii_off, d_script_off, d_probe_off, d_probe;
     DevBuf<u32> d_words, d_kidx, d_kpos, d_script;
     DevBuf<FaSeq> d_seq;
     DevBuf<FaPile> d_pile;
@@ -145,7 +145,7 @@ struct fa_batch {
         b.ascii = d_ascii.p; b.ascii_off = d_ascii_off.p; b.words = d_words.p;
         b.seq = d_seq.p; b.pile = d_pile.p; b.n_seq = n_seq; b.n_pile = n_pile;
         b.n_words = n_words; b.kidx = d_kidx.p; b.kpos = d_kpos.p; b.order = d_order.p;
-        b.range = d_range.p; b.aln = d_aln.p;
+        b.range = d_range.p; b.aln = d_aln.p; b.probe = d_probe.p; b.probe_off = d_probe_off.p;
         b.script = d_script.p; b.script_off = d_script_off.p; b.nodes = d_nodes.p;
         b.out_seq = d_out_seq.p; b.out_eqv = d_out_eqv.p; b.pile_out = d_pile_out.p;
         return b;
@@ -284,13 +284,16 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
     b->out_slots = out;
     // per-sequence scratch extents
     b->script_off.resize(g);
-    u64 so = 0;
+    b->probe_off.resize(g);
+    u64 so = 0, po = 0;
     int max_rows = 4;
     for (int i = 0; i < g; i++) {
         const FaSeq &s = b->seq[i];
         int T = b->pile[s.pile].seed_len;
         b->script_off[i] = so;
+        b->probe_off[i] = po;
         if (s.idx == 0) continue;
+        po += (u64)(s.len / 4 + 4);
         // diagonals q-t span at most len+T, binned by K*6 (kmer_lookup.c:350-355)
         b->max_bins = std::max(b->max_bins, (s.len + T) / (FA_K * 6) + 4);
         int rb = rows_bound(s.len, T, !pair_mode);
@@ -298,6 +301,7 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
         max_rows = std::max(max_rows, rb);
     }
     b->script_words = so;
+    b->probe_words = po;
     b->max_rows = max_rows;
     // longest reads first: the lanes of a k_chain wave and the tail of the
     // k_align work queue then see similar work
@@ -332,6 +336,8 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
     if (!pair_mode) {
         rc |= b->d_kidx.alloc((u64)n_pile * FA_IDX_STRIDE);
         rc |= b->d_kpos.alloc(kpos + 8);
+        rc |= b->d_probe_off.alloc(g);
+        rc |= b->d_probe.alloc(b->probe_words + 8);
         rc |= b->d_out_seq.alloc(b->out_slots + 8);
         rc |= b->d_out_eqv.alloc(b->out_slots + 8);
         rc |= b->d_pile_out.alloc(n_pile);
@@ -349,6 +355,8 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
     ok &= hipMemcpyAsync(b->d_pile.p, b->pile.data(), n_pile * sizeof(FaPile), hipMemcpyHostToDevice, s) == hipSuccess;
     ok &= hipMemcpyAsync(b->d_order.p, b->order.data(), g * sizeof(int), hipMemcpyHostToDevice, s) == hipSuccess;
     ok &= hipMemcpyAsync(b->d_script_off.p, b->script_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
+    if (!pair_mode)
+        ok &= hipMemcpyAsync(b->d_probe_off.p, b->probe_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
     trace_stage(s, "upload");
     if (ok) {
         fa_launch_pack(b->dev(), s);
@@ -378,7 +386,7 @@ extern "C" fa_batch *fa_batch_create(fa_ctx *ctx, int n_pile, const int *pile_n_
 extern "C" void fa_batch_free(fa_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
-    b->d_ascii.release(); b->d_ascii_off.release();
+    b->d_ascii.release(); b->d_ascii_off.release(); b->d_probe.release(); b->d_probe_off.release();
     b->d_script_off.release(); b->d_words.release(); b->d_kidx.release(); b->d_kpos.release();
     b->d_script.release(); b->d_seq.release(); b->d_pile.release();
     b->d_order.release(); b->d_range.release();

@@ -131,6 +131,8 @@ struct FaBatchDev {
     u32 *kidx;
     u32 *kpos;
     const int *order;      // sequence indices, longest first
+    u64 *probe;            // k_chain: per probe {bucket start, size}
+    const u64 *probe_off;  // [n_seq]
     FaRange *range;
     FaAln *aln;
     u32 *script;

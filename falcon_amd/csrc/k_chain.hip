@@ -38,6 +38,8 @@ struct ChainArgs {
     int n_seq;
     int lds_bins;
     FaRange *out;
+    uint2 *probe;            // per probe {first bucket entry, bucket size}: written by pass A
+    const u64 *probe_off;    // [n_seq]
 };
 
 typedef long long i64;
@@ -76,6 +78,8 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
     const u32 *T = A.kidx + pm.kidx_off;
     const u32 *P = A.kpos + pm.kpos_off;
     const int n_probe = (sq.len > FA_K) ? (sq.len - FA_K + 3) / 4 : 0;  // i = 4p < len-K
+    uint2 *pr = A.probe + A.probe_off[g];  // the two later passes re-read the bucket bounds
+                                           // coalesced instead of repeating the random lookups
 
     // ---- pass A: diagonal extent and hit count
     int d_min = 0x7fffffff, d_max = -0x7fffffff;
@@ -86,6 +90,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
             const int i = 4 * p;
             const u32 km = fa_kmer8(w, i);
             const u32 lo = T[km], hi = T[km + 1];
+            pr[p] = make_uint2(lo, hi - lo);
             if (hi > lo) {
                 n_hit += (int)(hi - lo);
                 d_min = min(d_min, i - (int)P[hi - 1]);  // buckets are ascending
@@ -123,8 +128,8 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
         const int p = p0 + lane;
         if (p < n_probe) {
             const int i = 4 * p;
-            const u32 km = fa_kmer8(w, i);
-            const u32 lo = T[km], hi = T[km + 1];
+            const uint2 v = pr[p];
+            const u32 lo = v.x, hi = v.x + v.y;
             for (u32 k = lo; k < hi; k++) {
                 const int b = (i - (int)P[k] - d_min) / CH_BIN;
                 atomicAdd(&bin_cnt[b], 1u);
@@ -168,8 +173,8 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
             int m = 0, t_first = 0, t_last = 0;
             const int q = 4 * p;
             if (p < n_probe) {
-                const u32 km = fa_kmer8(w, q);
-                const u32 lo = T[km], hi = T[km + 1];
+                const uint2 v = pr[p];
+                const u32 lo = v.x, hi = v.x + v.y;
                 for (u32 k = lo; k < hi; k++) {
                     const int t = (int)P[k];
                     const int b = (q - t - d_min) / CH_BIN;
@@ -275,6 +280,7 @@ void fa_launch_chain(const FaBatchDev &b, int max_bins, hipStream_t s) {
     ChainArgs A;
     A.words = b.words; A.seq = b.seq; A.pile = b.pile; A.kidx = b.kidx; A.kpos = b.kpos;
     A.order = b.order; A.n_seq = b.n_seq; A.out = b.range;
+    A.probe = (uint2 *)b.probe; A.probe_off = b.probe_off;
     A.lds_bins = (max_bins + 3) & ~3;
     size_t lds = (size_t)A.lds_bins * 2 * sizeof(u32);
     if (lds > 48 * 1024)

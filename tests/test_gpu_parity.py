@@ -161,3 +161,16 @@ def test_batch_is_order_preserving_and_rerunnable(engine):
     r2 = [bt.run(4, 8, 0.70).fetch().result(i) for i in range(len(piles))]
     assert r1 == r2 == a
     bt.free()
+
+
+def test_long_insertion_runs_and_tag_cutoff(engine, port):
+    """Insertion runs longer than a tag's 16 inline bases, and runs past the
+    reference's 255-column cut-off (falcon.c:138-152; beyond the reference's own
+    parity domain, so the oracle is the arbiter there)."""
+    from test_oracle_vs_ref import _pile_with_long_insertions
+    for runs in ([20, 40, 120, 200], [17, 300, 260]):
+        pile = _pile_with_long_insertions(runs)
+        (seq, eqv), = engine.consensus([pile], 2, 8, 0.70, want_eqv=True)
+        eseq, eeqv = port.generate_consensus(pile, 2, 8, 0.70)
+        assert len(seq) > 2500
+        assert seq == eseq and eqv == eeqv

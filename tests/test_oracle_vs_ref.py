@@ -35,3 +35,26 @@ def test_piles_random(port, ref):
         for min_cov, idt in ((4, 0.70), (0, 0.80)):
             assert port.generate_consensus(seqs, min_cov, 8, idt) == \
                 ref.generate_consensus(seqs, min_cov, 8, idt)
+
+
+def _pile_with_long_insertions(run_lengths, seed=77):
+    """A clean pile whose reads carry long inserted blocks (deep MSA insertion levels)."""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, 3000, dtype=np.uint8)
+    seed_read = noisy(g, rng, 0.02)
+    reads = []
+    for i in range(14):
+        r = noisy(g, rng, 0.03)
+        if i < len(run_lengths) * 2:
+            n = run_lengths[i % len(run_lengths)]
+            at = 900 + 150 * (i % len(run_lengths))
+            r = np.concatenate([r[:at], rng.integers(0, 4, n, dtype=np.uint8), r[at:]])
+        reads.append(r)
+    return [codes_to_str(x) for x in pile_to_seqs(seed_read, reads)]
+
+
+def test_long_insertion_runs(port, ref):
+    """Insertion runs beyond the inline capacity of a GPU tag (16) but inside the
+    reference's parity domain (< 248)."""
+    pile = _pile_with_long_insertions([20, 40, 120, 200])
+    assert port.generate_consensus(pile, 2, 8, 0.70) == ref.generate_consensus(pile, 2, 8, 0.70)
