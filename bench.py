@@ -70,7 +70,7 @@ def cpu_baseline(piles):
         pass
     kind = "reference" if have_ref() else "port"
     cores = max(1, min(os.cpu_count() or 1, 16, len(piles) // 3))
-    per = max(2, min(4, len(piles) // cores))
+    per = max(2, min(9, len(piles) // cores))  # 1 warm-up + up to 8 timed piles per worker
     jobs = [(kind, piles[i * per:(i + 1) * per]) for i in range(cores)]
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--piles", type=int, default=int(os.environ.get("FALCON_BENCH_PILES", "768")),
+    ap.add_argument("--piles", type=int, default=int(os.environ.get("FALCON_BENCH_PILES", "3072")),
                     help="piles per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -159,7 +159,7 @@ def main():
             "index": st.T // 4 + 8 * st.T + 2 * 4 * 65537 * st.n_piles,
             "chain": st.L // 4,
             "align": st.L // 4 + 4 * st.C + 8 * st.D,
-            "consensus": 16 * st.A + 12 * st.T + 5 * st.O,
+            "consensus": 16 * st.A + 12 * st.T + 5 * st.O,  # k_tags + k_links + k_score + k_backtrace
         }
         dom = max(stage_ms, key=lambda s: stage_ms[s])
         ach = alg[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
@@ -197,7 +197,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(piles[:64])
+                out["cpu_baseline"] = cpu_baseline(piles[:144])
             except Exception as e:  # the baseline is informative; never lose the GPU line
                 out["cpu_baseline"] = {"value": None, "unit": "bases/s", "cores": 0,
                                        "kind": "unavailable", "sample": "failed: %r" % (e,)}
