@@ -295,10 +295,9 @@ __global__ __launch_bounds__(64) void k_tscan(MsaArgs A) {
 __device__ __forceinline__ int tag_nins(u32 hi) { return (int)((hi >> TAG_NINS_SHIFT) & 0xffu); }
 // base `delta` (1-based) of the insertion run of a tag: runs of up to INL bases are
 // inline in the low word, longer runs live entirely in the byte array
-__device__ __forceinline__ int tag_ins_base(const MsaArgs &A, const FaTagAln &ta, u32 lo, u32 hi,
-                                            int delta) {
+__device__ __forceinline__ int tag_ins_base(const MsaArgs &A, u32 ins_off, u32 lo, u32 hi, int delta) {
     if (tag_nins(hi) <= INL) return (int)((lo >> (2 * (delta - 1))) & 3u);
-    return (int)A.insb[ta.ins_off + (hi & 0x3fffffu) + (u32)(delta - 1)];
+    return (int)A.insb[ins_off + (hi & 0x3fffffu) + (u32)(delta - 1)];
 }
 
 // NCHT = 1: segments overlapped by <= 64 alignments (the normal case below 64x
@@ -351,144 +350,174 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
         return;
     }
 
-    // per-chunk lane state
-    int s2v[NCHT], tcv[NCHT];
-    const u32 *dptr[NCHT];
-    FaTagAln tav[NCHT];
+    // per-chunk lane state.  (pbv, pnv) = base and insertion depth of the last column
+    // the lane's alignment contributed at the previous target position: the
+    // predecessor of its delta-0 tag at this one (falcon.c:129-160)
+    int s2v[NCHT], tcv[NCHT], pbv[NCHT], pnv[NCHT];
+    const uint2 *dptr[NCHT];
+    u32 insoff[NCHT];
 #pragma unroll
     for (int c = 0; c < NCHT; c++) {
-        s2v[c] = 0x7fffffff; tcv[c] = 0; dptr[c] = A.desc;
-        tav[c].desc_off = 0; tav[c].ins_off = 0; tav[c].s2 = 0; tav[c].g = 0; tav[c].pile = 0;
-        tav[c].pad = 0;
+        s2v[c] = 0x7fffffff; tcv[c] = 0; pbv[c] = 0; pnv[c] = 0; insoff[c] = 0;
+        dptr[c] = reinterpret_cast<const uint2 *>(A.desc);
         const int a = c * 64 + lane;
         if (c < nch && a < n_act) {
             const int i = act[a];
-            tav[c] = A.ta[i];
-            s2v[c] = tav[c].s2;
+            const FaTagAln ta = A.ta[i];
+            s2v[c] = ta.s2;
             tcv[c] = A.tcov[i];
-            dptr[c] = A.desc + 2 * tav[c].desc_off;
+            insoff[c] = ta.ins_off;
+            dptr[c] = reinterpret_cast<const uint2 *>(A.desc) + ta.desc_off;
+            const int u = t_lo - 1 - s2v[c];  // the position before the segment
+            if (u >= 0 && u < tcv[c]) {
+                const uint2 w = dptr[c][u];
+                const int pn = tag_nins(w.y);
+                pnv[c] = pn;
+                pbv[c] = pn > 0 ? tag_ins_base(A, insoff[c], w.x, w.y, pn)
+                                : ((w.y & TAG_DEL) ? 4 : (int)fa_base_at(seedw, t_lo - 1));
+            }
         }
     }
 
+    // The segment's position records and seed bases are fetched once, lanes =
+    // positions / words, and handed out with readlane; the tag words of position
+    // t + 1 are requested while position t is being grouped.
+    FaTInfo xr[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int tl = t_lo + 64 * h + lane;
+        xr[h].lvl_start = 0; xr[h].link_start = 0; xr[h].cov = 0; xr[h].nlev = 0;
+        if (tl < t_hi) xr[h] = ti[tl];
+    }
+    const int sw0 = t_lo >> 4;  // TSEG is a multiple of 16
+    const u32 seedv = (lane <= (t_hi - 1 - t_lo) >> 4) ? seedw[sw0 + lane] : 0u;
+    uint2 wnx[NCHT];
+#pragma unroll
+    for (int c = 0; c < NCHT; c++) {
+        wnx[c] = make_uint2(0u, 0u);
+        const int u = t_lo - s2v[c];
+        if (c < nch && u >= 0 && u < tcv[c]) wnx[c] = dptr[c][u];
+    }
+
     for (int t = t_lo; t < t_hi; t++) {
-        const FaTInfo x = ti[t];
-        if (x.cov == 0) continue;
-        const int sb = (int)fa_base_at(seedw, t);
-        const int sbp = t > 0 ? (int)fa_base_at(seedw, t - 1) : 0;
-        u32 out = x.link_start;
-        // tag words of the lanes covering t
+        const int j = t - t_lo;
+        u32 x_lvl, x_link, x_cn;
+        {
+            const FaTInfo &xs = xr[0], &xt = xr[1];
+            const u32 cn0 = (u32)xs.cov | ((u32)xs.nlev << 16), cn1 = (u32)xt.cov | ((u32)xt.nlev << 16);
+            if (j < 64) {
+                x_lvl = (u32)__builtin_amdgcn_readlane((int)xs.lvl_start, j);
+                x_link = (u32)__builtin_amdgcn_readlane((int)xs.link_start, j);
+                x_cn = (u32)__builtin_amdgcn_readlane((int)cn0, j);
+            } else {
+                x_lvl = (u32)__builtin_amdgcn_readlane((int)xt.lvl_start, j - 64);
+                x_link = (u32)__builtin_amdgcn_readlane((int)xt.link_start, j - 64);
+                x_cn = (u32)__builtin_amdgcn_readlane((int)cn1, j - 64);
+            }
+        }
+        FaTInfo x;
+        x.lvl_start = x_lvl; x.link_start = x_link; x.cov = (u16)(x_cn & 0xffffu); x.nlev = (u16)(x_cn >> 16);
+        // tag words of the lanes covering t (requested one position ago); request t + 1
         bool covd[NCHT];
         u32 wlo[NCHT], whi[NCHT];
-        int nins[NCHT], base0[NCHT];
 #pragma unroll
         for (int c = 0; c < NCHT; c++) {
-            covd[c] = false; wlo[c] = 0; whi[c] = 0; nins[c] = 0; base0[c] = 0;
+            covd[c] = false; wlo[c] = wnx[c].x; whi[c] = wnx[c].y;
             if (c < nch) {
                 const int u = t - s2v[c];
                 covd[c] = u >= 0 && u < tcv[c];
-                if (covd[c]) {
-                    wlo[c] = dptr[c][2 * u];
-                    whi[c] = dptr[c][2 * u + 1];
-                    nins[c] = tag_nins(whi[c]);
-                    base0[c] = (whi[c] & TAG_DEL) ? 4 : sb;
-                }
+                if (t + 1 < t_hi && u + 1 >= 0 && u + 1 < tcv[c]) wnx[c] = dptr[c][u + 1];
+            }
+        }
+        if (x.cov == 0) continue;
+        const int sb = (int)(((u32)__builtin_amdgcn_readlane((int)seedv, j >> 4) >> (2 * (j & 15))) & 3u);
+        u32 out = x.link_start;
+        int nins[NCHT], base0[NCHT];
+#pragma unroll
+        for (int c = 0; c < NCHT; c++) {
+            nins[c] = 0; base0[c] = 0;
+            if (covd[c]) {
+                nins[c] = tag_nins(whi[c]);
+                base0[c] = (whi[c] & TAG_DEL) ? 4 : sb;
             }
         }
         for (int dl = 0; dl < (int)x.nlev; dl++) {
-            // key of every participating lane: node base | prev base << 3 | prev delta << 6 | start << 14
-            bool part[NCHT];
+            // key of every participating lane (-1 = none):
+            //   node base | prev base << 3 | prev delta << 6 | start << 14
+            // and its link word without the count (falcon.c:232-263 update_col):
+            //   count | node base << 10 | prev score index (delta * 5 + base) << 13 | start << 24
             int key[NCHT];
+            u32 wv[NCHT];
 #pragma unroll
             for (int c = 0; c < NCHT; c++) {
-                part[c] = false; key[c] = 0;
+                key[c] = -1; wv[c] = 0;
                 if (c < nch) {
                     if (dl == 0) {
-                        part[c] = covd[c];
-                        if (part[c]) {
-                            const int u = t - s2v[c];
-                            if (u == 0) {
-                                key[c] = base0[c] | (5 << 3) | (1 << 14);  // first column: no predecessor
+                        if (covd[c]) {
+                            if (t == s2v[c]) {  // first column: no predecessor
+                                key[c] = base0[c] | (5 << 3) | (1 << 14);
+                                wv[c] = ((u32)base0[c] << 10) | (1u << 24);
                             } else {
-                                const u32 plo = dptr[c][2 * (u - 1)], phi = dptr[c][2 * (u - 1) + 1];
-                                const int pn = tag_nins(phi);
-                                const int pb = pn > 0 ? tag_ins_base(A, tav[c], plo, phi, pn)
-                                                      : ((phi & TAG_DEL) ? 4 : sbp);
-                                key[c] = base0[c] | (pb << 3) | (pn << 6);
+                                key[c] = base0[c] | (pbv[c] << 3) | (pnv[c] << 6);
+                                wv[c] = ((u32)base0[c] << 10) | ((u32)(pnv[c] * 5 + pbv[c]) << 13);
                             }
                         }
-                    } else {
-                        part[c] = covd[c] && nins[c] >= dl;
-                        if (part[c]) {
-                            const int b = tag_ins_base(A, tav[c], wlo[c], whi[c], dl);
-                            const int pb = dl == 1 ? base0[c]
-                                                   : tag_ins_base(A, tav[c], wlo[c], whi[c], dl - 1);
-                            key[c] = b | (pb << 3) | ((dl - 1) << 6);
-                        }
+                    } else if (covd[c] && nins[c] >= dl) {
+                        const int b = tag_ins_base(A, insoff[c], wlo[c], whi[c], dl);
+                        const int pb = dl == 1 ? base0[c]
+                                               : tag_ins_base(A, insoff[c], wlo[c], whi[c], dl - 1);
+                        key[c] = b | (pb << 3) | ((dl - 1) << 6);
+                        wv[c] = ((u32)b << 10) | ((u32)((dl - 1) * 5 + pb) << 13);
+                        if (nins[c] == dl) { pbv[c] = b; pnv[c] = dl; }
                     }
+                    if (dl == 0 && covd[c] && nins[c] == 0) { pbv[c] = base0[c]; pnv[c] = 0; }
                 }
             }
+            // lanes with equal keys are one link; links are visited in lowest-lane
+            // order = the reference's first-insertion order (Q5).  The lowest lane of
+            // a group (its leader) keeps the group's rank and size and stores the word.
             u64 rem[NCHT];
 #pragma unroll
-            for (int c = 0; c < NCHT; c++) rem[c] = (c < nch) ? __ballot(part[c]) : 0ull;
+            for (int c = 0; c < NCHT; c++) rem[c] = (c < nch) ? __ballot(key[c] >= 0) : 0ull;
             int n_link = 0;
-            u32 myw = 0;            // lane i keeps link i of the level (first 64)
-            bool spilled = false;   // more than 64 links: written in visiting order
+            int myrank[NCHT];
+#pragma unroll
+            for (int c = 0; c < NCHT; c++) myrank[c] = -1;
             for (;;) {
                 int c0 = -1;
 #pragma unroll
                 for (int c = NCHT - 1; c >= 0; c--)
                     if (rem[c]) c0 = c;
                 if (c0 < 0) break;
-                int kk = 0;
+                int kk = 0, ldr = 0;
 #pragma unroll
                 for (int c = 0; c < NCHT; c++)
-                    if (c == c0) kk = __builtin_amdgcn_readlane(key[c], __ffsll((long long)rem[c]) - 1);
+                    if (c == c0) {
+                        ldr = __ffsll((long long)rem[c]) - 1;
+                        kk = __builtin_amdgcn_readlane(key[c], ldr);
+                    }
                 int cnt = 0;
 #pragma unroll
                 for (int c = 0; c < NCHT; c++) {
                     if (c < nch) {
-                        const u64 m = __ballot(part[c] && key[c] == kk);
+                        const u64 m = __ballot(key[c] == kk);
                         cnt += __popcll(m);
                         rem[c] &= ~m;
                     }
                 }
-                // link word: count | node base << 10 | prev score index (delta*5+base) << 13 | start << 24
-                const u32 pidx = (u32)((kk >> 6) & 0xff) * 5u + (u32)((kk >> 3) & 7);
-                const bool st = (kk >> 14) & 1;
-                const u32 w = (u32)cnt | ((u32)(kk & 7) << 10) | ((st ? 0u : pidx) << 13) |
-                              ((u32)(st ? 1 : 0) << 24);
-                if (n_link < 64) {
-                    if (lane == n_link) myw = w;
-                } else {
-                    if (!spilled) {  // flush the 64 collected links unsorted
-                        links[out + (u32)lane] = myw;
-                        spilled = true;
+#pragma unroll
+                for (int c = 0; c < NCHT; c++)
+                    if (c == c0 && lane == ldr) {
+                        myrank[c] = n_link;
+                        wv[c] |= (u32)cnt;
                     }
-                    links[out + (u32)n_link] = w;  // every lane stores the same word
-                }
                 n_link++;
             }
-            if (!spilled) {
-                // stable node-major order + head flags: k_score reduces every node of the
-                // level with one segmented scan (links of a node stay in visiting order)
-                const bool have = lane < n_link;
-                const int nbv = have ? (int)((myw >> 10) & 7u) : 7;
-                int pos = 0, base_off = 0;
-                bool head = false;
 #pragma unroll
-                for (int b = 0; b < 5; b++) {
-                    const u64 mb = __ballot(nbv == b);
-                    if (nbv == b) {
-                        const u64 below = mb & ((lane == 0) ? 0ull : (~0ull >> (64 - lane)));
-                        pos = base_off + __popcll(below);
-                        head = below == 0ull;
-                    }
-                    base_off += __popcll(mb);
-                }
-                if (have) links[out + (u32)pos] = myw | (head ? (1u << 25) : 0u);
-            }
+            for (int c = 0; c < NCHT; c++)
+                if (myrank[c] >= 0) links[out + (u32)myrank[c]] = wv[c];
             out += (u32)n_link;
-            nlk[x.lvl_start + (u32)dl] = (u16)(n_link | (spilled ? 0x8000 : 0));
+            nlk[x.lvl_start + (u32)dl] = (u16)n_link;
         }
     }
 }
@@ -580,8 +609,7 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                 const u32 slot = y.lvl_start + (u32)dl;
                 int nl_raw;
                 if (bulk) nl_raw = (int)s_nlk[slot - lvl0]; else nl_raw = (int)nlk[slot];
-                const int n_link = nl_raw & 0x7fff;
-                const bool sorted = (nl_raw & 0x8000) == 0;
+                const int n_link = nl_raw;
                 const u32 plvl5 = (dl == 0 ? prev_lvl : y.lvl_start) * 5u;  // node id = plvl5 + pidx
                 // lanes 0..4 are the accumulators of the five nodes of the level
                 int acc_h = -2, acc_p = 0, acc_n = 0, acc_k = 0;
@@ -616,7 +644,6 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                         acc_n += mine ? 1 : 0;
                     }
                 }
-                (void)sorted;
                 lk += (u32)n_link;
                 // publish the five nodes of the level
                 if (lane < 5) {
