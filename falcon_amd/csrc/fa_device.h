@@ -23,17 +23,36 @@ __device__ __forceinline__ u32 fa_kmer8(const u32 *w, int i) {
     return (u32)(fa_window64(w, i) & 0xFFFFu);
 }
 
-// Wave-wide max of ints through DPP (no LDS traffic):
-// prefix-max inside each row of 16, then row_bcast15 / row_bcast31 (gfx9 DPP
-// controls, present on gfx950) carry it across rows; lane 63 holds the result.
+// Lane mask of a predicate.  Feed it ONE comparison: the compiler then emits just the
+// v_cmp; a compound condition is first materialised as 0/1 and compared again (two
+// extra VALU) -- combine masks with scalar and/or instead.
+__device__ __forceinline__ u64 fa_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// n consecutive lanes starting at lane lo, as a mask (s_bfm_b64); 0 < n <= 63.
+__device__ __forceinline__ u64 fa_lane_range(int lo, int n) { return ((1ull << n) - 1ull) << lo; }
+
+// mask ? b : a per lane, the lane mask given as a scalar (v_cndmask with an SGPR pair)
+__device__ __forceinline__ int fa_sel(u64 mask, int a, int b) {
+    int r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+    return r;
+}
+
+// Wave-wide max of ints through DPP (no LDS traffic): prefix-max inside each row
+// of 16, then row_bcast15 / row_bcast31 (gfx9 DPP controls, present on gfx950) carry
+// it across rows; lane 63 holds the result.  The DPP modifier sits on the v_max
+// itself, in place (lanes without a source keep their value): 6 VALU.  (Through
+// __builtin_amdgcn_update_dpp the compiler emits copy + v_mov_dpp + v_max per step.)
+// s_nop 1: a VGPR written by VALU needs 2 wait states before a DPP read.
 __device__ __forceinline__ int fa_wave_max(int v) {
-    int t;
-    t = __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false); v = max(v, t);  // row_shr:1
-    t = __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false); v = max(v, t);  // row_shr:2
-    t = __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false); v = max(v, t);  // row_shr:4
-    t = __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false); v = max(v, t);  // row_shr:8
-    t = __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false); v = max(v, t);  // row_bcast:15
-    t = __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false); v = max(v, t);  // row_bcast:31
+    asm volatile("s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                 : "+v"(v));
     return __builtin_amdgcn_readlane(v, 63);
 }
 

@@ -79,35 +79,49 @@ struct AlignArgs {
 // step: two packed words per sequence funnel-shifted (v_alignbit) into one
 // 16-base window, xor, find-first-set.  ffbl(0) = -1 turns into a huge count
 // that the min() against the remaining lengths clamps.
-template <class QP, class TP>
-__device__ __forceinline__ u32 snake_step(QP qL, TP tL, int qa, int ta, u32 lim) {
-    const u32 qw = __builtin_amdgcn_alignbit(qL[(qa >> 4) + 1], qL[qa >> 4], (u32)(qa & 15) * 2u);
-    const u32 tw = __builtin_amdgcn_alignbit(tL[(ta >> 4) + 1], tL[ta >> 4], (u32)(ta & 15) * 2u);
-    return min(((u32)(__ffs((int)(qw ^ tw)) - 1)) >> 1, lim);
+// v_ffbl_b32 as the hardware defines it: -1 for 0 (the compiler's ctz would be
+// undefined there and __ffs costs a compare and a select to patch it).
+__device__ __forceinline__ u32 ffbl_raw(u32 x) {
+    u32 r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 
+// (qa, ta: base offsets >= 0; unsigned word indices keep the address arithmetic in
+// 32 bits: SGPR base + VGPR offset loads instead of 64-bit VALU adds)
+template <class QP, class TP>
+__device__ __forceinline__ u32 snake_step(QP qL, TP tL, u32 qa, u32 ta, u32 lim) {
+    const u32 qi = qa >> 4, ti = ta >> 4;
+    const u32 qw = __builtin_amdgcn_alignbit(qL[qi + 1u], qL[qi], (qa & 15u) * 2u);
+    const u32 tw = __builtin_amdgcn_alignbit(tL[ti + 1u], tL[ti], (ta & 15u) * 2u);
+    return min(ffbl_raw(qw ^ tw) >> 1, lim);
+}
+
+// act lanes hold a cell of the row: 0 <= x <= q_len, 0 <= y <= t_len (a cell that
+// reached either end finishes the alignment in its own row, DW_banded.c:220).
 template <class QP, class TP>
 __device__ __forceinline__ void snake16(QP qL, TP tL, int qb, int tb, int q_len, int t_len,
                                         bool act, int &x, int &y) {
-    bool go = act && x < q_len && y < t_len;
+    u32 mlast;  // length of the lane's last step; 16 = a full window matched: go on
     {   // first step: every lane, predicated by selects (idle lanes probe offset 0)
-        const int xs = go ? x : 0, ys = go ? y : 0;
+        const int xs = act ? x : 0, ys = act ? y : 0;
         const u32 lim = min(16u, (u32)min(q_len - xs, t_len - ys));
-        u32 m = snake_step(qL, tL, qb + xs, tb + ys, lim);
-        const bool full = (m == lim);
-        m = go ? m : 0u;
+        u32 m = snake_step(qL, tL, (u32)(qb + xs), (u32)(tb + ys), lim);
+        m = act ? m : 0u;
         x += (int)m;
         y += (int)m;
-        go = go && full && x < q_len && y < t_len;
+        mlast = m;
     }
-    while (__ballot(go)) {  // only lanes inside a run of >= 16 matches get here
-        if (go) {
+    u64 gm = fa_ballot(mlast == 16u);
+    while (gm) {  // only lanes inside a run of >= 16 matches get here
+        if (mlast == 16u) {
             const u32 lim = min(16u, (u32)min(q_len - x, t_len - y));
-            const u32 m = snake_step(qL, tL, qb + x, tb + y, lim);
+            const u32 m = snake_step(qL, tL, (u32)(qb + x), (u32)(tb + y), lim);
             x += (int)m;
             y += (int)m;
-            go = (m == lim) && x < q_len && y < t_len;
+            mlast = m;
         }
+        gm = fa_ballot(mlast == 16u);
     }
 }
 
@@ -204,11 +218,16 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
 #define PUT_ROW_RECORD(dir0_, finished_)                                          \
     do {                                                                          \
         const int slot_ = d & 63;                                                 \
-        const bool mine_ = lane == slot_;                                         \
-        rc_off = mine_ ? row_off : rc_off;                                        \
-        rc_mink = mine_ ? (u32)min_k : rc_mink;                                   \
-        rc_dlo = mine_ ? (u32)(dir0_) : rc_dlo;                                   \
-        rc_dhi = mine_ ? (u32)((dir0_) >> 32) : rc_dhi;                           \
+        const u64 dw_ = (dir0_);                                                  \
+        /* (lane select in M0: a VOP3 may read only one SGPR besides it) */      \
+        asm volatile("s_mov_b32 m0, %8\n\t"                                       \
+                     "v_writelane_b32 %0, %4, m0\n\t"                             \
+                     "v_writelane_b32 %1, %5, m0\n\t"                             \
+                     "v_writelane_b32 %2, %6, m0\n\t"                             \
+                     "v_writelane_b32 %3, %7, m0"                                 \
+                     : "+v"(rc_off), "+v"(rc_mink), "+v"(rc_dlo), "+v"(rc_dhi)    \
+                     : "s"(row_off), "s"((u32)min_k), "s"((u32)dw_),              \
+                       "s"((u32)(dw_ >> 32)), "s"(slot_));                        \
         if (slot_ == 63 || (finished_)) {                                         \
             if (lane <= slot_) {                                                  \
                 const u32x4 rr_ = {rc_off, rc_mink, rc_dlo, rc_dhi};              \
@@ -251,27 +270,31 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             const int par = d & 1;
             const int hi = lo + n - 1;
             PROF(0);
+            // Lane sets are kept twice: as a predicate (act: stores, selects) and as a
+            // scalar mask (act_m: combined with single-compare ballots by the scalar unit).
             const bool act = lane >= lo && lane <= hi;
+            const u64 act_m = fa_lane_range(lo, n);
             const int k = kbase + 2 * lane + par;
-            // a = V[k-1], b = V[k+1]: own register and one wave shift
-            const int sh_dn = __builtin_amdgcn_update_dpp(vreg, vreg, 0x138, 0xf, 0xf, false);  // lane-1
-            const int sh_up = __builtin_amdgcn_update_dpp(vreg, vreg, 0x130, 0xf, 0xf, false);  // lane+1
+            // a = V[k-1], b = V[k+1]: own register and one wave shift (the wave's edge
+            // lanes are never inside the band: lo >= 1, hi <= 62)
+            const int sh_dn = __builtin_amdgcn_mov_dpp(vreg, 0x138, 0xf, 0xf, true);  // lane-1
+            const int sh_up = __builtin_amdgcn_mov_dpp(vreg, 0x130, 0xf, 0xf, true);  // lane+1
             const int a = par ? vreg : sh_dn;
             const int b = par ? sh_up : vreg;
-            const bool from_above = (lane == lo) || ((lane != hi) && (a < b));  // :190
-            int x = from_above ? b : a + 1;
+            // from_above: k == min_k, or k != max_k and V[k-1] < V[k+1]   (:190)
+            const u64 fa_m = ((fa_ballot(a < b) & ~(1ull << hi)) | (1ull << lo)) & act_m;
+            int x = fa_sel(fa_m, a + 1, b);
             int y = x - k;
             PROF(1);
             snake16(qL, tL, qb, tb, q_len, t_len, act, x, y);
             PROF(2);
             vreg = x;
-            g_u32 *rowp = cells + row_off - lo;
-            if (act) rowp[lane] = ((u32)x << 1) | (from_above ? 1u : 0u);
-            const u64 dir0 = __ballot(act && from_above) >> lo;
-            const u64 fin = __ballot(act && (x >= q_len || y >= t_len));  // :220
+            if (act) cells[(u32)((int)row_off - lo) + (u32)lane] = ((u32)x << 1) | (u32)fa_sel(fa_m, 0, 1);
+            const u64 dir0 = fa_m >> lo;
+            const u64 fin = (fa_ballot(x >= q_len) | fa_ballot(y >= t_len)) & act_m;  // :220
             PROF(3);
             if (fin) {
-                const int fl = __ffsll((long long)fin) - 1;
+                const int fl = __builtin_ctzll(fin);
                 fin_d = d;
                 fin_k = kbase + 2 * fl + par;
                 fin_x = __builtin_amdgcn_readlane(x, fl);
@@ -285,12 +308,12 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             // slower: 64 same-address atomics serialise)
             const int u = act ? x + y : -1;
             best_m = max(best_m, fa_wave_max(u));
-            const u64 in = __ballot(u >= best_m - band && u >= 0);  // :228-243
+            const u64 in = fa_ballot(u >= best_m - band) & act_m;  // :228-243
             PROF(4);
             PUT_ROW_RECORD(dir0, false);
             // `in` is never empty: best_m is attained inside the row
-            const int llo = __ffsll((long long)in) - 1;   // absolute lanes
-            const int lhi = 63 - __clzll((long long)in);
+            const int llo = __builtin_ctzll(in);          // absolute lanes
+            const int lhi = 63 - __builtin_clzll(in);
             row_off += (u32)n;
             min_k = min_k + 2 * (llo - lo) - 1;
             n = lhi - llo + 2;

@@ -39,7 +39,6 @@
 #define TSEG 128       // target positions per k_links wavefront
 #define MAXACT 512     // alignments overlapping one segment
 #define INL 16         // inserted bases stored inline in a tag
-#define SC_LCAP 16     // insertion levels whose scores are kept in LDS by k_score
 #define BT_WIN 64      // levels per back-trace window
 
 #define TAG_DEL 0x40000000u
@@ -523,23 +522,60 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
 }
 
 // ---------------------------------------------------------------------------
-// k_score: one wavefront per pile.  Blocks of target positions are staged in
-// LDS (position records, link counts, link words: three coalesced bursts), then
-// every (t, delta) level is scored with lanes = links: one LDS gather for the
-// previous-node scores, the per-node maximum resolved over the node's lanes in
-// link order (strict '>', first maximum, falcon.c:447).
+// k_score: one wavefront per pile, the score recurrence of falcon.c:405-475.
+//
+// The scores of the position being scored and of the one before it live in two
+// VGPRs, lane = delta * 5 + base for the first SC_REG insertion levels (deeper
+// levels are rare and take a generic path through LDS).  A level's links are
+// decoded with lanes = links, then visited in stored order (= the reference's
+// insertion order, Q5) with readlane: the previous node's score is a readlane of
+// the score register, the node's accumulator is the lane it will be read from
+// later, so the dependent chain of a level contains no memory access at all.
+// Link words of a block of positions are staged in LDS with coalesced bursts and
+// requested one level ahead; position records and link counts are handed out of
+// registers; node records leave with one coalesced store per position.
 // ---------------------------------------------------------------------------
-#define SC_TB 64          // target positions per block
 #define SC_LINKS 1280     // link words staged per block
-#define SC_LEVELS 128     // levels (link counts in, node records out) staged per block
-#define SC_RES 32         // insertion levels per position whose scores stay in LDS
+#define SC_LEVELS 128     // levels per block (their link counts sit in two VGPRs)
+#define SC_REG 12         // insertion levels whose scores live in registers
+#define SC_ZERO 63        // lane of the score registers that always holds 0 (start links)
+
+struct ScoreAcc { int h, p, k, n; };
+
+// Copy through an opaque VALU move: the wait for the load that produced v is paid
+// here, once, and the copy carries no pending-load state into the loops that read
+// it (otherwise the compiler's conservative s_waitcnt vmcnt(0) at every such read
+// also drains the node-record stores in flight).
+__device__ __forceinline__ u32 settled(u32 v) {
+    u32 r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+// visit n_here links (lanes 0 .. n_here-1 of nbv / cv / lidxv / pidv); accumulators
+// of node b are the lanes lane_base + b of acc.  FROM_CUR: predecessors are read
+// from acc.h itself (delta >= 1), else from src_h (previous position).
+template <bool FROM_CUR>
+__device__ __forceinline__ void score_links(ScoreAcc &acc, int src_h, int nbv, int cv, int lidxv,
+                                            int pidv, int n_here, int lane_rel) {
+    for (int l = 0; l < n_here; l++) {
+        const int nbl = __builtin_amdgcn_readlane(nbv, l);
+        const int cl = __builtin_amdgcn_readlane(cv, l);
+        const int li = __builtin_amdgcn_readlane(lidxv, l);
+        const int pl = __builtin_amdgcn_readlane(pidv, l);
+        const int ph = __builtin_amdgcn_readlane(FROM_CUR ? acc.h : src_h, li);
+        const int h = ph + cl;  // falcon.c:440-445, half units
+        const bool mine = lane_rel == nbl;
+        const bool better = mine && h > acc.h;  // strict: first maximum (:447)
+        acc.h = better ? h : acc.h;
+        acc.p = better ? pl : acc.p;
+        acc.k = better ? acc.n : acc.k;
+        acc.n += mine ? 1 : 0;
+    }
+}
 
 __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
-    __shared__ u32 s_links[SC_LINKS];
-    __shared__ u16 s_nlk[SC_LEVELS];
-    __shared__ FaTInfo s_ti[SC_TB];
-    __shared__ int s_sc[2][SC_RES * 5];  // node scores of the previous / current target position
-    __shared__ uint2 s_node[SC_LEVELS * 5];  // node records of the block, flushed coalesced
+    __shared__ u32 s_links[SC_LINKS + 64];
     const int lane = fa_lane();
     const int p = blockIdx.x;
     if (p >= A.n_pile) return;
@@ -547,151 +583,205 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
     FaScoreOut so = A.score_out[p];
     if (so.err) return;
     const int T = pm.seed_len;
-    const FaTInfo *ti = A.tinfo + A.t_off[p];
+    const u32 *tiw = reinterpret_cast<const u32 *>(A.tinfo + A.t_off[p]);  // 3 words per position
     const u32 *links = A.links + A.link_off[p];
     const u16 *nlk = A.lvl_nlink16 + pm.node_off / 5;
-    FaNode *nodes = A.nodes + pm.node_off;
+    typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 *nodes = reinterpret_cast<u32x2 *>(A.nodes + pm.node_off);
     const int min_cov = (int)A.min_cov;
-    int *ovf = A.score_ovf + (u64)p * (2 * 256 * 5);  // scores of levels >= SC_RES (rare)
+    // scores of levels >= SC_REG (rare): previous / current position, 2 x 256 x 5 ints in
+    // HBM -- LDS here would cost occupancy (one wave per pile must all be resident)
+    int *s_deep = A.score_ovf + (u64)p * (2 * 256 * 5);
+    const int ldl = lane / 5;
+    const int h_init = (lane == SC_ZERO) ? 0 : -2;
 
-    // every node lane (0..4) tracks the best node it has produced; the five are
-    // merged at the end in (level, base) order, which is the reference's scan order
-    int gl_h = -2, gl_slot = 0, gl_ck = 0;
-    int cur = 0;        // which half of s_sc holds the position being scored
+    ScoreAcc cur;
+    cur.h = h_init; cur.p = 0; cur.k = 0; cur.n = 0;
+    int prev_h = h_init;
+    int gl_h = -2, gl_slot = 0, gl_ck = 0;  // best node of this lane's (delta, base) class
+    int dg_h = -2, dg_slot = 0, dg_ck = 0;  // same for the deep levels (lanes 0..4)
+    int curbuf = 0;     // which half of s_deep belongs to the position being scored
     int prev_t = -2;    // last scored target position
     u32 prev_lvl = 0;   // its first level slot
-    if (ti[0].cov == 0 && lane < 5) {
+
+    if (lane < 5 && (tiw[2] & 0xffffu) == 0u) {
         // slot 0 = (t 0, delta 0): absent nodes, target of the zero back pointer (Q4)
-        FaNode nd;
-        nd.score_h = -2;
-        nd.link = (0 + 1) << 1;
-        nodes[lane] = nd;
+        u32x2 r;
+        r.x = (u32)-2; r.y = (u32)((0 + 1) << 1);
+        nodes[lane] = r;
     }
     int t0 = 0;
     while (t0 < T) {
-        // ---- stage a block of positions: as many (<= 63) as fit the LDS budgets.
+        // ---- a block of positions: as many (<= 63) as fit the staging budgets.
         // Lane j holds position t0+j; a block of length j ends where position t0+j
         // starts (or at the pile totals), so lane j can judge whether length j fits.
-        __syncthreads();
         const int tl = t0 + lane;
-        FaTInfo x;
-        x.lvl_start = 0; x.link_start = 0; x.cov = 0; x.nlev = 0;
-        if (tl < T) x = ti[tl];
-        s_ti[lane] = x;
-        const u32 lvl0 = (u32)__shfl((int)x.lvl_start, 0), lnk0 = (u32)__shfl((int)x.link_start, 0);
-        const u32 end_l = (tl < T) ? x.lvl_start : (u32)so.n_levels;
-        const u32 end_k = (tl < T) ? x.link_start : (u32)so.n_links;
+        u32 x_lvl = 0, x_link = 0, x_cn = 0;
+        if (tl < T) { x_lvl = tiw[3 * tl]; x_link = tiw[3 * tl + 1]; x_cn = tiw[3 * tl + 2]; }
+        const u32 lvl0 = (u32)__builtin_amdgcn_readfirstlane((int)x_lvl);
+        const u32 lnk0 = (u32)__builtin_amdgcn_readfirstlane((int)x_link);
+        const u32 end_l = (tl < T) ? x_lvl : (u32)so.n_levels;
+        const u32 end_k = (tl < T) ? x_link : (u32)so.n_links;
         const bool fits = lane >= 1 && tl <= T && (end_l - lvl0) <= SC_LEVELS &&
                           (end_k - lnk0) <= SC_LINKS;
         int nb = __popcll(__ballot(fits));  // prefix sums are monotone, so is `fits`
         const bool bulk = nb > 0;
-        if (!bulk) nb = 1;  // one oversized position: read it straight from HBM
+        if (!bulk) nb = 1;  // one oversized position: read straight from HBM
+        int nlk0 = 0, nlk1 = 0;
+        __syncthreads();
         if (bulk) {
-            const u32 n_l = (u32)__shfl((int)end_l, nb) - lvl0, n_k = (u32)__shfl((int)end_k, nb) - lnk0;
-            for (u32 i = lane; i < n_l; i += 64) s_nlk[i] = nlk[lvl0 + i];
+            const u32 n_l = (u32)__builtin_amdgcn_readlane((int)end_l, nb) - lvl0;
+            const u32 n_k = (u32)__builtin_amdgcn_readlane((int)end_k, nb) - lnk0;
             for (u32 i = lane; i < n_k; i += 64) s_links[i] = links[lnk0 + i];
-            // slot 0 of an uncovered position 0 stays "absent" (it is flushed with the block)
-            if (t0 == 0 && lane < 5 && (u32)__shfl((int)x.cov, 0) == 0u)
-                s_node[lane] = make_uint2((u32)-2, (u32)((0 + 1) << 1));
+            if ((u32)lane < n_l) nlk0 = (int)nlk[lvl0 + (u32)lane];
+            if ((u32)lane + 64u < n_l) nlk1 = (int)nlk[lvl0 + 64u + (u32)lane];
         }
         __syncthreads();
+        nlk0 = (int)settled((u32)nlk0);
+        nlk1 = (int)settled((u32)nlk1);
+        x_lvl = settled(x_lvl);
+        x_link = settled(x_link);
+        x_cn = settled(x_cn);
 
+        u32 w_nx = 0;          // link words requested ahead ...
+        u32 w_nx_rel = ~0u;    // ... for this offset into s_links
         for (int j = 0; j < nb; j++) {
             const int t = t0 + j;
-            const FaTInfo y = s_ti[j];
-            if (y.cov == 0) continue;
-            const int cov = (int)y.cov;
+            const u32 y_lvl = (u32)__builtin_amdgcn_readlane((int)x_lvl, j);
+            const u32 y_link = (u32)__builtin_amdgcn_readlane((int)x_link, j);
+            const u32 y_cn = (u32)__builtin_amdgcn_readlane((int)x_cn, j);
+            const int cov = (int)(y_cn & 0xffffu), nlev = (int)(y_cn >> 16);
+            if (cov == 0) continue;
             const int upper = cov > min_cov ? 1 : 0;  // falcon.c:498 (Q7)
             const bool adjacent = (prev_t == t - 1);
-            cur ^= 1;
-            u32 lk = y.link_start;
-            for (int dl = 0; dl < (int)y.nlev; dl++) {
-                const u32 slot = y.lvl_start + (u32)dl;
-                int nl_raw;
-                if (bulk) nl_raw = (int)s_nlk[slot - lvl0]; else nl_raw = (int)nlk[slot];
-                const int n_link = nl_raw;
-                const u32 plvl5 = (dl == 0 ? prev_lvl : y.lvl_start) * 5u;  // node id = plvl5 + pidx
-                // lanes 0..4 are the accumulators of the five nodes of the level
-                int acc_h = -2, acc_p = 0, acc_n = 0, acc_k = 0;
-                for (int c0 = 0; c0 < n_link; c0 += 64) {
-                    const int i = c0 + lane;
-                    const bool have = i < n_link;
-                    u32 w = 0;
-                    if (have) { if (bulk) w = s_links[lk - lnk0 + (u32)i]; else w = links[lk + (u32)i]; }
-                    const int cnt = (int)(w & 0x3ffu), nbase = (int)((w >> 10) & 7u);
-                    const int pidx = (int)((w >> 13) & 0x7ffu);
-                    const bool start = (w >> 24) & 1u;
-                    int ph = 0, pid = -1;
-                    if (have && !start) {
-                        const int which = (dl == 0) ? (cur ^ 1) : cur;
-                        if (pidx < SC_RES * 5) ph = s_sc[which][pidx];
-                        else ph = ovf[which * 1280 + pidx];
-                        if (dl == 0 && !adjacent) ph = -2;
-                        pid = (int)(plvl5 + (u32)pidx);
+            prev_h = adjacent ? cur.h : h_init;
+            cur.h = h_init; cur.p = 0; cur.k = 0; cur.n = 0;
+            curbuf ^= 1;
+            u32 lk = y_link;
+            for (int dl = 0; dl < nlev; dl++) {
+                const u32 slot = y_lvl + (u32)dl;
+                int n_link;
+                if (bulk) {
+                    const int li = (int)(slot - lvl0);
+                    const int a0 = __builtin_amdgcn_readlane(nlk0, li & 63);
+                    const int a1 = __builtin_amdgcn_readlane(nlk1, li & 63);
+                    n_link = li < 64 ? a0 : a1;
+                } else {
+                    n_link = __builtin_amdgcn_readfirstlane((int)nlk[slot]);
+                }
+                const u32 plvl5 = (dl == 0 ? prev_lvl : y_lvl) * 5u;  // node id = plvl5 + pidx
+                // first 64 links of the level, lanes = links
+                u32 w = 0;
+                if (bulk) {
+                    const u32 rel = lk - lnk0;
+                    if (w_nx_rel == rel) w = w_nx; else w = s_links[rel + (u32)lane];
+                    // request the next level's words (next position's when this is the last)
+                    u32 rel2 = rel + (u32)n_link;
+                    if (dl + 1 == nlev) {
+                        rel2 = (j + 1 < nb) ? (u32)__builtin_amdgcn_readlane((int)x_link, j + 1) - lnk0 : 0u;
                     }
-                    const int h = ph + 2 * cnt - cov;  // falcon.c:440-445, half units
-                    // the links in visiting order; node nb's accumulator lives in lane nb
-                    const int n_here = min(64, n_link - c0);
-                    for (int l = 0; l < n_here; l++) {
-                        const int nb_l = __builtin_amdgcn_readlane(nbase, l);
-                        const int h_l = __builtin_amdgcn_readlane(h, l);
-                        const int p_l = __builtin_amdgcn_readlane(pid, l);
-                        const bool mine = lane == nb_l;
-                        const bool better = mine && h_l > acc_h;  // strict: first maximum (:447)
-                        acc_h = better ? h_l : acc_h;
-                        acc_p = better ? p_l : acc_p;
-                        acc_k = better ? acc_n : acc_k;
-                        acc_n += mine ? 1 : 0;
+                    w_nx = s_links[min(rel2, (u32)SC_LINKS) + (u32)lane];
+                    w_nx_rel = rel2;
+                } else {
+                    if (lane < n_link) w = links[lk + (u32)lane];
+                    w = settled(w);
+                }
+                const bool have = lane < n_link;
+                const int cnt = (int)(w & 0x3ffu), nbase = (int)((w >> 10) & 7u);
+                const int pidx = (int)((w >> 13) & 0x7ffu);
+                const bool start = (w >> 24) & 1u;
+                const bool deep = have && !start && pidx >= SC_REG * 5;
+                if (dl < SC_REG && n_link <= 64 && __ballot(deep) == 0ull) {
+                    const int cv = 2 * cnt - cov;
+                    const int lidx = start ? SC_ZERO : pidx;
+                    const int pidv = start ? -1 : (int)(plvl5 + (u32)pidx);
+                    const int lane_rel = lane - dl * 5;
+                    if (dl == 0) score_links<false>(cur, prev_h, nbase, cv, lidx, pidv, n_link, lane_rel);
+                    else score_links<true>(cur, 0, nbase, cv, lidx, pidv, n_link, lane_rel);
+                } else {
+                    // generic level: any number of links, predecessors and/or the level
+                    // itself beyond the register-resident ones; accumulators in lanes 0..4
+                    ScoreAcc d;
+                    d.h = -2; d.p = 0; d.k = 0; d.n = 0;
+                    const int which = (dl == 0) ? (curbuf ^ 1) : curbuf;
+                    for (int c0 = 0; c0 < n_link; c0 += 64) {
+                        u32 wc = 0;
+                        if (c0 + lane < n_link) {
+                            if (bulk) wc = s_links[lk - lnk0 + (u32)(c0 + lane)];
+                            else wc = links[lk + (u32)(c0 + lane)];
+                        }
+                        wc = settled(wc);
+                        const int n_here = min(64, n_link - c0);
+                        for (int l = 0; l < n_here; l++) {
+                            const u32 wl = (u32)__builtin_amdgcn_readlane((int)wc, l);
+                            const int cnt_l = (int)(wl & 0x3ffu), nb_l = (int)((wl >> 10) & 7u);
+                            const int pidx_l = (int)((wl >> 13) & 0x7ffu);
+                            const bool start_l = (wl >> 24) & 1u;
+                            int ph = 0, pid = -1;
+                            if (!start_l) {
+                                if (pidx_l < SC_REG * 5) {
+                                    ph = (dl == 0) ? __builtin_amdgcn_readlane(prev_h, pidx_l)
+                                                   : __builtin_amdgcn_readlane(cur.h, pidx_l);
+                                } else {
+                                    ph = __builtin_amdgcn_readfirstlane(s_deep[which * 1280 + pidx_l]);
+                                    if (dl == 0 && !adjacent) ph = -2;
+                                }
+                                pid = (int)(plvl5 + (u32)pidx_l);
+                            }
+                            const int h = ph + 2 * cnt_l - cov;
+                            const bool mine = lane == nb_l;
+                            const bool better = mine && h > d.h;
+                            d.h = better ? h : d.h;
+                            d.p = better ? pid : d.p;
+                            d.k = better ? d.n : d.k;
+                            d.n += mine ? 1 : 0;
+                        }
+                    }
+                    if (dl < SC_REG) {  // hand the five nodes to their score lanes
+                        const int src = lane - dl * 5;
+                        const int vh = __shfl(d.h, src), vp = __shfl(d.p, src), vk = __shfl(d.k, src);
+                        if (src >= 0 && src < 5) { cur.h = vh; cur.p = vp; cur.k = vk; }
+                    } else if (lane < 5) {
+                        s_deep[curbuf * 1280 + dl * 5 + lane] = d.h;
+                        __threadfence_block();
+                        u32x2 r;
+                        r.x = (u32)d.h; r.y = (u32)(((d.p + 1) << 1) | upper);
+                        nodes[slot * 5u + (u32)lane] = r;
+                        if (d.h > dg_h) { dg_h = d.h; dg_slot = (int)slot; dg_ck = d.k; }
                     }
                 }
                 lk += (u32)n_link;
-                // publish the five nodes of the level
-                if (lane < 5) {
-                    if (dl < SC_RES) s_sc[cur][dl * 5 + lane] = acc_h;
-                    else { ovf[cur * 1280 + dl * 5 + lane] = acc_h; __threadfence_block(); }
-                    if (acc_h > gl_h) {  // strict: the lane's first maximum
-                        gl_h = acc_h;
-                        gl_slot = (int)slot;
-                        gl_ck = acc_k;
-                    }
-                    const uint2 rec = make_uint2((u32)acc_h, (u32)(((acc_p + 1) << 1) | upper));
-                    if (bulk) {
-                        s_node[(slot - lvl0) * 5u + (u32)lane] = rec;
-                    } else {
-                        FaNode nd;
-                        nd.score_h = (int)rec.x;
-                        nd.link = (int)rec.y;
-                        nodes[slot * 5u + (u32)lane] = nd;
-                    }
+            }
+            // the register-resident levels of the position: node records + lane bests
+            if (lane < min(nlev, SC_REG) * 5) {
+                u32x2 r;
+                r.x = (u32)cur.h; r.y = (u32)(((cur.p + 1) << 1) | upper);
+                nodes[y_lvl * 5u + (u32)lane] = r;
+                if (cur.h > gl_h) {  // strict: the lane's first maximum
+                    gl_h = cur.h;
+                    gl_slot = (int)y_lvl + ldl;
+                    gl_ck = cur.k;
                 }
-                // scores of this level are read by the next one: one wave, LDS is in order;
-                // only stop the compiler from moving LDS traffic across (a __syncthreads()
-                // here would also wait for the node stores, ~1 us per level)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             prev_t = t;
-            prev_lvl = y.lvl_start;
-        }
-        if (bulk) {  // one coalesced burst for the node records of the block
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const u32 n_rec = ((u32)__shfl((int)end_l, nb) - lvl0) * 5u;
-            uint2 *dst = reinterpret_cast<uint2 *>(nodes + (u64)lvl0 * 5u);
-            for (u32 i = lane; i < n_rec; i += 64) dst[i] = s_node[i];
+            prev_lvl = y_lvl;
         }
         t0 += nb;
     }
     // global best = first strict maximum in (t, delta, base) order (falcon.c:464-469):
     // the highest score; among equals the lowest level slot, then the lowest base
     int g_h = -2, g_node = -1, g_ck = 0, g_slot = 0x7fffffff;
-#pragma unroll
-    for (int bq = 0; bq < 5; bq++) {
-        const int hv = __builtin_amdgcn_readlane(gl_h, bq);
-        const int sv = __builtin_amdgcn_readlane(gl_slot, bq);
+    for (int i = 0; i < SC_REG * 5 + 5; i++) {
+        const bool dp = i >= SC_REG * 5;
+        const int src = dp ? i - SC_REG * 5 : i;
+        const int hv = dp ? __builtin_amdgcn_readlane(dg_h, src) : __builtin_amdgcn_readlane(gl_h, src);
+        const int sv = dp ? __builtin_amdgcn_readlane(dg_slot, src) : __builtin_amdgcn_readlane(gl_slot, src);
+        const int kv = dp ? __builtin_amdgcn_readlane(dg_ck, src) : __builtin_amdgcn_readlane(gl_ck, src);
         if (hv > g_h || (hv == g_h && hv > -2 && sv < g_slot)) {
             g_h = hv;
             g_slot = sv;
-            g_node = sv * 5 + bq;
-            g_ck = __builtin_amdgcn_readlane(gl_ck, bq);
+            g_node = sv * 5 + src % 5;
+            g_ck = kv;
         }
     }
     so.g_h = g_h;
