@@ -91,9 +91,12 @@ __device__ __forceinline__ u32 ffbl_raw(u32 x) {
 // 32 bits: SGPR base + VGPR offset loads instead of 64-bit VALU adds)
 template <class QP, class TP>
 __device__ __forceinline__ u32 snake_step(QP qL, TP tL, u32 qa, u32 ta, u32 lim) {
-    const u32 qi = qa >> 4, ti = ta >> 4;
-    const u32 qw = __builtin_amdgcn_alignbit(qL[qi + 1u], qL[qi], (qa & 15u) * 2u);
-    const u32 tw = __builtin_amdgcn_alignbit(tL[ti + 1u], tL[ti], (ta & 15u) * 2u);
+    // bit offsets first: (a + b) << 1 is one VALU op, word index and shift derive from it
+    // (v_alignbit only looks at the low 5 bits of the shift)
+    const u32 qs = qa << 1, ts = ta << 1;
+    const u32 qi = qs >> 5, ti = ts >> 5;
+    const u32 qw = __builtin_amdgcn_alignbit(qL[qi + 1u], qL[qi], qs);
+    const u32 tw = __builtin_amdgcn_alignbit(tL[ti + 1u], tL[ti], ts);
     return min(ffbl_raw(qw ^ tw) >> 1, lim);
 }
 
@@ -215,11 +218,11 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
     // the last <= 64 row records live in registers, lane (d & 63) holds row d;
     // they are flushed to the arena 64 at a time with one coalesced 16-byte store
     u32 rc_off = 0, rc_mink = 0, rc_dlo = 0, rc_dhi = 0;
-#define PUT_ROW_RECORD(dir0_, finished_)                                          \
+    // WRITE_ROW_RECORD: row d's record into lane d & 63 (v_writelane; lane select in M0:
+    // a VOP3 may read only one SGPR besides it).  FLUSH_ROW_RECORDS: rows d - (d & 63) .. d.
+#define WRITE_ROW_RECORD(dir0_)                                                   \
     do {                                                                          \
-        const int slot_ = d & 63;                                                 \
         const u64 dw_ = (dir0_);                                                  \
-        /* (lane select in M0: a VOP3 may read only one SGPR besides it) */      \
         asm volatile("s_mov_b32 m0, %8\n\t"                                       \
                      "v_writelane_b32 %0, %4, m0\n\t"                             \
                      "v_writelane_b32 %1, %5, m0\n\t"                             \
@@ -227,13 +230,20 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
                      "v_writelane_b32 %3, %7, m0"                                 \
                      : "+v"(rc_off), "+v"(rc_mink), "+v"(rc_dlo), "+v"(rc_dhi)    \
                      : "s"(row_off), "s"((u32)min_k), "s"((u32)dw_),              \
-                       "s"((u32)(dw_ >> 32)), "s"(slot_));                        \
-        if (slot_ == 63 || (finished_)) {                                         \
-            if (lane <= slot_) {                                                  \
-                const u32x4 rr_ = {rc_off, rc_mink, rc_dlo, rc_dhi};              \
-                rows[d - slot_ + lane] = rr_;                                     \
-            }                                                                     \
+                       "s"((u32)(dw_ >> 32)), "s"(d & 63));                       \
+    } while (0)
+#define FLUSH_ROW_RECORDS()                                                       \
+    do {                                                                          \
+        const int slot_ = d & 63;                                                 \
+        if (lane <= slot_) {                                                      \
+            const u32x4 rr_ = {rc_off, rc_mink, rc_dlo, rc_dhi};                  \
+            rows[d - slot_ + lane] = rr_;                                         \
         }                                                                         \
+    } while (0)
+#define PUT_ROW_RECORD(dir0_, finished_)                                          \
+    do {                                                                          \
+        WRITE_ROW_RECORD(dir0_);                                                  \
+        if ((d & 63) == 63 || (finished_)) FLUSH_ROW_RECORDS();                   \
     } while (0)
 
     // Register mode (rows of <= REG_MAX_N diagonals, i.e. nearly all of them):
@@ -255,6 +265,11 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
     PROF_DECL;
     while (!done && !dead) {
         // ================= register-mode rows =================
+        // (the finishing row only leaves the loop; what it found is worked out after
+        // it -- anything more inside and the compiler folds the row loop into the outer
+        // mode loop, at a dozen scalar instructions per row)
+        u64 fin = 0ull;
+        int x = 0, y = 0;
         for (;;) {
             // one sign test covers the four rare events: rows exhausted (:183), band too
             // wide (:184), row too wide for register mode, band drifting out of the wave
@@ -283,43 +298,44 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             const int b = par ? sh_up : vreg;
             // from_above: k == min_k, or k != max_k and V[k-1] < V[k+1]   (:190)
             const u64 fa_m = ((fa_ballot(a < b) & ~(1ull << hi)) | (1ull << lo)) & act_m;
-            int x = fa_sel(fa_m, a + 1, b);
-            int y = x - k;
+            x = fa_sel(fa_m, a + 1, b);
+            y = x - k;
             PROF(1);
             snake16(qL, tL, qb, tb, q_len, t_len, act, x, y);
             PROF(2);
             vreg = x;
             if (act) cells[(u32)((int)row_off - lo) + (u32)lane] = ((u32)x << 1) | (u32)fa_sel(fa_m, 0, 1);
             const u64 dir0 = fa_m >> lo;
-            const u64 fin = (fa_ballot(x >= q_len) | fa_ballot(y >= t_len)) & act_m;  // :220
+            fin = (fa_ballot(x >= q_len) | fa_ballot(y >= t_len)) & act_m;  // :220
             PROF(3);
-            if (fin) {
-                const int fl = __builtin_ctzll(fin);
-                fin_d = d;
-                fin_k = kbase + 2 * fl + par;
-                fin_x = __builtin_amdgcn_readlane(x, fl);
-                fin_y = __builtin_amdgcn_readlane(y, fl);
-                res.cells = (long long)row_off + (fl - lo) + 1;
-                PUT_ROW_RECORD(dir0, true);
-                done = true;
-                break;
-            }
+            WRITE_ROW_RECORD(dir0);
+            if (fin) break;  // (its records are flushed after the loop)
+            if ((d & 63) == 63) FLUSH_ROW_RECORDS();
             // (an LDS ds_max on one word instead of the DPP reduction was measured 2x
             // slower: 64 same-address atomics serialise)
             const int u = act ? x + y : -1;
             best_m = max(best_m, fa_wave_max(u));
             const u64 in = fa_ballot(u >= best_m - band) & act_m;  // :228-243
             PROF(4);
-            PUT_ROW_RECORD(dir0, false);
             // `in` is never empty: best_m is attained inside the row
             const int llo = __builtin_ctzll(in);          // absolute lanes
             const int lhi = 63 - __builtin_clzll(in);
             row_off += (u32)n;
             min_k = min_k + 2 * (llo - lo) - 1;
             n = lhi - llo + 2;
-            lo = par ? llo : llo - 1;  // even row -> odd row moves one lane down
+            lo = llo - 1 + par;  // even row -> odd row moves one lane down
             d++;
             PROF(5);
+        }
+        if (fin) {  // row d finished the alignment on its first (lowest) such diagonal
+            FLUSH_ROW_RECORDS();
+            const int fl = __builtin_ctzll(fin);
+            fin_d = d;
+            fin_k = kbase + 2 * fl + (d & 1);
+            fin_x = __builtin_amdgcn_readlane(x, fl);
+            fin_y = __builtin_amdgcn_readlane(y, fl);
+            res.cells = (long long)row_off + (fl - lo) + 1;
+            done = true;
         }
         if (done || dead) break;
         // ================= ring-mode rows (61..191 diagonals) =================
@@ -406,6 +422,8 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
         }
     }
 #undef PUT_ROW_RECORD
+#undef WRITE_ROW_RECORD
+#undef FLUSH_ROW_RECORDS
 
     if (!done) {  // unaligned: aln_str_size stays 0 (:171,:184-186)
         res.cells = row_off;
@@ -488,7 +506,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
 }
 
 template <bool SEQ_LDS>
-__global__ __launch_bounds__(64, (SEQ_LDS ? 3 : 6)) void k_align(AlignArgs A) {
+__global__ __launch_bounds__(64, (SEQ_LDS ? 3 : 8)) void k_align(AlignArgs A) {
     extern __shared__ __attribute__((aligned(16))) u32 smem[];
     u32 *qL = smem;
     u32 *tL = qL + A.lds_q_words;
