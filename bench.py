@@ -133,7 +133,7 @@ def main():
         batch.run(MIN_COV, K, MIN_IDT)
     sync()
     t0 = time.perf_counter()
-    ms_align = ms_cns = ms_chain = ms_index = 0.0
+    ms_align = ms_cns = ms_chain = ms_index = ms_total = 0.0
     for _ in range(args.steps):
         batch.run(MIN_COV, K, MIN_IDT)  # returns after the stream drained
         st = batch.stats()
@@ -141,6 +141,7 @@ def main():
         ms_cns += st.ms_consensus
         ms_chain += st.ms_chain
         ms_index += st.ms_index
+        ms_total += st.ms_total
     sync()
     elapsed = time.perf_counter() - t0
 
@@ -154,6 +155,9 @@ def main():
         k = max(1, args.steps)
         stage_ms = {"index": ms_index / k, "chain": ms_chain / k, "align": ms_align / k,
                     "consensus": ms_cns / k}
+        # between k_align and the MSA kernels the host sizes the MSA pools from the
+        # alignment summaries (D2H, O(#reads) loop, H2D): device-idle time of the step
+        host_gap = ms_total / k - sum(stage_ms.values())
         # algorithmic bytes per launch
         alg = {
             "index": st.T // 4 + 8 * st.T + 2 * 4 * 65537 * st.n_piles,
@@ -190,6 +194,7 @@ def main():
                 "traffic": None,
             },
             "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},
+            "host_plan_gap_ms": round(host_gap, 3),
             "path_b_alg_bytes_per_step": int(st.b_alg()),
             "path_frac_of_hbm_roofline": round(
                 st.b_alg() * world * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),

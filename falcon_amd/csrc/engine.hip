@@ -95,6 +95,38 @@ struct DevBuf {
     }
 };
 
+// Pinned host memory, grow only: D2H / H2D copies of it are true DMA transfers
+// (a pageable std::vector is first staged by the runtime, at a fraction of the rate).
+template <class T>
+struct HostBuf {
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    int resize(size_t count) {
+        if (count > cap) {
+            release();
+            hipError_t e = hipHostMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault);
+            if (e != hipSuccess) {
+                set_err("hipHostMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+                p = nullptr;
+                return -1;
+            }
+            cap = count;
+        }
+        n = count;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = cap = 0;
+    }
+    T *data() { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+
 struct fa_batch {
     fa_ctx *ctx = nullptr;
     int n_pile = 0, n_seq = 0;
@@ -130,9 +162,11 @@ struct fa_batch {
     DevBuf<int> d_out_eqv;
     DevBuf<FaPileOut> d_pile_out;
 
-    std::vector<FaRange> h_range;
-    std::vector<FaAln> h_aln;
-    std::vector<FaPileOut> h_pile_out;
+    HostBuf<FaRange> h_range;
+    HostBuf<FaAln> h_aln;
+    HostBuf<FaPileOut> h_pile_out;
+    HostBuf<FaTagAln> h_ta;
+    bool msa_static = false;  // seg lists and t_off (functions of the seed lengths) uploaded
     std::vector<char> h_out_seq;
     std::vector<int> h_out_eqv;
     std::vector<std::string> h_result;
@@ -395,6 +429,7 @@ extern "C" void fa_batch_free(fa_batch *b) {
     b->d_seg_t0.release(); b->d_wide.release(); b->d_insb.release(); b->d_t_off.release(); b->d_link_off.release();
     b->d_link_cap.release(); b->d_tinfo.release(); b->d_lvl_nlink.release(); b->d_score_out.release(); b->d_aln.release(); b->d_nodes.release();
     b->d_out_seq.release(); b->d_out_eqv.release(); b->d_pile_out.release();
+    b->h_range.release(); b->h_aln.release(); b->h_pile_out.release(); b->h_ta.release();
     delete b;
 }
 
@@ -439,7 +474,7 @@ static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes) {
 }
 
 static int fetch_aln(fa_batch *b) {
-    b->h_aln.resize(b->n_seq);
+    if (b->h_aln.resize(b->n_seq)) return -1;
     HIP_OK(hipMemcpyAsync(b->h_aln.data(), b->d_aln.p, (size_t)b->n_seq * sizeof(FaAln),
                           hipMemcpyDeviceToHost, b->ctx->stream));
     HIP_OK(hipStreamSynchronize(b->ctx->stream));
@@ -480,6 +515,10 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     fa_launch_chain(d, b->max_bins, s);
     HIP_OK(hipEventRecord(c->ev[2], s));
     trace_stage(s, "chain");
+    // s2 of every alignment (needed by the MSA plan) travels while k_align runs
+    if (b->h_range.resize(b->n_seq)) return -1;
+    HIP_OK(hipMemcpyAsync(b->h_range.data(), b->d_range.p, (size_t)b->n_seq * sizeof(FaRange),
+                          hipMemcpyDeviceToHost, s));
     fa_launch_align(d, c->arena, b->max_read_len, b->max_seed_len, max_diff, s);
     HIP_OK(hipEventRecord(c->ev[3], s));
     trace_stage(s, "align");
@@ -493,20 +532,53 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
         fprintf(stderr, "\n");
     }
     HIP_OK(hipGetLastError());
+    // ---- while k_align runs: the part of the MSA plan that only depends on the seed
+    // lengths (segment work list of k_links, per-pile offsets of the per-position arrays)
+    const int TSEG = 128;  // must match k_msa.hip
+    u64 t_tot = 0;
+    size_t n_seg = 0;
+    for (int p = 0; p < b->n_pile; p++) {
+        t_tot += (u64)b->pile[p].seed_len;
+        n_seg += (size_t)((b->pile[p].seed_len + TSEG - 1) / TSEG);
+    }
+    if (!b->msa_static) {
+        std::vector<int> seg_pile, seg_t0;
+        std::vector<u64> t_off(b->n_pile);
+        seg_pile.reserve(n_seg); seg_t0.reserve(n_seg);
+        u64 tt = 0;
+        for (int p = 0; p < b->n_pile; p++) {
+            t_off[p] = tt;
+            tt += (u64)b->pile[p].seed_len;
+            for (int t0 = 0; t0 < b->pile[p].seed_len; t0 += TSEG) {
+                seg_pile.push_back(p);
+                seg_t0.push_back(t0);
+            }
+        }
+        if (b->d_seg_pile.alloc(n_seg + 1) || b->d_seg_t0.alloc(n_seg + 1) ||
+            b->d_wide.alloc(n_seg + 2) || b->d_t_off.alloc((size_t)b->n_pile + 1))
+            return -1;
+        // (synchronous copies on the null stream; the context's stream is non-blocking,
+        // so they do not wait for k_align)
+        HIP_OK(hipMemcpy(b->d_seg_pile.p, seg_pile.data(), n_seg * sizeof(int), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(b->d_seg_t0.p, seg_t0.data(), n_seg * sizeof(int), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(b->d_t_off.p, t_off.data(), t_off.size() * sizeof(u64), hipMemcpyHostToDevice));
+        b->msa_static = true;
+    }
+    if (b->h_ta.resize((size_t)b->n_seq + 1)) return -1;
     // alignment summaries bound the MSA node pools (levels <= seed + insertions)
     if (int rc = fetch_aln(b)) return rc;
+    b->have_range = true;  // its copy was queued ahead of k_align
     // ---- plan the MSA stage from the alignment summaries (host, O(#reads))
-    u64 node_off = 0, desc_tot = 0, ins_tot = 0, t_tot = 0, link_tot = 0;
+    u64 node_off = 0, desc_tot = 0, ins_tot = 0, link_tot = 0;
     long long sC = 0, sD = 0, sA = 0, nal = 0;
-    std::vector<FaTagAln> ta;
+    FaTagAln *ta = b->h_ta.data();
+    size_t n_ta = 0;
     std::vector<u32> acc_first(b->n_pile + 1, 0);
-    std::vector<u64> t_off(b->n_pile), link_off(b->n_pile), link_cap(b->n_pile);
-    std::vector<int> seg_pile, seg_t0;
-    const int TSEG = 128;  // must match k_msa.hip
+    std::vector<u64> link_off(b->n_pile), link_cap(b->n_pile);
     for (int p = 0; p < b->n_pile; p++) {
         FaPile &pm = b->pile[p];
         u64 levels = (u64)pm.seed_len + 2, cols = 8;
-        acc_first[p] = (u32)ta.size();
+        acc_first[p] = (u32)n_ta;
         int n_acc = 0;
         for (int j = 1; j < pm.n_seq; j++) {
             const int g = pm.first + j;
@@ -518,14 +590,13 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
             sD += al.dist;
             sA += al.size;
             n_acc++;
-            FaTagAln x;
+            FaTagAln &x = ta[n_ta++];
             x.desc_off = desc_tot;
             x.ins_off = (u32)ins_tot;
-            x.s2 = 0;  // filled on the device side from range[g] (k_tags reads it); kept for k_links
+            x.s2 = b->h_range[g].s2;  // start of the alignment on the seed (chain stage)
             x.g = g;
             x.pile = p;
             x.pad = 0;
-            ta.push_back(x);
             desc_tot += (u64)al.t_e + 2;
             ins_tot += (u64)al.n_ins + 4;
         }
@@ -538,31 +609,15 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
         pm.node_off = node_off;
         pm.node_cap = levels * 5;
         node_off += pm.node_cap;
-        t_off[p] = t_tot;
-        t_tot += (u64)pm.seed_len;
         link_off[p] = link_tot;
         link_cap[p] = cols;
         link_tot += cols;
-        for (int t0 = 0; t0 < pm.seed_len; t0 += TSEG) {
-            seg_pile.push_back(p);
-            seg_t0.push_back(t0);
-        }
     }
-    acc_first[b->n_pile] = (u32)ta.size();
+    acc_first[b->n_pile] = (u32)n_ta;
     if (ins_tot >= 0xffffffffull || link_tot >= 0xffffffffull * 4) {
         set_err("falcon_amd: batch too large for the MSA stage");
         return -1;
     }
-    // s2 of every accepted alignment comes from the chain stage
-    {
-        b->h_range.resize(b->n_seq);
-        HIP_OK(hipMemcpyAsync(b->h_range.data(), b->d_range.p, (size_t)b->n_seq * sizeof(FaRange),
-                              hipMemcpyDeviceToHost, s));
-        HIP_OK(hipStreamSynchronize(s));
-        b->have_range = true;
-        for (auto &x : ta) x.s2 = b->h_range[x.g].s2;
-    }
-    const size_t n_ta = ta.size();
     const size_t tarr_ints = 3 * (size_t)(t_tot + (u64)b->n_pile);
     auto need = [&](auto &buf, size_t n) { return (buf.n < n) ? buf.alloc(n) : 0; };
     int rc2 = 0;
@@ -572,7 +627,6 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     rc2 |= need(b->d_desc, 2 * (size_t)desc_tot + 8);
     rc2 |= need(b->d_insb, (size_t)ins_tot + 8);
     rc2 |= need(b->d_tarr, tarr_ints + 8);
-    rc2 |= need(b->d_t_off, (size_t)b->n_pile);
     rc2 |= need(b->d_tinfo, (size_t)t_tot + 8);
     rc2 |= need(b->d_links, (size_t)link_tot + 8);
     rc2 |= need(b->d_link_off, (size_t)b->n_pile);
@@ -580,22 +634,16 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     rc2 |= need(b->d_lvl_nlink, (size_t)(node_off / 5) + 8);
     rc2 |= need(b->d_score_ovf, (size_t)b->n_pile * 2 * 256 * 5);
     rc2 |= need(b->d_score_out, (size_t)b->n_pile);
-    rc2 |= need(b->d_seg_pile, seg_pile.size() + 1);
-    rc2 |= need(b->d_seg_t0, seg_t0.size() + 1);
-    rc2 |= need(b->d_wide, seg_t0.size() + 2);
     rc2 |= need(b->d_nodes, (size_t)node_off + 8);
     if (rc2) return -1;
     auto up = [&](void *dst, const void *src, size_t bytes) {
         return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s) == hipSuccess;
     };
     bool okc = true;
-    okc &= up(b->d_ta.p, ta.data(), n_ta * sizeof(FaTagAln));
+    okc &= up(b->d_ta.p, ta, n_ta * sizeof(FaTagAln));
     okc &= up(b->d_acc_first.p, acc_first.data(), acc_first.size() * sizeof(u32));
-    okc &= up(b->d_t_off.p, t_off.data(), t_off.size() * sizeof(u64));
     okc &= up(b->d_link_off.p, link_off.data(), link_off.size() * sizeof(u64));
     okc &= up(b->d_link_cap.p, link_cap.data(), link_cap.size() * sizeof(u64));
-    okc &= up(b->d_seg_pile.p, seg_pile.data(), seg_pile.size() * sizeof(int));
-    okc &= up(b->d_seg_t0.p, seg_t0.data(), seg_t0.size() * sizeof(int));
     okc &= up(b->d_pile.p, b->pile.data(), (size_t)b->n_pile * sizeof(FaPile));
     if (!okc) {
         set_err("falcon_amd: uploading the MSA plan failed");
@@ -608,7 +656,7 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     md.links = b->d_links.p; md.link_off = b->d_link_off.p; md.link_cap = b->d_link_cap.p;
     md.lvl_nlink16 = b->d_lvl_nlink.p; md.score_ovf = b->d_score_ovf.p;
     md.score_out = b->d_score_out.p; md.seg_pile = b->d_seg_pile.p; md.seg_t0 = b->d_seg_t0.p;
-    md.n_seg = (int)seg_pile.size();
+    md.n_seg = (int)n_seg;
     md.wide_count = b->d_wide.p; md.wide_list = b->d_wide.p + 1;
     d = b->dev();
     HIP_OK(hipEventRecord(c->ev[4], s));
@@ -616,7 +664,7 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     HIP_OK(hipEventRecord(c->ev[5], s));
     trace_stage(s, "consensus");
     HIP_OK(hipGetLastError());
-    b->h_pile_out.resize(b->n_pile);
+    if (b->h_pile_out.resize(b->n_pile)) return -1;
     HIP_OK(hipMemcpyAsync(b->h_pile_out.data(), b->d_pile_out.p,
                           (size_t)b->n_pile * sizeof(FaPileOut), hipMemcpyDeviceToHost, s));
     HIP_OK(hipEventRecord(c->ev[6], s));
