@@ -624,7 +624,7 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     rc2 |= need(b->d_ta, n_ta + 1);
     rc2 |= need(b->d_acc_first, (size_t)b->n_pile + 1);
     rc2 |= need(b->d_tcov, n_ta + 1);
-    rc2 |= need(b->d_desc, 2 * (size_t)desc_tot + 8);
+    rc2 |= need(b->d_desc, (size_t)desc_tot + 8);
     rc2 |= need(b->d_insb, (size_t)ins_tot + 8);
     rc2 |= need(b->d_tarr, tarr_ints + 8);
     rc2 |= need(b->d_tinfo, (size_t)t_tot + 8);

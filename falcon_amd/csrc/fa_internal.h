@@ -94,7 +94,7 @@ struct FaPileOut {
 };
 
 struct FaTagAln {   // one per accepted alignment, grouped by pile in read order (host-built)
-    u64 desc_off;   // offset of its tag words (2 x u32 per covered target position)
+    u64 desc_off;   // offset of its tag words (one u32 per covered target position)
     u32 ins_off;    // offset of its inserted-base bytes
     int s2;         // first covered target position
     int g;          // sequence index

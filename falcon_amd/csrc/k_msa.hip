@@ -38,11 +38,17 @@
 
 #define TSEG 128       // target positions per k_links wavefront
 #define MAXACT 512     // alignments overlapping one segment
-#define INL 16         // inserted bases stored inline in a tag
+#define INL 11         // inserted bases stored inline in a tag
 #define BT_WIN 64      // levels per back-trace window
 
-#define TAG_DEL 0x40000000u
-#define TAG_NINS_SHIFT 22
+// tag word of one covered target position (one u32, written exactly once):
+//   bit 31      the alignment deletes the target base
+//   bits 30..23 length of the insertion run that follows it (0..254)
+//   bits 22..0  the run itself: up to INL bases inline (2 bits each, first base lowest),
+//               longer runs the index of their first base in the alignment's byte list
+#define TAG_DEL 0x80000000u
+#define TAG_NINS_SHIFT 23
+#define TAG_PAY_MASK 0x7fffffu
 
 struct MsaArgs {
     const u32 *words;
@@ -57,7 +63,7 @@ struct MsaArgs {
     int n_acc_total;
     int n_pile;
     int *tcov;                 // [n_acc_total] covered target positions (k_tags)
-    u32 *desc;                 // 2 x u32 per covered target position
+    u32 *desc;                 // one tag word per covered target position
     uint8_t *insb;             // inserted bases of runs longer than INL (and all others)
     int *tarr;                 // per pile 3 x (T+1): cov diff, max ins, sum ins
     const u64 *t_off;          // [n_pile] position offset of the pile's per-t arrays
@@ -137,14 +143,14 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
     const FaRange rg = A.range[g];
     const u32 *scr = A.script + A.script_off[g];
     const u32 *rw = A.words + A.seq[g].woff;
-    u32 *desc = A.desc + 2 * ta.desc_off;
+    u32 *desc = A.desc + ta.desc_off;
     uint8_t *insb = A.insb + ta.ins_off;
     int *tarr = A.tarr + 3 * (A.t_off[ta.pile] + (u64)ta.pile);  // (T+1) entries per array
     const int T1 = A.pile[ta.pile].seed_len + 1;
     int *a_cov = tarr, *a_max = tarr + T1, *a_sum = tarr + 2 * T1;
     const int dist = al.dist, te = al.t_e;
 
-    for (int u = lane; u < 2 * te; u += 64) desc[u] = 0u;
+    for (int u = lane; u < te; u += 64) desc[u] = 0u;
 
     // pre-pass: tagging stops at the first column whose insertion depth reaches
     // 255 (falcon.c:138-152); dcut = that row (dist + 1 if none)
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
             if (delta <= INL) inl = b << (2 * (delta - 1));
         }
 #pragma unroll
-        for (int off = 1; off < INL; off <<= 1) {
+        for (int off = 1; off < 16; off <<= 1) {  // 16 >= INL
             const u32 o = (u32)__shfl_up((int)inl, off);
             if (is_ins && delta - 1 >= off && lane >= off) inl |= o;
         }
@@ -213,15 +219,14 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
         // flag unless an insertion run hangs off the deleted base, in which case the
         // run's last row writes the whole word.
         if (is_del && !(m == 0 && d + 1 <= dlast && (en & 1u) == 0u)) {
-            desc[2 * tpos + 1] = TAG_DEL;
+            desc[tpos] = TAG_DEL;
         }
         if (ends) {
             const int us = tpos - 1;  // the target position the run hangs off
             const u32 es = (start_row >= 2) ? scr[start_row - 1] : 0u;  // column before the run
             const bool on_del = start_row >= 2 && (es & 1u) != 0u && (es >> 1) == 0u;
-            desc[2 * us] = inl;
-            desc[2 * us + 1] = ((u32)run_i & 0x3fffffu) | ((u32)delta << TAG_NINS_SHIFT) |
-                               (on_del ? TAG_DEL : 0u);
+            desc[us] = (delta <= INL ? inl : ((u32)run_i & TAG_PAY_MASK)) |
+                       ((u32)delta << TAG_NINS_SHIFT) | (on_del ? TAG_DEL : 0u);
             atomicMax(&a_max[rg.s2 + us], delta);
             atomicAdd(&a_sum[rg.s2 + us], delta);
         }
@@ -291,12 +296,12 @@ __global__ __launch_bounds__(64) void k_tscan(MsaArgs A) {
 // k_links
 // ---------------------------------------------------------------------------
 // tag word accessors
-__device__ __forceinline__ int tag_nins(u32 hi) { return (int)((hi >> TAG_NINS_SHIFT) & 0xffu); }
+__device__ __forceinline__ int tag_nins(u32 w) { return (int)((w >> TAG_NINS_SHIFT) & 0xffu); }
 // base `delta` (1-based) of the insertion run of a tag: runs of up to INL bases are
 // inline in the low word, longer runs live entirely in the byte array
-__device__ __forceinline__ int tag_ins_base(const MsaArgs &A, u32 ins_off, u32 lo, u32 hi, int delta) {
-    if (tag_nins(hi) <= INL) return (int)((lo >> (2 * (delta - 1))) & 3u);
-    return (int)A.insb[ins_off + (hi & 0x3fffffu) + (u32)(delta - 1)];
+__device__ __forceinline__ int tag_ins_base(const MsaArgs &A, u32 ins_off, u32 w, int delta) {
+    if (tag_nins(w) <= INL) return (int)((w >> (2 * (delta - 1))) & 3u);
+    return (int)A.insb[ins_off + (w & TAG_PAY_MASK) + (u32)(delta - 1)];
 }
 
 // NCHT = 1: segments overlapped by <= 64 alignments (the normal case below 64x
@@ -353,12 +358,12 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
     // the lane's alignment contributed at the previous target position: the
     // predecessor of its delta-0 tag at this one (falcon.c:129-160)
     int s2v[NCHT], tcv[NCHT], pbv[NCHT], pnv[NCHT];
-    const uint2 *dptr[NCHT];
+    const u32 *dptr[NCHT];
     u32 insoff[NCHT];
 #pragma unroll
     for (int c = 0; c < NCHT; c++) {
         s2v[c] = 0x7fffffff; tcv[c] = 0; pbv[c] = 0; pnv[c] = 0; insoff[c] = 0;
-        dptr[c] = reinterpret_cast<const uint2 *>(A.desc);
+        dptr[c] = A.desc;
         const int a = c * 64 + lane;
         if (c < nch && a < n_act) {
             const int i = act[a];
@@ -366,14 +371,14 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
             s2v[c] = ta.s2;
             tcv[c] = A.tcov[i];
             insoff[c] = ta.ins_off;
-            dptr[c] = reinterpret_cast<const uint2 *>(A.desc) + ta.desc_off;
+            dptr[c] = A.desc + ta.desc_off;
             const int u = t_lo - 1 - s2v[c];  // the position before the segment
             if (u >= 0 && u < tcv[c]) {
-                const uint2 w = dptr[c][u];
-                const int pn = tag_nins(w.y);
+                const u32 w = dptr[c][u];
+                const int pn = tag_nins(w);
                 pnv[c] = pn;
-                pbv[c] = pn > 0 ? tag_ins_base(A, insoff[c], w.x, w.y, pn)
-                                : ((w.y & TAG_DEL) ? 4 : (int)fa_base_at(seedw, t_lo - 1));
+                pbv[c] = pn > 0 ? tag_ins_base(A, insoff[c], w, pn)
+                                : ((w & TAG_DEL) ? 4 : (int)fa_base_at(seedw, t_lo - 1));
             }
         }
     }
@@ -390,10 +395,10 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
     }
     const int sw0 = t_lo >> 4;  // TSEG is a multiple of 16
     const u32 seedv = (lane <= (t_hi - 1 - t_lo) >> 4) ? seedw[sw0 + lane] : 0u;
-    uint2 wnx[NCHT];
+    u32 wnx[NCHT];
 #pragma unroll
     for (int c = 0; c < NCHT; c++) {
-        wnx[c] = make_uint2(0u, 0u);
+        wnx[c] = 0u;
         const int u = t_lo - s2v[c];
         if (c < nch && u >= 0 && u < tcv[c]) wnx[c] = dptr[c][u];
     }
@@ -418,10 +423,10 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
         x.lvl_start = x_lvl; x.link_start = x_link; x.cov = (u16)(x_cn & 0xffffu); x.nlev = (u16)(x_cn >> 16);
         // tag words of the lanes covering t (requested one position ago); request t + 1
         bool covd[NCHT];
-        u32 wlo[NCHT], whi[NCHT];
+        u32 wtag[NCHT];
 #pragma unroll
         for (int c = 0; c < NCHT; c++) {
-            covd[c] = false; wlo[c] = wnx[c].x; whi[c] = wnx[c].y;
+            covd[c] = false; wtag[c] = wnx[c];
             if (c < nch) {
                 const int u = t - s2v[c];
                 covd[c] = u >= 0 && u < tcv[c];
@@ -436,8 +441,8 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
         for (int c = 0; c < NCHT; c++) {
             nins[c] = 0; base0[c] = 0;
             if (covd[c]) {
-                nins[c] = tag_nins(whi[c]);
-                base0[c] = (whi[c] & TAG_DEL) ? 4 : sb;
+                nins[c] = tag_nins(wtag[c]);
+                base0[c] = (wtag[c] & TAG_DEL) ? 4 : sb;
             }
         }
         for (int dl = 0; dl < (int)x.nlev; dl++) {
@@ -462,9 +467,8 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
                             }
                         }
                     } else if (covd[c] && nins[c] >= dl) {
-                        const int b = tag_ins_base(A, insoff[c], wlo[c], whi[c], dl);
-                        const int pb = dl == 1 ? base0[c]
-                                               : tag_ins_base(A, insoff[c], wlo[c], whi[c], dl - 1);
+                        const int b = tag_ins_base(A, insoff[c], wtag[c], dl);
+                        const int pb = dl == 1 ? base0[c] : tag_ins_base(A, insoff[c], wtag[c], dl - 1);
                         key[c] = b | (pb << 3) | ((dl - 1) << 6);
                         wv[c] = ((u32)b << 10) | ((u32)((dl - 1) * 5 + pb) << 13);
                         if (nins[c] == dl) { pbv[c] = b; pnv[c] = dl; }
