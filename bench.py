@@ -89,6 +89,20 @@ def cpu_baseline(piles):
     }
 
 
+def measured_traffic(kernel, piles):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under
+    profiles/ (FETCH/WRITE counters cannot be read from inside this process); None unless
+    a measurement of this kernel at this batch size is on file."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f).get(kernel)
+        if rec and int(rec["piles_per_launch"]) == int(piles):
+            return int(rec["hbm_bytes_per_launch"]), rec.get("what", "")
+    except Exception:
+        pass
+    return None, "no PMC measurement of this kernel at this batch size under profiles/"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +148,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     ms_align = ms_cns = ms_chain = ms_index = ms_total = 0.0
+    ms_k = {"k_tags": 0.0, "k_links": 0.0, "k_score": 0.0, "k_backtrace": 0.0}
     for _ in range(args.steps):
         batch.run(MIN_COV, K, MIN_IDT)  # returns after the stream drained
         st = batch.stats()
@@ -142,6 +157,10 @@ def main():
         ms_chain += st.ms_chain
         ms_index += st.ms_index
         ms_total += st.ms_total
+        ms_k["k_tags"] += st.ms_tags          # k_tags + k_tscan (0.7 ms)
+        ms_k["k_links"] += st.ms_links
+        ms_k["k_score"] += st.ms_score
+        ms_k["k_backtrace"] += st.ms_backtrace
     sync()
     elapsed = time.perf_counter() - t0
 
@@ -165,8 +184,19 @@ def main():
             "align": st.L // 4 + 4 * st.C + 8 * st.D,
             "consensus": 16 * st.A + 12 * st.T + 5 * st.O,  # k_tags + k_links + k_score + k_backtrace
         }
-        dom = max(stage_ms, key=lambda s: stage_ms[s])
-        ach = alg[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+        # per kernel, HIP events on the engine's stream around every launch of the timed
+        # region (the index / chain / align stages are one kernel each)
+        kernel_ms = {"k_seed_index": stage_ms["index"], "k_chain": stage_ms["chain"],
+                     "k_align": stage_ms["align"]}
+        kernel_ms.update({n: v / k for n, v in ms_k.items()})
+        kalg = {"k_seed_index": alg["index"], "k_chain": alg["chain"], "k_align": alg["align"],
+                "k_tags": 8 * st.D + 4 * st.A,            # script in, one tag word per column out
+                "k_links": 4 * st.A + 12 * st.T,          # tag words in, per-position arrays
+                "k_score": 8 * st.A,                      # link words in, node records out (upper bound)
+                "k_backtrace": 5 * st.O}
+        domk = max(kernel_ms, key=lambda n: kernel_ms[n])
+        ach = kalg[domk] / (kernel_ms[domk] * 1e-3) / 1e9 if kernel_ms[domk] > 0 else 0.0
+        traffic, traffic_src = measured_traffic(domk, args.piles)
         out = {
             "metric": "consensus_bases_per_sec",
             "value": round(bases_all * args.steps / elapsed, 1),
@@ -186,14 +216,16 @@ def main():
             },
             "piles_per_sec": round(piles_all * args.steps / elapsed, 2),
             "roofline": {
-                "bound": "hbm", "kernel": "k_" + dom,
+                "bound": "hbm", "kernel": domk,
                 "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5),
-                "algorithmic_bytes_per_launch": int(alg[dom]),
-                "avg_launch_ms": round(stage_ms[dom], 4),
-                "traffic": None,
+                "algorithmic_bytes_per_launch": int(kalg[domk]),
+                "avg_launch_ms": round(kernel_ms[domk], 4),
+                "traffic": traffic,
+                "traffic_source": traffic_src,
             },
             "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},
+            "kernel_ms": {n: round(v, 4) for n, v in kernel_ms.items()},
             "host_plan_gap_ms": round(host_gap, 3),
             "path_b_alg_bytes_per_step": int(st.b_alg()),
             "path_frac_of_hbm_roofline": round(

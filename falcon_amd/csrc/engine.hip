@@ -66,7 +66,7 @@ struct fa_ctx {
     int n_cu = 0;
     size_t total_mem = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[12] = {};
     // alignment work-slot arena (grow only)
     FaAlignArena arena = {};
     size_t arena_cells_bytes = 0, arena_rows_bytes = 0;  // rows and rowx have equal size
@@ -660,7 +660,7 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     md.wide_count = b->d_wide.p; md.wide_list = b->d_wide.p + 1;
     d = b->dev();
     HIP_OK(hipEventRecord(c->ev[4], s));
-    fa_launch_msa(d, md, min_cov, s);
+    fa_launch_msa(d, md, min_cov, s, c->ev + 8);
     HIP_OK(hipEventRecord(c->ev[5], s));
     trace_stage(s, "consensus");
     HIP_OK(hipGetLastError());
@@ -686,6 +686,10 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     (void)hipEventElapsedTime(&st.ms_align, c->ev[2], c->ev[3]);
     (void)hipEventElapsedTime(&st.ms_consensus, c->ev[4], c->ev[5]);
     (void)hipEventElapsedTime(&st.ms_total, c->ev[0], c->ev[6]);
+    (void)hipEventElapsedTime(&st.ms_tags, c->ev[4], c->ev[8]);
+    (void)hipEventElapsedTime(&st.ms_links, c->ev[8], c->ev[9]);
+    (void)hipEventElapsedTime(&st.ms_score, c->ev[9], c->ev[10]);
+    (void)hipEventElapsedTime(&st.ms_backtrace, c->ev[10], c->ev[11]);
     return 0;
 }
 

@@ -184,6 +184,8 @@ struct FaMsaDev {
     int *wide_count;
     int *wide_list;
 };
-void fa_launch_msa(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov, hipStream_t s);
+// ev (optional): 4 events recorded after k_tags+k_tscan, k_links, k_score, k_backtrace
+void fa_launch_msa(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov, hipStream_t s,
+                   hipEvent_t *ev = nullptr);
 size_t fa_align_lds_bytes(int max_q_len, int max_t_len);
 int fa_align_blocks_per_cu(size_t lds_bytes);

@@ -882,7 +882,8 @@ __global__ __launch_bounds__(64) void k_backtrace(MsaArgs A) {
 }
 
 // ---------------------------------------------------------------------------
-void fa_launch_msa(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov, hipStream_t s) {
+void fa_launch_msa(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov, hipStream_t s,
+                   hipEvent_t *ev) {
     if (b.n_pile == 0) return;
     MsaArgs A;
     A.words = b.words; A.seq = b.seq; A.pile = b.pile; A.range = b.range; A.aln = b.aln;
@@ -898,11 +899,15 @@ void fa_launch_msa(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov, hip
     (void)hipMemsetAsync(m.tarr, 0, m.tarr_bytes, s);
     if (m.n_acc_total > 0) hipLaunchKernelGGL(k_tags, dim3(m.n_acc_total), dim3(64), 0, s, A);
     hipLaunchKernelGGL(k_tscan, dim3(b.n_pile), dim3(64), 0, s, A);
+    if (ev) (void)hipEventRecord(ev[0], s);
     if (m.n_seg > 0) {
         (void)hipMemsetAsync(m.wide_count, 0, sizeof(int), s);
         hipLaunchKernelGGL(k_links<1>, dim3(m.n_seg), dim3(64), 0, s, A);
         hipLaunchKernelGGL(k_links<8>, dim3(m.n_seg), dim3(64), 0, s, A);
     }
+    if (ev) (void)hipEventRecord(ev[1], s);
     hipLaunchKernelGGL(k_score, dim3(b.n_pile), dim3(64), 0, s, A);
+    if (ev) (void)hipEventRecord(ev[2], s);
     hipLaunchKernelGGL(k_backtrace, dim3(b.n_pile), dim3(64), 0, s, A);
+    if (ev) (void)hipEventRecord(ev[3], s);
 }

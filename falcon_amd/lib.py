@@ -25,7 +25,9 @@ class FaStats(C.Structure):
                 ("n_aligned", C.c_longlong),
                 ("ms_index", C.c_float), ("ms_chain", C.c_float), ("ms_align", C.c_float),
                 ("ms_consensus", C.c_float), ("ms_total", C.c_float),
-                ("align_slots", C.c_int)]
+                ("align_slots", C.c_int),
+                ("ms_tags", C.c_float), ("ms_links", C.c_float), ("ms_score", C.c_float),
+                ("ms_backtrace", C.c_float)]
 
     def b_alg(self) -> int:
         """Algorithmic bytes: L/4 + 4C + 8D + 16A + 12T + 5O."""

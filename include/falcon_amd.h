@@ -130,6 +130,8 @@ typedef struct {
     /* stage times of the last fa_batch_run, HIP events on the engine stream */
     float ms_index, ms_chain, ms_align, ms_consensus, ms_total;
     int align_slots; /* resident alignment work slots (wavefronts) */
+    /* the kernels of the consensus stage (k_msa.hip), same clock */
+    float ms_tags, ms_links, ms_score, ms_backtrace;
 } fa_stats;
 
 const char *fa_last_error(void);
