@@ -253,8 +253,8 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
     // (DW_banded.c:190-196) are then the lane's own register and ONE DPP wave
     // shift -- no LDS traffic for V at all.  Wider rows fall back to the LDS
     // ring (ring mode) until the band narrows again.  The two modes are two
-    // plain loops (the row loop must stay a simple loop: the scalar unit is the
-    // bottleneck of this kernel).
+    // plain loops (the row loop must stay a simple loop: instruction issue, scalar
+    // and vector alike, is the bottleneck of this kernel).
     const int REG_MAX_N = 60;
     const int nmax = min(REG_MAX_N, band + 1);
     int kbase = -62;       // diagonal 0 sits on lane 31

@@ -9,12 +9,12 @@
 // and it is a few operations per link:
 //
 //   k_tags      one wavefront per accepted alignment.  Prefix scans over the
-//               edit script turn it into position-major tags: one 8-byte word
+//               edit script turn it into position-major tags: one 4-byte word
 //               per covered target position {deleted?, insertion-run length,
-//               up to 16 inserted bases inline} (longer runs spill to a byte
-//               array).  Also accumulates, per target position, the coverage
-//               (difference array), the deepest insertion level and the number
-//               of tags.  This is SURVEY.md's "8 B packed tag written once".
+//               up to 11 inserted bases inline} (longer runs spill to a byte
+//               array), each written exactly once.  Also accumulates, per target
+//               position, the coverage (difference array), the deepest insertion
+//               level and the number of tags.
 //   k_tscan     one wavefront per pile: prefix sums over target positions ->
 //               level slot and link slot of every position (deterministic
 //               layout, node ids ascend in (t, delta) order).
@@ -22,13 +22,14 @@
 //               lanes = alignments overlapping the segment (compacted, in read
 //               order).  For every (t, delta) level the lanes holding the same
 //               (base, previous node) are one link of the reference
-//               (update_col, falcon.c:232-263): grouped with __ballot, group
+//               (update_col, falcon.c:232-263): grouped with ballots, group
 //               size = link count, groups visited in lowest-lane order = the
 //               reference's first-insertion order (Q5).  Emits one u32 per link.
-//   k_score     one LANE per pile: the score recurrence (falcon.c:405-475) over
-//               the link words, -1 floor, strict '>', first maximum; scores of
-//               the previous and current target position live in lane-private
-//               LDS; writes the 8-byte node records and the global best.
+//   k_score     one wavefront per pile: the score recurrence (falcon.c:405-475)
+//               over the link words, -1 floor, strict '>', first maximum; the
+//               scores of the previous and current target position live in two
+//               VGPRs (lane = delta * 5 + base); writes the 8-byte node records
+//               and the global best.
 //   k_backtrace one wavefront per pile: walks the node records through a
 //               64-level LDS window and writes the consensus right-aligned,
 //               64 characters per store (falcon.c:494-528, no reversal pass).
