@@ -477,45 +477,56 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
                     if (dl == 0 && covd[c] && nins[c] == 0) { pbv[c] = base0[c]; pnv[c] = 0; }
                 }
             }
-            // lanes with equal keys are one link; links are visited in lowest-lane
-            // order = the reference's first-insertion order (Q5).  The lowest lane of
-            // a group (its leader) keeps the group's rank and size and stores the word.
-            u64 rem[NCHT];
+            // lanes with equal keys are one link.  Links are emitted node-major (k_score
+            // resolves a level with one segmented scan over them) and, inside a node, in
+            // lowest-lane order = the reference's first-insertion order (Q5).  The lowest
+            // lane of a group (its leader) keeps the group's rank and size and stores the word.
+            int knode[NCHT];
 #pragma unroll
-            for (int c = 0; c < NCHT; c++) rem[c] = (c < nch) ? __ballot(key[c] >= 0) : 0ull;
+            for (int c = 0; c < NCHT; c++) knode[c] = (c < nch && key[c] >= 0) ? (key[c] & 7) : 7;
             int n_link = 0;
             int myrank[NCHT];
 #pragma unroll
             for (int c = 0; c < NCHT; c++) myrank[c] = -1;
-            for (;;) {
-                int c0 = -1;
-#pragma unroll
-                for (int c = NCHT - 1; c >= 0; c--)
-                    if (rem[c]) c0 = c;
-                if (c0 < 0) break;
-                int kk = 0, ldr = 0;
-#pragma unroll
-                for (int c = 0; c < NCHT; c++)
-                    if (c == c0) {
-                        ldr = __ffsll((long long)rem[c]) - 1;
-                        kk = __builtin_amdgcn_readlane(key[c], ldr);
-                    }
-                int cnt = 0;
+            for (int nbq = 0; nbq < 5; nbq++) {
+                u64 rem[NCHT];
+                bool any = false;
 #pragma unroll
                 for (int c = 0; c < NCHT; c++) {
-                    if (c < nch) {
-                        const u64 m = __ballot(key[c] == kk);
-                        cnt += __popcll(m);
-                        rem[c] &= ~m;
-                    }
+                    rem[c] = (c < nch) ? fa_ballot(knode[c] == nbq) : 0ull;
+                    any = any || rem[c] != 0ull;
                 }
+                if (!any) continue;
+                for (;;) {
+                    int c0 = -1;
 #pragma unroll
-                for (int c = 0; c < NCHT; c++)
-                    if (c == c0 && lane == ldr) {
-                        myrank[c] = n_link;
-                        wv[c] |= (u32)cnt;
+                    for (int c = NCHT - 1; c >= 0; c--)
+                        if (rem[c]) c0 = c;
+                    if (c0 < 0) break;
+                    int kk = 0, ldr = 0;
+#pragma unroll
+                    for (int c = 0; c < NCHT; c++)
+                        if (c == c0) {
+                            ldr = __builtin_ctzll(rem[c]);
+                            kk = __builtin_amdgcn_readlane(key[c], ldr);
+                        }
+                    int cnt = 0;
+#pragma unroll
+                    for (int c = 0; c < NCHT; c++) {
+                        if (c < nch) {
+                            const u64 m = fa_ballot(key[c] == kk);
+                            cnt += __popcll(m);
+                            rem[c] &= ~m;
+                        }
                     }
-                n_link++;
+#pragma unroll
+                    for (int c = 0; c < NCHT; c++)
+                        if (c == c0 && lane == ldr) {
+                            myrank[c] = n_link;
+                            wv[c] |= (u32)cnt;
+                        }
+                    n_link++;
+                }
             }
 #pragma unroll
             for (int c = 0; c < NCHT; c++)
@@ -544,6 +555,7 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
 #define SC_LEVELS 128     // levels per block (their link counts sit in two VGPRs)
 #define SC_REG 12         // insertion levels whose scores live in registers
 #define SC_ZERO 63        // lane of the score registers that always holds 0 (start links)
+#define SC_BIAS 1024      // makes every link score positive (score >= -2 - coverage, coverage <= 512)
 
 struct ScoreAcc { int h, p, k, n; };
 
@@ -695,8 +707,52 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                 const int cnt = (int)(w & 0x3ffu), nbase = (int)((w >> 10) & 7u);
                 const int pidx = (int)((w >> 13) & 0x7ffu);
                 const bool start = (w >> 24) & 1u;
-                const bool deep = have && !start && pidx >= SC_REG * 5;
-                if (dl < SC_REG && n_link <= 64 && __ballot(deep) == 0ull) {
+                // predecessors beyond the register-resident levels take the generic path
+                const u64 deep_m = fa_ballot((have && !start ? pidx : 0) >= SC_REG * 5);
+                if (dl < SC_REG && n_link <= 16 && deep_m == 0ull) {
+                    // ---- the usual level: <= 16 links in lanes 0..15, node-major (k_links).
+                    // One segmented max-scan resolves all five nodes; no loop, no branch.
+                    // Independent of the scores (issued while the gather below is in flight):
+                    const u64 have_m = (1ull << n_link) - 1ull;
+                    const int nbp = have ? nbase + 1 : 0;  // 0: no link in this lane
+                    const int n1 = __builtin_amdgcn_mov_dpp(nbp, 0x111, 0xf, 0xf, true);  // row_shr:1
+                    const int n2 = __builtin_amdgcn_mov_dpp(nbp, 0x112, 0xf, 0xf, true);
+                    const int n4 = __builtin_amdgcn_mov_dpp(nbp, 0x114, 0xf, 0xf, true);
+                    const int n8 = __builtin_amdgcn_mov_dpp(nbp, 0x118, 0xf, 0xf, true);
+                    const int nx = __builtin_amdgcn_mov_dpp(nbp, 0x101, 0xf, 0xf, true);  // row_shl:1
+                    const u64 m1 = fa_ballot(n1 == nbp) & have_m, m2 = fa_ballot(n2 == nbp) & have_m;
+                    const u64 m4 = fa_ballot(n4 == nbp) & have_m, m8 = fa_ballot(n8 == nbp) & have_m;
+                    const u64 tail_m = fa_ballot(nx != nbp) & have_m;  // last link of its node
+                    int ss = fa_sel(have_m & ~m1, 0, lane);            // first lane of my node:
+                    ss = max(ss, __builtin_amdgcn_update_dpp(0, ss, 0x111, 0xf, 0xf, true));
+                    ss = max(ss, __builtin_amdgcn_update_dpp(0, ss, 0x112, 0xf, 0xf, true));
+                    ss = max(ss, __builtin_amdgcn_update_dpp(0, ss, 0x114, 0xf, 0xf, true));
+                    ss = max(ss, __builtin_amdgcn_update_dpp(0, ss, 0x118, 0xf, 0xf, true));
+                    const int cv = 2 * cnt - cov;
+                    const int lidx = start ? SC_ZERO : pidx;
+                    const int pidv = start ? -1 : (int)(plvl5 + (u32)pidx);
+                    const int dst = fa_sel(tail_m, 62, dl * 5 + nbase);  // 62: a lane nobody reads
+                    // The dependent chain: previous scores -> link scores -> per node the first
+                    // maximum (falcon.c:440-447: strict '>', links in insertion order) -> the
+                    // node's score lane.  key = (score, 15 - lane): the larger score wins, among
+                    // equals the lower lane.
+                    const int ph = __builtin_amdgcn_ds_bpermute(lidx << 2, dl == 0 ? prev_h : cur.h);
+                    const int h = ph + cv;
+                    u32 key = have ? (((u32)(h + SC_BIAS) << 4) | (u32)(15 - lane)) : 0u;
+                    key = (u32)fa_sel(m1, (int)key, (int)max(key, (u32)__builtin_amdgcn_update_dpp(0, (int)key, 0x111, 0xf, 0xf, true)));
+                    key = (u32)fa_sel(m2, (int)key, (int)max(key, (u32)__builtin_amdgcn_update_dpp(0, (int)key, 0x112, 0xf, 0xf, true)));
+                    key = (u32)fa_sel(m4, (int)key, (int)max(key, (u32)__builtin_amdgcn_update_dpp(0, (int)key, 0x114, 0xf, 0xf, true)));
+                    key = (u32)fa_sel(m8, (int)key, (int)max(key, (u32)__builtin_amdgcn_update_dpp(0, (int)key, 0x118, 0xf, 0xf, true)));
+                    const int wl = 15 - (int)(key & 15u);  // lane of my node's winning link
+                    const int pidw = __builtin_amdgcn_ds_bpermute(wl << 2, pidv);
+                    const u32 pp = ((u32)(pidw + 1) << 4) | (u32)ss;
+                    const u32 r_key = (u32)__builtin_amdgcn_ds_permute(dst << 2, fa_sel(tail_m, 0, (int)key));
+                    const u32 r_pp = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)pp);
+                    const bool got = r_key != 0u;  // a node of this level landed on my lane
+                    cur.h = got ? (int)(r_key >> 4) - SC_BIAS : cur.h;
+                    cur.p = got ? (int)(r_pp >> 4) - 1 : cur.p;
+                    cur.k = got ? 15 - (int)(r_key & 15u) - (int)(r_pp & 15u) : cur.k;
+                } else if (dl < SC_REG && n_link <= 64 && deep_m == 0ull) {
                     const int cv = 2 * cnt - cov;
                     const int lidx = start ? SC_ZERO : pidx;
                     const int pidv = start ? -1 : (int)(plvl5 + (u32)pidx);
