@@ -134,7 +134,7 @@ struct fa_batch {
     int band = FA_BAND;
     std::vector<FaSeq> seq;
     std::vector<FaPile> pile;
-    std::vector<int> order;
+    std::vector<int> order, chain_order;
     std::vector<u64> ascii_off, script_off, probe_off;
     u64 n_words = 0, ascii_bytes = 0, script_words = 0, probe_words = 0;
     int max_read_len = 0, max_seed_len = 0, max_rows = 0, max_bins = 4;
@@ -145,7 +145,7 @@ struct fa_batch {
     DevBuf<u32> d_words, d_kidx, d_kpos, d_script;
     DevBuf<FaSeq> d_seq;
     DevBuf<FaPile> d_pile;
-    DevBuf<int> d_order;
+    DevBuf<int> d_order, d_chain_order;
     // MSA stage (k_msa.hip)
     DevBuf<FaTagAln> d_ta;
     DevBuf<u32> d_acc_first, d_desc, d_links;
@@ -179,6 +179,7 @@ struct fa_batch {
         b.ascii = d_ascii.p; b.ascii_off = d_ascii_off.p; b.words = d_words.p;
         b.seq = d_seq.p; b.pile = d_pile.p; b.n_seq = n_seq; b.n_pile = n_pile;
         b.n_words = n_words; b.kidx = d_kidx.p; b.kpos = d_kpos.p; b.order = d_order.p;
+        b.chain_order = d_chain_order.p; b.n_chain = (int)chain_order.size();
         b.range = d_range.p; b.aln = d_aln.p; b.probe = d_probe.p; b.probe_off = d_probe_off.p;
         b.script = d_script.p; b.script_off = d_script_off.p; b.nodes = d_nodes.p;
         b.out_seq = d_out_seq.p; b.out_eqv = d_out_eqv.p; b.pile_out = d_pile_out.p;
@@ -346,6 +347,21 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
         int ly = b->seq[y].idx == 0 ? -1 : b->seq[y].len;
         return lx > ly;
     });
+    // k_chain gathers from its pile's k-mer tables (262 KB + 4 B per seed base): its
+    // work list is pile-major so that a pile's reads run together, and dealt into 8
+    // interleaved streams (pile p -> stream p mod 8, workgroup b takes entry b / 8 of
+    // stream b mod 8) so that -- with workgroups dealt round-robin to the 8 XCDs -- a
+    // pile's tables live in ONE XCD's L2 (4 MB holds the ~7 piles an XCD works on).
+    {
+        std::vector<int> stream[8];
+        for (int p = 0; p < n_pile; p++)
+            for (int j = 0; j < b->pile[p].n_seq; j++) stream[p & 7].push_back(b->pile[p].first + j);
+        size_t longest = 0;
+        for (auto &v : stream) longest = std::max(longest, v.size());
+        b->chain_order.assign(longest * 8, -1);
+        for (int x = 0; x < 8; x++)
+            for (size_t j = 0; j < stream[x].size(); j++) b->chain_order[j * 8 + x] = stream[x][j];
+    }
 
     // stage ASCII through pinned memory
     uint8_t *h_ascii = nullptr;
@@ -363,6 +379,7 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
     rc |= b->d_seq.alloc(g);
     rc |= b->d_pile.alloc(n_pile);
     rc |= b->d_order.alloc(g);
+    rc |= b->d_chain_order.alloc(b->chain_order.size() + 1);
     rc |= b->d_range.alloc(g);
     rc |= b->d_aln.alloc(g);
     rc |= b->d_script_off.alloc(g);
@@ -388,6 +405,9 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
     ok &= hipMemcpyAsync(b->d_seq.p, b->seq.data(), g * sizeof(FaSeq), hipMemcpyHostToDevice, s) == hipSuccess;
     ok &= hipMemcpyAsync(b->d_pile.p, b->pile.data(), n_pile * sizeof(FaPile), hipMemcpyHostToDevice, s) == hipSuccess;
     ok &= hipMemcpyAsync(b->d_order.p, b->order.data(), g * sizeof(int), hipMemcpyHostToDevice, s) == hipSuccess;
+    ok &= b->chain_order.empty() ||
+          hipMemcpyAsync(b->d_chain_order.p, b->chain_order.data(), b->chain_order.size() * sizeof(int),
+                         hipMemcpyHostToDevice, s) == hipSuccess;
     ok &= hipMemcpyAsync(b->d_script_off.p, b->script_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
     if (!pair_mode)
         ok &= hipMemcpyAsync(b->d_probe_off.p, b->probe_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
@@ -423,7 +443,7 @@ extern "C" void fa_batch_free(fa_batch *b) {
     b->d_ascii.release(); b->d_ascii_off.release(); b->d_probe.release(); b->d_probe_off.release();
     b->d_script_off.release(); b->d_words.release(); b->d_kidx.release(); b->d_kpos.release();
     b->d_script.release(); b->d_seq.release(); b->d_pile.release();
-    b->d_order.release(); b->d_range.release();
+    b->d_order.release(); b->d_chain_order.release(); b->d_range.release();
     b->d_ta.release(); b->d_acc_first.release(); b->d_desc.release(); b->d_links.release();
     b->d_tcov.release(); b->d_tarr.release(); b->d_score_ovf.release(); b->d_seg_pile.release();
     b->d_seg_t0.release(); b->d_wide.release(); b->d_insb.release(); b->d_t_off.release(); b->d_link_off.release();

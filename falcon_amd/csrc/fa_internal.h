@@ -130,7 +130,9 @@ struct FaBatchDev {
     // stage buffers
     u32 *kidx;
     u32 *kpos;
-    const int *order;      // sequence indices, longest first
+    const int *order;      // sequence indices, longest first (k_align work queue)
+    const int *chain_order;  // k_chain work list: pile-major, 8 interleaved streams (-1 = padding)
+    int n_chain;
     u64 *probe;            // k_chain: per probe {bucket start, size}
     const u64 *probe_off;  // [n_seq]
     FaRange *range;

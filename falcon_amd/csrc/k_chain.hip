@@ -44,7 +44,15 @@ struct ChainArgs {
 
 typedef long long i64;
 
+#define CH_U 4  // probe chunks (of 64) whose dependent loads are issued together
+
+// The chain stage is a string of dependent random reads (packed read -> bucket bounds
+// -> seed positions); a wavefront that walks its probes 64 at a time spends its life
+// waiting for them (measured: 85 % of wave cycles in s_waitcnt).  Every pass therefore
+// issues the loads of CH_U chunks back to back before using any of them.
+
 // inclusive wave scan of the maps r -> max(u, r + v), composed left to right
+// (64-bit, LDS crossbar: the fallback for reads with huge k-mer buckets)
 __device__ __forceinline__ void scan_maps(i64 &u, i64 &v, int lane) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -57,12 +65,38 @@ __device__ __forceinline__ void scan_maps(i64 &u, i64 &v, int lane) {
     }
 }
 
+// the same scan on 32-bit values through DPP (row_shr 1,2,4,8, row_bcast 15 / 31);
+// lanes without a source compose with the identity map (u = NEG32, v = 0)
+#define NEG32 (-(1 << 30))
+#define SCAN32_STEP(ctrl, rmask)                                                        \
+    {                                                                                   \
+        const int pu_ = __builtin_amdgcn_update_dpp(NEG32, u, ctrl, rmask, 0xf, false); \
+        const int pv_ = __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false);     \
+        u = max(u, pu_ + v);                                                            \
+        v = pv_ + v;                                                                    \
+    }
+__device__ __forceinline__ void scan_maps32(int &u, int &v) {
+    SCAN32_STEP(0x111, 0xf)
+    SCAN32_STEP(0x112, 0xf)
+    SCAN32_STEP(0x114, 0xf)
+    SCAN32_STEP(0x118, 0xf)
+    SCAN32_STEP(0x142, 0xa)
+    SCAN32_STEP(0x143, 0xc)
+}
+
+__device__ __forceinline__ int wave_sum(int s) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    return s;
+}
+
 __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
     extern __shared__ __attribute__((aligned(16))) u32 smem[];
     u32 *bin_cnt = smem;
     u32 *bin_key = smem + A.lds_bins;
     const int lane = fa_lane();
     const int g = A.order[blockIdx.x];
+    if (g < 0) return;  // padding of the interleaved work list
     const FaSeq sq = A.seq[g];
     FaRange r;
     r.s1 = r.e1 = r.s2 = r.e2 = 0;
@@ -84,28 +118,46 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
     // ---- pass A: diagonal extent and hit count
     int d_min = 0x7fffffff, d_max = -0x7fffffff;
     int n_hit = 0;
-    for (int p0 = 0; p0 < n_probe; p0 += 64) {
-        const int p = p0 + lane;
-        if (p < n_probe) {
-            const int i = 4 * p;
-            const u32 km = fa_kmer8(w, i);
-            const u32 lo = T[km], hi = T[km + 1];
-            pr[p] = make_uint2(lo, hi - lo);
-            if (hi > lo) {
-                n_hit += (int)(hi - lo);
-                d_min = min(d_min, i - (int)P[hi - 1]);  // buckets are ascending
-                d_max = max(d_max, i - (int)P[lo]);
+    u32 cnt_max = 0;  // largest bucket a probe of this read hits
+    for (int p0 = 0; p0 < n_probe; p0 += 64 * CH_U) {
+        u32 km[CH_U], lo[CH_U], hi[CH_U], tl[CH_U], th[CH_U];
+#pragma unroll
+        for (int u = 0; u < CH_U; u++) {
+            const int p = p0 + 64 * u + lane;
+            km[u] = (p < n_probe) ? fa_kmer8(w, 4 * p) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < CH_U; u++) {
+            lo[u] = T[km[u]];
+            hi[u] = T[km[u] + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < CH_U; u++) {
+            const int p = p0 + 64 * u + lane;
+            if (p >= n_probe) hi[u] = lo[u];
+            const bool any = hi[u] > lo[u];
+            tl[u] = P[any ? lo[u] : 0u];          // buckets are ascending
+            th[u] = P[any ? hi[u] - 1u : 0u];
+        }
+#pragma unroll
+        for (int u = 0; u < CH_U; u++) {
+            const int p = p0 + 64 * u + lane;
+            if (p < n_probe) {
+                const int i = 4 * p;
+                pr[p] = make_uint2(lo[u], hi[u] - lo[u]);
+                if (hi[u] > lo[u]) {
+                    n_hit += (int)(hi[u] - lo[u]);
+                    cnt_max = max(cnt_max, hi[u] - lo[u]);
+                    d_min = min(d_min, i - (int)th[u]);
+                    d_max = max(d_max, i - (int)tl[u]);
+                }
             }
         }
     }
     d_min = fa_wave_min(d_min);
     d_max = fa_wave_max(d_max);
-    {   // wave sum
-        int s = n_hit;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        n_hit = s;
-    }
+    cnt_max = (u32)fa_wave_max((int)min(cnt_max, 0x7fffffffu));
+    n_hit = wave_sum(n_hit);
     r.n_hit = n_hit;
     if (n_hit == 0) {
         A.out[g] = r;
@@ -124,16 +176,26 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
     __syncthreads();
 
     // ---- pass B: histogram + first-hit order key per bin (:350-366)
-    for (int p0 = 0; p0 < n_probe; p0 += 64) {
-        const int p = p0 + lane;
-        if (p < n_probe) {
+    for (int p0 = 0; p0 < n_probe; p0 += 64 * CH_U) {
+        uint2 v[CH_U];
+        u32 t0[CH_U];
+#pragma unroll
+        for (int u = 0; u < CH_U; u++) {
+            const int p = p0 + 64 * u + lane;
+            v[u] = make_uint2(0u, 0u);
+            if (p < n_probe) v[u] = pr[p];
+        }
+#pragma unroll
+        for (int u = 0; u < CH_U; u++) t0[u] = P[v[u].y ? v[u].x : 0u];  // first hit of the probe
+#pragma unroll
+        for (int u = 0; u < CH_U; u++) {
+            const int p = p0 + 64 * u + lane;
             const int i = 4 * p;
-            const uint2 v = pr[p];
-            const u32 lo = v.x, hi = v.x + v.y;
-            for (u32 k = lo; k < hi; k++) {
-                const int b = (i - (int)P[k] - d_min) / CH_BIN;
+            for (u32 j = 0; j < v[u].y; j++) {
+                const int t = (int)(j == 0 ? t0[u] : P[v[u].x + j]);
+                const int b = (i - t - d_min) / CH_BIN;
                 atomicAdd(&bin_cnt[b], 1u);
-                atomicMin(&bin_key[b], ((u32)p << 17) | (k - lo));
+                atomicMin(&bin_key[b], ((u32)p << 17) | j);
             }
         }
     }
@@ -165,29 +227,42 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
     // ---- pass D: filter (:369-383) + running-score scan (:385-411)
     int kept_total = 0;
     if (top_bin >= 0 && (int)best_cnt > CH_TH) {
+        // 32-bit scan arithmetic is exact while 64 groups of the largest bucket cannot
+        // overflow it; reads that hit monster buckets take the 64-bit crossbar scan
+        // (per group |v| < len + 32 * bucket < 2^22 + 2^21; 64 of them stay below 2^29, so
+        // NEG32 + v cannot wrap)
+        const bool small = cnt_max < (1u << 16) && sq.len < (1 << 22);
         i64 carry_run = 0, best = 0;
         int carry_prev_q = -1;             // q of the last kept group so far (-1: none yet)
         int carry_start_q = 0, carry_start_t = 0;
+        // software pipeline: bucket bounds two chunks ahead, first hits one chunk ahead
+        uint2 v_nx = make_uint2(0u, 0u), v_n2 = make_uint2(0u, 0u);
+        u32 t0_nx = 0;
+        if (lane < n_probe) v_nx = pr[lane];
+        if (lane + 64 < n_probe) v_n2 = pr[lane + 64];
+        t0_nx = P[v_nx.y ? v_nx.x : 0u];
         for (int p0 = 0; p0 < n_probe; p0 += 64) {
             const int p = p0 + lane;
+            const uint2 v = v_nx;
+            const u32 t0 = t0_nx;
+            v_nx = v_n2;
+            t0_nx = P[v_nx.y ? v_nx.x : 0u];
+            v_n2 = make_uint2(0u, 0u);
+            if (p + 128 < n_probe) v_n2 = pr[p + 128];
             int m = 0, t_first = 0, t_last = 0;
             const int q = 4 * p;
-            if (p < n_probe) {
-                const uint2 v = pr[p];
-                const u32 lo = v.x, hi = v.x + v.y;
-                for (u32 k = lo; k < hi; k++) {
-                    const int t = (int)P[k];
-                    const int b = (q - t - d_min) / CH_BIN;
-                    int db = b - top_bin;
-                    if (db < 0) db = -db;
-                    if (db > 5 || (int)bin_cnt[b] <= CH_TH) continue;
-                    if (m == 0) t_first = t;
-                    t_last = t;
-                    m++;
-                }
+            for (u32 j = 0; j < v.y; j++) {  // (v.y == 0 beyond the last probe)
+                const int t = (int)(j == 0 ? t0 : P[v.x + j]);
+                const int b = (q - t - d_min) / CH_BIN;
+                int db = b - top_bin;
+                if (db < 0) db = -db;
+                if (db > 5 || (int)bin_cnt[b] <= CH_TH) continue;
+                if (m == 0) t_first = t;
+                t_last = t;
+                m++;
             }
             const bool has = m > 0;
-            const u64 hm = __ballot(has);
+            const u64 hm = fa_ballot(m > 0);
             if (!hm) continue;
             // q of the previous kept group
             const u64 below = hm & ((lane == 0) ? 0ull : (~0ull >> (64 - lane)));
@@ -196,28 +271,31 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
             // map of this group: r -> max(c, r + a + c)
             const i64 c = 32ll * (m - 1);
             const i64 a = first_ever ? 0 : (i64)(32 - (q - prev_q));
-            i64 u = has ? c : (i64)(-(1ll << 60));
-            i64 v = has ? (a + c) : 0;
-            const i64 my_v_only = v;
-            scan_maps(u, v, lane);
-            const i64 r_out = max(u, carry_run + v);       // score after my group
-            const i64 r_in = r_out - my_v_only;            // tentative: r_in + a + c
-            // entering score of my group = leaving score of the previous kept group
-            i64 r_prev = __shfl_up(r_out, 1);
-            {   // propagate over lanes without a group
-                // (r_out of a lane without a group equals that of the last group before it)
-                if (lane == 0) r_prev = carry_run;
+            i64 r_out;  // score after my group
+            if (small) {
+                int u = has ? (int)c : NEG32;
+                int vv = has ? (int)(a + c) : 0;
+                scan_maps32(u, vv);
+                // carry_run may be large: r_out = max(u, carry_run + vv) in 64 bits
+                r_out = max((i64)u, carry_run + (i64)vv);
+            } else {
+                i64 u = has ? c : (i64)(-(1ll << 60));
+                i64 vv = has ? (a + c) : 0;
+                scan_maps(u, vv, lane);
+                r_out = max(u, carry_run + vv);
             }
-            (void)r_in;
+            // entering score of my group = leaving score of the previous kept group
+            // (r_out of a lane without a group equals that of the last group before it)
+            i64 r_prev = __shfl_up(r_out, 1);
+            if (lane == 0) r_prev = carry_run;
             const bool reset = has && (first_ever || (r_prev + a < 0));
             // best so far: first strict maximum in order (:402)
-            i64 cand = has ? r_out : (i64)(-(1ll << 60));
-            // wave max of a 64-bit value
+            const i64 cand = has ? r_out : (i64)(-(1ll << 60));
             i64 wmax = cand;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, (i64)__shfl_xor(wmax, off));
             if (wmax > best) {
-                const u64 at = __ballot(has && cand == wmax);
+                const u64 at = fa_ballot(cand == wmax) & hm;
                 const int L = __ffsll((long long)at) - 1;
                 best = wmax;
                 const u64 rs = __ballot(reset) & ((L == 63) ? ~0ull : ((1ull << (L + 1)) - 1));
@@ -253,12 +331,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
                 carry_start_q = 4 * (p0 + R);
                 carry_start_t = __shfl(t_first, R);
             }
-            {
-                int s = m;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-                kept_total += s;
-            }
+            kept_total += wave_sum(m);
         }
     }
     if (kept_total <= 1) {  // :413-419
@@ -276,15 +349,15 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
 }
 
 void fa_launch_chain(const FaBatchDev &b, int max_bins, hipStream_t s) {
-    if (b.n_seq == 0) return;
+    if (b.n_seq == 0 || b.n_chain == 0) return;
     ChainArgs A;
     A.words = b.words; A.seq = b.seq; A.pile = b.pile; A.kidx = b.kidx; A.kpos = b.kpos;
-    A.order = b.order; A.n_seq = b.n_seq; A.out = b.range;
+    A.order = b.chain_order; A.n_seq = b.n_seq; A.out = b.range;
     A.probe = (uint2 *)b.probe; A.probe_off = b.probe_off;
     A.lds_bins = (max_bins + 3) & ~3;
     size_t lds = (size_t)A.lds_bins * 2 * sizeof(u32);
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-    hipLaunchKernelGGL(k_chain, dim3(b.n_seq), dim3(64), lds, s, A);
+    hipLaunchKernelGGL(k_chain, dim3(b.n_chain), dim3(64), lds, s, A);
 }
