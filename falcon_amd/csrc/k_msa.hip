@@ -36,6 +36,7 @@
 //
 // Integer only; per-column reduction over aligned bases; no MFMA.
 #include "fa_device.h"
+#include <type_traits>
 
 #define TSEG 128       // target positions per k_links wavefront
 #define MAXACT 512     // alignments overlapping one segment
@@ -618,6 +619,7 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
     int gl_h = -2, gl_slot = 0, gl_ck = 0;  // best node of this lane's (delta, base) class
     int dg_h = -2, dg_slot = 0, dg_ck = 0;  // same for the deep levels (lanes 0..4)
     int curbuf = 0;     // which half of s_deep belongs to the position being scored
+    int prev_nlev = 0;  // its number of levels
     int prev_t = -2;    // last scored target position
     u32 prev_lvl = 0;   // its first level slot
 
@@ -660,8 +662,14 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
         x_link = settled(x_link);
         x_cn = settled(x_cn);
 
-        u32 w_nx = 0;          // link words requested ahead ...
-        u32 w_nx_rel = ~0u;    // ... for this offset into s_links
+        // the block's positions; two instances of the code so that the oversized-position
+        // case (links read straight from HBM) costs the normal one no branches
+        auto run_block = [&](auto bulk_c) {
+        constexpr bool BULK = decltype(bulk_c)::value;
+        // link words of the level about to be scored, requested while the level before it
+        // is being scored (bulk blocks; a position's first level continues where the
+        // capacity of the position before it ends, uncovered positions have none)
+        u32 w_nx = BULK ? s_links[lane] : 0u;
         for (int j = 0; j < nb; j++) {
             const int t = t0 + j;
             const u32 y_lvl = (u32)__builtin_amdgcn_readlane((int)x_lvl, j);
@@ -675,10 +683,14 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
             cur.h = h_init; cur.p = 0; cur.k = 0; cur.n = 0;
             curbuf ^= 1;
             u32 lk = y_link;
+            // no level of this position and no predecessor of one lies beyond the
+            // register-resident levels: the per-level test of the fast path is one compare
+            const bool shallow = nlev <= SC_REG && prev_nlev <= SC_REG;
+            const u32 next_rel = (u32)__builtin_amdgcn_readlane((int)x_link, (j + 1) & 63) - lnk0;
             for (int dl = 0; dl < nlev; dl++) {
                 const u32 slot = y_lvl + (u32)dl;
                 int n_link;
-                if (bulk) {
+                if constexpr (BULK) {
                     const int li = (int)(slot - lvl0);
                     const int a0 = __builtin_amdgcn_readlane(nlk0, li & 63);
                     const int a1 = __builtin_amdgcn_readlane(nlk1, li & 63);
@@ -689,16 +701,11 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                 const u32 plvl5 = (dl == 0 ? prev_lvl : y_lvl) * 5u;  // node id = plvl5 + pidx
                 // first 64 links of the level, lanes = links
                 u32 w = 0;
-                if (bulk) {
-                    const u32 rel = lk - lnk0;
-                    if (w_nx_rel == rel) w = w_nx; else w = s_links[rel + (u32)lane];
-                    // request the next level's words (next position's when this is the last)
-                    u32 rel2 = rel + (u32)n_link;
-                    if (dl + 1 == nlev) {
-                        rel2 = (j + 1 < nb) ? (u32)__builtin_amdgcn_readlane((int)x_link, j + 1) - lnk0 : 0u;
-                    }
+                if constexpr (BULK) {
+                    w = w_nx;
+                    // request the next level's words (the next position's after the last level)
+                    const u32 rel2 = (dl + 1 == nlev) ? next_rel : lk - lnk0 + (u32)n_link;
                     w_nx = s_links[min(rel2, (u32)SC_LINKS) + (u32)lane];
-                    w_nx_rel = rel2;
                 } else {
                     if (lane < n_link) w = links[lk + (u32)lane];
                     w = settled(w);
@@ -707,9 +714,7 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                 const int cnt = (int)(w & 0x3ffu), nbase = (int)((w >> 10) & 7u);
                 const int pidx = (int)((w >> 13) & 0x7ffu);
                 const bool start = (w >> 24) & 1u;
-                // predecessors beyond the register-resident levels take the generic path
-                const u64 deep_m = fa_ballot((have && !start ? pidx : 0) >= SC_REG * 5);
-                if (dl < SC_REG && n_link <= 16 && deep_m == 0ull) {
+                if (shallow && n_link <= 16) {
                     // ---- the usual level: <= 16 links in lanes 0..15, node-major (k_links).
                     // One segmented max-scan resolves all five nodes; no loop, no branch.
                     // Independent of the scores (issued while the gather below is in flight):
@@ -752,7 +757,11 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                     cur.h = got ? (int)(r_key >> 4) - SC_BIAS : cur.h;
                     cur.p = got ? (int)(r_pp >> 4) - 1 : cur.p;
                     cur.k = got ? 15 - (int)(r_key & 15u) - (int)(r_pp & 15u) : cur.k;
-                } else if (dl < SC_REG && n_link <= 64 && deep_m == 0ull) {
+                } else if (dl < SC_REG && n_link <= 64 &&
+                           // predecessors beyond the register-resident levels take the generic
+                           // path (start links carry pidx 0)
+                           (fa_ballot(pidx >= SC_REG * 5) &
+                            (n_link >= 64 ? ~0ull : ((1ull << n_link) - 1ull))) == 0ull) {
                     const int cv = 2 * cnt - cov;
                     const int lidx = start ? SC_ZERO : pidx;
                     const int pidv = start ? -1 : (int)(plvl5 + (u32)pidx);
@@ -768,7 +777,7 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                     for (int c0 = 0; c0 < n_link; c0 += 64) {
                         u32 wc = 0;
                         if (c0 + lane < n_link) {
-                            if (bulk) wc = s_links[lk - lnk0 + (u32)(c0 + lane)];
+                            if constexpr (BULK) wc = s_links[lk - lnk0 + (u32)(c0 + lane)];
                             else wc = links[lk + (u32)(c0 + lane)];
                         }
                         wc = settled(wc);
@@ -826,7 +835,10 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
             }
             prev_t = t;
             prev_lvl = y_lvl;
+            prev_nlev = nlev;
         }
+        };
+        if (bulk) run_block(std::true_type{}); else run_block(std::false_type{});
         t0 += nb;
     }
     // global best = first strict maximum in (t, delta, base) order (falcon.c:464-469):
