@@ -1,0 +1,286 @@
+// reader.cpp -- native reader of the LA4Falcon "-fo" text stream.
+//
+// Host side of the consensus worker's ingest.  Restates, for whole
+// batches and without an interpreter in the loop,
+//   get_seq_data       falcon_kit/mains/consensus.py:161-209  (grammar, pile admission)
+//   get_longest_reads  falcon_kit/mains/consensus.py:26-45    (read selection)
+// and hands the selected piles to fa_batch_create() as plain pointer arrays.
+//
+// Grammar: a line that splits (on any run of white space) into exactly two tokens is
+// "<name> <bases>"; "+ +" ends a pile, "* *" ends and discards it, "- -" ends the
+// stream; every other line is skipped.  A sequence longer than 100000 is cut to 99999
+// (:162,:176-177).  The first sequence of a pile is the seed: it is stored as the target
+// and -- its name not having been seen yet -- once more as an ordinary read (:183-190).
+// A pile is admitted when it holds >= min_n_read sequences and its read bases cover the
+// seed >= min_cov_aln times (:196-198); admitted piles keep the seed plus the longest
+// reads, stable on stream order, at most max_n_read sequences, optionally stopping once
+// the depth exceeds max_cov_aln (:26-45).
+//
+// No HIP in this file: it is usable (and tested) without a GPU.
+#include <algorithm>
+#include <cerrno>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include <unistd.h>
+
+#include "../../include/falcon_amd.h"
+
+namespace {
+
+constexpr int kMaxSeqLen = 100000;  // consensus.py:162
+
+struct Tok {
+    size_t off;
+    int len;
+};
+
+inline bool is_space(unsigned char c) {
+    // str.split() without arguments: ASCII white space (the stream is ASCII)
+    return c == ' ' || (c >= '\t' && c <= '\r') || (c >= 0x1c && c <= 0x1f);
+}
+
+}  // namespace
+
+struct fa_reader {
+    int fd = -1;
+    int min_n_read = 0, min_len_aln = 0, min_cov_aln = 0, max_n_read = 0, max_cov_aln = 0;
+    bool eof = false;        // read() returned 0
+    bool finished = false;   // "- -" seen or eof reached and the buffer drained
+    std::string err;
+
+    // text of the batch being gathered; tokens are offsets into it until the batch is
+    // closed (it may grow), pointers afterwards
+    char *text = nullptr;    // (malloc'ed: growing it must not zero-fill)
+    size_t text_cap = 0;
+    size_t parsed = 0;       // bytes of `text` already split into lines
+    size_t filled = 0;       // bytes of `text` holding stream data
+    ~fa_reader() { free(text); }
+
+    // pile in progress
+    std::vector<Tok> pile;                  // seed, then reads in stream order
+    std::unordered_set<std::string> names;  // read names seen in this pile
+    Tok seed_name = {0, 0};
+    long long pile_bases = 0;
+
+    // closed piles of the batch
+    std::vector<int> pile_n_seq;
+    std::vector<Tok> sel;                   // selected sequences, pile after pile
+    std::vector<Tok> sel_name;              // seed name per pile
+    long long batch_bases = 0;
+
+    // what fa_reader_next() hands out
+    std::vector<const char *> out_seqs, out_ids;
+    std::vector<int> out_len;
+};
+
+static bool fill(fa_reader *r) {
+    // make room and read more of the stream; false at end of file
+    if (r->eof) return false;
+    const size_t want = 8u << 20;
+    if (r->text_cap < r->filled + want) {
+        const size_t cap = std::max(r->text_cap * 2, r->filled + want);
+        char *t = (char *)realloc(r->text, cap);
+        if (!t) {
+            r->err = "falcon_amd: out of memory while reading the pile stream";
+            r->eof = true;
+            return false;
+        }
+        r->text = t;
+        r->text_cap = cap;
+    }
+    for (;;) {
+        ssize_t n = read(r->fd, r->text + r->filled, r->text_cap - r->filled);
+        if (n > 0) {
+            r->filled += (size_t)n;
+            return true;
+        }
+        if (n == 0) {
+            r->eof = true;
+            return false;
+        }
+        if (errno == EINTR) continue;
+        r->err = std::string("falcon_amd: read() of the pile stream failed: ") + strerror(errno);
+        r->eof = true;
+        return false;
+    }
+}
+
+// get_longest_reads (consensus.py:26-45) on the pile in progress -> r->sel
+static void close_pile(fa_reader *r) {
+    std::vector<Tok> &p = r->pile;
+    std::vector<Tok> rest(p.begin() + 1, p.end());
+    std::stable_sort(rest.begin(), rest.end(), [](const Tok &a, const Tok &b) { return a.len > b.len; });
+    size_t keep = (size_t)std::max(r->max_n_read, 0);
+    if (r->max_cov_aln > 0) {
+        const long long seed_len = p[0].len;
+        long long depth_bases = 0;
+        size_t k = 1;
+        for (const Tok &t : rest) {
+            if (depth_bases / seed_len > r->max_cov_aln) break;
+            k++;
+            depth_bases += t.len;
+        }
+        keep = std::min(k, keep);
+    }
+    const size_t n = std::min(keep, rest.size() + 1);
+    if (n == 0) {  // max_n_read == 0: the reference would hand an empty list on; nothing to do
+        return;
+    }
+    r->sel.push_back(p[0]);
+    r->batch_bases += p[0].len;
+    for (size_t i = 0; i + 1 < n; i++) {
+        r->sel.push_back(rest[i]);
+        r->batch_bases += rest[i].len;
+    }
+    r->pile_n_seq.push_back((int)n);
+    r->sel_name.push_back(r->seed_name);
+}
+
+static void reset_pile(fa_reader *r) {
+    r->pile.clear();
+    r->names.clear();
+    r->pile_bases = 0;
+    r->seed_name = {0, 0};
+}
+
+// one line [b, e) of r->text (without its '\n'); returns false when "- -" ends the stream
+static bool take_line(fa_reader *r, size_t b, size_t e) {
+    const char *t = r->text;
+    Tok tok[2];
+    int n_tok = 0;
+    // the usual line is "<name> <bases>": one blank, nothing else at or below 0x20 (all
+    // white space is) -- checked with one vectorisable pass; anything else is tokenised
+    // byte by byte
+    const char *sp = (e > b) ? (const char *)memchr(t + b, ' ', e - b) : nullptr;
+    bool plain = sp != nullptr && sp != t + b && sp + 1 < t + e;
+    if (plain) {
+        size_t low = 0;
+        for (const char *p = t + b; p < t + e; p++) low += (unsigned char)*p <= 0x20;
+        plain = low == 1;
+    }
+    if (plain) {
+        tok[0] = {b, (int)(sp - (t + b))};
+        tok[1] = {(size_t)(sp + 1 - t), (int)std::min<size_t>((size_t)(t + e - (sp + 1)), 0x7fffffff)};
+        n_tok = 2;
+    } else {
+        size_t i = b;
+        while (i < e) {
+            while (i < e && is_space((unsigned char)t[i])) i++;
+            if (i >= e) break;
+            size_t j = i;
+            while (j < e && !is_space((unsigned char)t[j])) j++;
+            if (n_tok < 2) tok[n_tok] = {i, (int)std::min<size_t>(j - i, 0x7fffffff)};
+            n_tok++;
+            i = j;
+        }
+    }
+    if (n_tok != 2) return true;
+    Tok name = tok[0], seq = tok[1];
+    if (seq.len > kMaxSeqLen) seq.len = kMaxSeqLen - 1;
+    if (name.len == 1 && (t[name.off] == '+' || t[name.off] == '*' || t[name.off] == '-')) {
+        if (t[name.off] == '-') return false;
+        if (t[name.off] == '+' && !r->pile.empty() && (long long)r->pile.size() >= r->min_n_read &&
+            r->pile_bases / r->pile[0].len >= r->min_cov_aln)
+            close_pile(r);
+        reset_pile(r);
+        return true;
+    }
+    if (seq.len < r->min_len_aln) return true;
+    if (r->pile.empty()) {
+        r->pile.push_back(seq);
+        r->seed_name = name;
+    }
+    if (r->names.emplace(t + name.off, (size_t)name.len).second) {
+        r->pile.push_back(seq);
+        r->pile_bases += seq.len;
+    }
+    return true;
+}
+
+extern "C" fa_reader *fa_reader_open(int fd, int min_n_read, int min_len_aln, int min_cov_aln,
+                                     int max_n_read, int max_cov_aln) {
+    fa_reader *r = new fa_reader;
+    r->fd = fd;
+    r->min_n_read = min_n_read;
+    r->min_len_aln = min_len_aln;
+    r->min_cov_aln = min_cov_aln;
+    r->max_n_read = max_n_read;
+    r->max_cov_aln = max_cov_aln;
+    return r;
+}
+
+extern "C" void fa_reader_close(fa_reader *r) { delete r; }
+
+extern "C" const char *fa_reader_error(const fa_reader *r) { return r ? r->err.c_str() : ""; }
+
+extern "C" int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, const int **pile_n_seq,
+                              const char *const **seqs, const int **seq_len,
+                              const char *const **seed_ids) {
+    if (!r) return -1;
+    // drop the previous batch: keep the unparsed tail and the lines of the pile in progress
+    {
+        size_t keep_from = r->parsed;
+        for (const Tok &t : r->pile) keep_from = std::min(keep_from, t.off);
+        if (!r->pile.empty()) keep_from = std::min(keep_from, r->seed_name.off);
+        // (names of the pile in progress are owned copies)
+        if (keep_from > 0) {
+            memmove(r->text, r->text + keep_from, r->filled - keep_from);
+            r->filled -= keep_from;
+            r->parsed -= keep_from;
+            for (Tok &t : r->pile) t.off -= keep_from;
+            if (!r->pile.empty()) r->seed_name.off -= keep_from;
+        }
+        r->pile_n_seq.clear();
+        r->sel.clear();
+        r->sel_name.clear();
+        r->batch_bases = 0;
+    }
+    if (max_piles <= 0) max_piles = 0x7fffffff;
+    if (max_bases <= 0) max_bases = 0x7fffffffffffffffll;
+    while (!r->finished && (long long)r->pile_n_seq.size() < max_piles && r->batch_bases < max_bases) {
+        const char *t = r->text;
+        const char *nl = r->parsed < r->filled
+                             ? (const char *)memchr(t + r->parsed, '\n', r->filled - r->parsed)
+                             : nullptr;
+        if (!nl) {
+            if (fill(r)) continue;
+            if (!r->err.empty()) return -1;
+            // end of file: a last line without '\n' still counts (python iterates it too)
+            if (r->parsed < r->filled) {
+                const size_t b = r->parsed;
+                r->parsed = r->filled;
+                take_line(r, b, r->filled);
+            }
+            r->finished = true;
+            break;
+        }
+        const size_t b = r->parsed, e = (size_t)(nl - t);
+        r->parsed = e + 1;
+        if (!take_line(r, b, e)) r->finished = true;
+    }
+    // the batch is closed: offsets become pointers, tokens become C strings
+    const size_t n_sel = r->sel.size(), n_pile = r->pile_n_seq.size();
+    char *t = r->text;
+    r->out_seqs.resize(n_sel);
+    r->out_len.resize(n_sel);
+    r->out_ids.resize(n_pile);
+    for (size_t i = 0; i < n_sel; i++) {
+        r->out_seqs[i] = t + r->sel[i].off;
+        r->out_len[i] = r->sel[i].len;
+    }
+    for (size_t i = 0; i < n_pile; i++) {
+        t[r->sel_name[i].off + (size_t)r->sel_name[i].len] = '\0';  // the separator after the name
+        r->out_ids[i] = t + r->sel_name[i].off;
+    }
+    if (pile_n_seq) *pile_n_seq = r->pile_n_seq.data();
+    if (seqs) *seqs = r->out_seqs.data();
+    if (seq_len) *seq_len = r->out_len.data();
+    if (seed_ids) *seed_ids = r->out_ids.data();
+    return (int)n_pile;
+}

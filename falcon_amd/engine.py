@@ -17,8 +17,96 @@ def _b(s) -> bytes:
     return s if isinstance(s, bytes) else s.encode("ascii")
 
 
+class PileSet:
+    """Admitted piles of one ``fa_reader_next`` call: pointer arrays owned by the reader
+    (valid until its next call), in exactly the shape ``fa_batch_create`` takes."""
+
+    def __init__(self, n_pile, pile_n_seq, seqs, seq_len, seed_ids):
+        self.n_pile = n_pile
+        self.pile_n_seq, self.seqs, self.seq_len = pile_n_seq, seqs, seq_len
+        self.seed_ids = [seed_ids[i].decode("ascii", "replace") for i in range(n_pile)]
+        self.first = [0] * (n_pile + 1)
+        for p in range(n_pile):
+            self.first[p + 1] = self.first[p] + pile_n_seq[p]
+
+    def piles(self):
+        """Materialise as python lists of str (tests, --trim)."""
+        out = []
+        for p in range(self.n_pile):
+            out.append([C.string_at(self.seqs[g], self.seq_len[g]).decode("ascii")
+                        for g in range(self.first[p], self.first[p + 1])])
+        return out
+
+
+class Reader:
+    """Native LA4Falcon stream reader (falcon_amd/csrc/reader.cpp): grammar, pile
+    admission and read selection of consensus.py:161-209 and :26-45."""
+
+    def __init__(self, fd, min_n_read, min_len_aln, min_cov_aln, max_n_read, max_cov_aln):
+        self.lib = load()
+        self.h = self.lib.fa_reader_open(fd, min_n_read, min_len_aln, min_cov_aln, max_n_read,
+                                         max_cov_aln)
+        if not self.h:
+            raise FalconAmdError("fa_reader_open failed")
+
+    def next(self, max_piles=0, max_bases=0):
+        """The next PileSet, or None at the end of the stream."""
+        cnt = C.POINTER(C.c_int)()
+        seqs = C.POINTER(C.c_char_p)()
+        lens = C.POINTER(C.c_int)()
+        ids = C.POINTER(C.c_char_p)()
+        # (c_char_p arrays are only indexed for the NUL-terminated ids; the sequence
+        # pointers are passed through as raw addresses)
+        seqs_raw = C.cast(C.pointer(seqs), C.POINTER(C.POINTER(C.c_char_p)))
+        n = self.lib.fa_reader_next(self.h, max_piles, max_bases, C.byref(cnt), seqs_raw,
+                                    C.byref(lens), C.byref(ids))
+        if n < 0:
+            raise FalconAmdError(self.lib.fa_reader_error(self.h).decode("utf-8", "replace"))
+        if n == 0:
+            return None
+        return PileSet(n, cnt, C.cast(seqs, C.POINTER(C.c_void_p)), lens, ids)
+
+    def __iter__(self):
+        while True:
+            ps = self.next()
+            if ps is None:
+                return
+            for sid, pile in zip(ps.seed_ids, ps.piles()):
+                yield sid, pile
+
+    def close(self):
+        if self.h:
+            self.lib.fa_reader_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Batch:
     """A set of piles resident in HBM (2-bit packed)."""
+
+    @classmethod
+    def from_pileset(cls, engine: "Engine", ps: PileSet, p0: int = 0, p1: int = None) -> "Batch":
+        """Stage piles [p0, p1) of a PileSet: pointer arithmetic only, no per-sequence
+        python objects."""
+        p1 = ps.n_pile if p1 is None else p1
+        self = cls.__new__(cls)
+        self.engine, self.lib = engine, engine.lib
+        self.n_pile = p1 - p0
+        g0 = ps.first[p0]
+        self.n_seq = ps.first[p1] - g0
+        self.first = [ps.first[p] - g0 for p in range(p0, p1)]
+        cnt = C.cast(C.addressof(ps.pile_n_seq.contents) + 4 * p0, C.POINTER(C.c_int))
+        arr = C.cast(C.addressof(ps.seqs.contents) + C.sizeof(C.c_void_p) * g0, C.POINTER(C.c_char_p))
+        lens = C.cast(C.addressof(ps.seq_len.contents) + 4 * g0, C.POINTER(C.c_int))
+        self.h = self.lib.fa_batch_create(engine.h, self.n_pile, cnt, arr, lens)
+        if not self.h:
+            raise FalconAmdError(last_error())
+        return self
 
     def __init__(self, engine: "Engine", piles: Sequence[Sequence]):
         self.engine = engine
@@ -110,8 +198,9 @@ class Engine:
         return Batch(self, piles)
 
     def consensus(self, piles, min_cov=6, K=8, min_idt=0.70, want_eqv=False):
-        """Consensus of every pile (list of lists of sequences), in order."""
-        b = self.batch(piles)
+        """Consensus of every pile (list of lists of sequences, or a (PileSet, p0, p1)
+        slice straight from the native reader), in order."""
+        b = Batch.from_pileset(self, *piles) if isinstance(piles, tuple) else self.batch(piles)
         try:
             b.run(min_cov, K, min_idt).fetch(want_eqv)
             return [b.result(p) for p in range(b.n_pile)]

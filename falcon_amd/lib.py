@@ -77,6 +77,18 @@ def load() -> C.CDLL:
                                    C.POINTER(C.c_int), C.c_int, C.c_int,
                                    C.POINTER(C.POINTER(Alignment))]
     lib.free_alignment.argtypes = [C.POINTER(Alignment)]
+    # ingest (no GPU needed)
+    lib.fa_reader_open.restype = C.c_void_p
+    lib.fa_reader_open.argtypes = [C.c_int] * 6
+    lib.fa_reader_next.restype = C.c_int
+    lib.fa_reader_next.argtypes = [C.c_void_p, C.c_int, C.c_longlong,
+                                   C.POINTER(C.POINTER(C.c_int)),
+                                   C.POINTER(C.POINTER(C.c_char_p)),
+                                   C.POINTER(C.POINTER(C.c_int)),
+                                   C.POINTER(C.POINTER(C.c_char_p))]
+    lib.fa_reader_error.restype = C.c_char_p
+    lib.fa_reader_error.argtypes = [C.c_void_p]
+    lib.fa_reader_close.argtypes = [C.c_void_p]
     _lib = lib
     return lib
 

@@ -253,6 +253,46 @@ class GpuConsensus:
             raise errors[0]
         return [c for shard in results for c in shard]
 
+    # ---- native ingest: PileSets straight from falcon_amd/csrc/reader.cpp ----------
+    def stage(self, ps):
+        """Stage a PileSet in HBM: one batch per device over contiguous shards of piles
+        (host memcpy into pinned memory, H2D, 2-bit pack).  The PileSet may be recycled
+        by its reader once this returns."""
+        from falcon_amd.engine import Batch
+        n = len(self.engines)
+        if n == 1 or ps.n_pile < 2 * n:
+            return [Batch.from_pileset(self.engines[0], ps)]
+        step = -(-ps.n_pile // n)
+        return [Batch.from_pileset(self.engines[i], ps, p0, min(p0 + step, ps.n_pile))
+                for i, p0 in enumerate(range(0, ps.n_pile, step))]
+
+    def finish(self, batches):
+        """Run staged batches (one thread per device) and return the consensus strings in
+        pile order."""
+        results, errors = [None] * len(batches), []
+
+        def work(i):
+            b = batches[i]
+            try:
+                b.run(self.min_cov, KMER, self.min_idt).fetch(False)
+                results[i] = [b.result(p) for p in range(b.n_pile)]
+            except Exception as exc:  # surfaced below, in the caller's thread
+                errors.append(exc)
+            finally:
+                b.free()
+
+        if len(batches) == 1:
+            work(0)
+        else:
+            threads = [threading.Thread(target=work, args=(i,)) for i in range(len(batches))]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        if errors:
+            raise errors[0]
+        return [c for shard in results for c in shard]
+
     def close(self):
         for e in self.engines:
             e.close()
@@ -291,6 +331,54 @@ def fasta_records(seed_id, cns, output_full, output_multi):
     return "".join(text)
 
 
+def _stream_fd(stream):
+    """File descriptor behind ``stream`` when it is an OS-level stream (the native reader
+    takes it over and python must not have read from it), else None (StringIO & co)."""
+    if os.environ.get("FALCON_AMD_PY_READER"):
+        return None
+    try:
+        return getattr(stream, "buffer", stream).fileno()
+    except (AttributeError, OSError, ValueError):
+        return None
+
+
+def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
+    """Ingest thread (native reader + staging of batch i+1) overlapped with the GPU
+    work and the printing of batch i; records leave in input order."""
+    import queue
+    from falcon_amd.engine import Reader
+    reader = Reader(fd, args.min_n_read, args.min_len_aln, cfg.min_cov_aln, cfg.max_n_read,
+                    cfg.max_cov_aln)
+    per_call = (batch_bases or gpu.batch_bases) * len(gpu.engines)
+    staged = queue.Queue(maxsize=1)
+
+    def ingest():
+        try:
+            while True:
+                ps = reader.next(0, per_call)
+                if ps is None:
+                    break
+                staged.put((ps.seed_ids, gpu.stage(ps)))
+            staged.put(None)
+        except Exception as exc:
+            staged.put(exc)
+
+    t = threading.Thread(target=ingest, daemon=True)
+    t.start()
+    try:
+        while True:
+            item = staged.get()
+            if item is None:
+                break
+            if isinstance(item, Exception):
+                raise item
+            ids, batches = item
+            for sid, cns in zip(ids, gpu.finish(batches)):
+                stdout.write(fasta_records(sid, cns, args.output_full, args.output_multi))
+    finally:
+        reader.close()
+
+
 def run(args, stdin=None, stdout=None, consensus_map=None):
     """``consensus_map`` (tests) replaces the GPU map: iterable of piles -> iterable of
     consensus strings."""
@@ -311,6 +399,15 @@ def run(args, stdin=None, stdout=None, consensus_map=None):
         gpu = GpuConsensus(args.min_cov, args.min_idt)
         consensus_map = gpu.imap
         LOG.info("falcon_amd consensus on %d GPU(s)", len(gpu.engines))
+
+    fd = _stream_fd(stdin)
+    if gpu is not None and not args.trim and fd is not None:
+        try:
+            _run_native(args, cfg, fd, gpu, stdout)
+        finally:
+            gpu.close()
+        stdout.flush()
+        return
 
     seed_ids = []
 

@@ -167,6 +167,31 @@ int fa_align_pairs(fa_ctx *ctx, int n, const char *const *q, const int *q_len,
                    const char *const *t, const int *t_len, int band_tolerance, int get_aln_str,
                    alignment **out);
 
+/* ------------------------------------------------------------------------- */
+/* (3) Ingest -- replaces get_seq_data + get_longest_reads of                   */
+/*     falcon_kit/mains/consensus.py:161-209 and :26-45: the LA4Falcon "-fo"    */
+/*     text stream is parsed, piles are admitted and their reads selected in   */
+/*     native code, and handed to fa_batch_create() as pointer arrays.          */
+/* ------------------------------------------------------------------------- */
+typedef struct fa_reader fa_reader;
+
+/* fd: the stream (e.g. 0); the five numbers are --min-n-read, --min-len-aln,
+ * --min-cov-aln, --max-n-read, --max-cov-aln (consensus.py:225-236). */
+fa_reader *fa_reader_open(int fd, int min_n_read, int min_len_aln, int min_cov_aln, int max_n_read,
+                          int max_cov_aln);
+/* Gather the next admitted piles, in stream order, until max_piles piles or max_bases
+ * selected bases are reached (<= 0: no limit) or the stream ends.  Returns the number
+ * of piles (0: end of stream, < 0: read error, see fa_reader_error).  On return
+ *   pile_n_seq[p]            sequences of pile p (seed first), consecutive in
+ *   seqs[] / seq_len[]       base pointers (NOT NUL-terminated) and lengths,
+ *   seed_ids[p]              NUL-terminated name of the pile's seed;
+ * exactly the arguments of fa_batch_create().  The arrays and what they point to stay
+ * valid until the next fa_reader_next() / fa_reader_close() on this reader. */
+int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, const int **pile_n_seq,
+                   const char *const **seqs, const int **seq_len, const char *const **seed_ids);
+const char *fa_reader_error(const fa_reader *r);
+void fa_reader_close(fa_reader *r);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,135 @@
+"""The native LA4Falcon stream reader (falcon_amd/csrc/reader.cpp) against
+the python restatement of get_seq_data / get_longest_reads
+(/root/reference/falcon_kit/mains/consensus.py:161-209, :26-45) that the CLI tests pin
+against the reference's own driver (tests/golden/f5_cli).  No GPU needed."""
+import io
+import os
+import random
+import tempfile
+
+import pytest
+
+from falcon_amd.engine import Reader
+from falcon_amd.mains.consensus import PileReader, Settings, _run_native, parse_args, settings_from
+
+
+def _native(text, min_n_read, min_len_aln, min_cov_aln, max_n_read, max_cov_aln, max_piles=0,
+            max_bases=0, raw=False):
+    with tempfile.NamedTemporaryFile("wb", delete=False) as f:
+        f.write(text if raw else text.encode("ascii"))
+        path = f.name
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        r = Reader(fd, min_n_read, min_len_aln, min_cov_aln, max_n_read, max_cov_aln)
+        out, calls = [], 0
+        while True:
+            ps = r.next(max_piles, max_bases)
+            if ps is None:
+                break
+            calls += 1
+            out.extend(zip(ps.seed_ids, ps.piles()))
+        r.close()
+        return out, calls
+    finally:
+        os.close(fd)
+        os.unlink(path)
+
+
+def _python(text, min_n_read, min_len_aln, min_cov_aln, max_n_read, max_cov_aln):
+    cfg = Settings(4, 8, max_n_read, 0.70, 1000, 50, min_cov_aln, max_cov_aln)
+    return list(PileReader(io.StringIO(text), cfg, min_n_read, min_len_aln))
+
+
+def _rand_seq(rng, n):
+    return "".join(rng.choice("ACGT") for _ in range(n))
+
+
+def _rand_stream(rng, n_pile, with_noise):
+    lines = []
+    for p in range(n_pile):
+        n_read = rng.randint(1, 14)
+        seed_len = rng.randint(30, 200)
+        names = ["%06d" % rng.randint(0, 40) for _ in range(n_read)]
+        for i, nm in enumerate(names):
+            ln = seed_len if i == 0 else rng.randint(5, 260)
+            lines.append("%s %s" % (nm, _rand_seq(rng, ln)))
+            if with_noise and rng.random() < 0.08:
+                lines.append(rng.choice(["", "   ", "justonetoken", "a b c", "\t", "x  y  z w"]))
+            if with_noise and rng.random() < 0.05:
+                lines.append("%s\t %s  " % ("%06d" % rng.randint(0, 40), _rand_seq(rng, rng.randint(5, 90))))
+        lines.append(rng.choice(["+ +", "+ +", "+ +", "* *", "+ anything"]))
+    lines.append("- -")
+    lines.append("999999 ACGTACGT")  # after the end marker: never read
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_reader_equals_python_parser(seed):
+    rng = random.Random(seed)
+    text = _rand_stream(rng, rng.randint(1, 25), with_noise=seed % 2 == 1)
+    for opts in [(1, 0, 0, 500, 0), (4, 0, 1, 500, 0), (3, 40, 1, 6, 0), (2, 0, 0, 5, 2),
+                 (10, 0, 10, 200, 0)]:
+        want = _python(text, *opts)
+        got, _ = _native(text, *opts)
+        assert got == want, opts
+
+
+def test_batch_limits_do_not_change_the_piles():
+    rng = random.Random(77)
+    text = _rand_stream(rng, 40, with_noise=True)
+    opts = (2, 0, 0, 500, 0)
+    want = _python(text, *opts)
+    one, c1 = _native(text, *opts)
+    by3, c3 = _native(text, *opts, max_piles=3)
+    byb, cb = _native(text, *opts, max_bases=700)
+    assert one == want and by3 == want and byb == want
+    assert c1 == 1 and c3 == -(-len(want) // 3) and cb > 1
+
+
+def test_long_sequences_are_cut_and_stream_end_variants():
+    big = "A" * 100001
+    edge = "C" * 100000
+    text = "s1 %s\nr1 %s\nr2 ACGT\n+ +\n" % (big, edge)
+    for tail in ["- -\n", "", "s2 ACGT"]:  # explicit end, bare EOF, EOF inside a pile
+        want = _python(text + tail, 1, 0, 0, 500, 0)
+        got, _ = _native(text + tail, 1, 0, 0, 500, 0)
+        assert got == want
+        assert len(got) == 1 and len(got[0][1][0]) == 99999 and len(got[0][1][1]) == 100000
+    # CRLF line ends and a last line without newline
+    crlf = "s1 ACGTACGT\r\nr1 ACGTAC\r\n+ +\r\ns2 AAAA\r\nr9 CC\r\n+ +"
+    assert _native(crlf, 1, 0, 0, 500, 0)[0] == _python(crlf, 1, 0, 0, 500, 0)
+
+
+def test_cli_native_path_orders_and_prints(tmp_path):
+    """_run_native with a stand-in for the GPU: staging and finishing are called batch by
+    batch, records leave in input order."""
+    rng = random.Random(5)
+    text = _rand_stream(rng, 30, with_noise=False)
+    args = parse_args(["prog", "--min-n-read", "2", "--min-cov-aln", "0", "--output-full"])
+    cfg = settings_from(args)
+    want_piles = _python(text, 2, 0, 0, cfg.max_n_read, cfg.max_cov_aln)
+
+    class FakeGpu:
+        engines = [None]
+        batch_bases = 900
+        staged = 0
+
+        def stage(self, ps):
+            self.staged += 1
+            return ps.piles()
+
+        def finish(self, piles):
+            return [(p[0] * 20)[:600] for p in piles]  # >= 500 chars so a record is printed
+
+    path = tmp_path / "stream.txt"
+    path.write_text(text)
+    fd = os.open(str(path), os.O_RDONLY)
+    out = io.StringIO()
+    gpu = FakeGpu()
+    try:
+        _run_native(args, cfg, fd, gpu, out)
+    finally:
+        os.close(fd)
+    want = "".join(">%s_f\n%s\n" % (sid, (p[0] * 20)[:600]) for sid, p in want_piles)
+    assert out.getvalue() == want
+    assert gpu.staged > 1
