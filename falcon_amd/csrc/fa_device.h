@@ -56,6 +56,32 @@ __device__ __forceinline__ int fa_wave_max(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Same for values whose wave maximum is known to be >= 0: lanes without a DPP source
+// read 0 (bound_ctrl), so the first step can write a fresh register and the input
+// survives without a copy.
+__device__ __forceinline__ int fa_wave_max_nonneg(int v) {
+    int t;
+    asm volatile("s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                 : "=&v"(t)
+                 : "v"(v));
+    return __builtin_amdgcn_readlane(t, 63);
+}
+
+// 2 * x + (lane in mask): v_addc with the mask as carry-in -- (x << 1) | bit in one VALU op
+__device__ __forceinline__ u32 fa_twice_plus(int x, u64 mask) {
+    u32 r;
+    u64 carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(x), "s"(mask));
+    (void)carry_out;
+    return r;
+}
+
 __device__ __forceinline__ int fa_wave_min(int v) { return -fa_wave_max(-v); }
 
 // Force a wave-uniform value into SGPRs.  Arguments of out-of-line device

@@ -247,17 +247,18 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
     } while (0)
 
     // Register mode (rows of <= REG_MAX_N diagonals, i.e. nearly all of them):
-    // lane l owns diagonal kbase + 2l + (d & 1) for as long as the band stays
-    // inside the wave, and vreg holds the previous row's x on the lane's
-    // diagonal of the *other* parity.  The two neighbours a = V[k-1], b = V[k+1]
-    // (DW_banded.c:190-196) are then the lane's own register and ONE DPP wave
-    // shift -- no LDS traffic for V at all.  Wider rows fall back to the LDS
-    // ring (ring mode) until the band narrows again.  The two modes are two
+    // lane l owns diagonal kd + 2l, kd falling by one per row, for as long as the
+    // band stays inside the wave, and vreg holds the previous row's x on diagonal
+    // (kd + 1) + 2l.  The two neighbours a = V[k-1], b = V[k+1] (DW_banded.c:190-196)
+    // are then ONE DPP wave shift and the lane's own register -- no LDS traffic for V
+    // at all, no parity case.  The band climbs one lane every two rows and is
+    // re-seated with a shuffle every few dozen rows.  Wider rows fall back to the
+    // LDS ring (ring mode) until the band narrows again.  The two modes are two
     // plain loops (the row loop must stay a simple loop: instruction issue, scalar
     // and vector alike, is the bottleneck of this kernel).
     const int REG_MAX_N = 60;
     const int nmax = min(REG_MAX_N, band + 1);
-    int kbase = -62;       // diagonal 0 sits on lane 31
+    int kd = -62;          // diagonal of lane 0 in row d (row 0: diagonal 0 sits on lane 31)
     int lo = 31;           // lane of min_k in register mode
     int vreg = 0;          // reference: calloc'ed V (:153)
     int d = 0;
@@ -276,26 +277,26 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             if (((max_d - 1 - d) | (nmax - n) | (lo - 1) | (63 - lo - n)) < 0) {
                 if (d >= max_d || n - 1 > band) { dead = true; break; }
                 if (n > REG_MAX_N) break;
-                const int nlo = (64 - n) >> 1;  // re-centre the band inside the wave
+                // re-seat the band low inside the wave (it climbs one lane every two rows)
+                const int nlo = max(1, (64 - n) >> 2);
                 const int sh = lo - nlo;        // new lane l takes old lane l + sh
                 vreg = __shfl(vreg, lane + sh);
-                kbase += 2 * sh;
+                kd += 2 * sh;
                 lo = nlo;
             }
-            const int par = d & 1;
             const int hi = lo + n - 1;
             PROF(0);
             // Lane sets are kept twice: as a predicate (act: stores, selects) and as a
             // scalar mask (act_m: combined with single-compare ballots by the scalar unit).
             const bool act = lane >= lo && lane <= hi;
             const u64 act_m = fa_lane_range(lo, n);
-            const int k = kbase + 2 * lane + par;
-            // a = V[k-1], b = V[k+1]: own register and one wave shift (the wave's edge
-            // lanes are never inside the band: lo >= 1, hi <= 62)
-            const int sh_dn = __builtin_amdgcn_mov_dpp(vreg, 0x138, 0xf, 0xf, true);  // lane-1
-            const int sh_up = __builtin_amdgcn_mov_dpp(vreg, 0x130, 0xf, 0xf, true);  // lane+1
-            const int a = par ? vreg : sh_dn;
-            const int b = par ? sh_up : vreg;
+            // Lane l owns diagonal kd + 2l with kd falling by one per row: the lane's own
+            // register then always holds V[k+1] of the previous row and lane l-1 holds
+            // V[k-1] -- one DPP shift, no parity case.  (The wave's edge lanes are never
+            // inside the band: lo >= 1, hi <= 62.)
+            const int k = kd + 2 * lane;
+            const int a = __builtin_amdgcn_mov_dpp(vreg, 0x138, 0xf, 0xf, true);  // lane-1: V[k-1]
+            const int b = vreg;                                                  //         V[k+1]
             // from_above: k == min_k, or k != max_k and V[k-1] < V[k+1]   (:190)
             const u64 fa_m = ((fa_ballot(a < b) & ~(1ull << hi)) | (1ull << lo)) & act_m;
             x = fa_sel(fa_m, a + 1, b);
@@ -304,7 +305,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             snake16(qL, tL, qb, tb, q_len, t_len, act, x, y);
             PROF(2);
             vreg = x;
-            if (act) cells[(u32)((int)row_off - lo) + (u32)lane] = ((u32)x << 1) | (u32)fa_sel(fa_m, 0, 1);
+            if (act) cells[(u32)((int)row_off - lo) + (u32)lane] = fa_twice_plus(x, fa_m);  // x<<1 | from_above
             const u64 dir0 = fa_m >> lo;
             fin = (fa_ballot(x >= q_len) | fa_ballot(y >= t_len)) & act_m;  // :220
             PROF(3);
@@ -314,7 +315,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             // (an LDS ds_max on one word instead of the DPP reduction was measured 2x
             // slower: 64 same-address atomics serialise)
             const int u = act ? x + y : -1;
-            best_m = max(best_m, fa_wave_max(u));
+            best_m = max(best_m, fa_wave_max_nonneg(u));  // some lane is active: max >= 0
             const u64 in = fa_ballot(u >= best_m - band) & act_m;  // :228-243
             PROF(4);
             // `in` is never empty: best_m is attained inside the row
@@ -323,7 +324,8 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             row_off += (u32)n;
             min_k = min_k + 2 * (llo - lo) - 1;
             n = lhi - llo + 2;
-            lo = llo - 1 + par;  // even row -> odd row moves one lane down
+            lo = llo;  // the new lowest diagonal, one below, sits on the same lane one row on
+            kd--;
             d++;
             PROF(5);
         }
@@ -331,7 +333,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             FLUSH_ROW_RECORDS();
             const int fl = __builtin_ctzll(fin);
             fin_d = d;
-            fin_k = kbase + 2 * fl + (d & 1);
+            fin_k = kd + 2 * fl;
             fin_x = __builtin_amdgcn_readlane(x, fl);
             fin_y = __builtin_amdgcn_readlane(y, fl);
             res.cells = (long long)row_off + (fl - lo) + 1;
@@ -339,9 +341,9 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
         }
         if (done || dead) break;
         // ================= ring-mode rows (61..191 diagonals) =================
-        {   // spill the previous row into the ring: k_prev = kbase + 2l + (par^1)
+        {   // spill the previous row into the ring: lane l holds diagonal kd + 1 + 2l of it
             const int par = d & 1;
-            const int kp = kbase + 2 * lane + (par ^ 1);
+            const int kp = kd + 1 + 2 * lane;
             Vring[(par ^ 1) * RING + ((kp >> 1) & (RING - 1))] = vreg;
         }
         for (;;) {
@@ -413,11 +415,11 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             d++;
         }
         if (done || dead) break;
-        {   // reload into registers: put min_k on lane (64-n)/2
+        {   // reload into registers: put min_k on lane (64-n)/4
             const int par = d & 1;
-            lo = (64 - n) >> 1;
-            kbase = min_k - par - 2 * lo;
-            const int kp = kbase + 2 * lane + (par ^ 1);
+            lo = max(1, (64 - n) >> 2);
+            kd = min_k - 2 * lo;
+            const int kp = kd + 1 + 2 * lane;
             vreg = Vring[(par ^ 1) * RING + ((kp >> 1) & (RING - 1))];
         }
     }
