@@ -713,6 +713,58 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     return 0;
 }
 
+// --trim windows of every read (consensus.py:48-99 get_alignment): seed index, then
+// k_trimwin twice -- a counting pass sizes the per-wavefront scratch of the real one.
+extern "C" int fa_batch_trim_windows(fa_batch *b, unsigned K, int mask_threshold) {
+    if (!b || b->pair_mode) {
+        set_err("falcon_amd: fa_batch_trim_windows on an invalid batch");
+        return -1;
+    }
+    if (K != FA_K) {
+        set_err("falcon_amd: K=%u unsupported (the falcon_sense path hard-wires K=8, "
+                "falcon_kit/mains/consensus.py:50)", K);
+        return -1;
+    }
+    fa_ctx *c = b->ctx;
+    HIP_OK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    b->have_range = false;
+    FaBatchDev d = b->dev();
+    DevBuf<int> counter;
+    if (counter.alloc(4)) return -1;
+    const int n_slot = std::max(1, c->n_cu) * 4;  // 32 KB of LDS per wavefront
+    fa_launch_index(d, s);
+    fa_launch_trimwin(d, n_slot, counter.p, nullptr, 0, mask_threshold, 1, s);
+    if (b->h_range.resize(b->n_seq)) { counter.release(); return -1; }
+    HIP_OK(hipMemcpyAsync(b->h_range.data(), b->d_range.p, (size_t)b->n_seq * sizeof(FaRange),
+                          hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    long long n_max = 0;
+    for (int g = 0; g < b->n_seq; g++) n_max = std::max<long long>(n_max, b->h_range[g].n_hit);
+    u64 cap = 0;
+    DevBuf<u32> scratch;
+    if (n_max > 2048) {  // TW_LDS_N: larger hit lists work in an HBM slot per wavefront
+        cap = 4096;
+        while ((long long)cap < n_max) cap <<= 1;
+        if (scratch.alloc((size_t)n_slot * 4 * cap)) { counter.release(); return -1; }
+    }
+    fa_launch_trimwin(d, n_slot, counter.p, scratch.p, cap, mask_threshold, 0, s);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(b->h_range.data(), b->d_range.p, (size_t)b->n_seq * sizeof(FaRange),
+                          hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    counter.release();
+    scratch.release();
+    for (int g = 0; g < b->n_seq; g++) {
+        if (b->h_range[g].ok < 0) {
+            set_err("falcon_amd: trim window of sequence %d overflowed its scratch", g);
+            return -2;
+        }
+    }
+    b->have_range = true;
+    return 0;
+}
+
 extern "C" int fa_batch_fetch(fa_batch *b, int want_eqv) {
     if (!b || b->pair_mode || b->h_pile_out.empty()) {
         set_err("falcon_amd: fa_batch_fetch before fa_batch_run");

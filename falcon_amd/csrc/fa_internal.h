@@ -159,6 +159,11 @@ struct FaAlignArena {
 void fa_launch_pack(const FaBatchDev &b, hipStream_t s);
 void fa_launch_index(const FaBatchDev &b, hipStream_t s);
 void fa_launch_chain(const FaBatchDev &b, int max_bins, hipStream_t s);
+// --trim windows (k_trimwin.hip): count_only = 1 stores every read's hit count in
+// range[g].n_hit; the full pass needs scratch (n_slot x 4 x cap words) only when a read
+// has more hits than fit LDS
+void fa_launch_trimwin(const FaBatchDev &b, int n_slot, int *counter, u32 *scratch, u64 cap,
+                       int mask_th, int count_only, hipStream_t s);
 void fa_launch_align(const FaBatchDev &b, const FaAlignArena &a, int max_q_len, int max_t_len,
                      double max_diff, hipStream_t s);
 void fa_launch_align_band(const FaBatchDev &b, const FaAlignArena &a, int max_q_len,

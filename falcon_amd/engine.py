@@ -135,6 +135,12 @@ class Batch:
             raise FalconAmdError(last_error())
         return self
 
+    def trim_windows(self, K: int = 8, mask_threshold: int = 16) -> "Batch":
+        """--trim: find_best_aln_range2 of every read on its seed (results: ``range(g)``)."""
+        if self.lib.fa_batch_trim_windows(self.h, K, mask_threshold):
+            raise FalconAmdError(last_error())
+        return self
+
     def fetch(self, want_eqv: bool = False) -> "Batch":
         if self.lib.fa_batch_fetch(self.h, 1 if want_eqv else 0):
             raise FalconAmdError(last_error())

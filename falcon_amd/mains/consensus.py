@@ -144,8 +144,27 @@ class PileReader:
 
 
 # --------------------------------------------------------------------------
-# --trim (behaviour of consensus.py:48-99 and :123-146) on the legacy table ABI
+# --trim (behaviour of consensus.py:48-99 and :123-146).  The k-mer window of every read
+# comes from the GPU in one batch (GpuConsensus.trimmed -> k_trimwin.hip); the same
+# window through the legacy table ABI (host structs, one read at a time) is kept for
+# callers without an engine (tests with a stand-in consensus map).
 # --------------------------------------------------------------------------
+def window_from_range(rng, read_len, seed_len, edge_tolerance):
+    """Post-processing of the raw aln_range (consensus.py:66-99): (q_start, q_end, score)
+    or None."""
+    q0, q1, t0, t1, score = rng
+    pad = KMER + KMER // 2
+    q1 = min(q1 + pad, read_len)
+    t1 = min(t1 + pad, seed_len)
+    if q0 > edge_tolerance and t0 > edge_tolerance:
+        return None
+    if read_len - q1 > edge_tolerance and seed_len - t1 > edge_tolerance:
+        return None
+    if q1 - q0 <= 500:
+        return None
+    return q0, q1, int(score * 48)
+
+
 def mapped_window(kup, read, seed, edge_tolerance):
     """Chained k-mer span of ``read`` on ``seed``: (q_start, q_end, score) or None."""
     from ctypes import c_char_p
@@ -165,23 +184,19 @@ def mapped_window(kup, read, seed, edge_tolerance):
         kup.free_seq_addr_array(chain)
         kup.free_seq_array(codes)
         kup.free_kmer_lookup(table)
-    pad = KMER + KMER // 2
-    q1 = min(q1 + pad, len(read))
-    t1 = min(t1 + pad, len(seed))
-    if q0 > edge_tolerance and t0 > edge_tolerance:
-        return None
-    if len(read) - q1 > edge_tolerance and len(seed) - t1 > edge_tolerance:
-        return None
-    if q1 - q0 <= 500:
-        return None
-    return q0, q1, int(score * 48)
+    return window_from_range((q0, q1, t0, t1, score), len(read), len(seed), edge_tolerance)
 
 
-def trimmed_pile(kup, pile, cfg: Settings):
+def trimmed_pile(kup, pile, cfg: Settings, ranges=None):
+    """``ranges``: the raw aln_range of every read of the pile (seed entry unused) when
+    the GPU computed them, else they are computed one by one through ``kup``."""
     seed = pile[0]
     windows = []
-    for read in pile[1:]:
-        w = mapped_window(kup, read, seed, cfg.edge_tolerance)
+    for j, read in enumerate(pile[1:], 1):
+        if ranges is not None:
+            w = window_from_range(ranges[j], len(read), len(seed), cfg.edge_tolerance)
+        else:
+            w = mapped_window(kup, read, seed, cfg.edge_tolerance)
         if w is None:
             continue
         q0, q1, score = w
@@ -252,6 +267,35 @@ class GpuConsensus:
         if errors:
             raise errors[0]
         return [c for shard in results for c in shard]
+
+    # ---- --trim: windows of whole batches of piles on the GPU ----------------------
+    def trimmed(self, piles, cfg):
+        """Map piles -> trimmed piles (consensus.py:123-146), the k-mer windows of a batch
+        of piles computed in one go by the first engine."""
+        def flush(batch):
+            b = self.engines[0].batch(batch)
+            try:
+                b.trim_windows(KMER, 16)
+                g = 0
+                for pile in batch:
+                    rng = []
+                    for _ in pile:
+                        r = b.range(g)
+                        rng.append((r["s1"], r["e1"], r["s2"], r["e2"], r["score"]))
+                        g += 1
+                    yield trimmed_pile(None, pile, cfg, rng)
+            finally:
+                b.free()
+
+        batch, bases = [], 0
+        for p in piles:
+            batch.append(p)
+            bases += sum(map(len, p))
+            if bases >= self.batch_bases:
+                yield from flush(batch)
+                batch, bases = [], 0
+        if batch:
+            yield from flush(batch)
 
     # ---- native ingest: PileSets straight from falcon_amd/csrc/reader.cpp ----------
     def stage(self, ps):
@@ -391,9 +435,6 @@ def run(args, stdin=None, stdout=None, consensus_map=None):
         'Requested n_core={} > cpu_count={}'.format(args.n_core, multiprocessing.cpu_count())
     cfg = settings_from(args)
     kup = None
-    if args.trim:
-        from falcon_amd import falcon_kit as fk
-        kup = fk.kup
     gpu = None
     if consensus_map is None:
         gpu = GpuConsensus(args.min_cov, args.min_idt)
@@ -409,15 +450,21 @@ def run(args, stdin=None, stdout=None, consensus_map=None):
         stdout.flush()
         return
 
+    if args.trim and gpu is None:
+        from falcon_amd import falcon_kit as fk
+        kup = fk.kup
     seed_ids = []
 
     def piles():
         for seed_id, pile in PileReader(stdin, cfg, args.min_n_read, args.min_len_aln):
             seed_ids.append(seed_id)
-            yield trimmed_pile(kup, pile, cfg) if args.trim else pile
+            yield trimmed_pile(kup, pile, cfg) if kup is not None else pile
 
+    todo = piles()
+    if args.trim and gpu is not None:
+        todo = gpu.trimmed(todo, cfg)
     try:
-        for i, cns in enumerate(consensus_map(piles())):
+        for i, cns in enumerate(consensus_map(todo)):
             stdout.write(fasta_records(seed_ids[i], cns, args.output_full, args.output_multi))
     finally:
         if gpu is not None:

@@ -161,6 +161,12 @@ int fa_batch_range(fa_batch *b, int g, int *s1, int *e1, int *s2, int *e2, long 
 int fa_batch_alignment(fa_batch *b, int g, int *dist, int *q_e, int *t_e, int *size, int *accept,
                        long long *cells);
 
+/* --trim (falcon_kit/mains/consensus.py:48-99 get_alignment): for every read of the
+ * batch the window find_best_aln_range2 reports on its pile's seed, k-mers occurring
+ * more than mask_threshold times in the seed masked (the driver passes 16).  Results
+ * through fa_batch_range(): the raw aln_range (s1, e1, s2, e2, score), n_hit. */
+int fa_batch_trim_windows(fa_batch *b, unsigned K, int mask_threshold);
+
 /* Pairwise banded alignment of n independent (query, target) pairs in one
  * launch; out[i] receives a malloc'ed `alignment` (free with free_alignment). */
 int fa_align_pairs(fa_ctx *ctx, int n, const char *const *q, const int *q_len,

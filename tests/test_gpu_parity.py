@@ -174,3 +174,79 @@ def test_long_insertion_runs_and_tag_cutoff(engine, port):
         eseq, eeqv = port.generate_consensus(pile, 2, 8, 0.70)
         assert len(seq) > 2500
         assert seq == eseq and eqv == eeqv
+
+
+# --------------------------------------------------------------------------
+# --trim windows on the GPU: mask_k_mer + find_kmer_pos_for_seq +
+# find_best_aln_range2 of consensus.py:48-99, batched (k_trimwin.hip)
+# --------------------------------------------------------------------------
+def _trim_ranges(engine, piles, mask=16):
+    b = engine.batch(piles)
+    try:
+        b.trim_windows(8, mask)
+        out = []
+        g = 0
+        for pile in piles:
+            rows = []
+            for j in range(len(pile)):
+                r = b.range(g)
+                rows.append(([r["s1"], r["e1"], r["s2"], r["e2"], r["score"]], r["n_hit"]))
+                g += 1
+            out.append(rows)
+        return out
+    finally:
+        b.free()
+
+
+def test_trim_windows_golden(engine):
+    """Every golden case that carries the reference's own find_best_aln_range2 answer
+    (masked hits, mask = 16), all in one batch: pile = [seed, query]."""
+    cases = [c for c in F1 if "range2" in c and c["mask"] == 16]
+    assert cases
+    got = _trim_ranges(engine, [[c["seed"], c["query"]] for c in cases])
+    for c, rows in zip(cases, got):
+        assert rows[1][0] == c["range2"], c["name"]
+        assert rows[1][1] == c["count"], c["name"]
+
+
+def test_trim_windows_vs_oracle(engine):
+    """Seeded synthetic piles (noisy reads, partial overlaps, a repeat-rich seed whose
+    frequent k-mers get masked, reads with more hits than fit LDS) against the oracle."""
+    from oracle.pyoracle import Port
+    from falcon_amd.synth import codes_to_str, make_pile
+    port = Port()
+    rng = np.random.default_rng(11)
+    piles = []
+    for s, (S, cov) in enumerate([(3000, 12.0), (9000, 10.0), (20000, 6.0)]):
+        seed, reads = make_pile(500 + s, S=S, coverage=cov, mean_read=min(S, 6000) * 0.7,
+                                sd_read=600, min_read=1200)
+        piles.append([codes_to_str(seed)] + [codes_to_str(x) for x in reads])
+    # repeat-rich seed: a 40-mer tiled with mutations -> many k-mers above the mask threshold
+    unit = "".join("ACGT"[i] for i in rng.integers(0, 4, 40))
+    rep = []
+    for _ in range(120):
+        u = list(unit)
+        for _ in range(2):
+            u[int(rng.integers(0, 40))] = "ACGT"[int(rng.integers(0, 4))]
+        rep.append("".join(u))
+    rep_seed = "".join(rep)
+    rep_reads = [rep_seed[a:a + 2500] for a in (0, 700, 1500, 2200)]
+    piles.append([rep_seed] + rep_reads + ["".join("ACGT"[i] for i in rng.integers(0, 4, 1800))])
+    got = _trim_ranges(engine, piles)
+    n_window = 0
+    for pile, rows in zip(piles, got):
+        for j in range(1, len(pile)):
+            q, t = port.find_hits(pile[0], pile[j], 8, 16)
+            want = list(port.best_range2(q, t))
+            assert rows[j][1] == len(q), (j, rows[j][1], len(q))
+            assert rows[j][0] == want, (j, rows[j][0], want)
+            n_window += want[4] > 0
+    assert n_window > 20
+    # the low-mask variant floods nothing; an unmasked run (threshold above any bucket)
+    # makes hit lists that do not fit LDS and exercises the HBM scratch path
+    big = _trim_ranges(engine, piles[3:], mask=100000)
+    for j in range(1, len(piles[3])):
+        q, t = port.find_hits(piles[3][0], piles[3][j], 8, 100000)
+        assert big[0][j][1] == len(q)
+        assert big[0][j][0] == list(port.best_range2(q, t)), j
+    assert max(r[1] for r in big[0]) > 2048
