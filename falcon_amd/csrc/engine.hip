@@ -858,9 +858,12 @@ extern "C" int fa_align_pairs(fa_ctx *ctx, int n, const char *const *q, const in
                               const char *const *t, const int *t_len, int band_tolerance,
                               int get_aln_str, alignment **out) {
     if (n <= 0) return 0;
-    if (band_tolerance < 0 || band_tolerance + 1 > 64 * FA_ALIGN_MAXCH - 1) {
-        set_err("falcon_amd: band_tolerance %d unsupported by the GPU alignment kernel (max %d)",
-                band_tolerance, 64 * FA_ALIGN_MAXCH - 2);
+    // up to 190: the tuned kernel (k_align.hip); beyond, e.g. the 1500 of contig layout
+    // (graph_to_contig.py:52-105): the general one (k_align_wide.hip)
+    const bool wide = band_tolerance + 1 > 64 * FA_ALIGN_MAXCH - 1;
+    if (band_tolerance < 0 || band_tolerance > FA_WIDE_BAND_MAX) {
+        set_err("falcon_amd: band_tolerance %d unsupported by the GPU alignment kernels (max %d)",
+                band_tolerance, FA_WIDE_BAND_MAX);
         return -1;
     }
     std::vector<const char *> seqs(2 * (size_t)n);
@@ -908,7 +911,8 @@ extern "C" int fa_align_pairs(fa_ctx *ctx, int n, const char *const *q, const in
     trace_stage(s, "pair-arena");
     FaBatchDev d = b->dev();
     FaAlignArena ar = c->arena;
-    fa_launch_align_band(d, ar, max_q, max_t, 2.0, band_tolerance, s);
+    if (wide) fa_launch_align_wide(d, ar, 2.0, band_tolerance, s);
+    else fa_launch_align_band(d, ar, max_q, max_t, 2.0, band_tolerance, s);
     trace_stage(s, "pair-align");
     if (hipGetLastError() != hipSuccess) {
         set_err("falcon_amd: k_align launch failed");

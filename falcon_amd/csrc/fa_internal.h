@@ -159,6 +159,10 @@ struct FaAlignArena {
 void fa_launch_pack(const FaBatchDev &b, hipStream_t s);
 void fa_launch_index(const FaBatchDev &b, hipStream_t s);
 void fa_launch_chain(const FaBatchDev &b, int max_bins, hipStream_t s);
+// general banded alignment for band tolerances beyond FA_ALIGN_MAXCH chunks (k_align_wide.hip)
+#define FA_WIDE_BAND_MAX 2000
+void fa_launch_align_wide(const FaBatchDev &b, const FaAlignArena &a, double max_diff, int band,
+                          hipStream_t s);
 // --trim windows (k_trimwin.hip): count_only = 1 stores every read's hit count in
 // range[g].n_hit; the full pass needs scratch (n_slot x 4 x cap words) only when a read
 // has more hits than fit LDS

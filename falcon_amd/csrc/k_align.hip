@@ -75,59 +75,6 @@ struct AlignArgs {
     u64 *prof;  // FA_ALIGN_PROF builds: 8 section counters
 };
 
-// Snake (DW_banded.c:203-206): extend (x,y) while bases match, 16 bases per
-// step: two packed words per sequence funnel-shifted (v_alignbit) into one
-// 16-base window, xor, find-first-set.  ffbl(0) = -1 turns into a huge count
-// that the min() against the remaining lengths clamps.
-// v_ffbl_b32 as the hardware defines it: -1 for 0 (the compiler's ctz would be
-// undefined there and __ffs costs a compare and a select to patch it).
-__device__ __forceinline__ u32 ffbl_raw(u32 x) {
-    u32 r;
-    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-
-// (qa, ta: base offsets >= 0; unsigned word indices keep the address arithmetic in
-// 32 bits: SGPR base + VGPR offset loads instead of 64-bit VALU adds)
-template <class QP, class TP>
-__device__ __forceinline__ u32 snake_step(QP qL, TP tL, u32 qa, u32 ta, u32 lim) {
-    // bit offsets first: (a + b) << 1 is one VALU op, word index and shift derive from it
-    // (v_alignbit only looks at the low 5 bits of the shift)
-    const u32 qs = qa << 1, ts = ta << 1;
-    const u32 qi = qs >> 5, ti = ts >> 5;
-    const u32 qw = __builtin_amdgcn_alignbit(qL[qi + 1u], qL[qi], qs);
-    const u32 tw = __builtin_amdgcn_alignbit(tL[ti + 1u], tL[ti], ts);
-    return min(ffbl_raw(qw ^ tw) >> 1, lim);
-}
-
-// act lanes hold a cell of the row: 0 <= x <= q_len, 0 <= y <= t_len (a cell that
-// reached either end finishes the alignment in its own row, DW_banded.c:220).
-template <class QP, class TP>
-__device__ __forceinline__ void snake16(QP qL, TP tL, int qb, int tb, int q_len, int t_len,
-                                        bool act, int &x, int &y) {
-    u32 mlast;  // length of the lane's last step; 16 = a full window matched: go on
-    {   // first step: every lane, predicated by selects (idle lanes probe offset 0)
-        const int xs = act ? x : 0, ys = act ? y : 0;
-        const u32 lim = min(16u, (u32)min(q_len - xs, t_len - ys));
-        u32 m = snake_step(qL, tL, (u32)(qb + xs), (u32)(tb + ys), lim);
-        m = act ? m : 0u;
-        x += (int)m;
-        y += (int)m;
-        mlast = m;
-    }
-    u64 gm = fa_ballot(mlast == 16u);
-    while (gm) {  // only lanes inside a run of >= 16 matches get here
-        if (mlast == 16u) {
-            const u32 lim = min(16u, (u32)min(q_len - x, t_len - y));
-            const u32 m = snake_step(qL, tL, (u32)(qb + x), (u32)(tb + y), lim);
-            x += (int)m;
-            y += (int)m;
-            mlast = m;
-        }
-        gm = fa_ballot(mlast == 16u);
-    }
-}
-
 // One alignment.  qL/tL: LDS windows (word aligned), qb/tb: base offset of
 // window position 0 inside the first staged word.  Vring: 2 x RING ints.
 // (kept out of line: inlined into the persistent work loop, hipcc 7.2 fuses the

@@ -38,9 +38,10 @@ def test_native_library_is_loaded(engine):
     assert "libfalcon_amd.so" in maps
 
 
-@pytest.mark.parametrize("case", [c for c in F3 if c["band"] <= 190],
-                         ids=[c["name"] for c in F3 if c["band"] <= 190])
+@pytest.mark.parametrize("case", F3, ids=["%s_b%d" % (c["name"], c["band"]) for c in F3])
 def test_align_golden_legacy_abi(legacy, case):
+    """Every golden alignment, band 150 (k_align.hip) and the contig-layout band 1500
+    (k_align_wide.hip), through the legacy `align` symbol."""
     check_align_case(legacy, case)
 
 
@@ -52,10 +53,40 @@ def test_align_golden_one_launch(engine):
             assert r[k] == v, (c["name"], k)
 
 
-def test_wide_band_is_refused_loudly(engine):
+def test_absurd_band_is_refused_loudly(engine):
     from falcon_amd.lib import FalconAmdError
     with pytest.raises(FalconAmdError):
-        engine.align_pairs([("ACGT" * 10, "ACGT" * 10)], band=1500)
+        engine.align_pairs([("ACGT" * 10, "ACGT" * 10)], band=5000)
+
+
+def test_wide_band_vs_oracle(engine):
+    """band_tolerance 1500 (graph_to_contig.py:52-105): divergent pairs whose band grows
+    far past the tuned kernel's 190 diagonals, a pair with a 700-base indel (only a wide
+    band crosses it), identical and unalignable pairs -- against the oracle, strings
+    included, several pairs in one launch."""
+    from oracle.pyoracle import Port
+    from falcon_amd.synth import codes_to_str, noisy
+    port = Port()
+    rng = np.random.default_rng(3)
+    pairs = []
+    for n, e in [(3000, 0.20), (6000, 0.25), (12000, 0.15), (2500, 0.30)]:
+        t = rng.integers(0, 4, n).astype(np.uint8)
+        pairs.append((codes_to_str(noisy(t, rng, e)), codes_to_str(t)))
+    t = rng.integers(0, 4, 9000).astype(np.uint8)
+    q = np.concatenate([t[:4000], rng.integers(0, 4, 700).astype(np.uint8), t[4000:]])
+    pairs.append((codes_to_str(noisy(q, rng, 0.05)), codes_to_str(t)))
+    pairs.append((pairs[0][1], pairs[0][1]))
+    pairs.append((codes_to_str(rng.integers(0, 4, 2000).astype(np.uint8)),
+                  codes_to_str(rng.integers(0, 4, 2000).astype(np.uint8))))
+    got = engine.align_pairs(pairs, band=1500, want_str=True)
+    widest = 0
+    for (q, t), r in zip(pairs, got):
+        want = port.align(q, t, 1500, 1)
+        for k in ("aln_str_size", "dist", "aln_q_s", "aln_q_e", "aln_t_s", "aln_t_e",
+                  "q_aln_str", "t_aln_str"):
+            assert r[k] == want[k], k
+        widest = max(widest, want["dist"])
+    assert widest > 1500  # rows far wider than the 190-diagonal kernel could hold
 
 
 def test_chain_ranges_golden(engine):
