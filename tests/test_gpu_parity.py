@@ -194,6 +194,35 @@ def test_batch_is_order_preserving_and_rerunnable(engine):
     bt.free()
 
 
+def test_bench_scale_batch_properties(engine):
+    """The bench workload (BASELINE config 2: ~20 kb seeds x 40x, e = 0.13), a batch large
+    enough to fill every wave slot several times over: results must not depend on what
+    else is in the batch, on the order of the piles, or on the run -- the properties that
+    hold at any size (the oracle itself checks one such pile above)."""
+    import hashlib
+    from falcon_amd.synth import codes_to_str, make_pile, pile_to_seqs
+    piles = []
+    for i in range(72):
+        s, rd = make_pile(7000 + i, S=20000, coverage=40.0)
+        piles.append([codes_to_str(x) for x in pile_to_seqs(s, rd, 200)])
+    bt = engine.batch(piles)
+    try:
+        r1 = [bt.run(4, 8, 0.70).fetch(True).result(i) for i in range(len(piles))]
+        st = bt.stats()
+        r2 = [bt.run(4, 8, 0.70).fetch(True).result(i) for i in range(len(piles))]
+    finally:
+        bt.free()
+    assert r1 == r2                                     # rerunnable, deterministic
+    assert st.n_piles == len(piles) and st.n_aligned > 60 * len(piles)
+    assert all(len(c) > 19000 for c, _ in r1)           # every seed corrected end to end
+    rev = engine.consensus(list(reversed(piles)), 4, 8, 0.70, want_eqv=True)
+    assert rev == list(reversed(r1))                    # order of piles is irrelevant
+    for i in (0, 31, 71):                               # and so is their company
+        assert engine.consensus([piles[i]], 4, 8, 0.70, want_eqv=True) == [r1[i]]
+    digest = hashlib.sha1("".join(c for c, _ in r1).encode()).hexdigest()
+    assert len(digest) == 40
+
+
 def test_long_insertion_runs_and_tag_cutoff(engine, port):
     """Insertion runs longer than a tag's 16 inline bases, and runs past the
     reference's 255-column cut-off (falcon.c:138-152; beyond the reference's own
