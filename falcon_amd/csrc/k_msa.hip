@@ -51,6 +51,7 @@
 #define TAG_DEL 0x80000000u
 #define TAG_NINS_SHIFT 23
 #define TAG_PAY_MASK 0x7fffffu
+#define TG_WIN 1024    // target positions per k_tags LDS window
 
 struct MsaArgs {
     const u32 *words;
@@ -124,15 +125,27 @@ __device__ __forceinline__ int wave_incl_max(int v, int lane) {
 // column iff its edit bit is 0; it continues the run of the previous column iff
 // row d-1 is an insertion with an empty snake.  carry_open = depth of the last
 // row of the previous chunk (0 if that row is not an insertion).
-__device__ __forceinline__ int chunk_delta(const u32 *scr, int d, int d0, bool is_ins, int lane,
+__device__ __forceinline__ int chunk_delta(u32 ep, int d, int d0, bool is_ins, int lane,
                                            int carry_open, bool &cont, int &start_row) {
-    const u32 ep = (d >= 2) ? scr[d - 1] : 1u;
     cont = is_ins && d >= 2 && (ep & 1u) == 0u && (ep >> 1) == 0u;
     int start = (is_ins && !cont) ? d : -1;
     start = wave_incl_max(start, lane);
     start_row = start;
     if (!is_ins) return 0;
     return (start >= d0) ? (d - start + 1) : (carry_open + (d - d0) + 1);
+}
+
+// The script words of a chunk's rows: each lane its own (e), its predecessor's (ep) and
+// its successor's (en) -- one load per chunk, a chunk ahead; neighbours come from DPP
+// wave shifts, the chunk edges from the previous / next chunk's registers.
+struct ScrChunk { u32 e, ep, en; };
+__device__ __forceinline__ ScrChunk scr_chunk(u32 e_cur, u32 e_last_prev, u32 e_next_first, int lane) {
+    ScrChunk c;
+    c.e = e_cur;
+    c.ep = (u32)__builtin_amdgcn_update_dpp((int)e_last_prev, (int)e_cur, 0x138, 0xf, 0xf, false);  // wave_shr:1
+    c.en = (u32)__builtin_amdgcn_update_dpp((int)e_next_first, (int)e_cur, 0x130, 0xf, 0xf, false); // wave_shl:1
+    (void)lane;
+    return c;
 }
 
 __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
@@ -151,24 +164,33 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
     const int T1 = A.pile[ta.pile].seed_len + 1;
     int *a_cov = tarr, *a_max = tarr + T1, *a_sum = tarr + 2 * T1;
     const int dist = al.dist, te = al.t_e;
-
-    for (int u = lane; u < te; u += 64) desc[u] = 0u;
+    // Tag words leave in whole lines: the target positions a chunk of 64 script rows
+    // consumes are built in this LDS window (zeros, then the chunk's tags) and stored
+    // once, coalesced.  (Zero-filling the alignment's words up front and scattering the
+    // tags over them afterwards wrote every line twice, the second time as 4-byte
+    // fragments: 29 GB of HBM writes per launch instead of 10.)
+    __shared__ u32 win[TG_WIN];
 
     // pre-pass: tagging stops at the first column whose insertion depth reaches
     // 255 (falcon.c:138-152); dcut = that row (dist + 1 if none)
     int dcut = dist + 1;
     {
         int carry_open = 0, first_bad = 0x7fffffff;
+        u32 e_nx = (lane <= dist) ? scr[lane] : 1u, e_last = 1u;
         for (int d0 = 0; d0 <= dist; d0 += 64) {
             const int d = d0 + lane;
             const bool have = d <= dist;
-            const u32 e = have ? scr[d] : 1u;
+            const u32 e_cur = e_nx;
+            e_nx = (d + 64 <= dist) ? scr[d + 64] : 1u;
+            const ScrChunk sc = scr_chunk(e_cur, e_last, 1u, lane);
+            e_last = (u32)__builtin_amdgcn_readlane((int)e_cur, 63);
+            const u32 e = sc.e;
             const bool is_ins = have && d >= 1 && (e & 1u) == 0u;
             bool cont;
             int sr;
-            const int delta = chunk_delta(scr, d, d0, is_ins, lane, carry_open, cont, sr);
+            const int delta = chunk_delta(d >= 2 ? sc.ep : 1u, d, d0, is_ins, lane, carry_open, cont, sr);
             if (delta >= 255) first_bad = min(first_bad, d);
-            carry_open = __shfl(delta, 63);
+            carry_open = __builtin_amdgcn_readlane(delta, 63);
         }
         first_bad = fa_wave_min(first_bad);
         if (first_bad <= dist) dcut = first_bad;
@@ -179,11 +201,17 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
     const int dlast = min(dist, dcut - 1);
     int carry_t = 0, carry_q = rg.s1, carry_i = 0, carry_open = 0, carry_run_i = 0;
     int carry_start_row = 0;
-    u32 carry_inl = 0;
+    u32 carry_inl = 0, carry_es = 0;
+    u32 e_nx = (lane <= dlast) ? scr[lane] : 1u, e_last = 1u;
     for (int d0 = 0; d0 <= dlast; d0 += 64) {
         const int d = d0 + lane;
         const bool have = d <= dlast;
-        const u32 e = have ? scr[d] : 1u;
+        const u32 e_cur = e_nx;
+        e_nx = (d + 64 <= dlast) ? scr[d + 64] : 1u;  // rows beyond dlast read as "deletion, no snake"
+        const ScrChunk sc = scr_chunk(e_cur, e_last, (u32)__builtin_amdgcn_readfirstlane((int)e_nx), lane);
+        const u32 e_last_prev = e_last;
+        e_last = (u32)__builtin_amdgcn_readlane((int)e_cur, 63);
+        const u32 e = sc.e;
         const int m = have ? (int)(e >> 1) : 0;
         const bool is_edit = have && d >= 1;
         const bool is_del = is_edit && (e & 1u) != 0u;
@@ -196,14 +224,21 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
         const int iidx = carry_i + is - (is_ins ? 1 : 0);
         bool cont;
         int start_row = 0;
-        const int delta = chunk_delta(scr, d, d0, is_ins, lane, carry_open, cont, start_row);
+        const int delta = chunk_delta(d >= 2 ? sc.ep : 1u, d, d0, is_ins, lane, carry_open, cont, start_row);
         const bool from_prev_chunk = is_ins && (delta - 1 > d - d0);
         if (from_prev_chunk) start_row = carry_start_row;
         // index (in the alignment's insertion list) of the first base of my run
         const int run_i = is_ins ? (from_prev_chunk ? carry_run_i : iidx - (delta - 1)) : 0;
         // the run ends here unless the next row continues it
-        const u32 en = (d + 1 <= dlast) ? scr[d + 1] : 1u;
+        const u32 en = (d + 1 <= dlast) ? sc.en : 1u;
         const bool ends = is_ins && (m > 0 || (en & 1u) != 0u);
+        // the column before my run (decides whether the run hangs off a deleted base):
+        // a lane of this chunk, the last row of the previous one, or -- for a run that
+        // began in an earlier chunk -- what that chunk found
+        u32 es = (u32)__shfl((int)e, start_row - 1 - d0);
+        if (start_row - 1 == d0 - 1) es = e_last_prev;
+        if (from_prev_chunk) es = carry_es;
+        if (start_row < 2) es = 0u;
         // inline bases of my run so far: OR of b << 2(delta-1) over the run's rows
         u32 b = 0, inl = 0;
         if (is_ins) {
@@ -217,28 +252,40 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
             if (is_ins && delta - 1 >= off && lane >= off) inl |= o;
         }
         if (from_prev_chunk) inl |= carry_inl;
+        // the chunk's window of target positions [w0, w0 + span)
+        const int w0 = carry_t, span = __builtin_amdgcn_readlane(ts, 63);
+        const bool in_lds = span <= TG_WIN;  // (a very long match run: straight to HBM)
+        __syncthreads();
+        if (in_lds) { for (int i = lane; i < span; i += 64) win[i] = 0u; }
+        else { for (int i = lane; i < span; i += 64) desc[w0 + i] = 0u; }
+        __syncthreads();
         // Every tag word has exactly one writer (no atomics): a deletion writes its
         // flag unless an insertion run hangs off the deleted base, in which case the
         // run's last row writes the whole word.
         if (is_del && !(m == 0 && d + 1 <= dlast && (en & 1u) == 0u)) {
-            desc[tpos] = TAG_DEL;
+            if (in_lds) win[tpos - w0] = TAG_DEL; else desc[tpos] = TAG_DEL;
         }
         if (ends) {
-            const int us = tpos - 1;  // the target position the run hangs off
-            const u32 es = (start_row >= 2) ? scr[start_row - 1] : 0u;  // column before the run
+            const int us = tpos - 1;  // the target position the run hangs off (>= w0 - 1)
             const bool on_del = start_row >= 2 && (es & 1u) != 0u && (es >> 1) == 0u;
-            desc[us] = (delta <= INL ? inl : ((u32)run_i & TAG_PAY_MASK)) |
-                       ((u32)delta << TAG_NINS_SHIFT) | (on_del ? TAG_DEL : 0u);
+            const u32 word = (delta <= INL ? inl : ((u32)run_i & TAG_PAY_MASK)) |
+                             ((u32)delta << TAG_NINS_SHIFT) | (on_del ? TAG_DEL : 0u);
+            // (us == w0 - 1 lies in the window the previous chunk already stored: the
+            // later store of the same wavefront to the same word wins)
+            if (in_lds && us >= w0) win[us - w0] = word; else desc[us] = word;
             atomicMax(&a_max[rg.s2 + us], delta);
             atomicAdd(&a_sum[rg.s2 + us], delta);
         }
-        carry_t += __shfl(ts, 63);
-        carry_q += __shfl(qs, 63);
-        carry_i += __shfl(is, 63);
-        carry_open = __shfl(delta, 63);
-        carry_run_i = __shfl(run_i, 63);
-        carry_start_row = __shfl(start_row, 63);
-        carry_inl = (u32)__shfl((int)inl, 63);
+        __syncthreads();
+        if (in_lds) { for (int i = lane; i < span; i += 64) desc[w0 + i] = win[i]; }
+        carry_t += __builtin_amdgcn_readlane(ts, 63);
+        carry_q += __builtin_amdgcn_readlane(qs, 63);
+        carry_i += __builtin_amdgcn_readlane(is, 63);
+        carry_open = __builtin_amdgcn_readlane(delta, 63);
+        carry_run_i = __builtin_amdgcn_readlane(run_i, 63);
+        carry_start_row = __builtin_amdgcn_readlane(start_row, 63);
+        carry_inl = (u32)__builtin_amdgcn_readlane((int)inl, 63);
+        carry_es = (u32)__builtin_amdgcn_readlane((int)es, 63);
     }
     // rows >= dcut are dropped: the alignment covers only what the kept rows consumed
     const int t_cov = (dcut <= dist) ? carry_t : te;
