@@ -74,8 +74,7 @@ struct MsaArgs {
     u32 *links;                // link words
     const u64 *link_off;       // [n_pile]
     const u64 *link_cap;       // [n_pile]
-    uint8_t *lvl_nlink;        // per level slot: number of links (capped at 255 -> see k_links)
-    u16 *lvl_nlink16;          // same, 16 bit (the one that is read)
+    u16 *lvl_nlink16;          // per level slot: number of links
     FaNode *nodes;
     int *score_ovf;            // per pile 2 x 256 x 5 ints: scores of levels >= SC_LCAP
     FaScoreOut *score_out;     // per pile
@@ -1007,7 +1006,7 @@ void fa_launch_msa(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov, hip
     A.ta = m.ta; A.acc_first = m.acc_first; A.n_acc_total = m.n_acc_total; A.n_pile = b.n_pile;
     A.tcov = m.tcov; A.desc = m.desc; A.insb = m.insb; A.tarr = m.tarr; A.t_off = m.t_off;
     A.tinfo = m.tinfo; A.links = m.links; A.link_off = m.link_off; A.link_cap = m.link_cap;
-    A.lvl_nlink = nullptr; A.lvl_nlink16 = m.lvl_nlink16; A.nodes = b.nodes;
+    A.lvl_nlink16 = m.lvl_nlink16; A.nodes = b.nodes;
     A.score_ovf = m.score_ovf; A.score_out = m.score_out;
     A.out_seq = b.out_seq; A.out_eqv = b.out_eqv; A.pile_out = b.pile_out;
     A.seg_pile = m.seg_pile; A.seg_t0 = m.seg_t0; A.n_seg = m.n_seg; A.min_cov = min_cov;

@@ -59,6 +59,21 @@ def test_absurd_band_is_refused_loudly(engine):
         engine.align_pairs([("ACGT" * 10, "ACGT" * 10)], band=5000)
 
 
+def test_limits_are_errors_not_silent_degradation(engine):
+    """K != 8, a seed of >= 100 000 bases (the reference asserts, falcon.c:343): loud errors;
+    sequences with non-ACGT letters are packed like the reference's table does."""
+    from falcon_amd.lib import FalconAmdError
+    rng = np.random.default_rng(2)
+    seq = "".join("ACGT"[i] for i in rng.integers(0, 4, 1200))
+    b = engine.batch([[seq, seq, seq]])
+    with pytest.raises(FalconAmdError, match="K=9"):
+        b.run(4, 9, 0.70)
+    b.free()
+    big = "".join("ACGT"[i] for i in rng.integers(0, 4, 100000))
+    with pytest.raises(FalconAmdError, match="100000"):
+        engine.batch([[big, big[:5000]]])
+
+
 def test_wide_band_vs_oracle(engine):
     """band_tolerance 1500 (graph_to_contig.py:52-105): divergent pairs whose band grows
     far past the tuned kernel's 190 diagonals, a pair with a 700-base indel (only a wide
