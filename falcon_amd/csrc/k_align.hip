@@ -167,7 +167,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
     u32 rc_off = 0, rc_mink = 0, rc_dlo = 0, rc_dhi = 0;
     // WRITE_ROW_RECORD: row d's record into lane d & 63 (v_writelane; lane select in M0:
     // a VOP3 may read only one SGPR besides it).  FLUSH_ROW_RECORDS: rows d - (d & 63) .. d.
-#define WRITE_ROW_RECORD(dir0_)                                                   \
+#define WRITE_ROW_RECORD(dir0_, min_k_expr)                                       \
     do {                                                                          \
         const u64 dw_ = (dir0_);                                                  \
         asm volatile("s_mov_b32 m0, %8\n\t"                                       \
@@ -176,7 +176,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
                      "v_writelane_b32 %2, %6, m0\n\t"                             \
                      "v_writelane_b32 %3, %7, m0"                                 \
                      : "+v"(rc_off), "+v"(rc_mink), "+v"(rc_dlo), "+v"(rc_dhi)    \
-                     : "s"(row_off), "s"((u32)min_k), "s"((u32)dw_),              \
+                     : "s"(row_off), "s"((u32)(min_k_expr)), "s"((u32)dw_),       \
                        "s"((u32)(dw_ >> 32)), "s"(d & 63));                       \
     } while (0)
 #define FLUSH_ROW_RECORDS()                                                       \
@@ -189,7 +189,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
     } while (0)
 #define PUT_ROW_RECORD(dir0_, finished_)                                          \
     do {                                                                          \
-        WRITE_ROW_RECORD(dir0_);                                                  \
+        WRITE_ROW_RECORD(dir0_, min_k);                                           \
         if ((d & 63) == 63 || (finished_)) FLUSH_ROW_RECORDS();                   \
     } while (0)
 
@@ -218,18 +218,27 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
         // mode loop, at a dozen scalar instructions per row)
         u64 fin = 0ull;
         int x = 0, y = 0;
+        // The rare events -- rows exhausted (:183), band too wide (:184), row too wide
+        // for register mode, band climbing out of the wave -- are tested when a
+        // countdown runs out, not every row: each of their margins shrinks by at most
+        // one per row (d and the band's top lane grow by one, n by at most one; the
+        // band's bottom lane never moves down), so after a test that leaves a smallest
+        // margin of s the next s rows cannot trip any of them.
+        int safe = -1;
         for (;;) {
-            // one sign test covers the four rare events: rows exhausted (:183), band too
-            // wide (:184), row too wide for register mode, band drifting out of the wave
-            if (((max_d - 1 - d) | (nmax - n) | (lo - 1) | (63 - lo - n)) < 0) {
+            if (--safe < 0) {
+                min_k = kd + 2 * lo;  // (register mode keeps min_k implicit)
                 if (d >= max_d || n - 1 > band) { dead = true; break; }
                 if (n > REG_MAX_N) break;
-                // re-seat the band low inside the wave (it climbs one lane every two rows)
-                const int nlo = max(1, (64 - n) >> 2);
-                const int sh = lo - nlo;        // new lane l takes old lane l + sh
-                vreg = __shfl(vreg, lane + sh);
-                kd += 2 * sh;
-                lo = nlo;
+                if (63 - lo - n < 0 || lo < 1) {
+                    // re-seat the band low inside the wave (it climbs one lane every two rows)
+                    const int nlo = max(1, (64 - n) >> 2);
+                    const int sh = lo - nlo;        // new lane l takes old lane l + sh
+                    vreg = __shfl(vreg, lane + sh);
+                    kd += 2 * sh;
+                    lo = nlo;
+                }
+                safe = min(min(max_d - 1 - d, nmax - n), 63 - lo - n);
             }
             const int hi = lo + n - 1;
             PROF(0);
@@ -256,7 +265,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             const u64 dir0 = fa_m >> lo;
             fin = (fa_ballot(x >= q_len) | fa_ballot(y >= t_len)) & act_m;  // :220
             PROF(3);
-            WRITE_ROW_RECORD(dir0);
+            WRITE_ROW_RECORD(dir0, kd + 2 * lo);
             if (fin) break;  // (its records are flushed after the loop)
             if ((d & 63) == 63) FLUSH_ROW_RECORDS();
             // (an LDS ds_max on one word instead of the DPP reduction was measured 2x
@@ -269,13 +278,13 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             const int llo = __builtin_ctzll(in);          // absolute lanes
             const int lhi = 63 - __builtin_clzll(in);
             row_off += (u32)n;
-            min_k = min_k + 2 * (llo - lo) - 1;
             n = lhi - llo + 2;
-            lo = llo;  // the new lowest diagonal, one below, sits on the same lane one row on
-            kd--;
+            lo = llo;  // the new lowest diagonal (min_k = kd + 2 lo), one below, sits on the
+            kd--;      // same lane one row on
             d++;
             PROF(5);
         }
+        min_k = kd + 2 * lo;
         if (fin) {  // row d finished the alignment on its first (lowest) such diagonal
             FLUSH_ROW_RECORDS();
             const int fl = __builtin_ctzll(fin);
