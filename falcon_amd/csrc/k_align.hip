@@ -224,22 +224,20 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
         // one per row (d and the band's top lane grow by one, n by at most one; the
         // band's bottom lane never moves down), so after a test that leaves a smallest
         // margin of s the next s rows cannot trip any of them.
-        int safe = -1;
         for (;;) {
-            if (--safe < 0) {
-                min_k = kd + 2 * lo;  // (register mode keeps min_k implicit)
-                if (d >= max_d || n - 1 > band) { dead = true; break; }
-                if (n > REG_MAX_N) break;
-                if (63 - lo - n < 0 || lo < 1) {
-                    // re-seat the band low inside the wave (it climbs one lane every two rows)
-                    const int nlo = max(1, (64 - n) >> 2);
-                    const int sh = lo - nlo;        // new lane l takes old lane l + sh
-                    vreg = __shfl(vreg, lane + sh);
-                    kd += 2 * sh;
-                    lo = nlo;
-                }
-                safe = min(min(max_d - 1 - d, nmax - n), 63 - lo - n);
+            min_k = kd + 2 * lo;  // (register mode keeps min_k implicit)
+            if (d >= max_d || n - 1 > band) { dead = true; break; }
+            if (n > REG_MAX_N) break;
+            if (63 - lo - n < 0 || lo < 1) {
+                // re-seat the band low inside the wave (it climbs one lane every two rows)
+                const int nlo = max(1, (64 - n) >> 2);
+                const int sh = lo - nlo;        // new lane l takes old lane l + sh
+                vreg = __shfl(vreg, lane + sh);
+                kd += 2 * sh;
+                lo = nlo;
             }
+            // the hot loop: `safe` + 1 rows that cannot trip a rare event
+            for (int safe = min(min(max_d - 1 - d, nmax - n), 63 - lo - n); safe >= 0; safe--) {
             const int hi = lo + n - 1;
             PROF(0);
             // Lane sets are kept twice: as a predicate (act: stores, selects) and as a
@@ -283,6 +281,8 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             kd--;      // same lane one row on
             d++;
             PROF(5);
+            }
+            if (fin) break;
         }
         min_k = kd + 2 * lo;
         if (fin) {  // row d finished the alignment on its first (lowest) such diagonal
