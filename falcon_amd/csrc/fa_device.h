@@ -28,8 +28,17 @@ __device__ __forceinline__ u32 fa_kmer8(const u32 *w, int i) {
 // extra VALU) -- combine masks with scalar and/or instead.
 __device__ __forceinline__ u64 fa_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
-// n consecutive lanes starting at lane lo, as a mask (s_bfm_b64); 0 < n <= 63.
-__device__ __forceinline__ u64 fa_lane_range(int lo, int n) { return ((1ull << n) - 1ull) << lo; }
+// n consecutive lanes starting at lane lo, as a mask: one s_bfm_b64; 0 < n <= 63.
+__device__ __forceinline__ u64 fa_lane_range(int lo, int n) {
+    u64 m;
+    asm("s_bfm_b64 %0, %1, %2" : "=s"(m) : "s"(n), "s"(lo));
+    return m;
+}
+// mask with bit `clr` cleared and bit `set` set (s_bitset0_b64 / s_bitset1_b64)
+__device__ __forceinline__ u64 fa_mask_clr_set(u64 m, int clr, int set) {
+    asm("s_bitset0_b64 %0, %1\n\ts_bitset1_b64 %0, %2" : "+s"(m) : "s"(clr), "s"(set));
+    return m;
+}
 
 // mask ? b : a per lane, the lane mask given as a scalar (v_cndmask with an SGPR pair)
 __device__ __forceinline__ int fa_sel(u64 mask, int a, int b) {

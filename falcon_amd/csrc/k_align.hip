@@ -225,6 +225,9 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
         // band's bottom lane never moves down), so after a test that leaves a smallest
         // margin of s the next s rows cannot trip any of them.
         for (;;) {
+            // a block of 64 row records is complete: store it (the hot loop below never
+            // runs across such a boundary)
+            if ((d & 63) == 0 && d > 0) { d--; FLUSH_ROW_RECORDS(); d++; }
             min_k = kd + 2 * lo;  // (register mode keeps min_k implicit)
             if (d >= max_d || n - 1 > band) { dead = true; break; }
             if (n > REG_MAX_N) break;
@@ -237,7 +240,8 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
                 lo = nlo;
             }
             // the hot loop: `safe` + 1 rows that cannot trip a rare event
-            for (int safe = min(min(max_d - 1 - d, nmax - n), 63 - lo - n); safe >= 0; safe--) {
+            for (int safe = min(min(min(max_d - 1 - d, nmax - n), 63 - lo - n), 63 - (d & 63));
+                 safe >= 0; safe--) {
             const int hi = lo + n - 1;
             PROF(0);
             // Lane sets are kept twice: as a predicate (act: stores, selects) and as a
@@ -252,7 +256,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             const int a = __builtin_amdgcn_mov_dpp(vreg, 0x138, 0xf, 0xf, true);  // lane-1: V[k-1]
             const int b = vreg;                                                  //         V[k+1]
             // from_above: k == min_k, or k != max_k and V[k-1] < V[k+1]   (:190)
-            const u64 fa_m = ((fa_ballot(a < b) & ~(1ull << hi)) | (1ull << lo)) & act_m;
+            const u64 fa_m = fa_mask_clr_set(fa_ballot(a < b), hi, lo) & act_m;
             x = fa_sel(fa_m, a + 1, b);
             y = x - k;
             PROF(1);
@@ -264,8 +268,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             fin = (fa_ballot(x >= q_len) | fa_ballot(y >= t_len)) & act_m;  // :220
             PROF(3);
             WRITE_ROW_RECORD(dir0, kd + 2 * lo);
-            if (fin) break;  // (its records are flushed after the loop)
-            if ((d & 63) == 63) FLUSH_ROW_RECORDS();
+            if (fin) goto reg_rows_finished;  // (its records are flushed there)
             // (an LDS ds_max on one word instead of the DPP reduction was measured 2x
             // slower: 64 same-address atomics serialise)
             const int u = act ? x + y : -1;
@@ -282,8 +285,8 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             d++;
             PROF(5);
             }
-            if (fin) break;
         }
+    reg_rows_finished:
         min_k = kd + 2 * lo;
         if (fin) {  // row d finished the alignment on its first (lowest) such diagonal
             FLUSH_ROW_RECORDS();
