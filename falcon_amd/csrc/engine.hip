@@ -508,6 +508,14 @@ static int fetch_aln(fa_batch *b) {
     return 0;
 }
 
+// Stages after the windows are known (d_range on the device, h_range on the host or on
+// its way there): banded alignment, then the MSA stage.  `band` <= 190 runs the tuned
+// kernel, wider bands the general one; `force_accept_g` >= 0 names a sequence whose
+// alignment is used whatever its length (the unitig's copy of itself,
+// falcon.c:699-704).
+static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int band,
+                           int force_accept_g);
+
 extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double min_idt) {
     if (!b || b->pair_mode) {
         set_err("falcon_amd: fa_batch_run on an invalid batch");
@@ -539,7 +547,18 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     if (b->h_range.resize(b->n_seq)) return -1;
     HIP_OK(hipMemcpyAsync(b->h_range.data(), b->d_range.p, (size_t)b->n_seq * sizeof(FaRange),
                           hipMemcpyDeviceToHost, s));
-    fa_launch_align(d, c->arena, b->max_read_len, b->max_seed_len, max_diff, s);
+    return run_from_ranges(b, min_cov, max_diff, FA_BAND, -1);
+}
+
+static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int band,
+                           int force_accept_g) {
+    fa_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    FaBatchDev d = b->dev();
+    if (band + 1 > 64 * FA_ALIGN_MAXCH - 1)
+        fa_launch_align_wide(d, c->arena, max_diff, band, s);
+    else
+        fa_launch_align_band(d, c->arena, b->max_read_len, b->max_seed_len, max_diff, band, s);
     HIP_OK(hipEventRecord(c->ev[3], s));
     trace_stage(s, "align");
     if (getenv("FALCON_AMD_PROF")) {  // only meaningful in -DFA_ALIGN_PROF builds
@@ -588,6 +607,7 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     // alignment summaries bound the MSA node pools (levels <= seed + insertions)
     if (int rc = fetch_aln(b)) return rc;
     b->have_range = true;  // its copy was queued ahead of k_align
+    if (force_accept_g >= 0 && b->h_aln[force_accept_g].aligned) b->h_aln[force_accept_g].accept = 1;
     // ---- plan the MSA stage from the alignment summaries (host, O(#reads))
     u64 node_off = 0, desc_tot = 0, ins_tot = 0, link_tot = 0;
     long long sC = 0, sD = 0, sA = 0, nal = 0;
@@ -611,13 +631,13 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
             sA += al.size;
             n_acc++;
             FaTagAln &x = ta[n_ta++];
-            x.desc_off = desc_tot;
+            x.desc_off = desc_tot + 1;  // (the slot before: a leading insertion run, k_tags)
             x.ins_off = (u32)ins_tot;
             x.s2 = b->h_range[g].s2;  // start of the alignment on the seed (chain stage)
             x.g = g;
             x.pile = p;
             x.pad = 0;
-            desc_tot += (u64)al.t_e + 2;
+            desc_tot += (u64)al.t_e + 3;
             ins_tot += (u64)al.n_ins + 4;
         }
         if (n_acc > FA_CNS_MAX_ALN) {
@@ -678,6 +698,7 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     md.score_out = b->d_score_out.p; md.seg_pile = b->d_seg_pile.p; md.seg_t0 = b->d_seg_t0.p;
     md.n_seg = (int)n_seg;
     md.wide_count = b->d_wide.p; md.wide_list = b->d_wide.p + 1;
+    md.first_links_back = force_accept_g >= 0 ? 1 : 0;
     d = b->dev();
     HIP_OK(hipEventRecord(c->ev[4], s));
     fa_launch_msa(d, md, min_cov, s, c->ev + 8);
@@ -711,6 +732,75 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     (void)hipEventElapsedTime(&st.ms_score, c->ev[9], c->ev[10]);
     (void)hipEventElapsedTime(&st.ms_backtrace, c->ev[10], c->ev[11]);
     return 0;
+}
+
+// Unitig consensus (falcon.c:668-773 generate_utg_consensus): reads are placed on the
+// unitig by the caller's offsets instead of k-mer chaining, aligned with band 500, and
+// the unitig itself takes part as an all-match alignment; min_cov is 0 (:755).
+extern "C" fa_batch *fa_utg_consensus(fa_ctx *ctx, int n_seq, const char *const *seqs, int *offset,
+                                      double min_idt) {
+    if (!ctx || n_seq < 1 || !seqs) {
+        set_err("falcon_amd: fa_utg_consensus: bad arguments");
+        return nullptr;
+    }
+    // pile = [unitig, unitig again (its identity alignment, :699-704), reads 1..n_seq-1]
+    const int n = n_seq + 1;
+    std::vector<const char *> sq((size_t)n);
+    std::vector<int> ln((size_t)n);
+    sq[0] = sq[1] = seqs[0];
+    ln[0] = ln[1] = (int)strlen(seqs[0]);
+    for (int j = 1; j < n_seq; j++) {
+        sq[j + 1] = seqs[j];
+        ln[j + 1] = (int)strlen(seqs[j]);
+    }
+    const int band = 500;  // :723-745
+    fa_batch *b = batch_build(ctx, 1, &n, sq.data(), ln.data(), false, band);
+    if (!b) return nullptr;
+    auto fail = [&](const char *what) -> fa_batch * {
+        if (what) set_err("falcon_amd: fa_utg_consensus: %s", what);
+        fa_batch_free(b);
+        return nullptr;
+    };
+    const int utg_len = ln[0];
+    if (b->h_range.resize(b->n_seq)) return fail(nullptr);
+    FaRange *rg = b->h_range.data();
+    memset(rg, 0, (size_t)b->n_seq * sizeof(FaRange));
+    rg[1].e1 = rg[1].e2 = utg_len;
+    rg[1].ok = 1;
+    for (int j = 1; j < n_seq; j++) {
+        FaRange &r = rg[j + 1];
+        const int r_len = ln[j + 1];
+        int len;
+        if (offset[j] < 0) {  // the read starts before the unitig (:712-731)
+            if (r_len + offset[j] < 128) continue;
+            len = (r_len + offset[j] < utg_len) ? r_len + offset[j] : utg_len;
+            r.s1 = -offset[j];
+            r.s2 = 0;
+            offset[j] = 0;  // the reference rewrites the caller's array too (:731)
+        } else {
+            if (offset[j] > utg_len - 128) continue;
+            len = (offset[j] + r_len > utg_len) ? utg_len - offset[j] : r_len;
+            r.s1 = 0;
+            r.s2 = offset[j];
+        }
+        if (r.s1 + len > r_len) len = r_len - r.s1;  // (the reference would read past the read's end)
+        if (len <= 0) continue;
+        r.e1 = r.s1 + len;
+        r.e2 = r.s2 + len;
+        r.ok = 1;
+    }
+    fa_ctx *c = ctx;
+    if (hipSetDevice(c->device) != hipSuccess) return fail("hipSetDevice failed");
+    hipStream_t s = c->stream;
+    if (hipMemcpyAsync(b->d_range.p, rg, (size_t)b->n_seq * sizeof(FaRange), hipMemcpyHostToDevice, s) !=
+        hipSuccess)
+        return fail("range upload failed");
+    b->fetched = b->fetched_eqv = false;
+    b->have_aln = false;
+    if (ensure_arena(c, b, fa_align_lds_bytes(b->max_read_len, b->max_seed_len))) return fail(nullptr);
+    for (int i = 0; i < 3; i++) (void)hipEventRecord(c->ev[i], s);
+    if (run_from_ranges(b, 0, 1.0 - min_idt, band, 1)) return fail(nullptr);
+    return b;
 }
 
 // --trim windows of every read (consensus.py:48-99 get_alignment): seed index, then

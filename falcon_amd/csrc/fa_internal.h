@@ -192,6 +192,7 @@ struct FaMsaDev {
     const int *seg_pile;
     const int *seg_t0;
     int n_seg;
+    int first_links_back;  // unitig mode: a read's first column links back to (s2 - 1, 0, '-')
     int *wide_count;
     int *wide_list;
 };

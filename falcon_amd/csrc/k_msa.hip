@@ -52,6 +52,7 @@
 #define TAG_NINS_SHIFT 23
 #define TAG_PAY_MASK 0x7fffffu
 #define TG_WIN 1024    // target positions per k_tags LDS window
+#define TCOV_LEAD 0x40000000  // tcov flag: the alignment opens with an insertion run (see k_tags)
 
 struct MsaArgs {
     const u32 *words;
@@ -87,6 +88,7 @@ struct MsaArgs {
     int *wide_count;           // k_links<1> -> k_links<8> hand-over
     int *wide_list;
     unsigned min_cov;
+    int first_links_back;      // unitig mode (falcon.c:668-773): see k_links
 };
 
 // ---------------------------------------------------------------------------
@@ -169,6 +171,18 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
     // tags over them afterwards wrote every line twice, the second time as 4-byte
     // fragments: 29 GB of HBM writes per launch instead of 10.)
     __shared__ u32 win[TG_WIN];
+    // An alignment that opens with an insertion run (no target base consumed yet) hangs
+    // that run off the position BEFORE its first one (get_align_tags: j = start - 1,
+    // falcon.c:119-140), whose tag word lives in the slot before the alignment's own
+    // (desc[-1], zero = no such run); with nothing before it (start 0) the reference stops
+    // tagging at once (:138,:152): the alignment contributes nothing.  Cannot happen on the
+    // falcon_sense path (windows open on a k-mer match); unitig windows open anywhere.
+    const bool lead = dist >= 1 && (scr[0] >> 1) == 0u && (scr[1] & 1u) == 0u;
+    if (lane == 0) desc[-1] = 0u;
+    if (lead && rg.s2 == 0) {
+        if (lane == 0) A.tcov[k] = 0;
+        return;
+    }
 
     // pre-pass: tagging stops at the first column whose insertion depth reaches
     // 255 (falcon.c:138-152); dcut = that row (dist + 1 if none)
@@ -289,7 +303,7 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
     // rows >= dcut are dropped: the alignment covers only what the kept rows consumed
     const int t_cov = (dcut <= dist) ? carry_t : te;
     if (lane == 0) {
-        A.tcov[k] = t_cov;
+        A.tcov[k] = t_cov | (lead ? TCOV_LEAD : 0);
         atomicAdd(&a_cov[rg.s2], 1);
         atomicAdd(&a_cov[rg.s2 + t_cov], -1);
     }
@@ -383,8 +397,9 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
         const u32 i = i0 + lane;
         bool ov = false;
         if (i < a1) {
-            const int s2 = A.ta[i].s2, tc = A.tcov[i];
-            ov = s2 < t_hi && s2 + tc > t_lo;
+            const int tcw = A.tcov[i], ld = (tcw & TCOV_LEAD) ? 1 : 0;
+            const int s2 = A.ta[i].s2 - ld, tc = (tcw & ~TCOV_LEAD) + ld;  // a leading run sits at s2 - 1
+            ov = tc > ld && s2 < t_hi && s2 + tc > t_lo;
         }
         const u64 m = __ballot(ov);
         const int rank = __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
@@ -408,18 +423,21 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
     int s2v[NCHT], tcv[NCHT], pbv[NCHT], pnv[NCHT];
     const u32 *dptr[NCHT];
     u32 insoff[NCHT];
+    bool leadv[NCHT];  // position s2v of the lane is a leading insertion run: no delta-0 column
 #pragma unroll
     for (int c = 0; c < NCHT; c++) {
-        s2v[c] = 0x7fffffff; tcv[c] = 0; pbv[c] = 0; pnv[c] = 0; insoff[c] = 0;
+        s2v[c] = 0x7fffffff; tcv[c] = 0; pbv[c] = 0; pnv[c] = 0; insoff[c] = 0; leadv[c] = false;
         dptr[c] = A.desc;
         const int a = c * 64 + lane;
         if (c < nch && a < n_act) {
             const int i = act[a];
             const FaTagAln ta = A.ta[i];
-            s2v[c] = ta.s2;
-            tcv[c] = A.tcov[i];
+            const int tcw = A.tcov[i], ld = (tcw & TCOV_LEAD) ? 1 : 0;
+            leadv[c] = ld != 0;
+            s2v[c] = ta.s2 - ld;
+            tcv[c] = (tcw & ~TCOV_LEAD) + ld;
             insoff[c] = ta.ins_off;
-            dptr[c] = A.desc + ta.desc_off;
+            dptr[c] = A.desc + ta.desc_off - ld;
             const int u = t_lo - 1 - s2v[c];  // the position before the segment
             if (u >= 0 && u < tcv[c]) {
                 const u32 w = dptr[c][u];
@@ -504,11 +522,20 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
             for (int c = 0; c < NCHT; c++) {
                 key[c] = -1; wv[c] = 0;
                 if (c < nch) {
+                    const bool nocol = leadv[c] && t == s2v[c];  // insertion-only position
                     if (dl == 0) {
-                        if (covd[c]) {
-                            if (t == s2v[c]) {  // first column: no predecessor
+                        if (covd[c] && !nocol) {
+                            if (t == s2v[c] && (t == 0 || !A.first_links_back)) {
+                                // first column: no predecessor (p_t_pos == -1, falcon.c:434)
                                 key[c] = base0[c] | (5 << 3) | (1 << 14);
                                 wv[c] = ((u32)base0[c] << 10) | (1u << 24);
+                            } else if (t == s2v[c]) {
+                                // unitig mode: get_align_tags adds the read's offset to its
+                                // initial p_t_pos of -1 (:140), so the first column of a read
+                                // placed at t > 0 links to (t - 1, delta 0) with the '.' base,
+                                // which the scorer reads as '-' (:431)
+                                key[c] = base0[c] | (4 << 3) | (0 << 6) | (1 << 15);
+                                wv[c] = ((u32)base0[c] << 10) | ((u32)4 << 13);
                             } else {
                                 key[c] = base0[c] | (pbv[c] << 3) | (pnv[c] << 6);
                                 wv[c] = ((u32)base0[c] << 10) | ((u32)(pnv[c] * 5 + pbv[c]) << 13);
@@ -519,6 +546,17 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
                         const int pb = dl == 1 ? base0[c] : tag_ins_base(A, insoff[c], wtag[c], dl - 1);
                         key[c] = b | (pb << 3) | ((dl - 1) << 6);
                         wv[c] = ((u32)b << 10) | ((u32)((dl - 1) * 5 + pb) << 13);
+                        if (nocol && dl == 1) {
+                            // the alignment's very first tag: no predecessor on the
+                            // falcon_sense path, (t, delta 0, '.' read as '-') in unitig mode
+                            if (A.first_links_back) {
+                                key[c] = b | (4 << 3) | (1 << 15);
+                                wv[c] = ((u32)b << 10) | ((u32)4 << 13);
+                            } else {
+                                key[c] = b | (5 << 3) | (1 << 14);
+                                wv[c] = ((u32)b << 10) | (1u << 24);
+                            }
+                        }
                         if (nins[c] == dl) { pbv[c] = b; pnv[c] = dl; }
                     }
                     if (dl == 0 && covd[c] && nins[c] == 0) { pbv[c] = base0[c]; pnv[c] = 0; }
@@ -1011,6 +1049,7 @@ void fa_launch_msa(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov, hip
     A.out_seq = b.out_seq; A.out_eqv = b.out_eqv; A.pile_out = b.pile_out;
     A.seg_pile = m.seg_pile; A.seg_t0 = m.seg_t0; A.n_seg = m.n_seg; A.min_cov = min_cov;
     A.wide_count = m.wide_count; A.wide_list = m.wide_list;
+    A.first_links_back = m.first_links_back;
     (void)hipMemsetAsync(m.tarr, 0, m.tarr_bytes, s);
     if (m.n_acc_total > 0) hipLaunchKernelGGL(k_tags, dim3(m.n_acc_total), dim3(64), 0, s, A);
     hipLaunchKernelGGL(k_tscan, dim3(b.n_pile), dim3(64), 0, s, A);

@@ -65,6 +65,30 @@ extern "C" consensus_data *generate_consensus(char **input_seq, unsigned int n_s
     return r;
 }
 
+// ---- falcon.c:668-773 (exported by the reference's library, bound by nobody) --------
+extern "C" consensus_data *generate_utg_consensus(char **input_seq, seq_coor_t *offset,
+                                                  unsigned int n_seq, unsigned min_cov, unsigned K,
+                                                  double min_idt) {
+    (void)min_cov;  // the reference ignores it too: get_cns_from_align_tags(..., 0), :755
+    (void)K;        // no k-mer stage on this path
+    std::lock_guard<std::mutex> lk(g_mu);
+    fa_ctx *c = default_ctx();
+    fa_batch *b = fa_utg_consensus(c, (int)n_seq, (const char *const *)input_seq, offset, min_idt);
+    if (!b) die("generate_utg_consensus(run)");
+    if (fa_batch_fetch(b, 1)) die("generate_utg_consensus(fetch)");
+    const char *s = nullptr;
+    const int *e = nullptr;
+    int len = 0;
+    if (fa_batch_result(b, 0, &s, &len, &e)) die("generate_utg_consensus(result)");
+    consensus_data *r = (consensus_data *)calloc(1, sizeof(consensus_data));
+    r->sequence = (char *)calloc((size_t)len + 1, 1);
+    r->eqv = (int *)calloc((size_t)len + 1, sizeof(int));
+    memcpy(r->sequence, s, (size_t)len);
+    memcpy(r->eqv, e, (size_t)len * sizeof(int));
+    fa_batch_free(b);
+    return r;
+}
+
 extern "C" void free_consensus_data(consensus_data *c) {  // falcon.c:776
     if (!c) return;
     free(c->sequence);

@@ -107,6 +107,8 @@ alignment *align(char *query_seq, seq_coor_t q_len, char *target_seq, seq_coor_t
 void free_alignment(alignment *aln);
 
 /* falcon.c:562-666, :776 (falcon_kit.py:119-122, consensus.py:20-23) */
+consensus_data *generate_utg_consensus(char **input_seq, seq_coor_t *offset, unsigned int n_seq,
+                                       unsigned min_cov, unsigned K, double min_idt); /* falcon.c:668 */
 consensus_data *generate_consensus(char **input_seq, unsigned int n_seq, unsigned min_cov,
                                    unsigned K, double min_idt);
 void free_consensus_data(consensus_data *c);
@@ -166,6 +168,13 @@ int fa_batch_alignment(fa_batch *b, int g, int *dist, int *q_e, int *t_e, int *s
  * more than mask_threshold times in the seed masked (the driver passes 16).  Results
  * through fa_batch_range(): the raw aln_range (s1, e1, s2, e2, score), n_hit. */
 int fa_batch_trim_windows(fa_batch *b, unsigned K, int mask_threshold);
+
+/* Unitig consensus (src/c/falcon.c:668-773 generate_utg_consensus): seqs[0] is the unitig,
+ * seqs[j] (NUL terminated) lies at offset[j] on it (negative: starts before it; such
+ * entries are rewritten to 0 like the reference does).  Returns a batch holding one pile:
+ * fa_batch_fetch / fa_batch_result(b, 0, ...) / fa_batch_free as usual; NULL on error. */
+fa_batch *fa_utg_consensus(fa_ctx *ctx, int n_seq, const char *const *seqs, int *offset,
+                           double min_idt);
 
 /* Pairwise banded alignment of n independent (query, target) pairs in one
  * launch; out[i] receives a malloc'ed `alignment` (free with free_alignment). */

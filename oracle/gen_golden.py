@@ -299,13 +299,57 @@ def gen_f5_f6(R):
     dump("f6_cli_trim", dict(stdin_from="f5_cli", runs=trim_runs))
 
 
+def gen_f7(R):
+    """generate_utg_consensus (src/c/falcon.c:668-773): reads laid on a unitig by offsets."""
+    rng = np.random.default_rng(707)
+    cases = []
+
+    def add(name, seqs, offsets, min_idt=0.70):
+        seq, eqv, off_after = R.generate_utg_consensus(seqs, offsets, 0, 8, min_idt)
+        cases.append(dict(name=name, seqs=seqs, offsets=list(offsets), min_idt=min_idt,
+                          sequence=seq, eqv_sha=sha_ints(eqv), eqv_head=eqv[:64],
+                          offsets_after=off_after))
+        print("   utg  %-24s n_seq=%3d utg=%6d -> cns %6d" % (name, len(seqs), len(seqs[0]), len(seq)))
+
+    def layout(utg_codes, spans, e):
+        """reads = noisy copies of utg[a:b] (a may be negative / b beyond the end: the
+        overhang is random sequence); offset = a."""
+        seqs, offs = [codes_to_str(utg_codes)], [0]
+        L = utg_codes.shape[0]
+        for a, b in spans:
+            left = rng.integers(0, 4, max(0, -a)).astype(np.uint8)
+            right = rng.integers(0, 4, max(0, b - L)).astype(np.uint8)
+            body = utg_codes[max(a, 0):min(b, L)]
+            rd = noisy(np.concatenate([left, body, right]), rng, e)
+            seqs.append(codes_to_str(rd))
+            offs.append(int(a))
+        return seqs, offs
+
+    utg = rng.integers(0, 4, 6000).astype(np.uint8)
+    spans = [(0, 2500), (300, 3300), (1200, 4000), (2500, 6000), (3500, 6400), (-400, 2200),
+             (-900, 900), (5950, 7500), (-3000, 100), (4000, 5200), (100, 5900), (1800, 2500)]
+    add("utg6k_mixed_offsets", *layout(utg, spans, 0.10))
+    add("utg6k_clean_reads", *layout(utg, spans[:6], 0.0))
+    add("utg6k_noisy_idt85", *layout(utg, spans, 0.14), min_idt=0.85)
+    add("utg_alone", [codes_to_str(utg)], [0])
+    small = rng.integers(0, 4, 420).astype(np.uint8)      # shorter than the 500-column rule
+    add("utg420_short", *layout(small, [(0, 420), (-50, 400), (30, 420)], 0.05))
+    long_utg = rng.integers(0, 4, 15000).astype(np.uint8)
+    add("utg15k_longer_than_reads", *layout(long_utg, [(i, i + 4000) for i in range(-1000, 14000, 900)], 0.12))
+    dump("f7_utg", dict(cases=cases))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R = Ref()
+    if len(sys.argv) > 1 and sys.argv[1] == "f7":  # (the other fixtures are already committed)
+        gen_f7(R)
+        return
     gen_f1_f2(R)
     gen_f3(R)
     gen_f4(R)
     gen_f5_f6(R)
+    gen_f7(R)
 
 
 if __name__ == "__main__":

@@ -272,6 +272,22 @@ class LegacyABI:
         self.lib.free_consensus_data(c)
         return seq, eqv
 
+    def generate_utg_consensus(self, seqs, offsets, min_cov=0, K=8, min_idt=0.70):
+        """src/c/falcon.c:668-773 (exported, not bound by falcon_kit.py).  Returns the
+        consensus, its eqv and the offsets array as the callee left it."""
+        seqs = [_b(s) for s in seqs]
+        arr = (C.c_char_p * len(seqs))(*seqs)
+        off = (C.c_int * len(seqs))(*offsets)
+        fn = self.lib.generate_utg_consensus
+        fn.restype = C.POINTER(_ConsensusData)
+        fn.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_uint, C.c_uint, C.c_uint,
+                       C.c_double]
+        c = fn(arr, off, len(seqs), min_cov, K, min_idt)
+        seq = C.string_at(c[0].sequence).decode()
+        eqv = list(c[0].eqv[:len(seq)])
+        self.lib.free_consensus_data(c)
+        return seq, eqv, list(off)
+
 
 class Ref(LegacyABI):
     kind = "reference"

@@ -325,3 +325,50 @@ def test_trim_windows_vs_oracle(engine):
         assert big[0][j][1] == len(q)
         assert big[0][j][0] == list(port.best_range2(q, t)), j
     assert max(r[1] for r in big[0]) > 2048
+
+
+# --------------------------------------------------------------------------
+# generate_utg_consensus (src/c/falcon.c:668-773): reads laid on a
+# unitig by offsets, band 500, the unitig itself as an all-match alignment, min_cov 0
+# --------------------------------------------------------------------------
+F7 = load_golden("f7_utg")["cases"]
+
+
+@pytest.mark.parametrize("case", F7, ids=[c["name"] for c in F7])
+def test_utg_consensus_golden(legacy, case):
+    seq, eqv, off_after = legacy.generate_utg_consensus(case["seqs"], case["offsets"], 0, 8,
+                                                        case["min_idt"])
+    assert seq == case["sequence"]
+    assert sha_ints(eqv) == case["eqv_sha"] and eqv[:64] == case["eqv_head"]
+    assert off_after == case["offsets_after"]  # negative offsets are rewritten to 0 (:731)
+
+
+def test_utg_consensus_vs_reference_build(legacy):
+    """Randomised layouts against the compiled reference itself (oracle/_ref travels to the
+    GPU box as a built artefact; skipped where it is absent): reads opening with an
+    insertion (dropped at offset 0, hung off the base before otherwise), overhangs on
+    both ends, offsets that skip the read."""
+    from oracle.pyoracle import Ref, have_ref
+    from falcon_amd.synth import codes_to_str, noisy
+    if not have_ref():
+        pytest.skip("oracle/_ref/falcon_ref.so not built here")
+    ref = Ref()
+    rng = np.random.default_rng(99)
+    for trial in range(6):
+        L = int(rng.integers(700, 5000))
+        utg = rng.integers(0, 4, L).astype(np.uint8)
+        seqs, offs = [codes_to_str(utg)], [0]
+        for _ in range(int(rng.integers(3, 14))):
+            a = int(rng.integers(-600, L + 100))
+            b = a + int(rng.integers(200, 2500))
+            left = rng.integers(0, 4, max(0, -a)).astype(np.uint8)
+            right = rng.integers(0, 4, max(0, b - L)).astype(np.uint8)
+            body = utg[max(a, 0):min(b, L)]
+            rd = noisy(np.concatenate([left, body, right]), rng, float(rng.choice([0.0, 0.08, 0.15])))
+            if rd.shape[0] < 20:
+                continue
+            seqs.append(codes_to_str(rd))
+            offs.append(a)
+        want = ref.generate_utg_consensus(seqs, offs, 0, 8, 0.70)
+        got = legacy.generate_utg_consensus(seqs, offs, 0, 8, 0.70)
+        assert got == want, trial
