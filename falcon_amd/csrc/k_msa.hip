@@ -676,6 +676,106 @@ __device__ __forceinline__ void score_links(ScoreAcc &acc, int src_h, int nbv, i
     }
 }
 
+// ---- the unusual levels, out of line -----------------------------------------------
+// More than 16 links, a level beyond the register-resident ones, or a predecessor there.
+// Kept out of the hot loop as a by-value call: inlined, its control flow joins cost the
+// fast path a dozen register copies per level (measured: 32 -> 28 ms without them).
+struct ScoreSlowIo {
+    int cur_h, cur_p, cur_k;   // score lanes of the position being scored
+    int dg_h, dg_slot, dg_ck;  // best deep node so far (lanes 0..4)
+};
+typedef u32 sc_u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __noinline__ ScoreSlowIo score_level_slow(ScoreSlowIo io, int prev_h, u32 w_first, int dl_v,
+                                                     int n_link_v, u32 lk_v, u32 plvl5_v, u32 slot_v,
+                                                     int cov_v, int upper_v, int adjacent_v,
+                                                     int curbuf_v, const u32 *links_v,
+                                                     const u32 *s_links_v, int *s_deep_v,
+                                                     sc_u32x2 *nodes_v) {
+    // every scalar argument is wave-uniform; pin it (arguments arrive in VGPRs)
+    const int dl = fa_uni(dl_v), n_link = fa_uni(n_link_v), cov = fa_uni(cov_v);
+    const int upper = fa_uni(upper_v), curbuf = fa_uni(curbuf_v);
+    const bool adjacent = fa_uni(adjacent_v) != 0;
+    const u32 lk = fa_uni(lk_v), plvl5 = fa_uni(plvl5_v), slot = fa_uni(slot_v);
+    const u32 *links = fa_uni(links_v);        // the level's words in HBM ...
+    const u32 *s_links = fa_uni(s_links_v);    // ... or staged in LDS (then links is unused): generic pointer
+    int *s_deep = fa_uni(s_deep_v);
+    sc_u32x2 *nodes = fa_uni(nodes_v);
+    const int lane = fa_lane();
+    const bool have = lane < n_link;
+    const u32 w = w_first;
+    const int cnt = (int)(w & 0x3ffu), nbase = (int)((w >> 10) & 7u);
+    const int pidx = (int)((w >> 13) & 0x7ffu);
+    const bool start = (w >> 24) & 1u;
+    (void)have;
+    if (dl < SC_REG && n_link <= 64 &&
+        // predecessors beyond the register-resident levels take the generic path
+        // (start links carry pidx 0)
+        (fa_ballot(pidx >= SC_REG * 5) & (n_link >= 64 ? ~0ull : ((1ull << n_link) - 1ull))) == 0ull) {
+        ScoreAcc acc;
+        acc.h = io.cur_h; acc.p = io.cur_p; acc.k = io.cur_k; acc.n = 0;
+        const int cv = 2 * cnt - cov;
+        const int lidx = start ? SC_ZERO : pidx;
+        const int pidv = start ? -1 : (int)(plvl5 + (u32)pidx);
+        const int lane_rel = lane - dl * 5;
+        if (dl == 0) score_links<false>(acc, prev_h, nbase, cv, lidx, pidv, n_link, lane_rel);
+        else score_links<true>(acc, 0, nbase, cv, lidx, pidv, n_link, lane_rel);
+        io.cur_h = acc.h; io.cur_p = acc.p; io.cur_k = acc.k;
+        return io;
+    }
+    // generic level: any number of links, predecessors and/or the level itself beyond
+    // the register-resident ones; accumulators in lanes 0..4
+    ScoreAcc d;
+    d.h = -2; d.p = 0; d.k = 0; d.n = 0;
+    const int which = (dl == 0) ? (curbuf ^ 1) : curbuf;
+    for (int c0 = 0; c0 < n_link; c0 += 64) {
+        u32 wc = 0;
+        if (c0 + lane < n_link) {
+            if (s_links) wc = s_links[c0 + lane];
+            else wc = links[lk + (u32)(c0 + lane)];
+        }
+        wc = settled(wc);
+        const int n_here = min(64, n_link - c0);
+        for (int l = 0; l < n_here; l++) {
+            const u32 wl = (u32)__builtin_amdgcn_readlane((int)wc, l);
+            const int cnt_l = (int)(wl & 0x3ffu), nb_l = (int)((wl >> 10) & 7u);
+            const int pidx_l = (int)((wl >> 13) & 0x7ffu);
+            const bool start_l = (wl >> 24) & 1u;
+            int ph = 0, pid = -1;
+            if (!start_l) {
+                if (pidx_l < SC_REG * 5) {
+                    ph = (dl == 0) ? __builtin_amdgcn_readlane(prev_h, pidx_l)
+                                   : __builtin_amdgcn_readlane(io.cur_h, pidx_l);
+                } else {
+                    ph = __builtin_amdgcn_readfirstlane(s_deep[which * 1280 + pidx_l]);
+                    if (dl == 0 && !adjacent) ph = -2;
+                }
+                pid = (int)(plvl5 + (u32)pidx_l);
+            }
+            const int h = ph + 2 * cnt_l - cov;
+            const bool mine = lane == nb_l;
+            const bool better = mine && h > d.h;
+            d.h = better ? h : d.h;
+            d.p = better ? pid : d.p;
+            d.k = better ? d.n : d.k;
+            d.n += mine ? 1 : 0;
+        }
+    }
+    if (dl < SC_REG) {  // hand the five nodes to their score lanes
+        const int src = lane - dl * 5;
+        const int vh = __shfl(d.h, src), vp = __shfl(d.p, src), vk = __shfl(d.k, src);
+        if (src >= 0 && src < 5) { io.cur_h = vh; io.cur_p = vp; io.cur_k = vk; }
+    } else if (lane < 5) {
+        s_deep[curbuf * 1280 + dl * 5 + lane] = d.h;
+        __threadfence_block();
+        sc_u32x2 r;
+        r.x = (u32)d.h; r.y = (u32)(((d.p + 1) << 1) | upper);
+        nodes[slot * 5u + (u32)lane] = r;
+        if (d.h > io.dg_h) { io.dg_h = d.h; io.dg_slot = (int)slot; io.dg_ck = d.k; }
+    }
+    return io;
+}
+
 __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
     __shared__ u32 s_links[SC_LINKS + 64];
     const int lane = fa_lane();
@@ -764,7 +864,7 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
             const int upper = cov > min_cov ? 1 : 0;  // falcon.c:498 (Q7)
             const bool adjacent = (prev_t == t - 1);
             prev_h = adjacent ? cur.h : h_init;
-            cur.h = h_init; cur.p = 0; cur.k = 0; cur.n = 0;
+            cur.h = h_init; cur.p = 0; cur.k = 0;
             curbuf ^= 1;
             u32 lk = y_link;
             // no level of this position and no predecessor of one lies beyond the
@@ -841,68 +941,17 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                     cur.h = got ? (int)(r_key >> 4) - SC_BIAS : cur.h;
                     cur.p = got ? (int)(r_pp >> 4) - 1 : cur.p;
                     cur.k = got ? 15 - (int)(r_key & 15u) - (int)(r_pp & 15u) : cur.k;
-                } else if (dl < SC_REG && n_link <= 64 &&
-                           // predecessors beyond the register-resident levels take the generic
-                           // path (start links carry pidx 0)
-                           (fa_ballot(pidx >= SC_REG * 5) &
-                            (n_link >= 64 ? ~0ull : ((1ull << n_link) - 1ull))) == 0ull) {
-                    const int cv = 2 * cnt - cov;
-                    const int lidx = start ? SC_ZERO : pidx;
-                    const int pidv = start ? -1 : (int)(plvl5 + (u32)pidx);
-                    const int lane_rel = lane - dl * 5;
-                    if (dl == 0) score_links<false>(cur, prev_h, nbase, cv, lidx, pidv, n_link, lane_rel);
-                    else score_links<true>(cur, 0, nbase, cv, lidx, pidv, n_link, lane_rel);
                 } else {
-                    // generic level: any number of links, predecessors and/or the level
-                    // itself beyond the register-resident ones; accumulators in lanes 0..4
-                    ScoreAcc d;
-                    d.h = -2; d.p = 0; d.k = 0; d.n = 0;
-                    const int which = (dl == 0) ? (curbuf ^ 1) : curbuf;
-                    for (int c0 = 0; c0 < n_link; c0 += 64) {
-                        u32 wc = 0;
-                        if (c0 + lane < n_link) {
-                            if constexpr (BULK) wc = s_links[lk - lnk0 + (u32)(c0 + lane)];
-                            else wc = links[lk + (u32)(c0 + lane)];
-                        }
-                        wc = settled(wc);
-                        const int n_here = min(64, n_link - c0);
-                        for (int l = 0; l < n_here; l++) {
-                            const u32 wl = (u32)__builtin_amdgcn_readlane((int)wc, l);
-                            const int cnt_l = (int)(wl & 0x3ffu), nb_l = (int)((wl >> 10) & 7u);
-                            const int pidx_l = (int)((wl >> 13) & 0x7ffu);
-                            const bool start_l = (wl >> 24) & 1u;
-                            int ph = 0, pid = -1;
-                            if (!start_l) {
-                                if (pidx_l < SC_REG * 5) {
-                                    ph = (dl == 0) ? __builtin_amdgcn_readlane(prev_h, pidx_l)
-                                                   : __builtin_amdgcn_readlane(cur.h, pidx_l);
-                                } else {
-                                    ph = __builtin_amdgcn_readfirstlane(s_deep[which * 1280 + pidx_l]);
-                                    if (dl == 0 && !adjacent) ph = -2;
-                                }
-                                pid = (int)(plvl5 + (u32)pidx_l);
-                            }
-                            const int h = ph + 2 * cnt_l - cov;
-                            const bool mine = lane == nb_l;
-                            const bool better = mine && h > d.h;
-                            d.h = better ? h : d.h;
-                            d.p = better ? pid : d.p;
-                            d.k = better ? d.n : d.k;
-                            d.n += mine ? 1 : 0;
-                        }
-                    }
-                    if (dl < SC_REG) {  // hand the five nodes to their score lanes
-                        const int src = lane - dl * 5;
-                        const int vh = __shfl(d.h, src), vp = __shfl(d.p, src), vk = __shfl(d.k, src);
-                        if (src >= 0 && src < 5) { cur.h = vh; cur.p = vp; cur.k = vk; }
-                    } else if (lane < 5) {
-                        s_deep[curbuf * 1280 + dl * 5 + lane] = d.h;
-                        __threadfence_block();
-                        u32x2 r;
-                        r.x = (u32)d.h; r.y = (u32)(((d.p + 1) << 1) | upper);
-                        nodes[slot * 5u + (u32)lane] = r;
-                        if (d.h > dg_h) { dg_h = d.h; dg_slot = (int)slot; dg_ck = d.k; }
-                    }
+                    ScoreSlowIo io;
+                    io.cur_h = cur.h; io.cur_p = cur.p; io.cur_k = cur.k;
+                    io.dg_h = dg_h; io.dg_slot = dg_slot; io.dg_ck = dg_ck;
+                    const u32 *staged = nullptr;
+                    if constexpr (BULK) staged = s_links + (lk - lnk0);
+                    io = score_level_slow(io, prev_h, w, dl, n_link, lk, plvl5, slot, cov, upper,
+                                          adjacent ? 1 : 0, curbuf, links, staged, s_deep,
+                                          (sc_u32x2 *)nodes);
+                    cur.h = io.cur_h; cur.p = io.cur_p; cur.k = io.cur_k;
+                    dg_h = io.dg_h; dg_slot = io.dg_slot; dg_ck = io.dg_ck;
                 }
                 lk += (u32)n_link;
             }
