@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
 // k_backtrace: one wavefront per pile (falcon.c:494-528)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_backtrace(MsaArgs A) {
-    __shared__ u32 win[2 * 5 * BT_WIN];
+    __shared__ __attribute__((aligned(8))) u32 win[2 * 5 * BT_WIN];
     const int lane = fa_lane();
     const int p = blockIdx.x;
     if (p >= A.n_pile) return;
@@ -1037,23 +1037,22 @@ __global__ __launch_bounds__(64) void k_backtrace(MsaArgs A) {
                 }
                 __syncthreads();
             }
+            // (one 8-byte LDS read at a wave-uniform address; the walk itself is scalar)
+            const uint2 v = *reinterpret_cast<const uint2 *>(&win[2 * (node - win_lo)]);
             FaNode r;
-            r.score_h = (int)win[2 * (node - win_lo)];
-            r.link = (int)win[2 * (node - win_lo) + 1];
+            r.score_h = __builtin_amdgcn_readfirstlane((int)v.x);
+            r.link = __builtin_amdgcn_readfirstlane((int)v.y);
             return r;
         };
         FaNode rec = fetch(so.g_node);
         int out_c = 0, out_e = 0;  // lane (index & 63) holds character `index`
         for (;;) {
             const int up = rec.link & 1;
-            switch (ck) {
-            case 0: bb = up ? 'A' : 'a'; break;
-            case 1: bb = up ? 'C' : 'c'; break;
-            case 2: bb = up ? 'G' : 'g'; break;
-            case 3: bb = up ? 'T' : 't'; break;
-            case 4: bb = '-'; break;
-            default: break;  // a link index >= 5 keeps the previous character (Q2)
-            }
+            // 0..3: the base, upper case where the coverage allowed; 4: '-'; a link index
+            // >= 5 keeps the previous character (Q2) -- as arithmetic, not a jump table
+            const u32 letters = up ? 0x54474341u /* "ACGT" */ : 0x74676361u /* "acgt" */;
+            const char base_c = (char)((letters >> (8 * (ck & 3))) & 0xffu);
+            bb = ck < 4 ? base_c : (ck == 4 ? '-' : bb);
             const int score0 = rec.score_h;
             const int prev = (rec.link >> 1) - 1;
             if (prev == -1 || index >= lim) break;  // :517-519 (Q1)
