@@ -609,7 +609,7 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
     b->have_range = true;  // its copy was queued ahead of k_align
     if (force_accept_g >= 0 && b->h_aln[force_accept_g].aligned) b->h_aln[force_accept_g].accept = 1;
     // ---- plan the MSA stage from the alignment summaries (host, O(#reads))
-    u64 node_off = 0, desc_tot = 0, ins_tot = 0, link_tot = 0;
+    u64 node_off = 0, desc_tot = 4, ins_tot = 0, link_tot = 0;  // (desc: front padding, k_links loads groups of 4)
     long long sC = 0, sD = 0, sA = 0, nal = 0;
     FaTagAln *ta = b->h_ta.data();
     size_t n_ta = 0;

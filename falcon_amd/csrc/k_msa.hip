@@ -52,6 +52,7 @@
 #define TAG_NINS_SHIFT 23
 #define TAG_PAY_MASK 0x7fffffu
 #define TG_WIN 1024    // target positions per k_tags LDS window
+#define TG_BLK 16      // positions per k_links tag block
 #define TCOV_LEAD 0x40000000  // tcov flag: the alignment opens with an insertion run (see k_tags)
 
 struct MsaArgs {
@@ -354,6 +355,16 @@ __global__ __launch_bounds__(64) void k_tscan(MsaArgs A) {
     A.score_out[p] = so;  // every lane stores the same record
 }
 
+// Copy through an opaque VALU move: the wait for the load that produced v is paid
+// here, once, and the copy carries no pending-load state into the loops that read
+// it (otherwise the compiler's conservative s_waitcnt vmcnt(0) at every such read
+// also drains the node-record stores in flight).
+__device__ __forceinline__ u32 settled(u32 v) {
+    u32 r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
 // ---------------------------------------------------------------------------
 // k_links
 // ---------------------------------------------------------------------------
@@ -460,17 +471,63 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
         if (tl < t_hi) xr[h] = ti[tl];
     }
     const int sw0 = t_lo >> 4;  // TSEG is a multiple of 16
-    const u32 seedv = (lane <= (t_hi - 1 - t_lo) >> 4) ? seedw[sw0 + lane] : 0u;
+    u32 seedv = (lane <= (t_hi - 1 - t_lo) >> 4) ? seedw[sw0 + lane] : 0u;
+    // (loaded once, read with readlane at every position: without the opaque copy the
+    // compiler waits vmcnt(0) before each of those reads, i.e. for every store and
+    // prefetch in flight)
+    seedv = settled(seedv);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        xr[h].lvl_start = settled(xr[h].lvl_start);
+        xr[h].link_start = settled(xr[h].link_start);
+        const u32 cn = settled((u32)xr[h].cov | ((u32)xr[h].nlev << 16));
+        xr[h].cov = (u16)(cn & 0xffffu);
+        xr[h].nlev = (u16)(cn >> 16);
+    }
     u32 wnx[NCHT];
 #pragma unroll
     for (int c = 0; c < NCHT; c++) {
         wnx[c] = 0u;
         const int u = t_lo - s2v[c];
-        if (c < nch && u >= 0 && u < tcv[c]) wnx[c] = dptr[c][u];
+        if (NCHT > 1 && c < nch && u >= 0 && u < tcv[c]) wnx[c] = dptr[c][u];
     }
+    // One chunk (the normal case): the tag words are fetched 16 positions at a time, four
+    // 16-byte loads per lane issued a block ahead, and handed to the positions through
+    // LDS ([position][lane]).  One word per lane and position straight from HBM meant a
+    // wait per position -- for the word AND, the counter being shared, for the link
+    // stores of the position before (measured: 45 % of the wave cycles in s_waitcnt,
+    // 26 % L1 hit rate).
+    __shared__ u32 tagw[NCHT == 1 ? TG_BLK * 64 : 1];
+    typedef u32 tag_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+    tag_u32x4 tnx[4];
+    auto request_tags = [&](int tb) {  // positions tb .. tb + 15 of my alignment
+        const int u = tb - s2v[0];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            tnx[q] = (tag_u32x4){0u, 0u, 0u, 0u};
+            // (a partly covered group is loaded whole: the words beside the alignment's
+            // own belong to its neighbours or to the buffer's padding and are masked by
+            // `covd` below)
+            if (tb < t_hi && u + 4 * q + 3 >= 0 && u + 4 * q < tcv[0])
+                tnx[q] = *reinterpret_cast<const tag_u32x4 *>(dptr[0] + (u + 4 * q));
+        }
+    };
+    if (NCHT == 1) request_tags(t_lo);
 
     for (int t = t_lo; t < t_hi; t++) {
         const int j = t - t_lo;
+        if (NCHT == 1 && (j & (TG_BLK - 1)) == 0) {  // a new block of 16 positions
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                tagw[(4 * q + 0) * 64 + lane] = tnx[q].x;
+                tagw[(4 * q + 1) * 64 + lane] = tnx[q].y;
+                tagw[(4 * q + 2) * 64 + lane] = tnx[q].z;
+                tagw[(4 * q + 3) * 64 + lane] = tnx[q].w;
+            }
+            __syncthreads();
+            request_tags(t + TG_BLK);
+        }
         u32 x_lvl, x_link, x_cn;
         {
             const FaTInfo &xs = xr[0], &xt = xr[1];
@@ -496,7 +553,8 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
             if (c < nch) {
                 const int u = t - s2v[c];
                 covd[c] = u >= 0 && u < tcv[c];
-                if (t + 1 < t_hi && u + 1 >= 0 && u + 1 < tcv[c]) wnx[c] = dptr[c][u + 1];
+                if (NCHT == 1) wtag[c] = tagw[(j & (TG_BLK - 1)) * 64 + lane];
+                else if (t + 1 < t_hi && u + 1 >= 0 && u + 1 < tcv[c]) wnx[c] = dptr[c][u + 1];
             }
         }
         if (x.cov == 0) continue;
@@ -643,16 +701,6 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
 #define SC_BIAS 1024      // makes every link score positive (score >= -2 - coverage, coverage <= 512)
 
 struct ScoreAcc { int h, p, k, n; };
-
-// Copy through an opaque VALU move: the wait for the load that produced v is paid
-// here, once, and the copy carries no pending-load state into the loops that read
-// it (otherwise the compiler's conservative s_waitcnt vmcnt(0) at every such read
-// also drains the node-record stores in flight).
-__device__ __forceinline__ u32 settled(u32 v) {
-    u32 r;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(v));
-    return r;
-}
 
 // visit n_here links (lanes 0 .. n_here-1 of nbv / cv / lidxv / pidv); accumulators
 // of node b are the lanes lane_base + b of acc.  FROM_CUR: predecessors are read
