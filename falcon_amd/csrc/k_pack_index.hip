@@ -54,7 +54,7 @@ void fa_launch_pack(const FaBatchDev &b, hipStream_t s) {
 }
 
 // --------------------------------------------------------------------------
-// seed index: one 256-thread workgroup per pile.
+// seed index: one 1024-thread workgroup per pile.
 //   phase A  zero the table
 //   phase B  histogram of the seed's 8-mers (global atomics, L2)
 //   phase C  exclusive scan (tile of 1024 entries per step, LDS carry)
@@ -66,7 +66,9 @@ void fa_launch_pack(const FaBatchDev &b, hipStream_t s) {
 // After phase D, T[k+1] (the bucket cursor) equals the bucket end, and T[0]=0,
 // so bucket(k) = [T[k], T[k+1]).
 // --------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_seed_index(const u32 *__restrict__ words,
+#define SI_NT 1024  // threads per pile: few, fat workgroups keep the tables in flight (262 KB
+                    // each) within the 256 MB Infinity Cache; 256-thread ones put 537 MB in flight
+__global__ __launch_bounds__(SI_NT) void k_seed_index(const u32 *__restrict__ words,
                                                     const FaSeq *__restrict__ seq,
                                                     const FaPile *__restrict__ pile,
                                                     u32 *__restrict__ kidx,
@@ -79,42 +81,48 @@ __global__ __launch_bounds__(256) void k_seed_index(const u32 *__restrict__ word
     const int tid = threadIdx.x;
     const int n_pos = max(0, sd.len - FA_K);
 
-    for (int i = tid; i < FA_NKMER + 1; i += 256) T[i] = 0;
+    for (int i = tid; i < FA_NKMER + 1; i += SI_NT) T[i] = 0;
     __syncthreads();
 
-    for (int i = tid; i < n_pos; i += 256) atomicAdd(&T[fa_kmer8(w, i) + 1], 1u);
+    for (int i = tid; i < n_pos; i += SI_NT) atomicAdd(&T[fa_kmer8(w, i) + 1], 1u);
     __syncthreads();
 
-    // exclusive scan of T[1..65536] in place
-    __shared__ u32 s_part[256];
-    __shared__ u32 s_carry;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (int tile = 0; tile < FA_NKMER; tile += 1024) {
+    // exclusive scan of T[1..65536] in place: tiles of 4 entries per thread; DPP scan
+    // inside each wavefront, the wavefront totals through LDS (one barrier per tile)
+    constexpr int NW = SI_NT / 64;
+    __shared__ u32 s_wtot[2][NW];
+    u32 carry = 0;  // sum of all earlier tiles (kept by every thread)
+    for (int tile = 0, ph = 0; tile < FA_NKMER; tile += 4 * SI_NT, ph ^= 1) {
         u32 v[4];
         // T+1 is only 4-byte aligned, so read scalars
         v[0] = T[1 + tile + tid * 4 + 0];
         v[1] = T[1 + tile + tid * 4 + 1];
         v[2] = T[1 + tile + tid * 4 + 2];
         v[3] = T[1 + tile + tid * 4 + 3];
-        u32 sum = v[0] + v[1] + v[2] + v[3];
-        s_part[tid] = sum;
-        __syncthreads();
-        // Hillis-Steele inclusive scan over 256 partials
-        for (int off = 1; off < 256; off <<= 1) {
-            u32 add = (tid >= off) ? s_part[tid - off] : 0;
-            __syncthreads();
-            s_part[tid] += add;
-            __syncthreads();
+        const u32 sum = v[0] + v[1] + v[2] + v[3];
+        u32 inc = sum;  // inclusive scan over the 64 lanes (row_shr 1,2,4,8, row_bcast 15/31)
+        inc += (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);
+        inc += (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);
+        inc += (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);
+        inc += (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false);
+        inc += (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);
+        inc += (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);
+        const int wv = tid >> 6;
+        if ((tid & 63) == 63) s_wtot[ph][wv] = inc;
+        __syncthreads();  // (the other half of s_wtot is rewritten only after the next barrier)
+        u32 below = 0, all = 0;
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            const u32 wt = s_wtot[ph][q];
+            below += q < wv ? wt : 0u;
+            all += wt;
         }
-        u32 excl = s_part[tid] - sum + s_carry;
+        const u32 excl = carry + below + inc - sum;
         T[1 + tile + tid * 4 + 0] = excl;
         T[1 + tile + tid * 4 + 1] = excl + v[0];
         T[1 + tile + tid * 4 + 2] = excl + v[0] + v[1];
         T[1 + tile + tid * 4 + 3] = excl + v[0] + v[1] + v[2];
-        __syncthreads();
-        if (tid == 255) s_carry += s_part[255];
-        __syncthreads();
+        carry += all;
     }
     __threadfence_block();
     __syncthreads();
@@ -122,30 +130,47 @@ __global__ __launch_bounds__(256) void k_seed_index(const u32 *__restrict__ word
     if (tid >= 64) return;
     const int lane = tid;
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int i0 = 0; i0 < n_pos; i0 += 64) {
-        const int i = i0 + lane;
-        const bool valid = i < n_pos;
-        const u32 km = valid ? fa_kmer8(w, i) : 0u;
-        u64 peers = __ballot(valid);
+    // Eight steps of 64 positions at a time: their slot reservations (returning atomics,
+    // a round trip to L2 each) are issued back to back and consumed afterwards.  Atomics
+    // of one wavefront on one address execute in program order, so buckets still fill in
+    // ascending position order.
+    constexpr int U = 8;
+    for (int i0 = 0; i0 < n_pos; i0 += 64 * U) {
+        u32 km[U], base[U];
+        int rank[U], leader[U];
+        bool valid[U];
 #pragma unroll
-        for (int bit = 0; bit < 16; bit++) {
-            const bool one = (km >> bit) & 1u;
-            const u64 bal = __ballot(one);
-            peers &= one ? bal : ~bal;
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + 64 * u + lane;
+            valid[u] = i < n_pos;
+            km[u] = valid[u] ? fa_kmer8(w, i) : 0u;
         }
-        if (!valid) peers = 0;
-        const int rank = __popcll(peers & lt_mask);
-        const int cnt = __popcll(peers);
-        const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
-        u32 base = 0;
-        if (valid && lane == leader) base = atomicAdd(&T[km + 1], (u32)cnt);
-        base = __shfl(base, leader);
-        if (valid) P[base + rank] = (u32)i;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            u64 peers = __ballot(valid[u]);
+#pragma unroll
+            for (int bit = 0; bit < 16; bit++) {
+                const bool one = (km[u] >> bit) & 1u;
+                const u64 bal = __ballot(one);
+                peers &= one ? bal : ~bal;
+            }
+            if (!valid[u]) peers = 0;
+            rank[u] = __popcll(peers & lt_mask);
+            const int cnt = __popcll(peers);
+            leader[u] = valid[u] ? (__ffsll((long long)peers) - 1) : lane;
+            base[u] = 0;
+            if (valid[u] && lane == leader[u]) base[u] = atomicAdd(&T[km[u] + 1], (u32)cnt);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u32 b = (u32)__shfl((int)base[u], leader[u]);
+            if (valid[u]) P[b + (u32)rank[u]] = (u32)(i0 + 64 * u + lane);
+        }
     }
 }
 
 void fa_launch_index(const FaBatchDev &b, hipStream_t s) {
     if (b.n_pile == 0) return;
-    hipLaunchKernelGGL(k_seed_index, dim3(b.n_pile), dim3(256), 0, s, b.words, b.seq, b.pile,
+    hipLaunchKernelGGL(k_seed_index, dim3(b.n_pile), dim3(SI_NT), 0, s, b.words, b.seq, b.pile,
                        b.kidx, b.kpos);
 }
