@@ -27,6 +27,9 @@
 #include <unordered_set>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <emmintrin.h>
 #include <unistd.h>
 
 #include "../../include/falcon_amd.h"
@@ -56,11 +59,16 @@ struct fa_reader {
 
     // text of the batch being gathered; tokens are offsets into it until the batch is
     // closed (it may grow), pointers afterwards
-    char *text = nullptr;    // (malloc'ed: growing it must not zero-fill)
+    char *text = nullptr;    // (mmap'ed: grown by remapping, never copied or zero-filled by us)
     size_t text_cap = 0;
-    size_t parsed = 0;       // bytes of `text` already split into lines
+    size_t parsed = 0;       // start of the line being scanned (all lines before it are split)
+    size_t scanned = 0;      // bytes of `text` the scanner has looked at (>= parsed)
     size_t filled = 0;       // bytes of `text` holding stream data
-    ~fa_reader() { free(text); }
+    // white-space bytes (<= 0x20) seen so far in the line being scanned
+    size_t line_low = 0, line_first_low = 0;
+    ~fa_reader() {
+        if (text) munmap(text, text_cap);
+    }
 
     // pile in progress
     std::vector<Tok> pile;                  // seed, then reads in stream order
@@ -80,22 +88,25 @@ struct fa_reader {
 };
 
 static bool fill(fa_reader *r) {
-    // make room and read more of the stream; false at end of file
+    // make room and read more of the stream; false at end of file.  Reads are capped so
+    // that what is read is scanned while it is still in the cache, and so that the tail a
+    // closed batch leaves behind (moved to the front by the next call) stays small.
     if (r->eof) return false;
-    const size_t want = 8u << 20;
+    const size_t want = 4u << 20;
     if (r->text_cap < r->filled + want) {
-        const size_t cap = std::max(r->text_cap * 2, r->filled + want);
-        char *t = (char *)realloc(r->text, cap);
-        if (!t) {
+        const size_t cap = (std::max(r->text_cap * 2, r->filled + want) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+        void *t = r->text ? mremap(r->text, r->text_cap, cap, MREMAP_MAYMOVE)
+                          : mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (t == MAP_FAILED) {
             r->err = "falcon_amd: out of memory while reading the pile stream";
             r->eof = true;
             return false;
         }
-        r->text = t;
+        r->text = (char *)t;
         r->text_cap = cap;
     }
     for (;;) {
-        ssize_t n = read(r->fd, r->text + r->filled, r->text_cap - r->filled);
+        ssize_t n = read(r->fd, r->text + r->filled, want);
         if (n > 0) {
             r->filled += (size_t)n;
             return true;
@@ -149,26 +160,19 @@ static void reset_pile(fa_reader *r) {
     r->seed_name = {0, 0};
 }
 
-// one line [b, e) of r->text (without its '\n'); returns false when "- -" ends the stream
-static bool take_line(fa_reader *r, size_t b, size_t e) {
+// one line [b, e) of r->text (without its '\n') holding `n_low` bytes <= 0x20, the first of
+// them at `first_low`; returns false when "- -" ends the stream
+static bool take_line(fa_reader *r, size_t b, size_t e, size_t n_low, size_t first_low) {
     const char *t = r->text;
     Tok tok[2];
     int n_tok = 0;
-    // the usual line is "<name> <bases>": one blank, nothing else at or below 0x20 (all
-    // white space is) -- checked with one vectorisable pass; anything else is tokenised
-    // byte by byte
-    const char *sp = (e > b) ? (const char *)memchr(t + b, ' ', e - b) : nullptr;
-    bool plain = sp != nullptr && sp != t + b && sp + 1 < t + e;
-    if (plain) {
-        size_t low = 0;
-        for (const char *p = t + b; p < t + e; p++) low += (unsigned char)*p <= 0x20;
-        plain = low == 1;
-    }
-    if (plain) {
-        tok[0] = {b, (int)(sp - (t + b))};
-        tok[1] = {(size_t)(sp + 1 - t), (int)std::min<size_t>((size_t)(t + e - (sp + 1)), 0x7fffffff)};
+    // the usual line is "<name> <bases>": one blank inside it, nothing else at or below
+    // 0x20 (all white space is); anything else is tokenised byte by byte
+    if (n_low == 1 && t[first_low] == ' ' && first_low != b && first_low + 1 < e) {
+        tok[0] = {b, (int)(first_low - b)};
+        tok[1] = {first_low + 1, (int)std::min<size_t>(e - (first_low + 1), 0x7fffffff)};
         n_tok = 2;
-    } else {
+    } else if (n_low != 0) {
         size_t i = b;
         while (i < e) {
             while (i < e && is_space((unsigned char)t[i])) i++;
@@ -212,6 +216,10 @@ extern "C" fa_reader *fa_reader_open(int fd, int min_n_read, int min_len_aln, in
     r->min_cov_aln = min_cov_aln;
     r->max_n_read = max_n_read;
     r->max_cov_aln = max_cov_aln;
+#ifdef F_SETPIPE_SZ
+    // a pipe from LA4Falcon: fewer, larger reads (refused for anything that is not a pipe)
+    (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);
+#endif
     return r;
 }
 
@@ -233,6 +241,8 @@ extern "C" int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, 
             memmove(r->text, r->text + keep_from, r->filled - keep_from);
             r->filled -= keep_from;
             r->parsed -= keep_from;
+            r->scanned -= keep_from;
+            r->line_first_low -= std::min(r->line_first_low, keep_from);
             for (Tok &t : r->pile) t.off -= keep_from;
             if (!r->pile.empty()) r->seed_name.off -= keep_from;
         }
@@ -243,26 +253,54 @@ extern "C" int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, 
     }
     if (max_piles <= 0) max_piles = 0x7fffffff;
     if (max_bases <= 0) max_bases = 0x7fffffffffffffffll;
-    while (!r->finished && (long long)r->pile_n_seq.size() < max_piles && r->batch_bases < max_bases) {
-        const char *t = r->text;
-        const char *nl = r->parsed < r->filled
-                             ? (const char *)memchr(t + r->parsed, '\n', r->filled - r->parsed)
-                             : nullptr;
-        if (!nl) {
+    // One pass over the text: every byte <= 0x20 is an event (16 bytes per compare); a
+    // '\n' closes the line, anything else is counted as white space of the line.
+    auto batch_open = [&]() {
+        return !r->finished && (long long)r->pile_n_seq.size() < max_piles && r->batch_bases < max_bases;
+    };
+    auto event = [&](size_t i) {  // false: stop scanning (batch closed or stream finished)
+        if (r->text[i] != '\n') {
+            if (r->line_low++ == 0) r->line_first_low = i;
+            return true;
+        }
+        const size_t b = r->parsed, n_low = r->line_low, first_low = r->line_first_low;
+        r->parsed = r->scanned = i + 1;
+        r->line_low = 0;
+        if (!take_line(r, b, i, n_low, first_low)) r->finished = true;
+        return batch_open();
+    };
+    const __m128i lim = _mm_set1_epi8(0x20);
+    while (batch_open()) {
+        if (r->scanned == r->filled) {
             if (fill(r)) continue;
             if (!r->err.empty()) return -1;
             // end of file: a last line without '\n' still counts (python iterates it too)
             if (r->parsed < r->filled) {
                 const size_t b = r->parsed;
                 r->parsed = r->filled;
-                take_line(r, b, r->filled);
+                take_line(r, b, r->filled, r->line_low, r->line_first_low);
+                r->line_low = 0;
             }
             r->finished = true;
             break;
         }
-        const size_t b = r->parsed, e = (size_t)(nl - t);
-        r->parsed = e + 1;
-        if (!take_line(r, b, e)) r->finished = true;
+        const char *t = r->text;
+        size_t i = r->scanned;
+        const size_t end = r->filled;
+        bool go = true;
+        while (go && i + 16 <= end) {
+            const __m128i v = _mm_loadu_si128((const __m128i *)(t + i));
+            unsigned m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_min_epu8(v, lim), v));
+            for (; m; m &= m - 1)
+                if (!event(i + (size_t)__builtin_ctz(m))) {
+                    go = false;
+                    break;
+                }
+            i += 16;
+        }
+        for (; go && i < end; i++)
+            if ((unsigned char)t[i] <= 0x20 && !event(i)) go = false;
+        if (go) r->scanned = end;  // (a stop left `scanned` just behind its line feed)
     }
     // the batch is closed: offsets become pointers, tokens become C strings
     const size_t n_sel = r->sel.size(), n_pile = r->pile_n_seq.size();

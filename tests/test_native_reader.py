@@ -86,6 +86,44 @@ def test_batch_limits_do_not_change_the_piles():
     assert c1 == 1 and c3 == -(-len(want) // 3) and cb > 1
 
 
+def test_pipe_with_ragged_writes_and_control_bytes():
+    """The scanner keeps its per-line state across short reads (a pipe fed in odd-sized
+    pieces), across 16-byte compare blocks and across batch boundaries; control bytes that
+    are not white space do not split tokens."""
+    import threading
+    rng = random.Random(5)
+    text = _rand_stream(rng, 60, with_noise=True)
+    # bytes <= 0x20 that str.split() does not treat as separators, inside a name / alone
+    text = "na\x01me ACGTACGTAC\nr\x00x ACGTACGTACGT\n\x02\n+ +\n" + text
+    data = text.encode("latin-1")
+    opts = (2, 0, 0, 500, 0)
+    want = _python(text, *opts)
+    for max_bases in (0, 300):
+        rd, wr = os.pipe()
+
+        def feed():
+            i = 0
+            while i < len(data):
+                n = rng.choice([1, 2, 3, 7, 15, 16, 17, 31, 33, 64, 257, 4099])
+                os.write(wr, data[i:i + n])
+                i += n
+            os.close(wr)
+
+        t = threading.Thread(target=feed)
+        t.start()
+        r = Reader(rd, *opts)
+        got = []
+        while True:
+            ps = r.next(0, max_bases)
+            if ps is None:
+                break
+            got.extend(zip(ps.seed_ids, ps.piles()))
+        r.close()
+        os.close(rd)   # (a writer still blocked after "- -" gets EPIPE and ends)
+        t.join()
+        assert got == want
+
+
 def test_long_sequences_are_cut_and_stream_end_variants():
     big = "A" * 100001
     edge = "C" * 100000
