@@ -13,8 +13,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 static thread_local std::string g_err;
@@ -70,12 +72,23 @@ struct fa_ctx {
     // alignment work-slot arena (grow only)
     FaAlignArena arena = {};
     size_t arena_cells_bytes = 0, arena_rows_bytes = 0;  // rows and rowx have equal size
+    // staging of a batch's ASCII (grow only, one batch at a time): pinned host buffer, its
+    // device twin, and a stream of their own so that the upload and pack of batch i+1 run
+    // next to the kernels of batch i instead of queueing behind them
+    std::mutex stage_mu;
+    hipStream_t up_stream = nullptr;
+    uint8_t *h_stage = nullptr, *d_stage = nullptr;
+    size_t h_stage_cap = 0, d_stage_cap = 0;
 };
 
 template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }  // (error paths: whatever was allocated goes with its owner)
     int alloc(size_t count) {
         release();
         n = count;
@@ -101,6 +114,10 @@ template <class T>
 struct HostBuf {
     T *p = nullptr;
     size_t n = 0, cap = 0;
+    HostBuf() = default;
+    HostBuf(const HostBuf &) = delete;
+    HostBuf &operator=(const HostBuf &) = delete;
+    ~HostBuf() { release(); }
     int resize(size_t count) {
         if (count > cap) {
             release();
@@ -140,7 +157,7 @@ struct fa_batch {
     int max_read_len = 0, max_seed_len = 0, max_rows = 0, max_bins = 4;
     long long sum_len = 0, sum_seed = 0;
 
-    DevBuf<uint8_t> d_ascii;
+    const uint8_t *ascii_dev = nullptr;  // the context's staging buffer, while the batch is built
     DevBuf<u64> d_ascii_off, d_script_off, d_probe_off, d_probe;
     DevBuf<u32> d_words, d_kidx, d_kpos, d_script;
     DevBuf<FaSeq> d_seq;
@@ -176,7 +193,7 @@ struct fa_batch {
 
     FaBatchDev dev() const {
         FaBatchDev b;
-        b.ascii = d_ascii.p; b.ascii_off = d_ascii_off.p; b.words = d_words.p;
+        b.ascii = ascii_dev; b.ascii_off = d_ascii_off.p; b.words = d_words.p;
         b.seq = d_seq.p; b.pile = d_pile.p; b.n_seq = n_seq; b.n_pile = n_pile;
         b.n_words = n_words; b.kidx = d_kidx.p; b.kpos = d_kpos.p; b.order = d_order.p;
         b.chain_order = d_chain_order.p; b.n_chain = (int)chain_order.size();
@@ -213,6 +230,7 @@ extern "C" fa_ctx *fa_create(int device) {
     c->n_cu = prop.multiProcessorCount;
     c->total_mem = prop.totalGlobalMem;
     HIP_OK_P(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_OK_P(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
     for (auto &e : c->ev) HIP_OK_P(hipEventCreate(&e));
     HIP_OK_P(hipMalloc((void **)&c->arena.counter, sizeof(int)));
     HIP_OK_P(hipMalloc((void **)&c->arena.prof, 8 * sizeof(u64)));
@@ -229,6 +247,9 @@ extern "C" void fa_destroy(fa_ctx *c) {
     if (c->arena.counter) (void)hipFree(c->arena.counter);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -240,6 +261,46 @@ static int rows_bound(int len, int T, bool filtered) {
     double s = (double)len + (double)T;
     if (filtered) s = std::min(s, 2.106 * (double)len + 2.0);
     return (int)(0.3 * s) + 2;
+}
+
+// Grow the context's staging pair (pinned host buffer, device twin) to `bytes`.
+// Caller holds stage_mu.
+static int stage_reserve(fa_ctx *c, size_t bytes) {
+    if (bytes > c->h_stage_cap) {
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        c->h_stage = nullptr;
+        c->h_stage_cap = 0;
+        const size_t cap = bytes + bytes / 8;  // batches of one run differ by a few per cent
+        if (hipHostMalloc((void **)&c->h_stage, cap, hipHostMallocDefault) != hipSuccess) {
+            set_err("falcon_amd: hipHostMalloc(%zu) failed", cap);
+            c->h_stage = nullptr;
+            return -1;
+        }
+        c->h_stage_cap = cap;
+    }
+    if (bytes > c->d_stage_cap) {
+        if (c->d_stage) (void)hipFree(c->d_stage);
+        c->d_stage = nullptr;
+        c->d_stage_cap = 0;
+        const size_t cap = bytes + bytes / 8;
+        if (hipMalloc((void **)&c->d_stage, cap) != hipSuccess) {
+            set_err("falcon_amd: hipMalloc(%zu) failed", cap);
+            c->d_stage = nullptr;
+            return -1;
+        }
+        c->d_stage_cap = cap;
+    }
+    return 0;
+}
+
+// Threads that copy a batch into the staging buffer: one per 32 MB, at most 8 (or
+// FALCON_AMD_STAGE_THREADS), never more than the cores there are.
+static int stage_threads(u64 bytes) {
+    int cap = 8;
+    if (const char *e = getenv("FALCON_AMD_STAGE_THREADS")) cap = std::max(1, atoi(e));
+    const unsigned hc = std::thread::hardware_concurrency();
+    if (hc > 0) cap = std::min<int>(cap, (int)hc);
+    return (int)std::max<u64>(1, std::min<u64>((u64)cap, bytes >> 25));
 }
 
 static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
@@ -363,17 +424,10 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
             for (size_t j = 0; j < stream[x].size(); j++) b->chain_order[j * 8 + x] = stream[x][j];
     }
 
-    // stage ASCII through pinned memory
-    uint8_t *h_ascii = nullptr;
-    if (hipHostMalloc((void **)&h_ascii, b->ascii_bytes, hipHostMallocDefault) != hipSuccess) {
-        set_err("falcon_amd: hipHostMalloc(%llu) failed", (unsigned long long)b->ascii_bytes);
-        delete b;
-        return nullptr;
-    }
-    for (int i = 0; i < g; i++) memcpy(h_ascii + b->ascii_off[i], seqs[i], (size_t)b->seq[i].len);
-
+    // Stage the ASCII through the context's pinned buffer: sequences are copied in by a
+    // few threads (one memcpy stream does not come near the PCIe rate), uploaded, packed
+    // to 2 bits on the device; only the packed form stays resident.
     int rc = 0;
-    rc |= b->d_ascii.alloc(b->ascii_bytes);
     rc |= b->d_ascii_off.alloc(g);
     rc |= b->d_words.alloc(b->n_words + 8);
     rc |= b->d_seq.alloc(g);
@@ -394,32 +448,61 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
         rc |= b->d_pile_out.alloc(n_pile);
     }
     if (rc) {
-        (void)hipHostFree(h_ascii);
         delete b;
         return nullptr;
     }
-    hipStream_t s = ctx->stream;
     bool ok = true;
-    ok &= hipMemcpyAsync(b->d_ascii.p, h_ascii, b->ascii_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
-    ok &= hipMemcpyAsync(b->d_ascii_off.p, b->ascii_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
-    ok &= hipMemcpyAsync(b->d_seq.p, b->seq.data(), g * sizeof(FaSeq), hipMemcpyHostToDevice, s) == hipSuccess;
-    ok &= hipMemcpyAsync(b->d_pile.p, b->pile.data(), n_pile * sizeof(FaPile), hipMemcpyHostToDevice, s) == hipSuccess;
-    ok &= hipMemcpyAsync(b->d_order.p, b->order.data(), g * sizeof(int), hipMemcpyHostToDevice, s) == hipSuccess;
-    ok &= b->chain_order.empty() ||
-          hipMemcpyAsync(b->d_chain_order.p, b->chain_order.data(), b->chain_order.size() * sizeof(int),
-                         hipMemcpyHostToDevice, s) == hipSuccess;
-    ok &= hipMemcpyAsync(b->d_script_off.p, b->script_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
-    if (!pair_mode)
-        ok &= hipMemcpyAsync(b->d_probe_off.p, b->probe_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
-    trace_stage(s, "upload");
-    if (ok) {
-        fa_launch_pack(b->dev(), s);
-        ok &= hipGetLastError() == hipSuccess;
+    {
+        std::lock_guard<std::mutex> hold(ctx->stage_mu);
+        if (stage_reserve(ctx, b->ascii_bytes)) {
+            delete b;
+            return nullptr;
+        }
+        uint8_t *h_ascii = ctx->h_stage;
+        const u64 *aoffs = b->ascii_off.data();
+        const FaSeq *sq = b->seq.data();
+        auto copy_part = [=](int i0, int i1) {
+            for (int i = i0; i < i1; i++) memcpy(h_ascii + aoffs[i], seqs[i], (size_t)sq[i].len);
+        };
+        const int n_thr = stage_threads(b->ascii_bytes);
+        if (n_thr <= 1) {
+            copy_part(0, g);
+        } else {
+            // equal shares of the bytes: sequence ranges cut where ascii_off crosses k/n
+            std::vector<std::thread> pool;
+            int i0 = 0;
+            for (int k = 1; k <= n_thr; k++) {
+                const u64 cut = b->ascii_bytes / (u64)n_thr * (u64)k;
+                int i1 = k == n_thr ? g
+                                    : (int)(std::lower_bound(aoffs + i0, aoffs + g, cut) - aoffs);
+                if (i1 > i0) pool.emplace_back(copy_part, i0, i1);
+                i0 = i1;
+            }
+            for (auto &t : pool) t.join();
+        }
+        b->ascii_dev = ctx->d_stage;
+        hipStream_t s = ctx->up_stream;
+        ok &= hipMemcpyAsync(ctx->d_stage, h_ascii, b->ascii_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
+        ok &= hipMemcpyAsync(b->d_ascii_off.p, b->ascii_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
+        ok &= hipMemcpyAsync(b->d_seq.p, b->seq.data(), g * sizeof(FaSeq), hipMemcpyHostToDevice, s) == hipSuccess;
+        ok &= hipMemcpyAsync(b->d_pile.p, b->pile.data(), n_pile * sizeof(FaPile), hipMemcpyHostToDevice, s) == hipSuccess;
+        ok &= hipMemcpyAsync(b->d_order.p, b->order.data(), g * sizeof(int), hipMemcpyHostToDevice, s) == hipSuccess;
+        ok &= b->chain_order.empty() ||
+              hipMemcpyAsync(b->d_chain_order.p, b->chain_order.data(), b->chain_order.size() * sizeof(int),
+                             hipMemcpyHostToDevice, s) == hipSuccess;
+        ok &= hipMemcpyAsync(b->d_script_off.p, b->script_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
+        if (!pair_mode)
+            ok &= hipMemcpyAsync(b->d_probe_off.p, b->probe_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
+        trace_stage(s, "upload");
+        if (ok) {
+            fa_launch_pack(b->dev(), s);
+            ok &= hipGetLastError() == hipSuccess;
+        }
+        // (also on the error path: nothing may still read the staging buffers)
         ok &= hipStreamSynchronize(s) == hipSuccess;
+        trace_stage(s, "pack");
+        b->ascii_dev = nullptr;
     }
-    trace_stage(s, "pack");
-    (void)hipHostFree(h_ascii);
-    b->d_ascii.release();  // only the packed form stays resident
     if (!ok) {
         set_err("falcon_amd: staging the batch failed: %s", hipGetErrorString(hipGetLastError()));
         delete b;
@@ -440,16 +523,7 @@ extern "C" fa_batch *fa_batch_create(fa_ctx *ctx, int n_pile, const int *pile_n_
 extern "C" void fa_batch_free(fa_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
-    b->d_ascii.release(); b->d_ascii_off.release(); b->d_probe.release(); b->d_probe_off.release();
-    b->d_script_off.release(); b->d_words.release(); b->d_kidx.release(); b->d_kpos.release();
-    b->d_script.release(); b->d_seq.release(); b->d_pile.release();
-    b->d_order.release(); b->d_chain_order.release(); b->d_range.release();
-    b->d_ta.release(); b->d_acc_first.release(); b->d_desc.release(); b->d_links.release();
-    b->d_tcov.release(); b->d_tarr.release(); b->d_score_ovf.release(); b->d_seg_pile.release();
-    b->d_seg_t0.release(); b->d_wide.release(); b->d_insb.release(); b->d_t_off.release(); b->d_link_off.release();
-    b->d_link_cap.release(); b->d_tinfo.release(); b->d_lvl_nlink.release(); b->d_score_out.release(); b->d_aln.release(); b->d_nodes.release();
-    b->d_out_seq.release(); b->d_out_eqv.release(); b->d_pile_out.release();
-    b->h_range.release(); b->h_aln.release(); b->h_pile_out.release(); b->h_ta.release();
+    // (its device and pinned buffers release themselves)
     delete b;
 }
 
@@ -825,7 +899,7 @@ extern "C" int fa_batch_trim_windows(fa_batch *b, unsigned K, int mask_threshold
     const int n_slot = std::max(1, c->n_cu) * 4;  // 32 KB of LDS per wavefront
     fa_launch_index(d, s);
     fa_launch_trimwin(d, n_slot, counter.p, nullptr, 0, mask_threshold, 1, s);
-    if (b->h_range.resize(b->n_seq)) { counter.release(); return -1; }
+    if (b->h_range.resize(b->n_seq)) return -1;
     HIP_OK(hipMemcpyAsync(b->h_range.data(), b->d_range.p, (size_t)b->n_seq * sizeof(FaRange),
                           hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
@@ -836,7 +910,7 @@ extern "C" int fa_batch_trim_windows(fa_batch *b, unsigned K, int mask_threshold
     if (n_max > 2048) {  // TW_LDS_N: larger hit lists work in an HBM slot per wavefront
         cap = 4096;
         while ((long long)cap < n_max) cap <<= 1;
-        if (scratch.alloc((size_t)n_slot * 4 * cap)) { counter.release(); return -1; }
+        if (scratch.alloc((size_t)n_slot * 4 * cap)) return -1;
     }
     fa_launch_trimwin(d, n_slot, counter.p, scratch.p, cap, mask_threshold, 0, s);
     HIP_OK(hipGetLastError());

@@ -339,17 +339,48 @@ def gen_f7(R):
     dump("f7_utg", dict(cases=cases))
 
 
+# the full-size piles of SURVEY.md 8d: config 2/3 (E. coli-like), 4 (dmel-like: the
+# max_n_read = 200 cap binds), 5 (Arabidopsis-like: two haplotypes 0.5 % apart)
+F8_CONFIGS = [
+    dict(name="config2_ecoli_like", seed=7, S=20000, coverage=40.0, het=0.0),
+    dict(name="config4_dmel_like", seed=11, S=30000, coverage=80.0, het=0.0),
+    dict(name="config5_arabidopsis_like", seed=31, S=25000, coverage=60.0, het=0.005),
+]
+
+
+def f8_pile(cfg):
+    seed, reads = make_pile(cfg["seed"], S=cfg["S"], coverage=cfg["coverage"], het=cfg["het"])
+    return [codes_to_str(x) for x in pile_to_seqs(seed, reads, 200)]
+
+
+def gen_f8(R):
+    """One canonical pile per benchmark configuration at full size.  The inputs are a
+    pure function of the generator parameters (falcon_amd/synth.py), so the fixture
+    holds the parameters, a digest of the input and the reference's answer."""
+    cases = []
+    for cfg in F8_CONFIGS:
+        seqs = f8_pile(cfg)
+        seq, eqv = R.generate_consensus(seqs, 4, 8, 0.70)
+        cases.append(dict(cfg, n_seq=len(seqs), n_bases=sum(map(len, seqs)),
+                          input_sha=hashlib.sha1("\n".join(seqs).encode()).hexdigest(),
+                          min_cov=4, K=8, min_idt=0.70, sequence=seq, eqv_sha=sha_ints(eqv)))
+        print("   pile %-26s n_seq=%3d bases=%8d seed=%6d -> cns %6d"
+              % (cfg["name"], len(seqs), sum(map(len, seqs)), len(seqs[0]), len(seq)))
+    dump("f8_configs", dict(cases=cases))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R = Ref()
-    if len(sys.argv) > 1 and sys.argv[1] == "f7":  # (the other fixtures are already committed)
-        gen_f7(R)
+    if len(sys.argv) > 1 and sys.argv[1] in ("f7", "f8"):  # (the other fixtures are already committed)
+        {"f7": gen_f7, "f8": gen_f8}[sys.argv[1]](R)
         return
     gen_f1_f2(R)
     gen_f3(R)
     gen_f4(R)
     gen_f5_f6(R)
     gen_f7(R)
+    gen_f8(R)
 
 
 if __name__ == "__main__":

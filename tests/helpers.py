@@ -33,3 +33,20 @@ def check_pile_case(impl, c):
     assert seq == c["sequence"], c["name"]
     assert eqv[:64] == c["eqv_head"], c["name"]
     assert sha_ints(eqv) == c["eqv_sha"], c["name"]
+
+
+def config_pile(c):
+    """The full-size pile of a benchmark configuration (tests/golden/f8_configs): the
+    input is regenerated from the generator parameters and checked against its digest."""
+    from falcon_amd.synth import codes_to_str, make_pile, pile_to_seqs
+    seed, reads = make_pile(c["seed"], S=c["S"], coverage=c["coverage"], het=c["het"])
+    seqs = [codes_to_str(x) for x in pile_to_seqs(seed, reads, 200)]
+    assert len(seqs) == c["n_seq"] and sum(map(len, seqs)) == c["n_bases"], c["name"]
+    assert hashlib.sha1("\n".join(seqs).encode()).hexdigest() == c["input_sha"], c["name"]
+    return seqs
+
+
+def check_config_case(impl, c):
+    seq, eqv = impl.generate_consensus(config_pile(c), c["min_cov"], c["K"], c["min_idt"])
+    assert seq == c["sequence"], c["name"]
+    assert sha_ints(eqv) == c["eqv_sha"], c["name"]

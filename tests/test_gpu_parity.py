@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from helpers import check_align_case, check_pile_case, sha_ints
+from helpers import check_align_case, check_config_case, check_pile_case, config_pile, sha_ints
 
 pytestmark = pytest.mark.gpu
 
@@ -130,6 +130,26 @@ def test_piles_golden_one_batch(engine):
         for c, (seq, eqv) in zip(cases, res):
             assert seq == c["sequence"], c["name"]
             assert sha_ints(eqv) == c["eqv_sha"], c["name"]
+
+
+F8 = load_golden("f8_configs")["cases"]
+
+
+@pytest.mark.parametrize("case", F8, ids=[c["name"] for c in F8])
+def test_full_size_config_piles_golden(legacy, case):
+    """BASELINE configs 2, 4 (dmel-like, 200 reads of a 30 kb seed at 80x) and 5
+    (Arabidopsis-like, two haplotypes) at full size against the compiled reference's
+    answer, through the legacy C ABI."""
+    check_config_case(legacy, case)
+
+
+def test_full_size_config_piles_one_batch(engine):
+    """... and together in one batch (mixed seed lengths and depths side by side)."""
+    piles = [config_pile(c) for c in F8]
+    got = engine.consensus(piles + piles[::-1], 4, 8, 0.70, want_eqv=True)
+    for c, (seq, eqv) in zip(F8 + F8[::-1], got):
+        assert seq == c["sequence"], c["name"]
+        assert sha_ints(eqv) == c["eqv_sha"], c["name"]
 
 
 def _synthetic(seed, max_n_read=200, **kw):

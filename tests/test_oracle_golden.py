@@ -3,12 +3,13 @@ the compiled reference (oracle/gen_golden.py).  This is what pins the oracle."""
 import pytest
 
 from conftest import load_golden
-from helpers import check_align_case, check_hits_case, check_pile_case
+from helpers import check_align_case, check_config_case, check_hits_case, check_pile_case
 
 F1 = load_golden("f1_f2_hits_ranges")["cases"]
 F2X = load_golden("f2_ranges_extra")["cases"]
 F3 = load_golden("f3_align")["cases"]
 F4 = load_golden("f4_piles")["cases"]
+F8 = load_golden("f8_configs")["cases"]
 
 
 @pytest.mark.parametrize("case", F1, ids=[c["name"] for c in F1])
@@ -29,6 +30,13 @@ def test_align(port, case):
 @pytest.mark.parametrize("case", F4, ids=[c["name"] for c in F4])
 def test_piles(port, case):
     check_pile_case(port, case)
+
+
+@pytest.mark.parametrize("case", F8, ids=[c["name"] for c in F8])
+def test_full_size_config_piles(port, case):
+    """SURVEY.md 8d configs 2, 4 (the 200-read cap binds) and 5 (two haplotypes) at full
+    size: the reference's consensus of the canonical pile."""
+    check_config_case(port, case)
 
 
 def test_golden_quirks_are_present():
