@@ -89,6 +89,68 @@ def cpu_baseline(piles):
     }
 
 
+def write_la4falcon(piles, f):
+    """The LA4Falcon text a pile [seed, seed copy + reads by length] (falcon_amd.synth
+    pile_to_seqs) came from: the seed line, then the reads (the reader adds the seed's copy
+    itself, consensus.py:183-190)."""
+    for i, p in enumerate(piles):
+        lines, seen_copy = [b"%09d %s" % (i, p[0])], False
+        for j, r in enumerate(p[1:]):
+            if not seen_copy and r == p[0]:
+                seen_copy = True
+                continue
+            lines.append(b"%09d %s" % (1000000 + 1000 * i + j, r))
+        f.write(b"\n".join(lines) + b"\n+ +\n")
+    f.write(b"- -\n")
+
+
+def end_to_end(piles):
+    """SURVEY.md 8d "end-to-end": LA4Falcon text on stdin -> FASTA on stdout through the
+    consensus worker (falcon_amd.mains.consensus: native reader, staging, GPU stages,
+    printing) in a process of its own, on the piles of this workload written out as text.
+    Reported beside `value` (kernel-only, inputs resident in HBM), never as it."""
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.abspath(__file__))
+    with tempfile.TemporaryDirectory() as tmp:
+        src, dst = os.path.join(tmp, "piles.txt"), os.path.join(tmp, "cns.fasta")
+        with open(src, "wb") as f:
+            write_la4falcon(piles, f)
+        size = os.path.getsize(src)
+        cmd = [sys.executable, "-m", "falcon_amd.mains.consensus", "--output-multi", "--min-idt",
+               "0.70", "--min-cov", "4", "--max-n-read", "200", "--n-core", "1"]
+        t0 = time.perf_counter()
+        with open(src) as fin, open(dst, "w") as fout:
+            subprocess.run(cmd, stdin=fin, stdout=fout, check=True, cwd=root, timeout=600)
+        wall = time.perf_counter() - t0
+        with open(dst) as f:
+            bases = sum(len(ln) - 1 for ln in f if not ln.startswith(">"))
+    return {"piles_per_sec": round(len(piles) / wall, 1), "text_MB_per_sec": round(size / 1e6 / wall, 1),
+            "fasta_bases_per_sec": round(bases / wall, 1), "wall_s": round(wall, 2),
+            "what": "%d piles (%.0f MB of text from the page cache) -> FASTA, one worker process on "
+                    "one GPU, process start and HIP initialisation included" % (len(piles), size / 1e6)}
+
+
+def measured_stream_rate(torch, mib=1024, reps=5):
+    """GB/s (read + write) of a device-to-device copy of `mib` MiB: what HBM delivers to the
+    simplest streaming kernel on this box (outside the timed region; plumbing, not product)."""
+    try:
+        a = torch.empty(mib << 20, dtype=torch.uint8, device="cuda")
+        b = torch.empty_like(a)
+        b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        del a, b
+        return round(2.0 * (mib << 20) / (ms * 1e-3) / 1e9, 1)
+    except Exception:  # informative only
+        return None
+
+
 def measured_traffic(kernel, piles):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under
     profiles/ (FETCH/WRITE counters cannot be read from inside this process); None unless
@@ -111,6 +173,7 @@ def main():
     ap.add_argument("--piles", type=int, default=int(os.environ.get("FALCON_BENCH_PILES", "3072")),
                     help="piles per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -170,6 +233,8 @@ def main():
     t_up2 = time.perf_counter() - t_up2
     again.free()
 
+    stream_gbs = measured_stream_rate(torch)
+
     st = batch.stats()
     # whole-job aggregate: units summed over ranks, time = slowest rank
     from falcon_amd.multigpu import reduce_measurement
@@ -225,6 +290,10 @@ def main():
                 "bound": "hbm", "kernel": domk,
                 "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5),
+                # the peak a plain device copy reaches on this box, and the
+                # fraction against that denominator too
+                "peak_measured_copy": stream_gbs,
+                "frac_of_measured": round(ach / stream_gbs, 5) if stream_gbs else None,
                 "algorithmic_bytes_per_launch": int(kalg[domk]),
                 "avg_launch_ms": round(kernel_ms[domk], 4),
                 "traffic": traffic,
@@ -239,6 +308,11 @@ def main():
             "setup_s": {"generate": round(t_gen, 2), "stage_to_hbm_incl_pcie": round(t_up, 2),
                         "stage_to_hbm_incl_pcie_again": round(t_up2, 2)},
         }
+        if world == 1 and not args.no_end_to_end:
+            try:
+                out["end_to_end"] = end_to_end(piles[:1536])
+            except Exception as e:  # informative; never lose the GPU line
+                out["end_to_end"] = {"piles_per_sec": None, "what": "failed: %r" % (e,)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(piles[:144])

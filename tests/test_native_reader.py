@@ -236,3 +236,24 @@ def test_multi_device_sharding_of_a_pileset(monkeypatch):
     finally:
         os.close(fd)
         os.unlink(path)
+
+
+def test_bench_end_to_end_text_rebuilds_the_bench_piles(tmp_path):
+    """bench.py's end-to-end leg writes its piles out as LA4Falcon text: the reader hands
+    the worker exactly the piles the kernel-only legs run on."""
+    import bench
+    piles = [bench._gen_pile(s) for s in (5, 6)]
+    path = tmp_path / "piles.txt"
+    with open(path, "wb") as f:
+        bench.write_la4falcon(piles, f)
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        r = Reader(fd, 10, 0, 10, 200, 0)
+        ps = r.next()
+        got = list(ps.piles())
+        assert ps.seed_ids == ["%09d" % i for i in range(len(piles))]
+        assert r.next() is None
+        r.close()
+    finally:
+        os.close(fd)
+    assert got == [[x.decode("ascii") for x in p] for p in piles]
