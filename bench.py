@@ -104,7 +104,7 @@ def write_la4falcon(piles, f):
     f.write(b"- -\n")
 
 
-def end_to_end(piles):
+def end_to_end(piles, extra_args=()):
     """SURVEY.md 8d "end-to-end": LA4Falcon text on stdin -> FASTA on stdout through the
     consensus worker (falcon_amd.mains.consensus: native reader, staging, GPU stages,
     printing) in a process of its own, on the piles of this workload written out as text.
@@ -118,7 +118,7 @@ def end_to_end(piles):
             write_la4falcon(piles, f)
         size = os.path.getsize(src)
         cmd = [sys.executable, "-m", "falcon_amd.mains.consensus", "--output-multi", "--min-idt",
-               "0.70", "--min-cov", "4", "--max-n-read", "200", "--n-core", "1"]
+               "0.70", "--min-cov", "4", "--max-n-read", "200", "--n-core", "1"] + list(extra_args)
         t0 = time.perf_counter()
         with open(src) as fin, open(dst, "w") as fout:
             subprocess.run(cmd, stdin=fin, stdout=fout, check=True, cwd=root, timeout=600)

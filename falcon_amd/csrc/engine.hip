@@ -72,6 +72,7 @@ struct fa_ctx {
     // alignment work-slot arena (grow only)
     FaAlignArena arena = {};
     size_t arena_cells_bytes = 0, arena_rows_bytes = 0;  // rows and rowx have equal size
+    bool arena_full = false;  // an alignment outgrew the usual slot once: worst-case slots from now on
     // staging of a batch's ASCII (grow only, one batch at a time): pinned host buffer, its
     // device twin, and a stream of their own so that the upload and pack of batch i+1 run
     // next to the kernels of batch i instead of queueing behind them
@@ -481,7 +482,7 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
             for (auto &t : pool) t.join();
         }
         b->ascii_dev = ctx->d_stage;
-        hipStream_t s = ctx->up_stream;
+        hipStream_t s = getenv("FALCON_AMD_ONE_STREAM") ? ctx->stream : ctx->up_stream;
         ok &= hipMemcpyAsync(ctx->d_stage, h_ascii, b->ascii_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
         ok &= hipMemcpyAsync(b->d_ascii_off.p, b->ascii_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
         ok &= hipMemcpyAsync(b->d_seq.p, b->seq.data(), g * sizeof(FaSeq), hipMemcpyHostToDevice, s) == hipSuccess;
@@ -528,14 +529,27 @@ extern "C" void fa_batch_free(fa_batch *b) {
 }
 
 // Size the alignment arena: one slot per resident wavefront.
-static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes) {
+// Cells per slot: the worst case is rows x (band + 1) (every row as wide as the band
+// allows, DW_banded.c:184); alignments that end up accepted use a fraction of it (rows up
+// to 0.3 (q + t) are reserved, ~0.2 are walked; the band is ~26 diagonals wide on average
+// at 13 % error).  Slots are sized for FA_SLOT_WIDTH diagonals per row; an
+// alignment that outgrows its slot says so (FaAln.err == 2), the launch is repeated with
+// worst-case slots and the context keeps those.  The memory matters beyond its size:
+// amdgpu wipes released VRAM, and the next process on the device waits for that (a 60 GB
+// arena cost the next worker ~4 s).
+static const int FA_SLOT_WIDTH = 32;
+
+static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes, bool full) {
     int per_cu = fa_align_blocks_per_cu(lds_bytes);
     per_cu = std::max(1, std::min(per_cu, 32));
     int n_slot = c->n_cu * per_cu;
     n_slot = std::max(1, std::min(n_slot, b->n_seq));
     if (const char *e = getenv("FALCON_AMD_SLOTS")) n_slot = std::max(1, std::min(n_slot, atoi(e)));
     u64 rows = (u64)b->max_rows;
-    u64 cells = rows * (u64)(b->band + 1);
+    int width = FA_SLOT_WIDTH;
+    if (const char *e = getenv("FALCON_AMD_SLOT_WIDTH")) width = std::max(1, atoi(e));  // (tests)
+    if (full || c->arena_full || width > b->band + 1) width = b->band + 1;
+    u64 cells = std::max<u64>(rows * (u64)width, 4096);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     // never take more than half of what is free for the transient trace arena
@@ -567,17 +581,26 @@ static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes) {
     return 0;
 }
 
+// Alignment summaries to the host.  0: fine; 1: some alignment outgrew its work slot (the
+// caller repeats the launch with worst-case slots); < 0: error.
 static int fetch_aln(fa_batch *b) {
     if (b->h_aln.resize(b->n_seq)) return -1;
     HIP_OK(hipMemcpyAsync(b->h_aln.data(), b->d_aln.p, (size_t)b->n_seq * sizeof(FaAln),
                           hipMemcpyDeviceToHost, b->ctx->stream));
     HIP_OK(hipStreamSynchronize(b->ctx->stream));
     b->have_aln = true;
+    bool outgrown = false;
     for (int g = 0; g < b->n_seq; g++) {
-        if (b->h_aln[g].err) {
+        if (b->h_aln[g].err == 2) {
+            outgrown = true;
+        } else if (b->h_aln[g].err) {
             set_err("falcon_amd: alignment of sequence %d overflowed its work slot", g);
             return -2;
         }
+    }
+    if (outgrown) {
+        b->have_aln = false;
+        return 1;
     }
     return 0;
 }
@@ -607,7 +630,7 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     b->have_range = b->have_aln = false;
     const double max_diff = 1.0 - min_idt;  // falcon.c:580
     size_t lds = fa_align_lds_bytes(b->max_read_len, b->max_seed_len);
-    if (ensure_arena(c, b, lds)) return -1;
+    if (ensure_arena(c, b, lds, false)) return -1;
     FaBatchDev d = b->dev();
 
     HIP_OK(hipEventRecord(c->ev[0], s));
@@ -629,10 +652,13 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
     fa_ctx *c = b->ctx;
     hipStream_t s = c->stream;
     FaBatchDev d = b->dev();
-    if (band + 1 > 64 * FA_ALIGN_MAXCH - 1)
-        fa_launch_align_wide(d, c->arena, max_diff, band, s);
-    else
-        fa_launch_align_band(d, c->arena, b->max_read_len, b->max_seed_len, max_diff, band, s);
+    auto launch_align = [&]() {
+        if (band + 1 > 64 * FA_ALIGN_MAXCH - 1)
+            fa_launch_align_wide(d, c->arena, max_diff, band, s);
+        else
+            fa_launch_align_band(d, c->arena, b->max_read_len, b->max_seed_len, max_diff, band, s);
+    };
+    launch_align();
     HIP_OK(hipEventRecord(c->ev[3], s));
     trace_stage(s, "align");
     if (getenv("FALCON_AMD_PROF")) {  // only meaningful in -DFA_ALIGN_PROF builds
@@ -679,7 +705,24 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
     }
     if (b->h_ta.resize((size_t)b->n_seq + 1)) return -1;
     // alignment summaries bound the MSA node pools (levels <= seed + insertions)
-    if (int rc = fetch_aln(b)) return rc;
+    b->stats.align_relaunched = 0;
+    int rc_aln = fetch_aln(b);
+    if (rc_aln == 1) {
+        // some alignment outgrew its slot (written nowhere past it): worst-case slots, for
+        // this launch and for the rest of the context's life
+        c->arena_full = true;
+        if (ensure_arena(c, b, fa_align_lds_bytes(b->max_read_len, b->max_seed_len), true)) return -1;
+        launch_align();
+        HIP_OK(hipEventRecord(c->ev[3], s));
+        HIP_OK(hipGetLastError());
+        b->stats.align_relaunched = 1;
+        rc_aln = fetch_aln(b);
+        if (rc_aln == 1) {
+            set_err("falcon_amd: an alignment overflowed a worst-case work slot");
+            return -2;
+        }
+    }
+    if (rc_aln) return rc_aln;
     b->have_range = true;  // its copy was queued ahead of k_align
     if (force_accept_g >= 0 && b->h_aln[force_accept_g].aligned) b->h_aln[force_accept_g].accept = 1;
     // ---- plan the MSA stage from the alignment summaries (host, O(#reads))
@@ -796,6 +839,7 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
     fa_stats &st = b->stats;
     st.C = sC; st.D = sD; st.A = sA; st.O = sO; st.n_aligned = nal;
     st.align_slots = c->arena.n_slot;
+    st.align_slot_cells = (long long)c->arena.cells_per_slot;
     (void)hipEventElapsedTime(&st.ms_index, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&st.ms_chain, c->ev[1], c->ev[2]);
     (void)hipEventElapsedTime(&st.ms_align, c->ev[2], c->ev[3]);
@@ -871,7 +915,7 @@ extern "C" fa_batch *fa_utg_consensus(fa_ctx *ctx, int n_seq, const char *const 
         return fail("range upload failed");
     b->fetched = b->fetched_eqv = false;
     b->have_aln = false;
-    if (ensure_arena(c, b, fa_align_lds_bytes(b->max_read_len, b->max_seed_len))) return fail(nullptr);
+    if (ensure_arena(c, b, fa_align_lds_bytes(b->max_read_len, b->max_seed_len), true)) return fail(nullptr);
     for (int i = 0; i < 3; i++) (void)hipEventRecord(c->ev[i], s);
     if (run_from_ranges(b, 0, 1.0 - min_idt, band, 1)) return fail(nullptr);
     return b;
@@ -1071,7 +1115,7 @@ extern "C" int fa_align_pairs(fa_ctx *ctx, int n, const char *const *q, const in
         return fail(-1);
     }
     trace_stage(s, "pair-range");
-    if (ensure_arena(c, b, lds)) return fail(-1);
+    if (ensure_arena(c, b, lds, true)) return fail(-1);
     trace_stage(s, "pair-arena");
     FaBatchDev d = b->dev();
     FaAlignArena ar = c->arena;
@@ -1082,7 +1126,10 @@ extern "C" int fa_align_pairs(fa_ctx *ctx, int n, const char *const *q, const in
         set_err("falcon_amd: k_align launch failed");
         return fail(-1);
     }
-    if ((rc = fetch_aln(b))) return fail(rc);
+    if ((rc = fetch_aln(b))) {
+        if (rc == 1) set_err("falcon_amd: an alignment overflowed a worst-case work slot");
+        return fail(rc == 1 ? -2 : rc);
+    }
     std::vector<u32> script;
     if (get_aln_str > 0) {
         script.resize(b->script_words + 8);

@@ -100,7 +100,10 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
     const int band = fa_uni(band_v), q_off = fa_uni(q_off_v), qb = fa_uni(qb_v);
     const int q_len = fa_uni(q_len_v), t_off = fa_uni(t_off_v), tb = fa_uni(tb_v);
     const int t_len = fa_uni(t_len_v), v_off = fa_uni(v_off_v);
-    const u64 rows_per_slot = fa_uni(rows_per_slot_v);
+    // (one argument for both slot dimensions: rows in the low word, cells in the high one)
+    const u64 slot_dims = fa_uni(rows_per_slot_v);
+    const u64 rows_per_slot = slot_dims & 0xffffffffull;
+    const u32 cells_cap = (u32)(slot_dims >> 32);
     const double max_diff = fa_uni(max_diff_v);
     u32 *script_ = fa_uni(script_v);
     FaAln *aln_out_ = fa_uni(aln_out_v);
@@ -210,6 +213,9 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
     int vreg = 0;          // reference: calloc'ed V (:153)
     int d = 0;
     bool done = false, dead = false;
+    // the slot holds fewer cells than the worst case rows x (band + 1) (the engine sizes it
+    // for what alignments use, fa_internal.h): running out is reported, never written past
+    bool overflow = false;
     PROF_DECL;
     while (!done && !dead) {
         // ================= register-mode rows =================
@@ -231,6 +237,9 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             min_k = kd + 2 * lo;  // (register mode keeps min_k implicit)
             if (d >= max_d || n - 1 > band) { dead = true; break; }
             if (n > REG_MAX_N) break;
+            // rows of <= 64 cells that still fit the slot, less one
+            const int room = (int)((cells_cap - row_off) >> 6) - 1;
+            if (room < 0) { overflow = true; dead = true; break; }
             if (63 - lo - n < 0 || lo < 1) {
                 // re-seat the band low inside the wave (it climbs one lane every two rows)
                 const int nlo = max(1, (64 - n) >> 2);
@@ -240,7 +249,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
                 lo = nlo;
             }
             // the hot loop: `safe` + 1 rows that cannot trip a rare event
-            for (int safe = min(min(min(max_d - 1 - d, nmax - n), 63 - lo - n), 63 - (d & 63));
+            for (int safe = min(min(min(min(max_d - 1 - d, nmax - n), 63 - lo - n), 63 - (d & 63)), room);
                  safe >= 0; safe--) {
             const int hi = lo + n - 1;
             PROF(0);
@@ -308,6 +317,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
         for (;;) {
             if (d >= max_d || n - 1 > band) { dead = true; break; }
             if (n <= REG_MAX_N - 12) break;
+            if (row_off + (u32)n > cells_cap) { overflow = true; dead = true; break; }
             const int par = d & 1;
             const int max_k = min_k + 2 * (n - 1);
             int *Vcur = Vring + par * RING;
@@ -388,6 +398,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
 
     if (!done) {  // unaligned: aln_str_size stays 0 (:171,:184-186)
         res.cells = row_off;
+        res.err = overflow ? 2 : 0;  // 2: the engine repeats the launch with full-size slots
         store_result(res);
         return;
     }
@@ -523,12 +534,12 @@ __global__ __launch_bounds__(64, (SEQ_LDS ? 3 : 8)) void k_align(AlignArgs A) {
                 for (int i = lane; i < qn; i += 64) qL[i] = (i < qavail) ? qg[i] : 0u;
                 for (int i = lane; i < tn; i += 64) tL[i] = (i < tavail) ? tg[i] : 0u;
                 __syncthreads();
-                align_one<true>(A.band, A.rows_per_slot, A.max_diff, A.script + A.script_off[g],
+                align_one<true>(A.band, A.rows_per_slot | (A.cells_per_slot << 32), A.max_diff, A.script + A.script_off[g],
                                 A.aln + g, 0, s1 & 15, q_len, A.lds_q_words, s2 & 15, t_len,
                                 A.lds_q_words + A.lds_t_words, cells, rows, rowx, qg, tg, A.prof);
             } else {
                 (void)qavail; (void)tavail;
-                align_one<false>(A.band, A.rows_per_slot, A.max_diff, A.script + A.script_off[g],
+                align_one<false>(A.band, A.rows_per_slot | (A.cells_per_slot << 32), A.max_diff, A.script + A.script_off[g],
                                  A.aln + g, 0, s1 & 15, q_len, 0, s2 & 15, t_len, 0, cells, rows,
                                  rowx, qg, tg, A.prof);
             }

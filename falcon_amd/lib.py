@@ -27,7 +27,8 @@ class FaStats(C.Structure):
                 ("ms_consensus", C.c_float), ("ms_total", C.c_float),
                 ("align_slots", C.c_int),
                 ("ms_tags", C.c_float), ("ms_links", C.c_float), ("ms_score", C.c_float),
-                ("ms_backtrace", C.c_float)]
+                ("ms_backtrace", C.c_float),
+                ("align_slot_cells", C.c_longlong), ("align_relaunched", C.c_int)]
 
     def b_alg(self) -> int:
         """Algorithmic bytes: L/4 + 4C + 8D + 16A + 12T + 5O."""

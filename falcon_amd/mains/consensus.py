@@ -24,6 +24,7 @@ import os
 import re
 import sys
 import threading
+import time
 from collections import namedtuple
 
 LOG = logging.getLogger("falcon_amd.consensus")
@@ -399,10 +400,15 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
     def ingest():
         try:
             while True:
+                t0 = time.perf_counter()
                 ps = reader.next(0, per_call)
                 if ps is None:
                     break
-                staged.put((ps.seed_ids, gpu.stage(ps)))
+                t1 = time.perf_counter()
+                item = (ps.seed_ids, gpu.stage(ps))
+                LOG.debug("ingest: %d piles read in %.3f s, staged in %.3f s", ps.n_pile, t1 - t0,
+                          time.perf_counter() - t1)
+                staged.put(item)
             staged.put(None)
         except Exception as exc:
             staged.put(exc)
@@ -411,14 +417,20 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
     t.start()
     try:
         while True:
+            t0 = time.perf_counter()
             item = staged.get()
             if item is None:
                 break
             if isinstance(item, Exception):
                 raise item
             ids, batches = item
-            for sid, cns in zip(ids, gpu.finish(batches)):
+            t1 = time.perf_counter()
+            cns_all = gpu.finish(batches)
+            t2 = time.perf_counter()
+            for sid, cns in zip(ids, cns_all):
                 stdout.write(fasta_records(sid, cns, args.output_full, args.output_multi))
+            LOG.debug("worker: waited %.3f s for the batch, GPU stages + fetch %.3f s, printing %.3f s",
+                      t1 - t0, t2 - t1, time.perf_counter() - t2)
     finally:
         reader.close()
 

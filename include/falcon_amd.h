@@ -134,6 +134,10 @@ typedef struct {
     int align_slots; /* resident alignment work slots (wavefronts) */
     /* the kernels of the consensus stage (k_msa.hip), same clock */
     float ms_tags, ms_links, ms_score, ms_backtrace;
+    /* alignment work slots hold `align_slot_cells` cells each; 1 if the alignment launch
+     * had to be repeated with worst-case slots (some alignment outgrew the usual size) */
+    long long align_slot_cells;
+    int align_relaunched;
 } fa_stats;
 
 const char *fa_last_error(void);

@@ -249,6 +249,8 @@ def test_bench_scale_batch_properties(engine):
         bt.free()
     assert r1 == r2                                     # rerunnable, deterministic
     assert st.n_piles == len(piles) and st.n_aligned > 60 * len(piles)
+    # the usual work slots (32 diagonals per row, not the worst case 151) hold this workload
+    assert st.align_relaunched == 0 and st.align_slot_cells * 4 < 3 * 1024 * 1024
     assert all(len(c) > 19000 for c, _ in r1)           # every seed corrected end to end
     rev = engine.consensus(list(reversed(piles)), 4, 8, 0.70, want_eqv=True)
     assert rev == list(reversed(r1))                    # order of piles is irrelevant
@@ -256,6 +258,38 @@ def test_bench_scale_batch_properties(engine):
         assert engine.consensus([piles[i]], 4, 8, 0.70, want_eqv=True) == [r1[i]]
     digest = hashlib.sha1("".join(c for c, _ in r1).encode()).hexdigest()
     assert len(digest) == 40
+
+
+def test_outgrown_alignment_slots_are_relaunched(monkeypatch, port):
+    """Alignment work slots are sized for what alignments use, not for the worst case
+    rows x (band + 1); an alignment that outgrows its slot is reported by the kernel and
+    the launch repeated with worst-case slots, which the context then keeps.  Forced here
+    with slots of 2 diagonals per row: same results as the oracle, one relaunch, none after."""
+    from falcon_amd.engine import Engine
+    monkeypatch.setenv("FALCON_AMD_SLOT_WIDTH", "2")
+    piles = [
+        _synthetic(32, S=8000, coverage=25, min_read=1000, mean_read=5000, sd_read=2000),
+        _synthetic(34, S=6000, coverage=20, e=0.20, min_read=1000, mean_read=4000, sd_read=1500),
+    ]
+    want = [port.generate_consensus(p, 4, 8, 0.70) for p in piles]
+    eng = Engine(0)
+    try:
+        b = eng.batch(piles)
+        b.run(4, 8, 0.70).fetch(True)
+        st = b.stats()
+        got = [b.result(i) for i in range(len(piles))]
+        b.free()
+        assert st.align_relaunched == 1
+        assert [tuple(x) for x in got] == [tuple(x) for x in want]
+        b = eng.batch(piles[::-1])
+        b.run(4, 8, 0.70).fetch(True)
+        st2 = b.stats()
+        got2 = [b.result(i) for i in range(len(piles))]
+        b.free()
+        assert st2.align_relaunched == 0 and st2.align_slot_cells == st.align_slot_cells  # (worst case, kept)
+        assert [tuple(x) for x in got2] == [tuple(x) for x in want[::-1]]
+    finally:
+        eng.close()
 
 
 def test_long_insertion_runs_and_tag_cutoff(engine, port):
