@@ -550,6 +550,9 @@ static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes, bool ful
     if (const char *e = getenv("FALCON_AMD_SLOT_WIDTH")) width = std::max(1, atoi(e));  // (tests)
     if (full || c->arena_full || width > b->band + 1) width = b->band + 1;
     u64 cells = std::max<u64>(rows * (u64)width, 4096);
+    // slot stride = 4 KB x m + 256 B x 7: the slots' first pages (all waves start writing
+    // at their slot's base) spread over the memory channels instead of piling on a few
+    cells = ((cells + 1023) & ~(u64)1023) + 448;
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     // never take more than half of what is free for the transient trace arena
