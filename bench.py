@@ -310,7 +310,7 @@ def main():
         }
         if world == 1 and not args.no_end_to_end:
             try:
-                out["end_to_end"] = end_to_end(piles[:1536])
+                out["end_to_end"] = end_to_end(piles)
             except Exception as e:  # informative; never lose the GPU line
                 out["end_to_end"] = {"piles_per_sec": None, "what": "failed: %r" % (e,)}
         if world == 1 and not args.no_cpu_baseline:

@@ -387,19 +387,32 @@ def _stream_fd(stream):
         return None
 
 
+# bases per batch and device on the native path: large batches keep every wave slot of the
+# GPU busy (a 0.4 G batch runs at 40 % of the rate of a 2.6 G one); the text of a batch and
+# its pinned copy sit in host memory, so the batch over all devices is capped too
+NATIVE_BATCH_BASES = 1_300_000_000
+NATIVE_BATCH_BASES_ALL_DEVICES = 4_000_000_000
+
+
 def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
-    """Ingest thread (native reader + staging of batch i+1) overlapped with the GPU
-    work and the printing of batch i; records leave in input order."""
+    """Three overlapped stages, records leaving in input order: an ingest thread (native
+    reader + staging of batch i+1), the GPU stages of batch i in the caller's thread (the
+    library releases the GIL), and a printer thread formatting batch i-1."""
     import queue
     from falcon_amd.engine import Reader
     reader = Reader(fd, args.min_n_read, args.min_len_aln, cfg.min_cov_aln, cfg.max_n_read,
                     cfg.max_cov_aln)
-    per_call = (batch_bases or gpu.batch_bases) * len(gpu.engines)
+    if batch_bases is None:
+        batch_bases = int(os.environ.get("FALCON_AMD_BATCH_BASES", NATIVE_BATCH_BASES))
+    per_call = min(batch_bases * len(gpu.engines), max(batch_bases, NATIVE_BATCH_BASES_ALL_DEVICES))
     staged = queue.Queue(maxsize=1)
+    done = queue.Queue(maxsize=2)
+    failed = []
+    stop = threading.Event()
 
     def ingest():
         try:
-            while True:
+            while not stop.is_set():
                 t0 = time.perf_counter()
                 ps = reader.next(0, per_call)
                 if ps is None:
@@ -413,10 +426,28 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
         except Exception as exc:
             staged.put(exc)
 
-    t = threading.Thread(target=ingest, daemon=True)
-    t.start()
+    def printer():
+        try:
+            while True:
+                item = done.get()
+                if item is None:
+                    return
+                t0 = time.perf_counter()
+                ids, cns_all = item
+                for sid, cns in zip(ids, cns_all):
+                    stdout.write(fasta_records(sid, cns, args.output_full, args.output_multi))
+                LOG.debug("printer: %d piles in %.3f s", len(ids), time.perf_counter() - t0)
+        except Exception as exc:  # (a closed stdout, say): stop the pipeline, report below
+            failed.append(exc)
+            stop.set()
+            while done.get() is not None:
+                pass
+
+    threads = [threading.Thread(target=ingest, daemon=True), threading.Thread(target=printer, daemon=True)]
+    for t in threads:
+        t.start()
     try:
-        while True:
+        while not stop.is_set():
             t0 = time.perf_counter()
             item = staged.get()
             if item is None:
@@ -426,13 +457,26 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
             ids, batches = item
             t1 = time.perf_counter()
             cns_all = gpu.finish(batches)
-            t2 = time.perf_counter()
-            for sid, cns in zip(ids, cns_all):
-                stdout.write(fasta_records(sid, cns, args.output_full, args.output_multi))
-            LOG.debug("worker: waited %.3f s for the batch, GPU stages + fetch %.3f s, printing %.3f s",
-                      t1 - t0, t2 - t1, time.perf_counter() - t2)
+            LOG.debug("worker: waited %.3f s for the batch, GPU stages + fetch %.3f s", t1 - t0,
+                      time.perf_counter() - t1)
+            done.put((ids, cns_all))
     finally:
+        stop.set()
+        done.put(None)
+        threads[1].join()
+        # the reader may only be closed once the ingest thread has left it; what it had
+        # staged meanwhile is released
+        while threads[0].is_alive():
+            try:
+                item = staged.get(timeout=0.05)
+            except queue.Empty:
+                continue
+            if isinstance(item, tuple):
+                for b in item[1]:
+                    getattr(b, "free", lambda: None)()
         reader.close()
+    if failed:
+        raise failed[0]
 
 
 def run(args, stdin=None, stdout=None, consensus_map=None):

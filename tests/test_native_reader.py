@@ -165,12 +165,24 @@ def test_cli_native_path_orders_and_prints(tmp_path):
     out = io.StringIO()
     gpu = FakeGpu()
     try:
-        _run_native(args, cfg, fd, gpu, out)
+        _run_native(args, cfg, fd, gpu, out, batch_bases=900)
     finally:
         os.close(fd)
     want = "".join(">%s_f\n%s\n" % (sid, (p[0] * 20)[:600]) for sid, p in want_piles)
     assert out.getvalue() == want
     assert gpu.staged > 1
+
+    # a failing output (closed pipe) ends the run with that error instead of hanging
+    class Broken(io.StringIO):
+        def write(self, _text):
+            raise BrokenPipeError("stdout is gone")
+
+    fd = os.open(str(path), os.O_RDONLY)
+    try:
+        with pytest.raises(BrokenPipeError):
+            _run_native(args, cfg, fd, FakeGpu(), Broken(), batch_bases=900)
+    finally:
+        os.close(fd)
 
 
 def test_multi_device_sharding_of_a_pileset(monkeypatch):
