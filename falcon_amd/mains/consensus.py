@@ -388,9 +388,12 @@ def _stream_fd(stream):
 
 
 # bases per batch and device on the native path: large batches keep every wave slot of the
-# GPU busy (a 0.4 G batch runs at 40 % of the rate of a 2.6 G one); the text of a batch and
-# its pinned copy sit in host memory, so the batch over all devices is capped too
+# GPU busy (a 0.4 G batch runs at 40 % of the rate of a 2.6 G one), small first batches get
+# the pipeline going while the host buffers (text, pinned copy) are still growing -- so the
+# batch size doubles from FIRST up to the full size.  The text of a batch and its pinned
+# copy sit in host memory, so the batch over all devices is capped too.
 NATIVE_BATCH_BASES = 1_300_000_000
+NATIVE_BATCH_BASES_FIRST = 400_000_000
 NATIVE_BATCH_BASES_ALL_DEVICES = 4_000_000_000
 
 
@@ -404,7 +407,8 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
                     cfg.max_cov_aln)
     if batch_bases is None:
         batch_bases = int(os.environ.get("FALCON_AMD_BATCH_BASES", NATIVE_BATCH_BASES))
-    per_call = min(batch_bases * len(gpu.engines), max(batch_bases, NATIVE_BATCH_BASES_ALL_DEVICES))
+    first = int(os.environ.get("FALCON_AMD_BATCH_BASES_FIRST", NATIVE_BATCH_BASES_FIRST))
+    sizes = [min(first, batch_bases)]  # (a list: the ingest thread advances it)
     staged = queue.Queue(maxsize=1)
     done = queue.Queue(maxsize=2)
     failed = []
@@ -414,6 +418,8 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
         try:
             while not stop.is_set():
                 t0 = time.perf_counter()
+                per_call = min(sizes[0] * len(gpu.engines), max(sizes[0], NATIVE_BATCH_BASES_ALL_DEVICES))
+                sizes[0] = min(2 * sizes[0], batch_bases)
                 ps = reader.next(0, per_call)
                 if ps is None:
                     break
