@@ -387,13 +387,12 @@ def _stream_fd(stream):
         return None
 
 
-# bases per batch and device on the native path: large batches keep every wave slot of the
-# GPU busy (a 0.4 G batch runs at 40 % of the rate of a 2.6 G one), small first batches get
-# the pipeline going while the host buffers (text, pinned copy) are still growing -- so the
-# batch size doubles from FIRST up to the full size.  The text of a batch and its pinned
-# copy sit in host memory, so the batch over all devices is capped too.
-NATIVE_BATCH_BASES = 1_300_000_000
-NATIVE_BATCH_BASES_FIRST = 400_000_000
+# Bases per batch and device on the native path.  Measured on 3072 E. coli-like piles of
+# text (scripts/exp_batch_policy.py, profiles/r01_v8_batch_policy.txt): constant 0.4 G
+# 3020 piles/s, constant 1.3 G 2076, doubling from 0.4 G to 1.3 G 1372-1679 -- larger
+# batches run the kernels at a better rate, but the host buffers they need (text, pinned
+# copy: page faults, pinning) cost more than that buys, and small batches pipeline sooner.
+NATIVE_BATCH_BASES = 400_000_000
 NATIVE_BATCH_BASES_ALL_DEVICES = 4_000_000_000
 
 
@@ -407,8 +406,7 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
                     cfg.max_cov_aln)
     if batch_bases is None:
         batch_bases = int(os.environ.get("FALCON_AMD_BATCH_BASES", NATIVE_BATCH_BASES))
-    first = int(os.environ.get("FALCON_AMD_BATCH_BASES_FIRST", NATIVE_BATCH_BASES_FIRST))
-    sizes = [min(first, batch_bases)]  # (a list: the ingest thread advances it)
+    per_call = min(batch_bases * len(gpu.engines), max(batch_bases, NATIVE_BATCH_BASES_ALL_DEVICES))
     staged = queue.Queue(maxsize=1)
     done = queue.Queue(maxsize=2)
     failed = []
@@ -418,8 +416,6 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
         try:
             while not stop.is_set():
                 t0 = time.perf_counter()
-                per_call = min(sizes[0] * len(gpu.engines), max(sizes[0], NATIVE_BATCH_BASES_ALL_DEVICES))
-                sizes[0] = min(2 * sizes[0], batch_bases)
                 ps = reader.next(0, per_call)
                 if ps is None:
                     break
