@@ -269,3 +269,29 @@ def test_bench_end_to_end_text_rebuilds_the_bench_piles(tmp_path):
     finally:
         os.close(fd)
     assert got == [[x.decode("ascii") for x in p] for p in piles]
+
+
+def test_fuzzed_streams_match_the_python_parser():
+    """Arbitrary ASCII byte soup -- control bytes, blank runs, empty and endless lines, marker
+    look-alikes, no final newline -- parses like the python restatement, for several
+    admission settings and batch limits (hypothesis; the reader is C++ over untrusted text)."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+
+    token = st.one_of(
+        st.sampled_from(["+", "*", "-", "+ +", "* *", "- -", "", " ", "\t", "\r", "\x00", "\x1c", "\x0b",
+                         "r1", "r2", "r3", "seed", "x" * 40]),
+        st.text(alphabet="ACGT", min_size=0, max_size=70),
+        st.text(alphabet="ACGTN acgt\t\r\x00\x01\x1f+*-", min_size=0, max_size=30))
+    line = st.lists(token, min_size=0, max_size=4).map(" ".join)
+    stream = st.tuples(st.lists(line, min_size=0, max_size=60), st.booleans()).map(
+        lambda t: "\n".join(t[0]) + ("\n" if t[1] else ""))
+
+    @settings(max_examples=500, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(stream, st.sampled_from([(1, 0, 0, 500, 0), (2, 3, 0, 4, 0), (3, 0, 1, 500, 2), (2, 0, 0, 3, 1)]),
+           st.sampled_from([(0, 0), (1, 0), (0, 64), (3, 200)]))
+    def check(text, opts, limits):
+        want = _python(text, *opts)
+        got, _ = _native(text, *opts, max_piles=limits[0], max_bases=limits[1])
+        assert got == want
+
+    check()
