@@ -221,7 +221,12 @@ def run(args, pool=None, backend=None):
             raise RuntimeError("falcon_amd: no HIP device visible (there is no CPU fallback)")
         env = os.environ.get("FALCON_AMD_DEVICES")
         devices = [int(x) for x in env.split(",")] if env else list(range(n_dev))
-        pool = DevicePool([Engine(d) for d in devices])
+        # engines (contexts, each with its own streams and work slots) per GPU: with 2, the
+        # latency-bound consensus kernels of one job's batch run next to the alignment
+        # kernel of another's (+6 % at 3072-pile batches with two contexts;
+        # not measured at the worker's batch size yet, hence 1)
+        per_gpu = max(1, int(os.environ.get("FALCON_AMD_ENGINES_PER_DEVICE", "1")))
+        pool = DevicePool([Engine(d) for d in devices for _ in range(per_gpu)])
     if backend is None:
         backend = EngineBackend(args.min_cov, args.min_idt)
     LOG.info("falcon_amd consensus: %d job(s) on %d GPU(s)", len(args.jobs), len(pool.devices))
