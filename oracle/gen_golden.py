@@ -220,11 +220,14 @@ def import_reference_driver():
     import falcon_kit.multiproc  # noqa: F401
     for fn_name in ("get_consensus_without_trim", "get_consensus_with_trim"):
         orig = getattr(mod, fn_name)
+        if getattr(orig, "_marshalling_wrapped", False):  # (imported before in this process)
+            continue
 
         def wrapped(c_input, _orig=orig):
             seqs, seed_id, config = c_input
             cns, sid = _orig(([s.encode("ascii") for s in seqs], seed_id, config))
             return cns.decode("ascii"), sid
+        wrapped._marshalling_wrapped = True
         setattr(mod, fn_name, wrapped)
     return mod
 
