@@ -121,7 +121,11 @@ def end_to_end(piles, extra_args=()):
                "0.70", "--min-cov", "4", "--max-n-read", "200", "--n-core", "1"] + list(extra_args)
         t0 = time.perf_counter()
         with open(src) as fin, open(dst, "w") as fout:
-            subprocess.run(cmd, stdin=fin, stdout=fout, check=True, cwd=root, timeout=600)
+            # (a profiler wrapped around this process stays with this process: the worker's
+            # launches are at another batch size and would blur its per-kernel averages)
+            env = {k: v for k, v in os.environ.items()
+                   if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTRACER", "HSA_TOOLS"))}
+            subprocess.run(cmd, stdin=fin, stdout=fout, check=True, cwd=root, timeout=600, env=env)
         wall = time.perf_counter() - t0
         with open(dst) as f:
             bases = sum(len(ln) - 1 for ln in f if not ln.startswith(">"))

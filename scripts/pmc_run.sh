@@ -18,6 +18,6 @@ esac
 i=0
 for ctrs in "${PASSES[@]}"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $R/gpurun_out/$TAG/p$i -o p$i -- python $R/bench.py --steps 1 --warmup 0 --piles $PILES --no-cpu-baseline > $R/gpurun_out/$TAG/p$i.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $R/gpurun_out/$TAG/p$i -o p$i -- python $R/bench.py --steps 1 --warmup 0 --piles $PILES --no-cpu-baseline --no-end-to-end > $R/gpurun_out/$TAG/p$i.log 2>&1
   grep -i "error\|invalid\|unknown" $R/gpurun_out/$TAG/p$i.log | head -3
 done
