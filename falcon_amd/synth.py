@@ -59,12 +59,16 @@ def make_pile(seed: int, S: int = 20000, coverage: float = 40.0, e: float = 0.13
     reads = []
     total = 0
     target = coverage * S
+    rejected = 0
     while total < target:
         L = int(max(min_read, rng.normal(mean_read, sd_read)))
         # read [start, start+L) must overlap window [S, 2S) by >= 1000 bp
         start = int(rng.integers(S - L + 1000, 2 * S - 1000 + 1))
         lo, hi = max(start, S), min(start + L, 2 * S)
         if hi - lo < 1000:
+            rejected += 1
+            if rejected > 100000 and not reads:
+                raise ValueError("no read of this length distribution overlaps the seed window by 1000 bp")
             continue
         hap = haps[int(rng.integers(0, len(haps)))] if len(haps) > 1 else genome
         rd = noisy(hap[lo:hi], rng, e)
