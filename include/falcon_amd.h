@@ -203,7 +203,8 @@ fa_reader *fa_reader_open(int fd, int min_n_read, int min_len_aln, int min_cov_a
  * of piles (0: end of stream, < 0: read error, see fa_reader_error).  On return
  *   pile_n_seq[p]            sequences of pile p (seed first), consecutive in
  *   seqs[] / seq_len[]       base pointers (NOT NUL-terminated) and lengths,
- *   seed_ids[p]              NUL-terminated name of the pile's seed;
+ *   seed_ids[p]              NUL-terminated name of the pile's seed (a name holding a
+ *                            NUL byte therefore ends there);
  * exactly the arguments of fa_batch_create().  The arrays and what they point to stay
  * valid until the next fa_reader_next() / fa_reader_close() on this reader. */
 int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, const int **pile_n_seq,
