@@ -184,7 +184,7 @@ def _open_source(src):
         def close():
             proc.stdout.close()
             rc = proc.wait()
-            if rc not in (0, -13):  # (-13: we stop reading at "- -", the producer may see SIGPIPE)
+            if rc not in (0, -13, 141):  # (SIGPIPE, directly or through the shell: we stop reading at "- -")
                 raise RuntimeError("producer %r exited with status %d" % (src[4:], rc))
         return proc.stdout.fileno(), close
     fd = os.open(src, os.O_RDONLY)
