@@ -482,7 +482,7 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
             for (auto &t : pool) t.join();
         }
         b->ascii_dev = ctx->d_stage;
-        hipStream_t s = getenv("FALCON_AMD_ONE_STREAM") ? ctx->stream : ctx->up_stream;
+        hipStream_t s = ctx->up_stream;
         ok &= hipMemcpyAsync(ctx->d_stage, h_ascii, b->ascii_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
         ok &= hipMemcpyAsync(b->d_ascii_off.p, b->ascii_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
         ok &= hipMemcpyAsync(b->d_seq.p, b->seq.data(), g * sizeof(FaSeq), hipMemcpyHostToDevice, s) == hipSuccess;
