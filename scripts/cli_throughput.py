@@ -4,7 +4,6 @@
 import os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench
 from falcon_amd.synth import make_pile, pile_to_la4falcon
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 def one(s):
