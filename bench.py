@@ -1,27 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- FALCON pre-assembly consensus hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload ecoli|dmel|arab]
 
 A "step" is one pass of the whole hot path (seed k-mer index -> k-mer chaining ->
 banded O(ND) alignment + trace-back -> MSA sweep + consensus back-trace) over one
-resident batch of synthetic LA4Falcon-style piles, BASELINE.json configs[1]:
-E. coli-like ~20 kb seeds x 40x coverage, flags of examples/fc_run_ecoli.cfg:33
-(--min-cov 4 --min-idt 0.70 --max-n-read 200).  Inputs are 2-bit packed and resident
-in HBM before the timed region starts; every rank owns its own piles (piles are
+resident batch of synthetic LA4Falcon-style piles.  Default workload = BASELINE.json
+configs[1]: E. coli-like ~20 kb seeds x 40x coverage, flags of
+examples/fc_run_ecoli.cfg:33 (--min-cov 4 --min-idt 0.70 --max-n-read 200); `dmel`
+(configs[3], 30 kb x 80x, the 200-read cap binding) and `arab` (configs[4], 25 kb x 60x,
+two haplotypes 0.5 % apart) are SURVEY.md 8d's other two.  Inputs are 2-bit packed and
+resident in HBM before the timed region starts; every rank owns its own piles (piles are
 independent: no collective on the data path, weak scaling).
+
+`--gpus N` with N > 1 starts N ranks itself (one process per GPU under
+torch.distributed.run, 127.0.0.1 rendezvous) unless a launcher already did
+(WORLD_SIZE set); the line is only printed when the ranks that ran == N.
 
 Prints ONE JSON line (rank 0): metric = consensus bases/s over all GPUs, plus
   roofline     -- dominant kernel, algorithmic bytes / HIP-event time
   cpu_baseline -- the reference C path (oracle/_ref, else our restatement) timed on the
-                  host cores on a bounded sample of the same piles (rank 0, N=1 only).
+                  host cores on a bounded sample of the same piles (rank 0, N=1 only), and
+  parity_*     -- the GPU's consensus of exactly those sample piles compared with the
+                  strings the CPU baseline just produced (outside the timed region).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import multiprocessing as mp
 import os
+import socket
 import sys
 import time
 
@@ -33,19 +43,35 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 MIN_COV, K, MIN_IDT, MAX_N_READ = 4, 8, 0.70, 200
 
+# SURVEY.md 8d configs 2/3, 4, 5; the flags are the same cfg line in all three
+# (examples/fc_run_ecoli.cfg:33, fc_run_dmel.cfg:34, fc_run_arab.cfg:34)
+WORKLOADS = {
+    "ecoli": dict(S=20000, coverage=40.0, het=0.0, piles=3072,
+                  text="E. coli-like piles: ~20 kb seed x 40x coverage, e=0.13 "
+                       "(BASELINE.json configs[1]; falcon_amd/synth.py, SURVEY.md 8d)"),
+    "dmel": dict(S=30000, coverage=80.0, het=0.0, piles=1024,
+                 text="D. melanogaster-like piles: ~30 kb seed x 80x coverage, e=0.13, the "
+                      "200-read cap binding (BASELINE.json configs[3]; SURVEY.md 8d config 4)"),
+    "arab": dict(S=25000, coverage=60.0, het=0.005, piles=1536,
+                 text="Arabidopsis-like piles: ~25 kb seed x 60x coverage, e=0.13, two haplotypes "
+                      "0.5 % apart (BASELINE.json configs[4]; SURVEY.md 8d config 5)"),
+}
 
-def _gen_pile(seed):
+
+def _gen_pile(job):
     from falcon_amd.synth import codes_to_str, make_pile, pile_to_seqs
-    s, rd = make_pile(seed, S=20000, coverage=40.0)
+    seed, S, cov, het = job
+    s, rd = make_pile(seed, S=S, coverage=cov, het=het)
     return [codes_to_str(x).encode("ascii") for x in pile_to_seqs(s, rd, MAX_N_READ)]
 
 
-def gen_piles(seeds, procs):
-    if procs <= 1 or len(seeds) < 4:
-        return [_gen_pile(s) for s in seeds]
+def gen_piles(seeds, procs, wl):
+    jobs = [(s, wl["S"], wl["coverage"], wl["het"]) for s in seeds]
+    if procs <= 1 or len(jobs) < 4:
+        return [_gen_pile(j) for j in jobs]
     ctx = mp.get_context("fork")
     with ctx.Pool(procs) as pool:
-        return pool.map(_gen_pile, seeds, chunksize=4)
+        return pool.map(_gen_pile, jobs, chunksize=4)
 
 
 # ---- CPU baseline workers (own processes: the reference C is not re-entrant,
@@ -56,37 +82,87 @@ def _cpu_worker(args):
     impl = Ref() if kind == "reference" else Port()
     impl.generate_consensus(piles[0], MIN_COV, K, MIN_IDT)  # warm-up, untimed
     t0 = time.perf_counter()
-    bases = 0
-    for p in piles[1:]:
-        bases += len(impl.generate_consensus(p, MIN_COV, K, MIN_IDT)[0])
-    return bases, len(piles) - 1, time.perf_counter() - t0
+    out = [impl.generate_consensus(p, MIN_COV, K, MIN_IDT)[0] for p in piles[1:]]
+    return out, time.perf_counter() - t0
 
 
-def cpu_baseline(piles):
+def host_cores():
+    """(logical cpus this process may use, physical cores of the host or None)."""
+    try:
+        logical = len(os.sched_getaffinity(0))
+    except AttributeError:
+        logical = os.cpu_count() or 1
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False)
+    except Exception:
+        phys = None
+    return logical, phys
+
+
+def _mem_available_gb():
+    try:
+        with open("/proc/meminfo") as f:
+            for ln in f:
+                if ln.startswith("MemAvailable:"):
+                    return int(ln.split()[1]) / 1048576.0
+    except OSError:
+        pass
+    return None
+
+
+def cpu_baseline(piles, timed_per_worker=20):
+    """-> (the cpu_baseline object, {pile index: consensus string} of the timed piles).
+
+    SURVEY.md 8d "CPU baseline timing": P worker processes = the host's physical cores (never
+    more than this process may run on, nor than memory allows: the reference keeps a 0.9 GB
+    workspace per process), one untimed warm-up pile per worker, `timed_per_worker` timed
+    piles each, taken from the front of this rank's batch."""
     from oracle.pyoracle import build, have_ref
     try:
         build()
     except Exception:
         pass
     kind = "reference" if have_ref() else "port"
-    cores = max(1, min(os.cpu_count() or 1, 16, len(piles) // 3))
-    per = max(2, min(9, len(piles) // cores))  # 1 warm-up + up to 8 timed piles per worker
+    logical, phys = host_cores()
+    cores = max(1, min(logical, phys or logical))
+    mem = _mem_available_gb()
+    if mem is not None:
+        cores = max(1, min(cores, int(mem / 2.0)))  # 0.9 GB workspace + the piles + headroom
+    per = timed_per_worker + 1
+    cores = max(1, min(cores, len(piles) // per)) if len(piles) >= per else 1
+    per = min(per, len(piles))
     jobs = [(kind, piles[i * per:(i + 1) * per]) for i in range(cores)]
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
         res = pool.map(_cpu_worker, jobs)
     wall = time.perf_counter() - t0
-    bases = sum(r[0] for r in res)
-    n = sum(r[1] for r in res)
-    busy = max(r[2] for r in res)  # workers run concurrently: timed span of the slowest
+    strings = {}
+    for w, (out, _) in enumerate(res):
+        for j, s in enumerate(out):
+            strings[w * per + 1 + j] = s
+    bases = sum(len(s) for s in strings.values())
+    n = len(strings)
+    busy = max(r[1] for r in res)  # workers run concurrently: timed span of the slowest
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {
         "value": round(bases / busy, 1), "unit": "bases/s", "cores": cores, "kind": kind,
         "piles_per_sec": round(n / busy, 3),
-        "per_core_bases_per_sec": round(bases / sum(r[2] for r in res), 1),
-        "sample": "%d piles of this workload (+1 untimed warm-up pile per worker process), "
-                  "%d worker processes, %.1f s wall incl. warm-up" % (n, cores, wall),
-    }
+        "per_core_bases_per_sec": round(bases / sum(r[1] for r in res), 1),
+        "host_cpu_count": logical, "host_physical_cores": phys, "host_cpu_model": cpu_model,
+        "sample": "%d piles of this workload (%d timed per worker process + 1 untimed warm-up "
+                  "pile each), %d worker processes = min(physical cores, cpus allowed, "
+                  "memory / 2 GB), %.1f s wall incl. warm-up" % (n, per - 1, cores, wall),
+    }, strings
 
 
 def write_la4falcon(piles, f):
@@ -104,11 +180,13 @@ def write_la4falcon(piles, f):
     f.write(b"- -\n")
 
 
-def end_to_end(piles, extra_args=()):
+def end_to_end(piles, extra_args=(), expect=None):
     """SURVEY.md 8d "end-to-end": LA4Falcon text on stdin -> FASTA on stdout through the
     consensus worker (falcon_amd.mains.consensus: native reader, staging, GPU stages,
     printing) in a process of its own, on the piles of this workload written out as text.
-    Reported beside `value` (kernel-only, inputs resident in HBM), never as it."""
+    Reported beside `value` (kernel-only, inputs resident in HBM), never as it.
+    `expect`: consensus strings of these piles from the resident batch -- the FASTA must be
+    what the output rules (consensus.py:275-299) make of them, byte for byte."""
     import subprocess
     import tempfile
     root = os.path.dirname(os.path.abspath(__file__))
@@ -128,11 +206,18 @@ def end_to_end(piles, extra_args=()):
             subprocess.run(cmd, stdin=fin, stdout=fout, check=True, cwd=root, timeout=600, env=env)
         wall = time.perf_counter() - t0
         with open(dst) as f:
-            bases = sum(len(ln) - 1 for ln in f if not ln.startswith(">"))
-    return {"piles_per_sec": round(len(piles) / wall, 1), "text_MB_per_sec": round(size / 1e6 / wall, 1),
-            "fasta_bases_per_sec": round(bases / wall, 1), "wall_s": round(wall, 2),
-            "what": "%d piles (%.0f MB of text from the page cache) -> FASTA, one worker process on "
-                    "one GPU, process start and HIP initialisation included" % (len(piles), size / 1e6)}
+            text = f.read()
+        bases = sum(len(ln) for ln in text.split("\n") if not ln.startswith(">"))
+    out = {"piles_per_sec": round(len(piles) / wall, 1), "text_MB_per_sec": round(size / 1e6 / wall, 1),
+           "fasta_bases_per_sec": round(bases / wall, 1), "wall_s": round(wall, 2),
+           "what": "%d piles (%.0f MB of text from the page cache) -> FASTA, one worker process on "
+                   "one GPU, process start and HIP initialisation included" % (len(piles), size / 1e6)}
+    if expect is not None:
+        from falcon_amd.mains.consensus import fasta_records
+        want = "".join(fasta_records("%09d" % i, c, False, True) for i, c in enumerate(expect))
+        out["fasta_identical_to_resident_batch"] = (want == text)
+        out["fasta_sha1"] = hashlib.sha1(text.encode()).hexdigest()[:16]
+    return out
 
 
 def measured_stream_rate(torch, mib=1024, reps=5):
@@ -155,97 +240,152 @@ def measured_stream_rate(torch, mib=1024, reps=5):
         return None
 
 
-def measured_traffic(kernel, piles):
+KERNEL_SOURCE = {"k_align": "k_align.hip", "k_score": "k_msa.hip", "k_links": "k_msa.hip",
+                 "k_tags": "k_msa.hip", "k_backtrace": "k_msa.hip", "k_chain": "k_chain.hip",
+                 "k_seed_index": "k_pack_index.hip"}
+
+
+def kernel_source_sha(kernel):
+    """Digest of the source file a kernel lives in: a PMC measurement is only presented as
+    this build's when it was taken on this source."""
+    try:
+        with open(os.path.join(ROOT, "falcon_amd", "csrc", KERNEL_SOURCE[kernel]), "rb") as f:
+            return hashlib.sha1(f.read()).hexdigest()[:16]
+    except (KeyError, OSError):
+        return None
+
+
+def measured_traffic(kernel, piles, workload):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under
-    profiles/ (FETCH/WRITE counters cannot be read from inside this process); None unless
-    a measurement of this kernel at this batch size is on file."""
+    profiles/ (the TCC counters cannot be read from inside this process); None unless a
+    measurement of this kernel's CURRENT source, at this batch size and workload, is on file
+    (profiles/pmc_traffic.json, written by scripts/pmc_traffic_record.py)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             rec = json.load(f).get(kernel)
-        if rec and int(rec["piles_per_launch"]) == int(piles):
-            return int(rec["hbm_bytes_per_launch"]), rec.get("what", "")
-    except Exception:
-        pass
-    return None, "no PMC measurement of this kernel at this batch size under profiles/"
+        if not rec:
+            return None, "no PMC measurement of this kernel under profiles/"
+        if int(rec["piles_per_launch"]) != int(piles) or rec.get("workload", "ecoli") != workload:
+            return None, "the PMC measurement on file is of another batch size or workload"
+        if rec.get("source_sha") != kernel_source_sha(kernel):
+            return None, ("the PMC measurement on file (%s) was taken on an older source of this "
+                          "kernel" % rec.get("taken_on", "?"))
+        return int(rec["hbm_bytes_per_launch"]), rec.get("what", "")
+    except Exception as e:
+        return None, "profiles/pmc_traffic.json unreadable: %r" % (e,)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--piles", type=int, default=int(os.environ.get("FALCON_BENCH_PILES", "3072")),
-                    help="piles per step per GPU")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="ecoli")
+    ap.add_argument("--piles", type=int, default=int(os.environ.get("FALCON_BENCH_PILES", "0")),
+                    help="piles per step per GPU (default: 3072 ecoli, 1024 dmel, 1536 arab)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.piles <= 0:
+        args.piles = WORKLOADS[args.workload]["piles"]
+    return args
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
 
-    # synthetic input first (forks worker processes; no GPU state exists yet)
-    ncpu = os.cpu_count() or 1
-    procs = max(1, min(32, ncpu // max(1, world)))
-    seeds = [1000003 * (rank + 1) + i for i in range(args.piles)]
-    t_gen = time.perf_counter()
-    piles = gen_piles(seeds, procs)
-    t_gen = time.perf_counter() - t_gen
+def relaunch_under_torchrun(args, argv):
+    """`bench.py --gpus N` started bare: become N ranks (one per GPU, RCCL) the way the
+    driver would have started them.  Fails loudly when the box has fewer devices."""
+    from falcon_amd.lib import load
+    n_dev = load().fa_device_count()
+    if n_dev < args.gpus:
+        sys.exit("bench.py: --gpus %d asked for, %d HIP device(s) visible -- refusing to run "
+                 "fewer ranks than asked for" % (args.gpus, n_dev))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    os.execv(sys.executable, cmd)
 
-    import torch
-    import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from falcon_amd.engine import Engine
+class Plumbing:
+    """Device/rendezvous plumbing of a rank: torch.distributed over RCCL ("nccl") on the GPU
+    box; the CPU tests run the same rank logic over gloo with a stand-in engine."""
 
-    eng = Engine(local_rank)
+    def __init__(self, rank, local_rank, world, backend="nccl"):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.local_rank, self.world, self.backend = rank, local_rank, world, backend
+        self.cuda = backend == "nccl"
+        if self.cuda:
+            torch.cuda.set_device(local_rank)
+        if world > 1:
+            kw = {"device_id": torch.device("cuda", local_rank)} if self.cuda else {}
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+            if dist.get_world_size() != world:
+                raise RuntimeError("rendezvous saw %d ranks, %d expected" % (dist.get_world_size(), world))
+
+    def sync(self):
+        if self.cuda:
+            self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
+    """What one rank does with its piles.  Returns the JSON object on rank 0 (also printed),
+    else None."""
+    rank, world = plumb.rank, plumb.world
+    wl = WORKLOADS[args.workload]
+    out = sys.stdout if out is None else out
+
+    eng = make_engine(plumb.local_rank)
     t_up = time.perf_counter()
     batch = eng.batch(piles)  # ASCII -> HBM, packed to 2 bits/base on the GPU
     t_up = time.perf_counter() - t_up
 
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
     for _ in range(args.warmup):
         batch.run(MIN_COV, K, MIN_IDT)
-    sync()
+    plumb.sync()
     t0 = time.perf_counter()
-    ms_align = ms_cns = ms_chain = ms_index = ms_total = 0.0
-    ms_k = {"k_tags": 0.0, "k_links": 0.0, "k_score": 0.0, "k_backtrace": 0.0}
+    acc = {}
     for _ in range(args.steps):
         batch.run(MIN_COV, K, MIN_IDT)  # returns after the stream drained
         st = batch.stats()
-        ms_align += st.ms_align
-        ms_cns += st.ms_consensus
-        ms_chain += st.ms_chain
-        ms_index += st.ms_index
-        ms_total += st.ms_total
-        ms_k["k_tags"] += st.ms_tags          # k_tags + k_tscan (0.7 ms)
-        ms_k["k_links"] += st.ms_links
-        ms_k["k_score"] += st.ms_score
-        ms_k["k_backtrace"] += st.ms_backtrace
-    sync()
+        for n in ("ms_align", "ms_consensus", "ms_chain", "ms_index", "ms_total", "ms_tags",
+                  "ms_links", "ms_score", "ms_backtrace"):
+            acc[n] = acc.get(n, 0.0) + getattr(st, n)
+    plumb.sync()
     elapsed = time.perf_counter() - t0
 
-    stream_gbs = measured_stream_rate(torch)
+    stream_gbs = measured_stream_rate(plumb.torch) if plumb.cuda else None
 
     st = batch.stats()
     # whole-job aggregate: units summed over ranks, time = slowest rank
     from falcon_amd.multigpu import reduce_measurement
     bases_all, piles_all, elapsed = reduce_measurement(float(st.O), float(st.n_piles), elapsed,
-                                                       device="cuda")
-
+                                                       device="cuda" if plumb.cuda else None)
+    ranks_ran = world
+    if world > 1:
+        one = plumb.torch.ones(1, dtype=plumb.torch.float64, device="cuda" if plumb.cuda else None)
+        plumb.dist.all_reduce(one)
+        ranks_ran = int(one.item())
+    res = None
     if rank == 0:
+        if ranks_ran != args.gpus:
+            raise RuntimeError("bench.py --gpus %d: %d rank(s) took part" % (args.gpus, ranks_ran))
         k = max(1, args.steps)
-        stage_ms = {"index": ms_index / k, "chain": ms_chain / k, "align": ms_align / k,
-                    "consensus": ms_cns / k}
+        stage_ms = {"index": acc["ms_index"] / k, "chain": acc["ms_chain"] / k,
+                    "align": acc["ms_align"] / k, "consensus": acc["ms_consensus"] / k}
         # between k_align and the MSA kernels the host sizes the MSA pools from the
         # alignment summaries (D2H, O(#reads) loop, H2D): device-idle time of the step
-        host_gap = ms_total / k - sum(stage_ms.values())
+        host_gap = acc["ms_total"] / k - sum(stage_ms.values())
         # algorithmic bytes per launch (DESIGN.md section 5)
         alg = {
             "index": st.T // 4 + 8 * st.T + 2 * 4 * 65537 * st.n_piles,
@@ -256,8 +396,10 @@ def main():
         # per kernel, HIP events on the engine's stream around every launch of the timed
         # region (the index / chain / align stages are one kernel each)
         kernel_ms = {"k_seed_index": stage_ms["index"], "k_chain": stage_ms["chain"],
-                     "k_align": stage_ms["align"]}
-        kernel_ms.update({n: v / k for n, v in ms_k.items()})
+                     "k_align": stage_ms["align"],
+                     "k_tags": acc["ms_tags"] / k,          # k_tags + k_tscan (0.7 ms)
+                     "k_links": acc["ms_links"] / k, "k_score": acc["ms_score"] / k,
+                     "k_backtrace": acc["ms_backtrace"] / k}
         kalg = {"k_seed_index": alg["index"], "k_chain": alg["chain"], "k_align": alg["align"],
                 "k_tags": 8 * st.D + 4 * st.A,            # script in, one tag word per column out
                 "k_links": 4 * st.A + 12 * st.T,          # tag words in, per-position arrays
@@ -265,19 +407,18 @@ def main():
                 "k_backtrace": 5 * st.O}
         domk = max(kernel_ms, key=lambda n: kernel_ms[n])
         ach = kalg[domk] / (kernel_ms[domk] * 1e-3) / 1e9 if kernel_ms[domk] > 0 else 0.0
-        traffic, traffic_src = measured_traffic(domk, args.piles)
-        out = {
+        traffic, traffic_src = measured_traffic(domk, args.piles, args.workload)
+        res = {
             "metric": "consensus_bases_per_sec",
             "value": round(bases_all * args.steps / elapsed, 1),
             "unit": "bases/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": ranks_ran, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int32 (2-bit packed bases, integer DP)",
             "data": "synthetic",
             "config": {
-                "workload": "E. coli-like piles: ~20 kb seed x 40x coverage, e=0.13 "
-                            "(BASELINE.json configs[1]; falcon_amd/synth.py, SURVEY.md 8d)",
+                "workload": wl["text"],
                 "piles_per_step_per_gpu": args.piles,
                 "flags": "--min-cov 4 --min-idt 0.70 --max-n-read 200 (K=8)",
                 "sequences_per_step_per_gpu": int(st.n_seqs),
@@ -300,17 +441,28 @@ def main():
             "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},
             "kernel_ms": {n: round(v, 4) for n, v in kernel_ms.items()},
             "host_plan_gap_ms": round(host_gap, 3),
+            # the counts B_alg = L/4 + 4C + 8D + 16A + 12T + 5O is made of, per step and GPU
+            "work": {"L": int(st.L), "C": int(st.C), "D": int(st.D), "A": int(st.A), "T": int(st.T),
+                     "O": int(st.O)},
             "path_b_alg_bytes_per_step": int(st.b_alg()),
             "path_frac_of_hbm_roofline": round(
                 st.b_alg() * world * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),
             "setup_s": {"generate": round(t_gen, 2), "stage_to_hbm_incl_pcie": round(t_up, 2),
                         "stage_to_hbm_incl_pcie_again": None},
         }
+        gpu_cns = None
+        if world == 1 and not (args.no_end_to_end and args.no_cpu_baseline):
+            # the consensus strings of the resident batch, for the two comparisons below
+            try:
+                batch.fetch(False)
+                gpu_cns = [batch.result(p) for p in range(batch.n_pile)]
+            except Exception:
+                gpu_cns = None
         if world == 1 and not args.no_end_to_end:
             try:
-                out["end_to_end"] = end_to_end(piles)
+                res["end_to_end"] = end_to_end(piles, expect=gpu_cns)
             except Exception as e:  # informative; never lose the GPU line
-                out["end_to_end"] = {"piles_per_sec": None, "what": "failed: %r" % (e,)}
+                res["end_to_end"] = {"piles_per_sec": None, "what": "failed: %r" % (e,)}
         if world == 1:
             # staging again, now that the context's pinned and device staging buffers exist:
             # the steady-state cost of handing a batch of host buffers over (outside `value`;
@@ -321,20 +473,53 @@ def main():
                 again = eng.batch(piles)
                 t_up2 = time.perf_counter() - t_up2
                 again.free()
-                out["setup_s"]["stage_to_hbm_incl_pcie_again"] = round(t_up2, 2)
+                res["setup_s"]["stage_to_hbm_incl_pcie_again"] = round(t_up2, 2)
             except Exception:  # informative; never lose the GPU line
                 pass
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(piles[:144])
+                res["cpu_baseline"], cpu_cns = cpu_baseline(piles)
+                if gpu_cns is not None:
+                    bad = [i for i, s in cpu_cns.items() if gpu_cns[i] != s]
+                    res["parity_checked_piles"] = len(cpu_cns)
+                    res["parity_mismatches"] = len(bad)
+                    res["parity_against"] = res["cpu_baseline"]["kind"]
+                    if bad:
+                        res["parity_mismatching_piles"] = bad[:16]
             except Exception as e:  # the baseline is informative; never lose the GPU line
-                out["cpu_baseline"] = {"value": None, "unit": "bases/s", "cores": 0,
+                res["cpu_baseline"] = {"value": None, "unit": "bases/s", "cores": 0,
                                        "kind": "unavailable", "sample": "failed: %r" % (e,)}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(res), file=out, flush=True)
     batch.free()
     eng.close()
-    if world > 1:
-        dist.destroy_process_group()
+    return res
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args, argv)  # does not return
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)"
+                 % (args.gpus, world))
+    wl = WORKLOADS[args.workload]
+    # synthetic input first (forks worker processes; no GPU state exists yet)
+    ncpu = os.cpu_count() or 1
+    procs = max(1, min(32, ncpu // max(1, world)))
+    seeds = [1000003 * (rank + 1) + i for i in range(args.piles)]
+    t0 = time.perf_counter()
+    piles = gen_piles(seeds, procs, wl)
+    gen_s = time.perf_counter() - t0
+    plumb = Plumbing(rank, local_rank, world, "nccl")
+    from falcon_amd.engine import Engine
+    try:
+        bench_rank(args, plumb, Engine, piles, gen_s)
+    finally:
+        plumb.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,131 @@
+"""bench.py's N > 1 path on CPU: the rank logic (bench_rank: barrier-bracketed timing, sum of
+units over ranks / max time, the ranks-that-ran check) over gloo with a stand-in engine, the
+refusal to run fewer ranks than --gpus asks for, and the launcher/--gpus consistency check.
+On the GPU box the same function runs over RCCL with falcon_amd.engine.Engine."""
+import io
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Stats:
+    def __init__(self, n_piles, bases):
+        self.O, self.n_piles, self.n_seqs, self.n_aligned = bases, n_piles, 10 * n_piles, 9 * n_piles
+        self.L, self.C, self.D, self.A, self.T = 1000 * n_piles, 5000 * n_piles, 100 * n_piles, 900 * n_piles, 100 * n_piles
+        for n in ("ms_align", "ms_consensus", "ms_chain", "ms_index", "ms_tags", "ms_links",
+                  "ms_score", "ms_backtrace"):
+            setattr(self, n, 1.0)
+        self.ms_total = 9.0
+
+    def b_alg(self):
+        return self.L // 4 + 4 * self.C + 8 * self.D + 16 * self.A + 12 * self.T + 5 * self.O
+
+
+class _Batch:
+    def __init__(self, piles):
+        self.n_pile = len(piles)
+        self.bases = sum(len(p[0]) for p in piles)
+
+    def run(self, *a):
+        import time
+        time.sleep(0.05)  # (a step long enough for the rounded ms_per_step to be exact to 1e-3)
+        return self
+
+    def stats(self):
+        return _Stats(self.n_pile, self.bases)
+
+    def free(self):
+        pass
+
+
+class StandInEngine:
+    def __init__(self, device):
+        self.device = device
+
+    def batch(self, piles):
+        return _Batch(piles)
+
+    def close(self):
+        pass
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _rank(rank, world, port, gpus, q):
+    sys.path.insert(0, ROOT)
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    args = bench.parse_args(["--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--piles", "4",
+                             "--no-cpu-baseline", "--no-end-to-end"])
+    plumb = bench.Plumbing(rank, rank, world, backend="gloo")
+    piles = [[b"A" * (100 * (rank + 1))] * 3 for _ in range(args.piles)]  # rank r: 4 piles x 100(r+1) "bases"
+    out = io.StringIO()
+    try:
+        res = bench.bench_rank(args, plumb, StandInEngine, piles, out=out)
+        q.put((rank, "ok", out.getvalue(), res is not None))
+    except Exception as e:
+        q.put((rank, "error", repr(e), False))
+    finally:
+        plumb.close()
+
+
+def _run_world(world, gpus):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank, args=(r, world, port, gpus, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    return res
+
+
+def test_two_ranks_reduce_to_one_line():
+    res = _run_world(2, 2)
+    assert [r[1] for r in res] == ["ok", "ok"], res
+    assert res[1][2] == "" and not res[1][3]          # only rank 0 prints
+    line = json.loads(res[0][2])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 2
+    # whole-job aggregate: 4 piles x 100 bases on rank 0 + 4 x 200 on rank 1, per step
+    assert line["value"] * line["ms_per_step"] * 1e-3 == pytest.approx(1200.0, rel=5e-3)
+    assert line["piles_per_sec"] * line["ms_per_step"] * 1e-3 == pytest.approx(8.0, rel=5e-3)
+    assert "cpu_baseline" not in line and "end_to_end" not in line  # rank 0, N = 1 only
+
+
+def test_rank_count_must_match_gpus():
+    res = _run_world(2, 4)   # --gpus 4 but only two ranks took part
+    assert res[0][1] == "error" and "2 rank(s) took part" in res[0][2]
+
+
+def test_bare_gpus_n_refuses_without_devices():
+    """`python bench.py --gpus 2` on a box with fewer than 2 devices fails loudly (it would
+    re-exec itself under torch.distributed.run otherwise)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                       capture_output=True, text=True, timeout=120,
+                       env={k: v for k, v in os.environ.items() if k != "WORLD_SIZE"})
+    if r.returncode == 0:
+        pytest.skip("this box has >= 2 HIP devices")
+    assert "refusing to run fewer ranks" in r.stderr
+
+
+def test_launcher_world_size_must_match_gpus():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "launcher started 2 rank(s)" in r.stderr
