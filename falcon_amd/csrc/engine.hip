@@ -80,6 +80,7 @@ struct fa_ctx {
     hipStream_t up_stream = nullptr;
     uint8_t *h_stage = nullptr, *d_stage = nullptr;
     size_t h_stage_cap = 0, d_stage_cap = 0;
+    int *d_first_bad = nullptr;  // k_pack: lowest sequence index holding a byte other than ACGT
 };
 
 template <class T>
@@ -234,6 +235,7 @@ extern "C" fa_ctx *fa_create(int device) {
     HIP_OK_P(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
     for (auto &e : c->ev) HIP_OK_P(hipEventCreate(&e));
     HIP_OK_P(hipMalloc((void **)&c->arena.counter, sizeof(int)));
+    HIP_OK_P(hipMalloc((void **)&c->d_first_bad, sizeof(int)));
     HIP_OK_P(hipMalloc((void **)&c->arena.prof, 8 * sizeof(u64)));
     HIP_OK_P(hipMemset(c->arena.prof, 0, 8 * sizeof(u64)));
     return c;
@@ -246,6 +248,7 @@ extern "C" void fa_destroy(fa_ctx *c) {
     if (c->arena.rows) (void)hipFree(c->arena.rows);
     if (c->arena.rowx) (void)hipFree(c->arena.rowx);
     if (c->arena.counter) (void)hipFree(c->arena.counter);
+    if (c->d_first_bad) (void)hipFree(c->d_first_bad);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -495,14 +498,29 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
         if (!pair_mode)
             ok &= hipMemcpyAsync(b->d_probe_off.p, b->probe_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
         trace_stage(s, "upload");
+        int first_bad = 0x7fffffff;
         if (ok) {
-            fa_launch_pack(b->dev(), s);
+            ok &= hipMemcpyAsync(ctx->d_first_bad, &first_bad, sizeof(int), hipMemcpyHostToDevice, s) == hipSuccess;
+            fa_launch_pack(b->dev(), ctx->d_first_bad, s);
             ok &= hipGetLastError() == hipSuccess;
+            ok &= hipMemcpyAsync(&first_bad, ctx->d_first_bad, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess;
         }
         // (also on the error path: nothing may still read the staging buffers)
         ok &= hipStreamSynchronize(s) == hipSuccess;
         trace_stage(s, "pack");
         b->ascii_dev = nullptr;
+        if (ok && first_bad != 0x7fffffff) {
+            // the reference aligns raw characters and codes other bytes specially
+            // (kmer_lookup.c:159-171, :236-249): outside the parity domain, refused
+            const FaSeq &sq = b->seq[first_bad];
+            int at = 0;
+            while (at < sq.len && strchr("ACGT", seqs[first_bad][at]) && seqs[first_bad][at]) at++;
+            set_err("falcon_amd: sequence %d of pile %d holds byte 0x%02x at position %d; only "
+                    "upper-case A, C, G, T are supported (what LA4Falcon emits)", sq.idx, sq.pile,
+                    at < sq.len ? (unsigned)(unsigned char)seqs[first_bad][at] : 0u, at);
+            delete b;
+            return nullptr;
+        }
     }
     if (!ok) {
         set_err("falcon_amd: staging the batch failed: %s", hipGetErrorString(hipGetLastError()));

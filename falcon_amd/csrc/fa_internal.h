@@ -156,7 +156,9 @@ struct FaAlignArena {
     u64 *prof;         // 8 debug counters (FA_ALIGN_PROF builds)
 };
 
-void fa_launch_pack(const FaBatchDev &b, hipStream_t s);
+// first_bad: device int, preset to INT_MAX; receives the lowest sequence index holding a byte
+// other than upper-case A, C, G, T
+void fa_launch_pack(const FaBatchDev &b, int *first_bad, hipStream_t s);
 void fa_launch_index(const FaBatchDev &b, hipStream_t s);
 void fa_launch_chain(const FaBatchDev &b, int max_bins, hipStream_t s);
 // general banded alignment for band tolerances beyond FA_ALIGN_MAXCH chunks (k_align_wide.hip)

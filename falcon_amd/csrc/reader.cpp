@@ -258,8 +258,14 @@ extern "C" int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, 
     auto batch_open = [&]() {
         return !r->finished && (long long)r->pile_n_seq.size() < max_piles && r->batch_bases < max_bases;
     };
+    // Line ends are python's universal newlines (a text-mode sys.stdin, which is what
+    // consensus.py:170 iterates): '\n', '\r\n', and a lone '\r'.  A '\r' in front of a '\n'
+    // is just white space of its line; the scanner never looks at a '\r' whose successor is
+    // not in the buffer yet (see `end` below), so text[i + 1] exists here unless the stream
+    // has ended.
     auto event = [&](size_t i) {  // false: stop scanning (batch closed or stream finished)
-        if (r->text[i] != '\n') {
+        const char c = r->text[i];
+        if (c != '\n' && !(c == '\r' && (i + 1 >= r->filled || r->text[i + 1] != '\n'))) {
             if (r->line_low++ == 0) r->line_first_low = i;
             return true;
         }
@@ -271,9 +277,13 @@ extern "C" int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, 
     };
     const __m128i lim = _mm_set1_epi8(0x20);
     while (batch_open()) {
-        if (r->scanned == r->filled) {
+        // a '\r' at the very end of what has been read waits for its successor
+        size_t end = r->filled;
+        if (!r->eof && end > r->scanned && r->text[end - 1] == '\r') end--;
+        if (r->scanned >= end) {
             if (fill(r)) continue;
             if (!r->err.empty()) return -1;
+            if (r->scanned < r->filled) continue;  // the '\r' that waited: the stream ends behind it
             // end of file: a last line without '\n' still counts (python iterates it too)
             if (r->parsed < r->filled) {
                 const size_t b = r->parsed;
@@ -286,7 +296,6 @@ extern "C" int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, 
         }
         const char *t = r->text;
         size_t i = r->scanned;
-        const size_t end = r->filled;
         bool go = true;
         while (go && i + 16 <= end) {
             const __m128i v = _mm_loadu_si128((const __m128i *)(t + i));

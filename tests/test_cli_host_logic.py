@@ -3,6 +3,7 @@ formatting against the CLI golden vectors produced by the reference's own
 driver.  The consensus calls themselves are served by the CPU oracle here (this
 is a test harness; the product CLI only ever uses the GPU engine)."""
 import io
+import os
 
 import pytest
 
@@ -70,3 +71,30 @@ def test_pile_reader_grammar():
     cfg = cli.Settings(4, 8, 500, 0.7, 1000, 50, 0, 0)
     piles = list(cli.PileReader(io.StringIO(text), cfg, 1, 0))
     assert piles == [("s1", ["ACGT", "ACGT", "AAAA", "GG"])]
+
+
+def test_dropin_overlay_falls_through_to_the_reference_package(tmp_path):
+    """PYTHONPATH=dropin:<reference>: the overlay answers falcon_kit, falcon_kit.falcon_kit and
+    falcon_kit.mains.consensus; every other submodule (the consensus job imports
+    falcon_kit.mains.consensus_task, falcon_kit.io, ... first: pype_tasks.py:38,
+    consensus_task.py:8-9) must still resolve in the package behind it.  The package behind
+    it here is a stand-in with the same shape."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = tmp_path / "ref" / "falcon_kit"
+    (ref / "mains").mkdir(parents=True)
+    (ref / "__init__.py").write_text("WHO = 'reference'\n")
+    (ref / "io.py").write_text("WHO = 'reference io'\n")
+    (ref / "falcon_kit.py").write_text("WHO = 'reference falcon_kit'\n")
+    (ref / "mains" / "__init__.py").write_text("")
+    (ref / "mains" / "consensus_task.py").write_text("from .. import io\nWHO = 'reference task ' + io.WHO\n")
+    (ref / "mains" / "consensus.py").write_text("WHO = 'reference consensus'\n")
+    code = ("import falcon_kit, falcon_kit.io, falcon_kit.falcon_kit, falcon_kit.mains.consensus_task as t, "
+            "falcon_kit.mains.consensus as c\n"
+            "print(t.WHO); print(falcon_kit.io.WHO); print(hasattr(falcon_kit, 'kup'), "
+            "hasattr(falcon_kit.falcon_kit, 'kup'), hasattr(c, 'parse_args'), hasattr(c, 'WHO'))\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "dropin"), str(tmp_path / "ref"), root]))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split("\n")[:3] == ["reference task reference io", "reference io", "True True True False"]

@@ -60,8 +60,10 @@ def test_absurd_band_is_refused_loudly(engine):
 
 
 def test_limits_are_errors_not_silent_degradation(engine):
-    """K != 8, a seed of >= 100 000 bases (the reference asserts, falcon.c:343): loud errors;
-    sequences with non-ACGT letters are packed like the reference's table does."""
+    """K != 8, a seed of >= 100 000 bases (the reference asserts, falcon.c:343), bytes other
+    than upper-case ACGT (the reference aligns raw characters and codes other bytes 0xff / 0
+    in its k-mer tables, kmer_lookup.c:159-171,236-249: outside the parity domain): loud
+    errors naming the offender, never a silently different answer."""
     from falcon_amd.lib import FalconAmdError
     rng = np.random.default_rng(2)
     seq = "".join("ACGT"[i] for i in rng.integers(0, 4, 1200))
@@ -72,6 +74,15 @@ def test_limits_are_errors_not_silent_degradation(engine):
     big = "".join("ACGT"[i] for i in rng.integers(0, 4, 100000))
     with pytest.raises(FalconAmdError, match="100000"):
         engine.batch([[big, big[:5000]]])
+    for bad, at in (("N", 700), ("a", 0), ("\r", 1199)):
+        dirty = seq[:at] + bad + seq[at + 1:]
+        with pytest.raises(FalconAmdError, match="sequence 2 of pile 1 holds byte 0x%02x at position %d" % (ord(bad), at)):
+            engine.batch([[seq, seq, seq], [seq, seq, dirty, seq]])
+        with pytest.raises(FalconAmdError, match="holds byte"):
+            engine.align_pairs([(seq, seq), (dirty, seq)], band=150)
+    b = engine.batch([[seq, seq, seq]])  # the context is fine afterwards
+    b.run(4, 8, 0.70)
+    b.free()
 
 
 def test_wide_band_vs_oracle(engine):

@@ -37,7 +37,8 @@ def _native(text, min_n_read, min_len_aln, min_cov_aln, max_n_read, max_cov_aln,
 
 def _python(text, min_n_read, min_len_aln, min_cov_aln, max_n_read, max_cov_aln):
     cfg = Settings(4, 8, max_n_read, 0.70, 1000, 50, min_cov_aln, max_cov_aln)
-    return list(PileReader(io.StringIO(text), cfg, min_n_read, min_len_aln))
+    # newline=None: universal newlines, like the text-mode sys.stdin the worker iterates
+    return list(PileReader(io.StringIO(text, newline=None), cfg, min_n_read, min_len_aln))
 
 
 def _rand_seq(rng, n):
@@ -139,6 +140,42 @@ def test_long_sequences_are_cut_and_stream_end_variants():
     # CRLF line ends and a last line without newline
     crlf = "s1 ACGTACGT\r\nr1 ACGTAC\r\n+ +\r\ns2 AAAA\r\nr9 CC\r\n+ +"
     assert _native(crlf, 1, 0, 0, 500, 0)[0] == _python(crlf, 1, 0, 0, 500, 0)
+
+
+def test_lone_carriage_returns_end_lines_like_universal_newlines():
+    """A text-mode sys.stdin (what consensus.py:170 iterates) ends lines at '\\n', '\\r\\n' and a
+    lone '\\r'; the native reader agrees byte for byte, also when the '\\r' is the last byte
+    of a read() or of the stream."""
+    opts = (2, 0, 0, 500, 0)
+    for text in ("s1 ACGTACGT\rr1 ACGTAC\r+ +\rs2 AAAA\rr9 CC\r+ +\r",
+                 "s1 ACGTACGT\rr1 ACGTAC\r\n+ +\r\r\ns2 AAAA\n\rr9 CC\r+ +",
+                 "s1 ACGT\r", "\r", "s1 AC\rr1 GG\r+ +\r- -\rs2 AAAA\rr9 CC\r+ +\r"):
+        got, _ = _native(text, *opts)
+        assert got == _python(text, *opts), repr(text)
+    # the '\r' falls on the end of a pipe read: fed byte by byte
+    text = "s1 ACGTACGT\rr1 ACGTAC\r+ +\rs2 AAAA\r\nr9 CC\r+ +\r"
+    rd, wr = os.pipe()
+
+    def feed():
+        for ch in text.encode():
+            os.write(wr, bytes([ch]))
+            time.sleep(0.001)
+        os.close(wr)
+    import threading
+    import time
+    th = threading.Thread(target=feed)
+    th.start()
+    r = Reader(rd, *opts)
+    out = []
+    while True:
+        ps = r.next()
+        if ps is None:
+            break
+        out.extend(zip(ps.seed_ids, ps.piles()))
+    r.close()
+    th.join()
+    os.close(rd)
+    assert out == _python(text, *opts)
 
 
 def test_cli_native_path_orders_and_prints(tmp_path):
@@ -257,7 +294,7 @@ def test_bench_end_to_end_text_rebuilds_the_bench_piles(tmp_path):
     """bench.py's end-to-end leg writes its piles out as LA4Falcon text: the reader hands
     the worker exactly the piles the kernel-only legs run on."""
     import bench
-    piles = [bench._gen_pile(s) for s in (5, 6)]
+    piles = bench.gen_piles([5, 6], 1, bench.WORKLOADS["ecoli"])
     path = tmp_path / "piles.txt"
     with open(path, "wb") as f:
         bench.write_la4falcon(piles, f)
