@@ -985,7 +985,10 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                     const u32 pp = ((u32)(pidw + 1) << 4) | (u32)ss;
                     const u32 r_key = (u32)__builtin_amdgcn_ds_permute(dst << 2, fa_sel(tail_m, 0, (int)key));
                     const u32 r_pp = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)pp);
-                    const bool got = r_key != 0u;  // a node of this level landed on my lane
+                    // a node of this level landed on my lane, with a link above the floor: a
+                    // node keeps -1 (-2 half units) and the zero back pointer unless some link
+                    // scores strictly more (falcon.c:420,447; Q4)
+                    const bool got = r_key > (((u32)(SC_BIAS - 2) << 4) | 15u);
                     cur.h = got ? (int)(r_key >> 4) - SC_BIAS : cur.h;
                     cur.p = got ? (int)(r_pp >> 4) - 1 : cur.p;
                     cur.k = got ? 15 - (int)(r_key & 15u) - (int)(r_pp & 15u) : cur.k;

@@ -5,7 +5,13 @@ as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- WRITE_SIZE and FETCH_SIZ
 passes, both in KiB, each calibrated on a kernel of this very run whose traffic is known
 exactly: k_pack streams the staged ASCII in (16 bytes per lane) and the 2-bit words out.
 
-    python scripts/pmc_traffic_record.py gpurun_out/<dir with p*/ passes> [kernel] [workload]
+    python scripts/pmc_traffic_record.py gpurun_out/<dir with p*/ passes> [kernel] [workload] [read factor]
+
+FETCH_SIZE counts 64 bytes per request to the fabric: k_pack's wide streaming reads go out
+as 128-byte requests and need x1.90 (the guide's "double it"); k_align's reads are the
+trace-back's 4-byte gathers, one 64-byte request each (sum of edit distances = 0.58 G
+gathers x 64 B = 37.1 GB predicted, 37.7 GB counted), so for k_align the read side is
+taken raw (read factor 1.0) -- the k_pack factor is recorded beside it.
 
 The record carries the digest of the kernel's source file; bench.py presents it as
 `roofline.traffic` only while that source is unchanged."""
@@ -55,7 +61,8 @@ def main():
     rd, wr = mean(kernel, "FETCH_SIZE"), mean(kernel, "WRITE_SIZE")
     if rd is None or wr is None:
         sys.exit("passes for FETCH_SIZE and WRITE_SIZE of %s are both needed" % kernel)
-    rd_b = rd * 1024.0 * (cal["FETCH_SIZE"] or 1.0)
+    rd_factor = float(sys.argv[4]) if len(sys.argv) > 4 else (cal["FETCH_SIZE"] or 1.0)
+    rd_b = rd * 1024.0 * rd_factor
     wr_b = wr * 1024.0 * (cal["WRITE_SIZE"] or 1.0)
     alg = line["roofline"]["algorithmic_bytes_per_launch"] if line["roofline"]["kernel"] == kernel else None
     rec = {
@@ -64,12 +71,15 @@ def main():
         "read_bytes": int(rd_b), "write_bytes": int(wr_b),
         "raw_KiB": {"FETCH_SIZE": rd, "WRITE_SIZE": wr},
         "calibration_on_k_pack": {k: (round(v, 4) if v else None) for k, v in cal.items()},
+        "read_factor_applied": rd_factor,
         "algorithmic_bytes_per_launch": alg,
         "source_sha": bench.kernel_source_sha(kernel),
         "taken_on": os.path.basename(os.path.normpath(d)),
         "what": "FETCH_SIZE + WRITE_SIZE (KiB) of %s, separate --pmc passes of `bench.py --steps 1 "
-                "--warmup 0` (kernel-trace only), each scaled by the factor that makes k_pack's "
-                "counter equal its exactly known traffic in the same pass" % kernel,
+                "--warmup 0` (kernel-trace only, --kernel-include-regex 'k_align|k_pack'); WRITE_SIZE "
+                "scaled by the factor that makes k_pack's counter equal its exactly known output "
+                "(0.999), FETCH_SIZE by %.2f (k_pack's 16-byte streaming reads need 1.90: 128-byte "
+                "requests counted as 64; 4-byte gathers are one 64-byte request each)" % (kernel, rd_factor),
     }
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:

@@ -101,18 +101,19 @@ __global__ __launch_bounds__(64, 8) void k_s_b64(unsigned *out, unsigned long lo
 }
 // k_align's mix: one scalar instruction beside every vector one (different pipes: do they overlap?)
 #define VS8 \
-    "v_add_u32 %0, %0, %8\n\t" "s_add_u32 %9, %9, %13\n\t" "v_add_u32 %1, %1, %8\n\t" "s_add_u32 %10, %10, %13\n\t" \
-    "v_add_u32 %2, %2, %8\n\t" "s_add_u32 %11, %11, %13\n\t" "v_add_u32 %3, %3, %8\n\t" "s_add_u32 %12, %12, %13\n\t" \
-    "v_add_u32 %4, %4, %8\n\t" "s_add_u32 %9, %9, %13\n\t" "v_add_u32 %5, %5, %8\n\t" "s_add_u32 %10, %10, %13\n\t" \
-    "v_add_u32 %6, %6, %8\n\t" "s_add_u32 %11, %11, %13\n\t" "v_add_u32 %7, %7, %8\n\t" "s_add_u32 %12, %12, %13\n\t"
+    "v_add_u32 %0, %0, %12\n\t" "s_add_u32 %8, %8, %13\n\t" "v_add_u32 %1, %1, %12\n\t" "s_add_u32 %9, %9, %13\n\t" \
+    "v_add_u32 %2, %2, %12\n\t" "s_add_u32 %10, %10, %13\n\t" "v_add_u32 %3, %3, %12\n\t" "s_add_u32 %11, %11, %13\n\t" \
+    "v_add_u32 %4, %4, %12\n\t" "s_add_u32 %8, %8, %13\n\t" "v_add_u32 %5, %5, %12\n\t" "s_add_u32 %9, %9, %13\n\t" \
+    "v_add_u32 %6, %6, %12\n\t" "s_add_u32 %10, %10, %13\n\t" "v_add_u32 %7, %7, %12\n\t" "s_add_u32 %11, %11, %13\n\t"
 __global__ __launch_bounds__(64, 8) void k_mix(unsigned *out, unsigned long long *clk) {
     unsigned a = threadIdx.x, b = a + 1, c = a + 2, d = a + 3, e = a + 4, f = a + 5, g = a + 6, h = a + 7, k = blockIdx.x | 1;
     unsigned s0 = blockIdx.x, s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3, sk = blockIdx.x | 1;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < ITER; i++)
         asm volatile(REP32(VS8)
-                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h)
-                     : "v"(k), "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(sk) : "scc");
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h),
+                       "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3)
+                     : "v"(k), "s"(sk) : "scc");
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * 64 + threadIdx.x] = a + b + c + d + e + f + g + h + s0 + s1 + s2 + s3;
     if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
@@ -147,6 +148,7 @@ static void run(const char *name, kern_t k, double per_iter, int waves_per_simd,
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     hipDeviceProp_t p;
     CHECK(hipGetDeviceProperties(&p, 0));
     printf("%s: %d CUs, clockRate %d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
