@@ -67,8 +67,18 @@ struct fa_ctx {
     int device = 0;
     int n_cu = 0;
     size_t total_mem = 0;
+    // Three streams.  `stream` (front): seed index, k-mer chaining, alignment, tags, links --
+    // the throughput kernels, one batch at a time (they share the alignment arena; front_mu).
+    // `back_stream`: k_score + k_backtrace, one wavefront per pile walking its levels in
+    // sequence, latency-bound at a few wavefronts per SIMD: they run next to the NEXT
+    // batch's front stages (fa_batch_submit / fa_batch_wait).  `dl_stream`: result
+    // download, so that a fetch never queues behind another batch's kernels.
     hipStream_t stream = nullptr;
-    hipEvent_t ev[12] = {};
+    hipStream_t back_stream = nullptr;
+    hipStream_t dl_stream = nullptr;
+    std::mutex front_mu, fetch_mu;
+    char *h_dl = nullptr;    // pinned landing buffer of the downloads (grow only; fetch_mu)
+    size_t h_dl_cap = 0;
     // alignment work-slot arena (grow only)
     FaAlignArena arena = {};
     size_t arena_cells_bytes = 0, arena_rows_bytes = 0;  // rows and rowx have equal size
@@ -186,12 +196,23 @@ struct fa_batch {
     HostBuf<FaPileOut> h_pile_out;
     HostBuf<FaTagAln> h_ta;
     bool msa_static = false;  // seg lists and t_off (functions of the seed lengths) uploaded
-    std::vector<char> h_out_seq;
     std::vector<int> h_out_eqv;
     std::vector<std::string> h_result;
     bool have_range = false, have_aln = false, fetched = false, fetched_eqv = false;
     u64 out_slots = 0;
     fa_stats stats = {};
+    // timing events of the last run (0..7 on the front stream, 8..11 on the back stream)
+    hipEvent_t ev[12] = {};
+    bool in_flight = false;  // fa_batch_submit done, fa_batch_wait pending
+    ~fa_batch() {
+        for (auto &e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+    int ensure_events() {
+        for (auto &e : ev)
+            if (!e && hipEventCreate(&e) != hipSuccess) return -1;
+        return 0;
+    }
 
     FaBatchDev dev() const {
         FaBatchDev b;
@@ -232,8 +253,9 @@ extern "C" fa_ctx *fa_create(int device) {
     c->n_cu = prop.multiProcessorCount;
     c->total_mem = prop.totalGlobalMem;
     HIP_OK_P(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_OK_P(hipStreamCreateWithFlags(&c->back_stream, hipStreamNonBlocking));
+    HIP_OK_P(hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
     HIP_OK_P(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
-    for (auto &e : c->ev) HIP_OK_P(hipEventCreate(&e));
     HIP_OK_P(hipMalloc((void **)&c->arena.counter, sizeof(int)));
     HIP_OK_P(hipMalloc((void **)&c->d_first_bad, sizeof(int)));
     HIP_OK_P(hipMalloc((void **)&c->arena.prof, 8 * sizeof(u64)));
@@ -249,8 +271,9 @@ extern "C" void fa_destroy(fa_ctx *c) {
     if (c->arena.rowx) (void)hipFree(c->arena.rowx);
     if (c->arena.counter) (void)hipFree(c->arena.counter);
     if (c->d_first_bad) (void)hipFree(c->d_first_bad);
-    for (auto &e : c->ev)
-        if (e) (void)hipEventDestroy(e);
+    if (c->h_dl) (void)hipHostFree(c->h_dl);
+    if (c->back_stream) (void)hipStreamDestroy(c->back_stream);
+    if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
@@ -542,6 +565,7 @@ extern "C" fa_batch *fa_batch_create(fa_ctx *ctx, int n_pile, const int *pile_n_
 extern "C" void fa_batch_free(fa_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
+    if (b->in_flight && b->ev[6]) (void)hipEventSynchronize(b->ev[6]);  // its kernels still read it
     // (its device and pinned buffers release themselves)
     delete b;
 }
@@ -633,10 +657,19 @@ static int fetch_aln(fa_batch *b) {
 // falcon.c:699-704).
 static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int band,
                            int force_accept_g);
+static int finish_run(fa_batch *b);
 
-extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double min_idt) {
+// Front stages of a run (seed index, chaining, alignment, MSA plan, tags, links) on the
+// context's front stream -- this call returns when they are done -- then k_score and
+// k_backtrace are queued on the back stream and the call returns without waiting for
+// them: the next batch's fa_batch_submit overlaps their latency-bound walk.
+extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double min_idt) {
     if (!b || b->pair_mode) {
-        set_err("falcon_amd: fa_batch_run on an invalid batch");
+        set_err("falcon_amd: fa_batch_submit on an invalid batch");
+        return -1;
+    }
+    if (b->in_flight) {
+        set_err("falcon_amd: fa_batch_submit on a batch that is still running (fa_batch_wait first)");
         return -1;
     }
     if (K != FA_K) {
@@ -646,6 +679,11 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     }
     fa_ctx *c = b->ctx;
     HIP_OK(hipSetDevice(c->device));
+    if (b->ensure_events()) {
+        set_err("falcon_amd: hipEventCreate failed");
+        return -1;
+    }
+    std::lock_guard<std::mutex> front(c->front_mu);  // one batch at a time on the front stream
     hipStream_t s = c->stream;
     b->fetched = b->fetched_eqv = false;
     b->have_range = b->have_aln = false;
@@ -654,18 +692,35 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     if (ensure_arena(c, b, lds, false)) return -1;
     FaBatchDev d = b->dev();
 
-    HIP_OK(hipEventRecord(c->ev[0], s));
+    HIP_OK(hipEventRecord(b->ev[0], s));
     fa_launch_index(d, s);
-    HIP_OK(hipEventRecord(c->ev[1], s));
+    HIP_OK(hipEventRecord(b->ev[1], s));
     trace_stage(s, "index");
     fa_launch_chain(d, b->max_bins, s);
-    HIP_OK(hipEventRecord(c->ev[2], s));
+    HIP_OK(hipEventRecord(b->ev[2], s));
     trace_stage(s, "chain");
     // s2 of every alignment (needed by the MSA plan) travels while k_align runs
     if (b->h_range.resize(b->n_seq)) return -1;
     HIP_OK(hipMemcpyAsync(b->h_range.data(), b->d_range.p, (size_t)b->n_seq * sizeof(FaRange),
                           hipMemcpyDeviceToHost, s));
     return run_from_ranges(b, min_cov, max_diff, FA_BAND, -1);
+}
+
+// The rest of a submitted run: waits for the back stream's kernels, checks every pile's
+// verdict, fills the statistics.
+extern "C" int fa_batch_wait(fa_batch *b) {
+    if (!b || !b->in_flight) {
+        set_err("falcon_amd: fa_batch_wait without fa_batch_submit");
+        return -1;
+    }
+    HIP_OK(hipSetDevice(b->ctx->device));
+    return finish_run(b);
+}
+
+extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double min_idt) {
+    int rc = fa_batch_submit(b, min_cov, K, min_idt);
+    if (rc) return rc;
+    return fa_batch_wait(b);
 }
 
 static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int band,
@@ -680,7 +735,7 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
             fa_launch_align_band(d, c->arena, b->max_read_len, b->max_seed_len, max_diff, band, s);
     };
     launch_align();
-    HIP_OK(hipEventRecord(c->ev[3], s));
+    HIP_OK(hipEventRecord(b->ev[3], s));
     trace_stage(s, "align");
     if (getenv("FALCON_AMD_PROF")) {  // only meaningful in -DFA_ALIGN_PROF builds
         u64 pf[8];
@@ -734,7 +789,7 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
         c->arena_full = true;
         if (ensure_arena(c, b, fa_align_lds_bytes(b->max_read_len, b->max_seed_len), true)) return -1;
         launch_align();
-        HIP_OK(hipEventRecord(c->ev[3], s));
+        HIP_OK(hipEventRecord(b->ev[3], s));
         HIP_OK(hipGetLastError());
         b->stats.align_relaunched = 1;
         rc_aln = fetch_aln(b);
@@ -838,16 +893,33 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
     md.wide_count = b->d_wide.p; md.wide_list = b->d_wide.p + 1;
     md.first_links_back = force_accept_g >= 0 ? 1 : 0;
     d = b->dev();
-    HIP_OK(hipEventRecord(c->ev[4], s));
-    fa_launch_msa(d, md, min_cov, s, c->ev + 8);
-    HIP_OK(hipEventRecord(c->ev[5], s));
-    trace_stage(s, "consensus");
+    HIP_OK(hipEventRecord(b->ev[4], s));
+    fa_launch_msa_front(d, md, min_cov, s, b->ev[8], b->ev[9]);  // k_tags + k_tscan | k_links
+    HIP_OK(hipEventRecord(b->ev[5], s));
+    trace_stage(s, "links");
+    HIP_OK(hipGetLastError());
+    // k_score + k_backtrace on the back stream, behind this batch's links
+    hipStream_t sb = c->back_stream;
+    HIP_OK(hipStreamWaitEvent(sb, b->ev[5], 0));
+    HIP_OK(hipEventRecord(b->ev[7], sb));
+    fa_launch_msa_back(d, md, min_cov, sb, b->ev[10], b->ev[11]);  // k_score | k_backtrace
+    trace_stage(sb, "consensus");
     HIP_OK(hipGetLastError());
     if (b->h_pile_out.resize(b->n_pile)) return -1;
     HIP_OK(hipMemcpyAsync(b->h_pile_out.data(), b->d_pile_out.p,
-                          (size_t)b->n_pile * sizeof(FaPileOut), hipMemcpyDeviceToHost, s));
-    HIP_OK(hipEventRecord(c->ev[6], s));
-    HIP_OK(hipStreamSynchronize(s));
+                          (size_t)b->n_pile * sizeof(FaPileOut), hipMemcpyDeviceToHost, sb));
+    HIP_OK(hipEventRecord(b->ev[6], sb));
+    // what the statistics need of this plan
+    b->stats.C = sC; b->stats.D = sD; b->stats.A = sA; b->stats.n_aligned = nal;
+    b->stats.align_slots = c->arena.n_slot;
+    b->stats.align_slot_cells = (long long)c->arena.cells_per_slot;
+    b->in_flight = true;
+    return 0;
+}
+
+static int finish_run(fa_batch *b) {
+    b->in_flight = false;
+    HIP_OK(hipEventSynchronize(b->ev[6]));
     long long sO = 0;
     for (int p = 0; p < b->n_pile; p++) {
         if (b->h_pile_out[p].err) {
@@ -858,18 +930,18 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
         sO += b->h_pile_out[p].len;
     }
     fa_stats &st = b->stats;
-    st.C = sC; st.D = sD; st.A = sA; st.O = sO; st.n_aligned = nal;
-    st.align_slots = c->arena.n_slot;
-    st.align_slot_cells = (long long)c->arena.cells_per_slot;
-    (void)hipEventElapsedTime(&st.ms_index, c->ev[0], c->ev[1]);
-    (void)hipEventElapsedTime(&st.ms_chain, c->ev[1], c->ev[2]);
-    (void)hipEventElapsedTime(&st.ms_align, c->ev[2], c->ev[3]);
-    (void)hipEventElapsedTime(&st.ms_consensus, c->ev[4], c->ev[5]);
-    (void)hipEventElapsedTime(&st.ms_total, c->ev[0], c->ev[6]);
-    (void)hipEventElapsedTime(&st.ms_tags, c->ev[4], c->ev[8]);
-    (void)hipEventElapsedTime(&st.ms_links, c->ev[8], c->ev[9]);
-    (void)hipEventElapsedTime(&st.ms_score, c->ev[9], c->ev[10]);
-    (void)hipEventElapsedTime(&st.ms_backtrace, c->ev[10], c->ev[11]);
+    st.O = sO;
+    (void)hipEventElapsedTime(&st.ms_index, b->ev[0], b->ev[1]);
+    (void)hipEventElapsedTime(&st.ms_chain, b->ev[1], b->ev[2]);
+    (void)hipEventElapsedTime(&st.ms_align, b->ev[2], b->ev[3]);
+    (void)hipEventElapsedTime(&st.ms_tags, b->ev[4], b->ev[8]);
+    (void)hipEventElapsedTime(&st.ms_links, b->ev[8], b->ev[9]);
+    (void)hipEventElapsedTime(&st.ms_score, b->ev[7], b->ev[10]);
+    (void)hipEventElapsedTime(&st.ms_backtrace, b->ev[10], b->ev[11]);
+    // the consensus stage = its four kernels (the last two may have run beside another
+    // batch's front stages); total = first launch to last result, whatever ran in between
+    st.ms_consensus = st.ms_tags + st.ms_links + st.ms_score + st.ms_backtrace;
+    (void)hipEventElapsedTime(&st.ms_total, b->ev[0], b->ev[6]);
     return 0;
 }
 
@@ -936,9 +1008,14 @@ extern "C" fa_batch *fa_utg_consensus(fa_ctx *ctx, int n_seq, const char *const 
         return fail("range upload failed");
     b->fetched = b->fetched_eqv = false;
     b->have_aln = false;
-    if (ensure_arena(c, b, fa_align_lds_bytes(b->max_read_len, b->max_seed_len), true)) return fail(nullptr);
-    for (int i = 0; i < 3; i++) (void)hipEventRecord(c->ev[i], s);
-    if (run_from_ranges(b, 0, 1.0 - min_idt, band, 1)) return fail(nullptr);
+    if (b->ensure_events()) return fail("hipEventCreate failed");
+    {
+        std::lock_guard<std::mutex> front(c->front_mu);
+        if (ensure_arena(c, b, fa_align_lds_bytes(b->max_read_len, b->max_seed_len), true)) return fail(nullptr);
+        for (int i = 0; i < 3; i++) (void)hipEventRecord(b->ev[i], s);
+        if (run_from_ranges(b, 0, 1.0 - min_idt, band, 1)) return fail(nullptr);
+    }
+    if (finish_run(b)) return fail(nullptr);
     return b;
 }
 
@@ -956,6 +1033,7 @@ extern "C" int fa_batch_trim_windows(fa_batch *b, unsigned K, int mask_threshold
     }
     fa_ctx *c = b->ctx;
     HIP_OK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> front(c->front_mu);
     hipStream_t s = c->stream;
     b->have_range = false;
     FaBatchDev d = b->dev();
@@ -995,26 +1073,40 @@ extern "C" int fa_batch_trim_windows(fa_batch *b, unsigned K, int mask_threshold
 }
 
 extern "C" int fa_batch_fetch(fa_batch *b, int want_eqv) {
-    if (!b || b->pair_mode || b->h_pile_out.empty()) {
-        set_err("falcon_amd: fa_batch_fetch before fa_batch_run");
+    if (!b || b->pair_mode || b->h_pile_out.empty() || b->in_flight) {
+        set_err("falcon_amd: fa_batch_fetch before a completed fa_batch_run");
         return -1;
     }
     fa_ctx *c = b->ctx;
     HIP_OK(hipSetDevice(c->device));
-    b->h_out_seq.resize(b->out_slots + 8);
-    HIP_OK(hipMemcpyAsync(b->h_out_seq.data(), b->d_out_seq.p, b->out_slots, hipMemcpyDeviceToHost,
-                          c->stream));
-    if (want_eqv) {
-        b->h_out_eqv.resize(b->out_slots + 8);
-        HIP_OK(hipMemcpyAsync(b->h_out_eqv.data(), b->d_out_eqv.p, b->out_slots * sizeof(int),
-                              hipMemcpyDeviceToHost, c->stream));
+    // Through the context's pinned landing buffer, on the download stream: a true DMA
+    // transfer that queues behind no kernel.  A pile's consensus sits right-aligned in its
+    // 2T slots; what is used of a batch is one contiguous span per pile, fetched whole
+    // (the slots are contiguous) and cut up on the host.
+    std::lock_guard<std::mutex> hold(c->fetch_mu);
+    const size_t per_slot = want_eqv ? 1 + sizeof(int) : 1;
+    const size_t need = (b->out_slots + 8) * per_slot;
+    if (need > c->h_dl_cap) {
+        if (c->h_dl) (void)hipHostFree(c->h_dl);
+        c->h_dl = nullptr;
+        c->h_dl_cap = 0;
+        const size_t cap = need + need / 8;
+        HIP_OK(hipHostMalloc((void **)&c->h_dl, cap, hipHostMallocDefault));
+        c->h_dl_cap = cap;
     }
-    HIP_OK(hipStreamSynchronize(c->stream));
+    char *h_seq = c->h_dl;
+    int *h_eqv = reinterpret_cast<int *>(c->h_dl + ((b->out_slots + 8 + 15) & ~(size_t)15));
+    HIP_OK(hipMemcpyAsync(h_seq, b->d_out_seq.p, b->out_slots, hipMemcpyDeviceToHost, c->dl_stream));
+    if (want_eqv)
+        HIP_OK(hipMemcpyAsync(h_eqv, b->d_out_eqv.p, b->out_slots * sizeof(int), hipMemcpyDeviceToHost,
+                              c->dl_stream));
+    HIP_OK(hipStreamSynchronize(c->dl_stream));
     b->h_result.assign(b->n_pile, std::string());
     for (int p = 0; p < b->n_pile; p++) {
         const FaPileOut &po = b->h_pile_out[p];
-        b->h_result[p].assign(b->h_out_seq.data() + b->pile[p].out_off + po.start, (size_t)po.len);
+        b->h_result[p].assign(h_seq + b->pile[p].out_off + po.start, (size_t)po.len);
     }
+    if (want_eqv) b->h_out_eqv.assign(h_eqv, h_eqv + b->out_slots);
     b->fetched = true;
     b->fetched_eqv = want_eqv != 0;
     return 0;
@@ -1107,6 +1199,7 @@ extern "C" int fa_align_pairs(fa_ctx *ctx, int n, const char *const *q, const in
     if (!b) return -1;
     int rc = 0;
     fa_ctx *c = ctx;
+    std::lock_guard<std::mutex> front(c->front_mu);
     hipStream_t s = c->stream;
     std::vector<FaRange> rg(b->n_seq);
     int max_q = 0, max_t = 0;

@@ -198,8 +198,12 @@ struct FaMsaDev {
     int *wide_count;
     int *wide_list;
 };
-// ev (optional): 4 events recorded after k_tags+k_tscan, k_links, k_score, k_backtrace
-void fa_launch_msa(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov, hipStream_t s,
-                   hipEvent_t *ev = nullptr);
+// the consensus stage in two halves (k_msa.hip): graph building (k_tags, k_tscan, k_links) and
+// the per-pile sequential walk (k_score, k_backtrace); events (optional) are recorded after
+// k_tags + k_tscan, k_links, k_score, k_backtrace
+void fa_launch_msa_front(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov, hipStream_t s,
+                         hipEvent_t ev_tags, hipEvent_t ev_links);
+void fa_launch_msa_back(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov, hipStream_t s,
+                        hipEvent_t ev_score, hipEvent_t ev_backtrace);
 size_t fa_align_lds_bytes(int max_q_len, int max_t_len);
 int fa_align_blocks_per_cu(size_t lds_bytes);

@@ -1134,9 +1134,7 @@ __global__ __launch_bounds__(64) void k_backtrace(MsaArgs A) {
 }
 
 // ---------------------------------------------------------------------------
-void fa_launch_msa(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov, hipStream_t s,
-                   hipEvent_t *ev) {
-    if (b.n_pile == 0) return;
+static MsaArgs msa_args(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov) {
     MsaArgs A;
     A.words = b.words; A.seq = b.seq; A.pile = b.pile; A.range = b.range; A.aln = b.aln;
     A.script = b.script; A.script_off = b.script_off;
@@ -1149,18 +1147,36 @@ void fa_launch_msa(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov, hip
     A.seg_pile = m.seg_pile; A.seg_t0 = m.seg_t0; A.n_seg = m.n_seg; A.min_cov = min_cov;
     A.wide_count = m.wide_count; A.wide_list = m.wide_list;
     A.first_links_back = m.first_links_back;
+    return A;
+}
+
+// The graph-building half: tags, position scan, links -- throughput kernels.
+// ev_tags / ev_links: recorded after k_tags + k_tscan and after k_links.
+void fa_launch_msa_front(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov, hipStream_t s,
+                         hipEvent_t ev_tags, hipEvent_t ev_links) {
+    if (b.n_pile == 0) return;
+    MsaArgs A = msa_args(b, m, min_cov);
     (void)hipMemsetAsync(m.tarr, 0, m.tarr_bytes, s);
     if (m.n_acc_total > 0) hipLaunchKernelGGL(k_tags, dim3(m.n_acc_total), dim3(64), 0, s, A);
     hipLaunchKernelGGL(k_tscan, dim3(b.n_pile), dim3(64), 0, s, A);
-    if (ev) (void)hipEventRecord(ev[0], s);
+    if (ev_tags) (void)hipEventRecord(ev_tags, s);
     if (m.n_seg > 0) {
         (void)hipMemsetAsync(m.wide_count, 0, sizeof(int), s);
         hipLaunchKernelGGL(k_links<1>, dim3(m.n_seg), dim3(64), 0, s, A);
         hipLaunchKernelGGL(k_links<8>, dim3(m.n_seg), dim3(64), 0, s, A);
     }
-    if (ev) (void)hipEventRecord(ev[1], s);
+    if (ev_links) (void)hipEventRecord(ev_links, s);
+}
+
+// The sequential half: one wavefront per pile walks the graph (scores, then the best path
+// backwards).  Latency-bound at a few wavefronts per SIMD -- the engine runs it on a stream
+// of its own, beside the next batch's throughput kernels.
+void fa_launch_msa_back(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov, hipStream_t s,
+                        hipEvent_t ev_score, hipEvent_t ev_backtrace) {
+    if (b.n_pile == 0) return;
+    MsaArgs A = msa_args(b, m, min_cov);
     hipLaunchKernelGGL(k_score, dim3(b.n_pile), dim3(64), 0, s, A);
-    if (ev) (void)hipEventRecord(ev[2], s);
+    if (ev_score) (void)hipEventRecord(ev_score, s);
     hipLaunchKernelGGL(k_backtrace, dim3(b.n_pile), dim3(64), 0, s, A);
-    if (ev) (void)hipEventRecord(ev[3], s);
+    if (ev_backtrace) (void)hipEventRecord(ev_backtrace, s);
 }

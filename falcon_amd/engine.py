@@ -135,6 +135,19 @@ class Batch:
             raise FalconAmdError(last_error())
         return self
 
+    def submit(self, min_cov: int = 6, K: int = 8, min_idt: float = 0.70) -> "Batch":
+        """First half of ``run``: returns once the throughput stages are done and the
+        per-pile sequential ones (score recurrence, back-trace) are queued on their own
+        stream.  Submit the next batch of the same engine before ``wait`` to overlap them."""
+        if self.lib.fa_batch_submit(self.h, min_cov, K, min_idt):
+            raise FalconAmdError(last_error())
+        return self
+
+    def wait(self) -> "Batch":
+        if self.lib.fa_batch_wait(self.h):
+            raise FalconAmdError(last_error())
+        return self
+
     def trim_windows(self, K: int = 8, mask_threshold: int = 16) -> "Batch":
         """--trim: find_best_aln_range2 of every read on its seed (results: ``range(g)``)."""
         if self.lib.fa_batch_trim_windows(self.h, K, mask_threshold):

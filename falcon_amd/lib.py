@@ -64,6 +64,8 @@ def load() -> C.CDLL:
     lib.fa_batch_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int),
                                     C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
     lib.fa_batch_run.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_double]
+    lib.fa_batch_submit.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_double]
+    lib.fa_batch_wait.argtypes = [C.c_void_p]
     lib.fa_batch_fetch.argtypes = [C.c_void_p, C.c_int]
     lib.fa_batch_trim_windows.argtypes = [C.c_void_p, C.c_uint, C.c_int]
     lib.fa_batch_result.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p),

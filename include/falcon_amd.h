@@ -153,6 +153,15 @@ fa_batch *fa_batch_create(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
                           const char *const *seqs, const int *seq_len);
 /* Run the whole path on the resident batch (may be called repeatedly). */
 int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double min_idt);
+/* The same in two halves, for callers that keep two batches of one context in flight:
+ * fa_batch_submit returns when the throughput stages (seed index, chaining, alignment,
+ * tags, links) are done and the per-pile sequential stages (score recurrence, back-trace)
+ * are queued on a stream of their own; fa_batch_wait collects them.  Submitting batch i+1
+ * between the two calls for batch i runs its throughput stages beside batch i's sequential
+ * ones (they need few wavefronts and mostly wait).  Same results as fa_batch_run, which is
+ * submit + wait.  Calls on different batches of a context may come from different threads. */
+int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double min_idt);
+int fa_batch_wait(fa_batch *b);
 /* Copy results to the host (want_eqv != 0 also copies the eqv arrays). */
 int fa_batch_fetch(fa_batch *b, int want_eqv);
 /* Consensus of pile p: *seq is NUL terminated and owned by the batch. */

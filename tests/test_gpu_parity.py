@@ -240,6 +240,62 @@ def test_batch_is_order_preserving_and_rerunnable(engine):
     bt.free()
 
 
+def test_pipelined_submit_wait_equals_run(engine):
+    """fa_batch_submit / fa_batch_wait: two (and three) batches of one context in flight, the
+    next one's throughput stages beside the previous one's score recurrence and back-trace
+    on their own stream -- same strings, same eqv, same statistics as fa_batch_run; also
+    with the batches driven from different threads, and freed while in flight."""
+    import threading
+    sets = [[_synthetic(300 + 10 * k + i, S=3000 + 500 * k, coverage=14, min_read=600, mean_read=1800,
+                        sd_read=500) for i in range(8)] for k in range(3)]
+    want, stats = [], []
+    for ps in sets:
+        b = engine.batch(ps)
+        b.run(4, 8, 0.70).fetch(True)
+        want.append([b.result(i) for i in range(len(ps))])
+        stats.append((b.stats().C, b.stats().D, b.stats().A, b.stats().O))
+        b.free()
+    bs = [engine.batch(ps) for ps in sets]
+    for rounds in range(3):
+        bs[0].submit(4, 8, 0.70)
+        bs[1].submit(4, 8, 0.70)
+        bs[0].wait()
+        bs[2].submit(4, 8, 0.70)
+        got0 = [bs[0].fetch(True).result(i) for i in range(len(sets[0]))]
+        bs[0].submit(4, 8, 0.70)          # again while the other two are still out
+        bs[1].wait(); bs[2].wait(); bs[0].wait()
+        got = [got0] + [[b.fetch(True).result(i) for i in range(b.n_pile)] for b in bs[1:]]
+        assert got == want
+        assert [(b.stats().C, b.stats().D, b.stats().A, b.stats().O) for b in bs] == stats
+    # one thread per batch on the same context
+    out, errs = [None] * 3, []
+
+    def work(k):
+        try:
+            for _ in range(4):
+                bs[k].submit(4, 8, 0.70)
+                bs[k].wait()
+                out[k] = [bs[k].fetch(True).result(i) for i in range(bs[k].n_pile)]
+        except Exception as e:
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs and out == want
+    from falcon_amd.lib import FalconAmdError
+    bs[1].submit(4, 8, 0.70)
+    with pytest.raises(FalconAmdError, match="still running"):
+        bs[1].submit(4, 8, 0.70)
+    with pytest.raises(FalconAmdError):
+        bs[1].fetch()
+    for b in bs:
+        b.free()              # (bs[1] is in flight: free waits for its kernels)
+    with pytest.raises(FalconAmdError):
+        engine.batch(sets[0]).wait()
+
+
 def test_bench_scale_batch_properties(engine):
     """The bench workload (BASELINE config 2: ~20 kb seeds x 40x, e = 0.13), a batch large
     enough to fill every wave slot several times over: results must not depend on what
