@@ -1,0 +1,157 @@
+"""Devices shared by batches: the replacement of the reference's process pool over piles
+(falcon_kit/mains/consensus.py:264-274, falcon_kit/multiproc.py:28-36).
+
+One engine (context) per GPU -- or several, FALCON_AMD_ENGINES_PER_DEVICE -- each with its own
+work queue: a batch of piles goes to the engine with the least work queued (work per pile
+varies 3x, so shards are never cut ahead of time), at most ``MAX_QUEUED`` batches resident
+per engine.  Piles never interact, so there is no collective anywhere; results are put
+back in input order by whoever prints them.
+
+A batch runs in two halves (falcon_amd.h: fa_batch_submit / fa_batch_wait): the throughput
+stages hold the engine's front lock, the per-pile sequential stages (score recurrence,
+back-trace) run on a stream of their own while the NEXT batch's throughput stages hold the
+lock -- two batches in flight per engine."""
+from __future__ import annotations
+
+import os
+import threading
+
+KMER = 8  # consensus.py:270 hard-wires K = 8
+
+
+class Device:
+    """One engine shared by whoever has batches for it: staging is serialised inside the
+    library (the context's staging buffers), the throughput stages by ``run_lock``."""
+
+    def __init__(self, engine, index):
+        self.engine, self.index = engine, index
+        self.run_lock = threading.Lock()
+        self.queued = 0      # batches staged or being staged, not finished yet
+        self.batches = 0     # batches this device has been given (statistics, tests)
+
+
+class DevicePool:
+    # batches staged (resident in HBM, ~5 GB each at the default size) but not finished, per
+    # device: enough to keep the device busy, bounded however many producers there are
+    MAX_QUEUED = 4
+
+    def __init__(self, engines):
+        self.devices = [Device(e, i) for i, e in enumerate(engines)]
+        self._lock = threading.Condition()
+        self._next = 0
+
+    def take(self) -> Device:
+        """The device with the least work queued (round robin among equals); waits while
+        every device has MAX_QUEUED batches waiting."""
+        with self._lock:
+            n = len(self.devices)
+            while True:
+                order = [self.devices[(self._next + i) % n] for i in range(n)]
+                dev = min(order, key=lambda d: d.queued)
+                if dev.queued < self.MAX_QUEUED:
+                    break
+                self._lock.wait()
+            self._next = (dev.index + 1) % n
+            dev.queued += 1
+            dev.batches += 1
+            return dev
+
+    def give_back(self, dev: Device):
+        with self._lock:
+            dev.queued -= 1
+            self._lock.notify_all()
+
+    def close(self):
+        for d in self.devices:
+            d.engine.close()
+
+
+def open_engines():
+    """One engine per visible GPU (FALCON_AMD_DEVICES narrows the list), times
+    FALCON_AMD_ENGINES_PER_DEVICE.  Raises without a HIP device: there is no CPU fallback."""
+    from falcon_amd.engine import Engine
+    from falcon_amd.lib import load
+    n_dev = load().fa_device_count()
+    if n_dev <= 0:
+        raise RuntimeError("falcon_amd: no HIP device visible (there is no CPU fallback)")
+    env = os.environ.get("FALCON_AMD_DEVICES")
+    devices = [int(x) for x in env.split(",")] if env else list(range(n_dev))
+    per_gpu = max(1, int(os.environ.get("FALCON_AMD_ENGINES_PER_DEVICE", "1")))
+    return [Engine(d) for d in devices for _ in range(per_gpu)]
+
+
+class EngineBackend:
+    """What a worker does with a device (replaced by a stand-in in the CPU tests)."""
+
+    def __init__(self, min_cov, min_idt):
+        self.min_cov, self.min_idt = min_cov, min_idt
+
+    def stage(self, engine, ps):
+        """ps: a PileSet of the native reader, or a list of piles (lists of sequences)."""
+        from falcon_amd.engine import Batch
+        if isinstance(ps, list):
+            return engine.batch(ps)
+        return Batch.from_pileset(engine, ps)
+
+    def submit(self, batch):
+        """Throughput stages (under the device's run_lock)."""
+        batch.submit(self.min_cov, KMER, self.min_idt)
+
+    def collect(self, batch):
+        """Sequential stages + download (outside the lock); frees the batch."""
+        try:
+            batch.wait()
+            batch.fetch(False)
+            return [batch.result(p) for p in range(batch.n_pile)]
+        finally:
+            batch.free()
+
+    def release(self, batch):
+        batch.free()
+
+
+class SharedGpu:
+    """The ``gpu`` object ``consensus._run_native`` drives: every batch goes to one device
+    of the (possibly shared) pool."""
+
+    def __init__(self, pool: DevicePool, backend):
+        self.pool, self.backend = pool, backend
+        self.engines = tuple(d.engine for d in pool.devices)
+        # batches this worker may have between submit and collect: two per engine
+        self.parallel = 2 * len(pool.devices)
+
+    def stage(self, ps):
+        dev = self.pool.take()
+        try:
+            return Staged(self, dev, self.backend.stage(dev.engine, ps))
+        except BaseException:
+            self.pool.give_back(dev)
+            raise
+
+    def finish(self, st):
+        try:
+            try:
+                with st.dev.run_lock:
+                    st.done = True
+                    self.backend.submit(st.batch)
+            except BaseException:
+                self.backend.release(st.batch)
+                raise
+            return self.backend.collect(st.batch)
+        finally:
+            self.pool.give_back(st.dev)
+
+
+class Staged:
+    """A staged batch and the device it sits on (``free``: dropped unfinished, on errors)."""
+
+    def __init__(self, gpu, dev, batch):
+        self.gpu, self.dev, self.batch, self.done = gpu, dev, batch, False
+
+    def free(self):
+        if not self.done:
+            self.done = True
+            try:
+                self.gpu.backend.release(self.batch)
+            finally:
+                self.gpu.pool.give_back(self.dev)

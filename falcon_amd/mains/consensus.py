@@ -215,132 +215,98 @@ def trimmed_pile(kup, pile, cfg: Settings, ranges=None):
 # --------------------------------------------------------------------------
 # batching over one or more GPUs
 # --------------------------------------------------------------------------
+def ordered_parallel(fn, items, workers, window=None):
+    """``fn`` over ``items`` on ``workers`` threads, results in input order (the shape of
+    ``Pool.imap``, consensus.py:274); at most ``window`` items are out at any time."""
+    import collections
+    from concurrent.futures import ThreadPoolExecutor
+    window = window or 2 * workers
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        out = collections.deque()
+        for it in items:
+            out.append(pool.submit(fn, it))
+            if len(out) >= window:
+                yield out.popleft().result()
+        while out:
+            yield out.popleft().result()
+
+
 class GpuConsensus:
     """Ordered map over piles on the visible GPU(s).
 
-    Piles are cut into batches; a batch is split into contiguous shards, one per
-    device, each handled by its own engine on its own thread (independent work
-    queues -- piles never interact, so there is no collective)."""
+    Piles are cut into batches of ``batch_bases``; every batch goes to the engine with the
+    least work queued (falcon_amd/devices.py: independent work queues -- piles never
+    interact, so there is no collective) and two batches per engine are in flight, the
+    sequential stages of one beside the throughput stages of the next."""
 
-    def __init__(self, min_cov, min_idt, devices=None, batch_bases=400_000_000):
-        from falcon_amd.engine import Engine
-        from falcon_amd.lib import load
-        n_dev = load().fa_device_count()
-        if n_dev <= 0:
-            raise RuntimeError("falcon_amd: no HIP device visible (there is no CPU fallback)")
-        if devices is None:
-            env = os.environ.get("FALCON_AMD_DEVICES")
-            devices = [int(x) for x in env.split(",")] if env else list(range(n_dev))
-        self.engines = [Engine(d) for d in devices]
+    def __init__(self, min_cov, min_idt, engines=None, batch_bases=400_000_000, backend=None):
+        from falcon_amd.devices import DevicePool, EngineBackend, SharedGpu, open_engines
+        engines = open_engines() if engines is None else engines
+        self.pool = DevicePool(engines)
+        self.shared = SharedGpu(self.pool, backend or EngineBackend(min_cov, min_idt))
+        self.engines = self.shared.engines
+        self.parallel = self.shared.parallel
         self.min_cov, self.min_idt = min_cov, min_idt
         self.batch_bases = batch_bases
 
-    def imap(self, piles):
+    @staticmethod
+    def _batches(piles, batch_bases):
         batch, bases = [], 0
         for p in piles:
             batch.append(p)
             bases += sum(map(len, p))
-            if bases >= self.batch_bases * len(self.engines):
-                yield from self._run_batch(batch)
+            if bases >= batch_bases:
+                yield batch
                 batch, bases = [], 0
         if batch:
-            yield from self._run_batch(batch)
+            yield batch
 
-    def _run_batch(self, batch):
-        n = len(self.engines)
-        if n == 1 or len(batch) < 2 * n:
-            return self.engines[0].consensus(batch, self.min_cov, KMER, self.min_idt)
-        step = -(-len(batch) // n)
-        shards = [batch[i:i + step] for i in range(0, len(batch), step)]
-        results, errors = [None] * len(shards), []
-
-        def work(i):
-            try:
-                results[i] = self.engines[i].consensus(shards[i], self.min_cov, KMER, self.min_idt)
-            except Exception as exc:  # surfaced below, in the caller's thread
-                errors.append(exc)
-
-        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(shards))]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if errors:
-            raise errors[0]
-        return [c for shard in results for c in shard]
+    def imap(self, piles):
+        """Consensus strings of an iterable of piles (lists of sequences), in order."""
+        def one(batch):
+            return self.shared.finish(self.shared.stage(batch))
+        for res in ordered_parallel(one, self._batches(piles, self.batch_bases), self.parallel):
+            yield from res
 
     # ---- --trim: windows of whole batches of piles on the GPU ----------------------
     def trimmed(self, piles, cfg):
         """Map piles -> trimmed piles (consensus.py:123-146), the k-mer windows of a batch
-        of piles computed in one go by the first engine."""
-        def flush(batch):
-            b = self.engines[0].batch(batch)
+        of piles computed in one go on the least loaded engine."""
+        def one(batch):
+            dev = self.pool.take()
             try:
-                b.trim_windows(KMER, 16)
-                g = 0
-                for pile in batch:
-                    rng = []
-                    for _ in pile:
-                        r = b.range(g)
-                        rng.append((r["s1"], r["e1"], r["s2"], r["e2"], r["score"]))
-                        g += 1
-                    yield trimmed_pile(None, pile, cfg, rng)
+                b = dev.engine.batch(batch)
+                try:
+                    with dev.run_lock:
+                        b.trim_windows(KMER, 16)
+                    out, g = [], 0
+                    for pile in batch:
+                        rng = []
+                        for _ in pile:
+                            r = b.range(g)
+                            rng.append((r["s1"], r["e1"], r["s2"], r["e2"], r["score"]))
+                            g += 1
+                        out.append(trimmed_pile(None, pile, cfg, rng))
+                    return out
+                finally:
+                    b.free()
             finally:
-                b.free()
-
-        batch, bases = [], 0
-        for p in piles:
-            batch.append(p)
-            bases += sum(map(len, p))
-            if bases >= self.batch_bases:
-                yield from flush(batch)
-                batch, bases = [], 0
-        if batch:
-            yield from flush(batch)
+                self.pool.give_back(dev)
+        for res in ordered_parallel(one, self._batches(piles, self.batch_bases), len(self.engines)):
+            yield from res
 
     # ---- native ingest: PileSets straight from falcon_amd/csrc/reader.cpp ----------
     def stage(self, ps):
-        """Stage a PileSet in HBM: one batch per device over contiguous shards of piles
-        (host memcpy into pinned memory, H2D, 2-bit pack).  The PileSet may be recycled
-        by its reader once this returns."""
-        from falcon_amd.engine import Batch
-        n = len(self.engines)
-        if n == 1 or ps.n_pile < 2 * n:
-            return [Batch.from_pileset(self.engines[0], ps)]
-        step = -(-ps.n_pile // n)
-        return [Batch.from_pileset(self.engines[i], ps, p0, min(p0 + step, ps.n_pile))
-                for i, p0 in enumerate(range(0, ps.n_pile, step))]
+        """Stage a PileSet on the least loaded engine (host memcpy into pinned memory, H2D,
+        2-bit pack).  The PileSet may be recycled by its reader once this returns."""
+        return self.shared.stage(ps)
 
-    def finish(self, batches):
-        """Run staged batches (one thread per device) and return the consensus strings in
-        pile order."""
-        results, errors = [None] * len(batches), []
-
-        def work(i):
-            b = batches[i]
-            try:
-                b.run(self.min_cov, KMER, self.min_idt).fetch(False)
-                results[i] = [b.result(p) for p in range(b.n_pile)]
-            except Exception as exc:  # surfaced below, in the caller's thread
-                errors.append(exc)
-            finally:
-                b.free()
-
-        if len(batches) == 1:
-            work(0)
-        else:
-            threads = [threading.Thread(target=work, args=(i,)) for i in range(len(batches))]
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
-        if errors:
-            raise errors[0]
-        return [c for shard in results for c in shard]
+    def finish(self, staged):
+        """Run a staged batch and return its consensus strings in pile order."""
+        return self.shared.finish(staged)
 
     def close(self):
-        for e in self.engines:
-            e.close()
+        self.pool.close()
 
 
 # --------------------------------------------------------------------------
@@ -387,95 +353,133 @@ def _stream_fd(stream):
         return None
 
 
-# Bases per batch and device on the native path.  Measured on 3072 E. coli-like piles of
-# text (scripts/exp_batch_policy.py, profiles/r01_v8_batch_policy.txt): constant 0.4 G
-# 3020 piles/s, constant 1.3 G 2076, doubling from 0.4 G to 1.3 G 1372-1679 -- larger
-# batches run the kernels at a better rate, but the host buffers they need (text, pinned
-# copy: page faults, pinning) cost more than that buys, and small batches pipeline sooner.
+# Bases per batch on the native path.  Measured on 3072 E. coli-like piles of text
+# (scripts/exp_batch_policy.py, profiles/r01_v8_batch_policy.txt): constant 0.4 G 3020 piles/s,
+# constant 1.3 G 2076, doubling from 0.4 G to 1.3 G 1372-1679 -- larger batches run the
+# kernels at a better rate, but the host buffers they need (text, pinned copy: page faults,
+# pinning) cost more than that buys, and small batches pipeline sooner.
 NATIVE_BATCH_BASES = 400_000_000
-NATIVE_BATCH_BASES_ALL_DEVICES = 4_000_000_000
 
 
 def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
-    """Three overlapped stages, records leaving in input order: an ingest thread (native
-    reader + staging of batch i+1), the GPU stages of batch i in the caller's thread (the
-    library releases the GIL), and a printer thread formatting batch i-1."""
+    """The worker's pipeline, records leaving in input order:
+
+      ingest thread    native reader -> the next batch (``batch_bases`` bases) staged on the
+                       device with the least work queued (``gpu.stage``)
+      runner threads   ``gpu.parallel`` of them (two per engine): a batch's GPU stages
+                       (``gpu.finish``: throughput stages under the engine's lock, then the
+                       per-pile sequential stages beside the next batch's) and the download
+      printer thread   batches back in input order -> FASTA text
+
+    ``gpu``: ``stage(pileset) -> handle`` (``handle.free()`` drops it), ``finish(handle) ->
+    consensus strings``, optionally ``parallel``."""
     import queue
     from falcon_amd.engine import Reader
     reader = Reader(fd, args.min_n_read, args.min_len_aln, cfg.min_cov_aln, cfg.max_n_read,
                     cfg.max_cov_aln)
     if batch_bases is None:
         batch_bases = int(os.environ.get("FALCON_AMD_BATCH_BASES", NATIVE_BATCH_BASES))
-    per_call = min(batch_bases * len(gpu.engines), max(batch_bases, NATIVE_BATCH_BASES_ALL_DEVICES))
-    staged = queue.Queue(maxsize=1)
-    done = queue.Queue(maxsize=2)
+    n_run = max(1, int(getattr(gpu, "parallel", 1)))
+    staged = queue.Queue(maxsize=n_run)
+    done = queue.Queue(maxsize=2 * n_run + 2)
     failed = []
     stop = threading.Event()
+    END = object()
+
+    def fail(exc):
+        failed.append(exc)
+        stop.set()
 
     def ingest():
+        seq = 0
         try:
             while not stop.is_set():
                 t0 = time.perf_counter()
-                ps = reader.next(0, per_call)
+                ps = reader.next(0, batch_bases)
                 if ps is None:
                     break
                 t1 = time.perf_counter()
-                item = (ps.seed_ids, gpu.stage(ps))
-                LOG.debug("ingest: %d piles read in %.3f s, staged in %.3f s", ps.n_pile, t1 - t0,
-                          time.perf_counter() - t1)
+                item = (seq, ps.seed_ids, gpu.stage(ps))
+                LOG.debug("ingest: batch %d, %d piles read in %.3f s, staged in %.3f s", seq, ps.n_pile,
+                          t1 - t0, time.perf_counter() - t1)
+                seq += 1
                 staged.put(item)
-            staged.put(None)
         except Exception as exc:
-            staged.put(exc)
+            fail(exc)
+        finally:
+            staged.put(END)
+
+    def runner():
+        try:
+            while True:
+                item = staged.get()
+                if item is END:
+                    staged.put(END)  # the other runners see it too
+                    return
+                seq, ids, handle = item
+                if stop.is_set():
+                    getattr(handle, "free", lambda: None)()
+                    continue
+                t0 = time.perf_counter()
+                cns_all = gpu.finish(handle)
+                LOG.debug("runner: batch %d, GPU stages + download %.3f s", seq, time.perf_counter() - t0)
+                done.put((seq, ids, cns_all))
+        except Exception as exc:
+            fail(exc)
+            # keep draining so that the ingest thread never blocks on a full queue
+            while True:
+                item = staged.get()
+                if item is END:
+                    staged.put(END)
+                    return
+                getattr(item[2], "free", lambda: None)()
 
     def printer():
+        waiting, want = {}, 0
         try:
             while True:
                 item = done.get()
-                if item is None:
+                if item is END:
                     return
-                t0 = time.perf_counter()
-                ids, cns_all = item
-                for sid, cns in zip(ids, cns_all):
-                    stdout.write(fasta_records(sid, cns, args.output_full, args.output_multi))
-                LOG.debug("printer: %d piles in %.3f s", len(ids), time.perf_counter() - t0)
+                waiting[item[0]] = item
+                while want in waiting:
+                    t0 = time.perf_counter()
+                    _, ids, cns_all = waiting.pop(want)
+                    want += 1
+                    if stop.is_set():
+                        continue
+                    stdout.write("".join(fasta_records(sid, cns, args.output_full, args.output_multi)
+                                         for sid, cns in zip(ids, cns_all)))
+                    LOG.debug("printer: %d piles in %.3f s", len(ids), time.perf_counter() - t0)
         except Exception as exc:  # (a closed stdout, say): stop the pipeline, report below
-            failed.append(exc)
-            stop.set()
-            while done.get() is not None:
+            fail(exc)
+            while done.get() is not END:
                 pass
 
-    threads = [threading.Thread(target=ingest, daemon=True), threading.Thread(target=printer, daemon=True)]
-    for t in threads:
+    t_in = threading.Thread(target=ingest, daemon=True)
+    t_run = [threading.Thread(target=runner, daemon=True) for _ in range(n_run)]
+    t_out = threading.Thread(target=printer, daemon=True)
+    for t in [t_in, t_out] + t_run:
         t.start()
     try:
-        while not stop.is_set():
-            t0 = time.perf_counter()
-            item = staged.get()
-            if item is None:
-                break
-            if isinstance(item, Exception):
-                raise item
-            ids, batches = item
-            t1 = time.perf_counter()
-            cns_all = gpu.finish(batches)
-            LOG.debug("worker: waited %.3f s for the batch, GPU stages + fetch %.3f s", t1 - t0,
-                      time.perf_counter() - t1)
-            done.put((ids, cns_all))
-    finally:
+        for t in t_run:
+            t.join()
+    except BaseException:
         stop.set()
-        done.put(None)
-        threads[1].join()
+        raise
+    finally:
+        done.put(END)   # (behind everything the runners delivered)
+        t_out.join()
+        stop.set()
         # the reader may only be closed once the ingest thread has left it; what it had
         # staged meanwhile is released
-        while threads[0].is_alive():
+        while t_in.is_alive():
             try:
                 item = staged.get(timeout=0.05)
             except queue.Empty:
                 continue
-            if isinstance(item, tuple):
-                for b in item[1]:
-                    getattr(b, "free", lambda: None)()
+            if item is not END:
+                getattr(item[2], "free", lambda: None)()
         reader.close()
     if failed:
         raise failed[0]
@@ -497,7 +501,7 @@ def run(args, stdin=None, stdout=None, consensus_map=None):
     if consensus_map is None:
         gpu = GpuConsensus(args.min_cov, args.min_idt)
         consensus_map = gpu.imap
-        LOG.info("falcon_amd consensus on %d GPU(s)", len(gpu.engines))
+        LOG.info("falcon_amd consensus on %d engine(s)", len(gpu.engines))
 
     fd = _stream_fd(stdin)
     if gpu is not None and not args.trim and fd is not None:

@@ -36,116 +36,9 @@ from falcon_amd.mains import consensus as single
 LOG = logging.getLogger("falcon_amd.consensus_multi")
 
 
-class Device:
-    """One engine (one GPU) shared by the jobs: staging is serialised inside the library
-    (the context's staging buffers), the GPU stages by ``run_lock``."""
-
-    def __init__(self, engine, index):
-        self.engine, self.index = engine, index
-        self.run_lock = threading.Lock()
-        self.queued = 0      # batches staged or being staged, not finished yet
-        self.batches = 0     # batches this device has been given (statistics, tests)
-
-
-class DevicePool:
-    # batches staged (resident in HBM, ~5 GB each at the default size) but not finished, per
-    # device: enough to keep the device busy, bounded however many jobs there are
-    MAX_QUEUED = 4
-
-    def __init__(self, engines):
-        self.devices = [Device(e, i) for i, e in enumerate(engines)]
-        self._lock = threading.Condition()
-        self._next = 0
-
-    def take(self) -> Device:
-        """The device with the least work queued (round robin among equals); waits while
-        every device has MAX_QUEUED batches waiting."""
-        with self._lock:
-            n = len(self.devices)
-            while True:
-                order = [self.devices[(self._next + i) % n] for i in range(n)]
-                dev = min(order, key=lambda d: d.queued)
-                if dev.queued < self.MAX_QUEUED:
-                    break
-                self._lock.wait()
-            self._next = (dev.index + 1) % n
-            dev.queued += 1
-            dev.batches += 1
-            return dev
-
-    def give_back(self, dev: Device):
-        with self._lock:
-            dev.queued -= 1
-            self._lock.notify_all()
-
-    def close(self):
-        for d in self.devices:
-            d.engine.close()
-
-
-class EngineBackend:
-    """What a job does with a device (replaced by a stand-in in the CPU tests)."""
-
-    def __init__(self, min_cov, min_idt):
-        self.min_cov, self.min_idt = min_cov, min_idt
-
-    def stage(self, engine, ps):
-        from falcon_amd.engine import Batch
-        return Batch.from_pileset(engine, ps)
-
-    def finish(self, batch):
-        try:
-            batch.run(self.min_cov, single.KMER, self.min_idt).fetch(False)
-            return [batch.result(p) for p in range(batch.n_pile)]
-        finally:
-            batch.free()
-
-    def release(self, batch):
-        batch.free()
-
-
-class SharedGpu:
-    """The ``gpu`` object ``consensus._run_native`` drives, for one job: every batch goes
-    to one device of the shared pool."""
-
-    engines = (None,)  # (_run_native sizes a batch per entry: one device per batch here)
-
-    def __init__(self, pool: DevicePool, backend):
-        self.pool, self.backend = pool, backend
-
-    def stage(self, ps):
-        dev = self.pool.take()
-        try:
-            return [_Staged(self, dev, self.backend.stage(dev.engine, ps))]
-        except BaseException:
-            self.pool.give_back(dev)
-            raise
-
-    def finish(self, batches):
-        out = []
-        for st in batches:
-            try:
-                with st.dev.run_lock:
-                    st.done = True
-                    out.extend(self.backend.finish(st.batch))
-            finally:
-                self.pool.give_back(st.dev)
-        return out
-
-
-class _Staged:
-    """A staged batch and the device it sits on (``free``: dropped unfinished, on errors)."""
-
-    def __init__(self, gpu, dev, batch):
-        self.gpu, self.dev, self.batch, self.done = gpu, dev, batch, False
-
-    def free(self):
-        if not self.done:
-            self.done = True
-            try:
-                self.gpu.backend.release(self.batch)
-            finally:
-                self.gpu.pool.give_back(self.dev)
+# the devices, their work queues and what a job does with one: falcon_amd/devices.py
+from falcon_amd.devices import (Device, DevicePool, EngineBackend, SharedGpu,  # noqa: E402,F401
+                                Staged as _Staged, open_engines)
 
 
 def parse_args(argv):
@@ -214,19 +107,10 @@ def run(args, pool=None, backend=None):
     cfg = single.settings_from(args)
     own_pool = pool is None
     if own_pool:
-        from falcon_amd.engine import Engine
-        from falcon_amd.lib import load
-        n_dev = load().fa_device_count()
-        if n_dev <= 0:
-            raise RuntimeError("falcon_amd: no HIP device visible (there is no CPU fallback)")
-        env = os.environ.get("FALCON_AMD_DEVICES")
-        devices = [int(x) for x in env.split(",")] if env else list(range(n_dev))
-        # engines (contexts, each with its own streams and work slots) per GPU: with 2, the
-        # latency-bound consensus kernels of one job's batch run next to the alignment
-        # kernel of another's (+6 % at 3072-pile batches with two contexts;
-        # not measured at the worker's batch size yet, hence 1)
-        per_gpu = max(1, int(os.environ.get("FALCON_AMD_ENGINES_PER_DEVICE", "1")))
-        pool = DevicePool([Engine(d) for d in devices for _ in range(per_gpu)])
+        # engines (contexts, each with its own streams and work slots) per GPU:
+        # FALCON_AMD_ENGINES_PER_DEVICE (1: an engine already keeps two batches in flight, the
+        # sequential stages of one beside the throughput stages of the next)
+        pool = DevicePool(open_engines())
     if backend is None:
         backend = EngineBackend(args.min_cov, args.min_idt)
     LOG.info("falcon_amd consensus: %d job(s) on %d GPU(s)", len(args.jobs), len(pool.devices))

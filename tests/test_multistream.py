@@ -23,27 +23,39 @@ class FakeEngine:
 
 
 class FakeBackend:
-    """Consensus of a pile := 600 characters of its seed, repeated (>= 500: printed)."""
+    """Consensus of a pile := 600 characters of its seed, repeated (>= 500: printed).
+    ``submit`` = the throughput stages (one batch at a time per engine: the engine's lock),
+    ``collect`` = the sequential stages + download (beside the next batch's ``submit``)."""
 
     def __init__(self):
         self.lock = threading.Lock()
         self.staged = self.finished = self.released = 0
-        self.running = {}       # engine -> batches in finish() right now (must never exceed 1)
+        self.running = {}       # engine -> batches in submit() right now (must never exceed 1)
         self.overlap = False
+        self.in_flight = {}     # engine -> batches between submit and the end of collect
+        self.peak_in_flight = 0
 
     def stage(self, engine, ps):
         with self.lock:
             self.staged += 1
         return (engine, ps.piles())
 
-    def finish(self, batch):
+    def submit(self, batch):
         engine, piles = batch
         with self.lock:
             self.running[engine] = self.running.get(engine, 0) + 1
             self.overlap |= self.running[engine] > 1
+            self.in_flight[engine] = self.in_flight.get(engine, 0) + 1
+            self.peak_in_flight = max(self.peak_in_flight, self.in_flight[engine])
         time.sleep(0.002)
         with self.lock:
             self.running[engine] -= 1
+
+    def collect(self, batch):
+        engine, piles = batch
+        time.sleep(0.002)
+        with self.lock:
+            self.in_flight[engine] -= 1
             self.finished += 1
         return [(p[0] * 20)[:600] for p in piles]
 
@@ -95,8 +107,69 @@ def test_jobs_share_devices_and_print_what_the_single_worker_prints(tmp_path, mo
         assert got == _single_stream_output(text, args), i
         assert not (tmp_path / ("cns_%d.fasta.tmp" % i)).exists()
     assert backend.staged == backend.finished > len(texts) and backend.released == 0
-    assert not backend.overlap                       # one batch at a time per device
+    assert not backend.overlap                       # one batch at a time in a device's throughput stages
     assert all(d.batches > 0 and d.queued == 0 for d in pool.devices)
+
+
+def test_single_stream_worker_on_several_engines(tmp_path):
+    """falcon_amd.mains.consensus on a node with several GPUs: GpuConsensus with
+    three stand-in engines behind the worker's pipeline -- batches go to the engine with the
+    least work queued (no contiguous split ahead of time, no per-batch join), two batches per
+    engine in flight (one in the throughput stages), records printed in input order; the
+    python-parser path (``imap``, e.g. --trim) shares the same queues."""
+    rng = random.Random(21)
+    text = _rand_stream(rng, 120, with_noise=True)
+    args = single.parse_args(["prog"] + OPTS)
+    cfg = single.settings_from(args)
+    want = _single_stream_output(text, args)
+    assert want.count(">") > 60
+
+    class SlowFirst(FakeBackend):
+        """engine 0 is slow: a static split would wait for it, the queues route around it"""
+        def submit(self, batch):
+            if batch[0].name == "dev0":
+                time.sleep(0.03)
+            super().submit(batch)
+
+    class Named(FakeEngine):
+        def __init__(self, name):
+            self.name, self.closed = name, False
+
+        def close(self):
+            self.closed = True
+
+    engines = [Named("dev%d" % i) for i in range(3)]
+    backend = SlowFirst()
+    gpu = single.GpuConsensus(args.min_cov, args.min_idt, engines=engines, backend=backend)
+    assert gpu.parallel == 6 and len(gpu.engines) == 3
+    rd, wr = os.pipe()
+    t = threading.Thread(target=lambda: (os.write(wr, text.encode()), os.close(wr)))
+    t.start()
+    out = io.StringIO()
+    try:
+        single._run_native(args, cfg, rd, gpu, out, batch_bases=900)
+    finally:
+        os.close(rd)
+        t.join()
+    assert out.getvalue() == want                     # input order, nothing lost
+    per_dev = [d.batches for d in gpu.pool.devices]
+    assert all(n > 0 for n in per_dev) and per_dev[0] < min(per_dev[1:])   # least loaded first
+    assert not backend.overlap and 2 <= backend.peak_in_flight <= multi.DevicePool.MAX_QUEUED
+    assert backend.staged == backend.finished and all(d.queued == 0 for d in gpu.pool.devices)
+    # the python-parser path over the same pool
+    piles = [pile for _, pile in single.PileReader(io.StringIO(text), cfg, args.min_n_read, args.min_len_aln)]
+    gpu.batch_bases = 900
+
+    class ListBackend(SlowFirst):
+        def stage(self, engine, ps):
+            with self.lock:
+                self.staged += 1
+            return (engine, ps)
+    gpu.shared.backend = ListBackend()
+    got = list(gpu.imap(iter(piles)))
+    assert got == [(p[0] * 20)[:600] for p in piles]
+    gpu.close()
+    assert all(e.closed for e in engines)
 
 
 def test_more_jobs_than_queue_slots_still_finish(tmp_path, monkeypatch):
@@ -134,10 +207,10 @@ def test_a_failing_job_is_reported_and_the_others_finish(tmp_path, monkeypatch):
     good.write_text(text)
 
     class Flaky(FakeBackend):
-        def finish(self, batch):
+        def collect(self, batch):
             if any(p[0].startswith("BOOM") for p in batch[1]):
                 raise RuntimeError("device fault")
-            return super().finish(batch)
+            return super().collect(batch)
 
     bad = tmp_path / "bad.txt"
     bad.write_text("s BOOM%s\nr1 ACGTACGTACGT\nr2 ACGTACGTACG\n+ +\n" % ("A" * 40) + text)

@@ -225,71 +225,6 @@ def test_cli_native_path_orders_and_prints(tmp_path):
         os.close(fd)
 
 
-def test_multi_device_sharding_of_a_pileset(monkeypatch):
-    """GpuConsensus.stage cuts a PileSet into contiguous shards, one per engine, by pointer
-    arithmetic; finish() returns the results in pile order.  (Engines and batches are
-    stand-ins: the arithmetic is what is checked, against the materialised piles.)"""
-    import ctypes as C
-    import falcon_amd.engine as eng
-    from falcon_amd.mains.consensus import GpuConsensus
-
-    rng = random.Random(9)
-    text = _rand_stream(rng, 23, with_noise=False)
-    with tempfile.NamedTemporaryFile("w", delete=False) as f:
-        f.write(text)
-        path = f.name
-    fd = os.open(path, os.O_RDONLY)
-    try:
-        r = Reader(fd, 1, 0, 0, 500, 0)
-        ps = r.next()
-        want = ps.piles()
-
-        class FakeBatch:
-            def __init__(self, engine, ps_, p0, p1, piles):
-                self.engine, self.n_pile, self.piles = engine, p1 - p0, piles
-
-            def run(self, *a):
-                return self
-
-            def fetch(self, *a):
-                return self
-
-            def result(self, p):
-                return "%s|%d|%s" % (self.engine, len(self.piles[p]), self.piles[p][0][:12])
-
-            def free(self):
-                pass
-
-        def fake_from_pileset(engine, ps_, p0=0, p1=None):
-            p1 = ps_.n_pile if p1 is None else p1
-            # read the shard exactly as fa_batch_create would: through the shifted pointers
-            g0 = ps_.first[p0]
-            cnt = C.cast(C.addressof(ps_.pile_n_seq.contents) + 4 * p0, C.POINTER(C.c_int))
-            arr = C.cast(C.addressof(ps_.seqs.contents) + C.sizeof(C.c_void_p) * g0,
-                         C.POINTER(C.c_void_p))
-            lens = C.cast(C.addressof(ps_.seq_len.contents) + 4 * g0, C.POINTER(C.c_int))
-            piles, g = [], 0
-            for p in range(p1 - p0):
-                piles.append([C.string_at(arr[g + j], lens[g + j]).decode() for j in range(cnt[p])])
-                g += cnt[p]
-            return FakeBatch(engine, ps_, p0, p1, piles)
-
-        monkeypatch.setattr(eng.Batch, "from_pileset", staticmethod(fake_from_pileset))
-        gpu = GpuConsensus.__new__(GpuConsensus)
-        gpu.engines = ["dev0", "dev1", "dev2"]
-        gpu.min_cov, gpu.min_idt, gpu.batch_bases = 4, 0.70, 10**9
-        batches = gpu.stage(ps)
-        assert [b.engine for b in batches] == ["dev0", "dev1", "dev2"]
-        assert sum(b.n_pile for b in batches) == len(want)
-        assert [p for b in batches for p in b.piles] == want   # contiguous, in order, complete
-        got = gpu.finish(batches)
-        assert [g.split("|", 1)[1] for g in got] == ["%d|%s" % (len(p), p[0][:12]) for p in want]
-        r.close()
-    finally:
-        os.close(fd)
-        os.unlink(path)
-
-
 def test_bench_end_to_end_text_rebuilds_the_bench_piles(tmp_path):
     """bench.py's end-to-end leg writes its piles out as LA4Falcon text: the reader hands
     the worker exactly the piles the kernel-only legs run on."""
