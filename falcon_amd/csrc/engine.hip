@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -93,10 +94,62 @@ struct fa_ctx {
     int *d_first_bad = nullptr;  // k_pack: lowest sequence index holding a byte other than ACGT
 };
 
+// Device and pinned-host blocks are recycled per device for the life of the process: a
+// worker builds and frees a batch (two dozen buffers) every ~50 ms, and hipFree waits for
+// the whole device while hipMalloc of released VRAM waits for the driver to wipe it.  A
+// freed block goes to a size-ordered free list; a request takes the smallest block that
+// fits without wasting more than half of it, else allocates (sizes rounded up so that the
+// batches of one stream, which differ by a few per cent, find each other's blocks).
+// fa_destroy of a device's last context releases its lists.
+struct BlockCache {
+    std::mutex mu;
+    std::multimap<size_t, void *> dev_free, host_free;
+    static size_t round_up(size_t bytes) {
+        if (bytes < 4096) return 4096;
+        size_t step = (size_t)1 << (63 - __builtin_clzll(bytes));  // largest power of two <= bytes
+        step >>= 3;                                                 // eighth-octave steps
+        return (bytes + step - 1) & ~(step - 1);
+    }
+    void *take(std::multimap<size_t, void *> &fl, size_t bytes, size_t *got) {
+        std::lock_guard<std::mutex> hold(mu);
+        auto it = fl.lower_bound(bytes);
+        if (it != fl.end() && it->first <= bytes + bytes / 2 + 4096) {
+            void *p = it->second;
+            *got = it->first;
+            fl.erase(it);
+            return p;
+        }
+        return nullptr;
+    }
+    void give(std::multimap<size_t, void *> &fl, void *p, size_t bytes) {
+        std::lock_guard<std::mutex> hold(mu);
+        fl.emplace(bytes, p);
+    }
+    void drop_all() {
+        std::lock_guard<std::mutex> hold(mu);
+        for (auto &kv : dev_free) (void)hipFree(kv.second);
+        for (auto &kv : host_free) (void)hipHostFree(kv.second);
+        dev_free.clear();
+        host_free.clear();
+    }
+};
+static std::mutex g_cache_mu;
+static std::map<int, BlockCache *> g_cache;   // per device
+static std::map<int, int> g_ctx_count;
+static BlockCache *cache_of_current_device() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> hold(g_cache_mu);
+    BlockCache *&c = g_cache[dev];
+    if (!c) c = new BlockCache();
+    return c;
+}
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
-    size_t n = 0;
+    size_t n = 0, bytes = 0;
+    BlockCache *home = nullptr;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -105,18 +158,29 @@ struct DevBuf {
         release();
         n = count;
         if (count == 0) count = 1;
-        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        home = cache_of_current_device();
+        const size_t want = count * sizeof(T);
+        p = (T *)home->take(home->dev_free, want, &bytes);
+        if (p) return 0;
+        bytes = BlockCache::round_up(want);
+        hipError_t e = hipMalloc((void **)&p, bytes);
         if (e != hipSuccess) {
-            set_err("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+            // the free lists may hold what is missing
+            home->drop_all();
+            e = hipMalloc((void **)&p, bytes);
+        }
+        if (e != hipSuccess) {
+            set_err("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
             p = nullptr;
+            bytes = 0;
             return -1;
         }
         return 0;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) home->give(home->dev_free, p, bytes);
         p = nullptr;
-        n = 0;
+        n = bytes = 0;
     }
 };
 
@@ -125,7 +189,8 @@ struct DevBuf {
 template <class T>
 struct HostBuf {
     T *p = nullptr;
-    size_t n = 0, cap = 0;
+    size_t n = 0, cap = 0, bytes = 0;
+    BlockCache *home = nullptr;
     HostBuf() = default;
     HostBuf(const HostBuf &) = delete;
     HostBuf &operator=(const HostBuf &) = delete;
@@ -133,21 +198,28 @@ struct HostBuf {
     int resize(size_t count) {
         if (count > cap) {
             release();
-            hipError_t e = hipHostMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault);
-            if (e != hipSuccess) {
-                set_err("hipHostMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
-                p = nullptr;
-                return -1;
+            home = cache_of_current_device();
+            const size_t want = std::max<size_t>(count, 1) * sizeof(T);
+            p = (T *)home->take(home->host_free, want, &bytes);
+            if (!p) {
+                bytes = BlockCache::round_up(want);
+                hipError_t e = hipHostMalloc((void **)&p, bytes, hipHostMallocDefault);
+                if (e != hipSuccess) {
+                    set_err("hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+                    p = nullptr;
+                    bytes = 0;
+                    return -1;
+                }
             }
-            cap = count;
+            cap = bytes / sizeof(T);
         }
         n = count;
         return 0;
     }
     void release() {
-        if (p) (void)hipHostFree(p);
+        if (p) home->give(home->host_free, p, bytes);
         p = nullptr;
-        n = cap = 0;
+        n = cap = bytes = 0;
     }
     T *data() { return p; }
     size_t size() const { return n; }
@@ -250,6 +322,10 @@ extern "C" fa_ctx *fa_create(int device) {
     HIP_OK_P(hipGetDeviceProperties(&prop, device));
     fa_ctx *c = new fa_ctx();
     c->device = device;
+    {
+        std::lock_guard<std::mutex> hold(g_cache_mu);
+        g_ctx_count[device]++;
+    }
     c->n_cu = prop.multiProcessorCount;
     c->total_mem = prop.totalGlobalMem;
     HIP_OK_P(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -278,6 +354,17 @@ extern "C" void fa_destroy(fa_ctx *c) {
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    {   // the device's last context takes the recycled blocks with it
+        BlockCache *bc = nullptr;
+        {
+            std::lock_guard<std::mutex> hold(g_cache_mu);
+            if (--g_ctx_count[c->device] <= 0) {
+                auto it = g_cache.find(c->device);
+                if (it != g_cache.end()) bc = it->second;
+            }
+        }
+        if (bc) bc->drop_all();
+    }
     delete c;
 }
 
