@@ -93,6 +93,13 @@ __device__ __forceinline__ u32 fa_twice_plus(int x, u64 mask) {
 
 __device__ __forceinline__ int fa_wave_min(int v) { return -fa_wave_max(-v); }
 
+// a + b + s with s wave-uniform: one v_add3_u32 (the compiler emits two adds)
+__device__ __forceinline__ int fa_add3(int a, int b, int s) {
+    int r;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(s));
+    return r;
+}
+
 // Force a wave-uniform value into SGPRs.  Arguments of out-of-line device
 // functions arrive in VGPRs and the compiler must treat them as divergent;
 // readfirstlane makes the uniformity explicit so branches on them stay scalar.

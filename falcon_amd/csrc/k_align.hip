@@ -152,7 +152,9 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
     res.dist = 0; res.q_e = 0; res.t_e = 0; res.size = 0; res.accept = 0; res.n_ins = 0;
     res.aligned = 0; res.err = 0; res.cells = 0;
 
-    const int max_d = (int)(0.3 * (double)(q_len + t_len));  // DW_banded.c:149
+    // (the double arithmetic runs on the VALU: pin the result, or every loop bound derived
+    // from it -- the hot loop's row countdown -- lives in a VGPR)
+    const int max_d = fa_uni((int)(0.3 * (double)(q_len + t_len)));  // DW_banded.c:149
     if ((u64)max_d > rows_per_slot) {  // host sized the slot from the same formula
         res.err = 1;
         store_result(res);
@@ -206,6 +208,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
     // LDS ring (ring mode) until the band narrows again.  The two modes are two
     // plain loops (the row loop must stay a simple loop: instruction issue, scalar
     // and vector alike, is the bottleneck of this kernel).
+    const int m2lane = -2 * lane;
     const int REG_MAX_N = 60;
     const int nmax = min(REG_MAX_N, band + 1);
     int kd = -62;          // diagonal of lane 0 in row d (row 0: diagonal 0 sits on lane 31)
@@ -248,26 +251,31 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
                 kd += 2 * sh;
                 lo = nlo;
             }
-            // the hot loop: `safe` + 1 rows that cannot trip a rare event
-            for (int safe = min(min(min(min(max_d - 1 - d, nmax - n), 63 - lo - n), 63 - (d & 63)), room);
-                 safe >= 0; safe--) {
-            const int hi = lo + n - 1;
+            // the hot loop: `safe` + 1 rows that cannot trip a rare event.  Two exits, one join
+            // (a finishing row | the countdown): with a jump out of both loops the compiler
+            // builds a state machine around the row, a dozen scalar instructions per row on
+            // the CU's one scalar pipe -- which is what bounds this kernel.
+            // (`safe` pinned: left to itself the compiler keeps this wave-uniform countdown
+            // in a VGPR -- three VALU operations per row)
+            int safe = fa_uni(min(min(min(min(max_d - 1 - d, nmax - n), 63 - lo - n), 63 - (d & 63)), room));
+            int hi = lo + n - 1;
+            for (;;) {
             PROF(0);
             // Lane sets are kept twice: as a predicate (act: stores, selects) and as a
             // scalar mask (act_m: combined with single-compare ballots by the scalar unit).
-            const bool act = lane >= lo && lane <= hi;
             const u64 act_m = fa_lane_range(lo, n);
+            // the same set as a predicate, straight from the mask: no per-row v_cmp pair
+            const bool act = __builtin_amdgcn_inverse_ballot_w64(act_m);
             // Lane l owns diagonal kd + 2l with kd falling by one per row: the lane's own
             // register then always holds V[k+1] of the previous row and lane l-1 holds
             // V[k-1] -- one DPP shift, no parity case.  (The wave's edge lanes are never
             // inside the band: lo >= 1, hi <= 62.)
-            const int k = kd + 2 * lane;
             const int a = __builtin_amdgcn_mov_dpp(vreg, 0x138, 0xf, 0xf, true);  // lane-1: V[k-1]
             const int b = vreg;                                                  //         V[k+1]
             // from_above: k == min_k, or k != max_k and V[k-1] < V[k+1]   (:190)
             const u64 fa_m = fa_mask_clr_set(fa_ballot(a < b), hi, lo) & act_m;
             x = fa_sel(fa_m, a + 1, b);
-            y = x - k;
+            y = fa_add3(x, m2lane, -kd);  // x - k, k = kd + 2 lane: one v_add3
             PROF(1);
             snake16(qL, tL, qb, tb, q_len, t_len, act, x, y);
             PROF(2);
@@ -277,7 +285,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             fin = (fa_ballot(x >= q_len) | fa_ballot(y >= t_len)) & act_m;  // :220
             PROF(3);
             WRITE_ROW_RECORD(dir0, kd + 2 * lo);
-            if (fin) goto reg_rows_finished;  // (its records are flushed there)
+            if (fin) break;  // (its records are flushed below)
             // (an LDS ds_max on one word instead of the DPP reduction was measured 2x
             // slower: 64 same-address atomics serialise)
             const int u = act ? x + y : -1;
@@ -285,15 +293,16 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             const u64 in = fa_ballot(u >= best_m - band) & act_m;  // :228-243
             PROF(4);
             // `in` is never empty: best_m is attained inside the row
-            const int llo = __builtin_ctzll(in);          // absolute lanes
-            const int lhi = 63 - __builtin_clzll(in);
             row_off += (u32)n;
-            n = lhi - llo + 2;
-            lo = llo;  // the new lowest diagonal (min_k = kd + 2 lo), one below, sits on the
-            kd--;      // same lane one row on
+            lo = __builtin_ctzll(in);            // absolute lanes: the new lowest diagonal
+            hi = 64 - __builtin_clzll(in);       // (min_k = kd + 2 lo), one below, sits on the
+            n = hi - lo + 1;                     // same lane one row on; the highest one lane up
+            kd--;
             d++;
             PROF(5);
+            if (--safe < 0) break;
             }
+            if (fin) break;
         }
     reg_rows_finished:
         min_k = kd + 2 * lo;
