@@ -259,6 +259,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             // in a VGPR -- three VALU operations per row)
             int safe = fa_uni(min(min(min(min(max_d - 1 - d, nmax - n), 63 - lo - n), 63 - (d & 63)), room));
             int hi = lo + n - 1;
+            int nkd = -kd;  // (the loop carries -kd: what the row adds)
             for (;;) {
             PROF(0);
             // Lane sets are kept twice: as a predicate (act: stores, selects) and as a
@@ -275,16 +276,18 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             // from_above: k == min_k, or k != max_k and V[k-1] < V[k+1]   (:190)
             const u64 fa_m = fa_mask_clr_set(fa_ballot(a < b), hi, lo) & act_m;
             x = fa_sel(fa_m, a + 1, b);
-            y = fa_add3(x, m2lane, -kd);  // x - k, k = kd + 2 lane: one v_add3
+            y = fa_add3(x, m2lane, nkd);  // x - k, k = kd + 2 lane: one v_add3
             PROF(1);
             snake16(qL, tL, qb, tb, q_len, t_len, act, x, y);
             PROF(2);
             vreg = x;
+            // (storing from every lane, the idle ones to a spare cell, to save the exec-mask
+            // round trip was measured: 72 -> 88 ms, the same-address stores serialise)
             if (act) cells[(u32)((int)row_off - lo) + (u32)lane] = fa_twice_plus(x, fa_m);  // x<<1 | from_above
             const u64 dir0 = fa_m >> lo;
             fin = (fa_ballot(x >= q_len) | fa_ballot(y >= t_len)) & act_m;  // :220
             PROF(3);
-            WRITE_ROW_RECORD(dir0, kd + 2 * lo);
+            WRITE_ROW_RECORD(dir0, 2 * lo - nkd);
             if (fin) break;  // (its records are flushed below)
             // (an LDS ds_max on one word instead of the DPP reduction was measured 2x
             // slower: 64 same-address atomics serialise)
@@ -297,11 +300,12 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             lo = __builtin_ctzll(in);            // absolute lanes: the new lowest diagonal
             hi = 64 - __builtin_clzll(in);       // (min_k = kd + 2 lo), one below, sits on the
             n = hi - lo + 1;                     // same lane one row on; the highest one lane up
-            kd--;
+            nkd++;
             d++;
             PROF(5);
             if (--safe < 0) break;
             }
+            kd = -nkd;
             if (fin) break;
         }
     reg_rows_finished:
