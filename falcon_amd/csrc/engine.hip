@@ -857,7 +857,7 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
             }
         }
         if (b->d_seg_pile.alloc(n_seg + 1) || b->d_seg_t0.alloc(n_seg + 1) ||
-            b->d_wide.alloc(n_seg + 2) || b->d_t_off.alloc((size_t)b->n_pile + 1))
+            b->d_wide.alloc(3 * (n_seg + 1) + 1) || b->d_t_off.alloc((size_t)b->n_pile + 1))
             return -1;
         // (synchronous copies on the null stream; the context's stream is non-blocking,
         // so they do not wait for k_align)

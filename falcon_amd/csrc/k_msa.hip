@@ -86,8 +86,8 @@ struct MsaArgs {
     const int *seg_pile;       // k_links work list
     const int *seg_t0;
     int n_seg;
-    int *wide_count;           // k_links<1> -> k_links<8> hand-over
-    int *wide_list;
+    int *wide_count;           // to-do lists of the wider k_links instances (3 lists of 1 + n_seg
+    int *wide_list;            // ints: [count, segments...]; wide_count = first list's count)
     unsigned min_cov;
     int first_links_back;      // unitig mode (falcon.c:668-773): see k_links
 };
@@ -384,10 +384,15 @@ template <int NCHT>
 __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
     __shared__ int act[MAXACT];
     const int lane = fa_lane();
+    // instance NCHT works off the list the narrower one before it filled and hands what
+    // is too wide for itself to the next (1 -> 2 -> 4 -> 8 chunks of 64 alignments)
+    constexpr int LVL = NCHT == 1 ? -1 : NCHT == 2 ? 0 : NCHT == 4 ? 1 : 2;
+    const int lstride = A.n_seg + 1;
     int sidx = blockIdx.x;
     if (NCHT > 1) {
-        if (sidx >= A.wide_count[0]) return;
-        sidx = A.wide_list[sidx];
+        const int *in = A.wide_count + LVL * lstride;
+        if (sidx >= in[0]) return;
+        sidx = in[1 + sidx];
     }
     if (sidx >= A.n_seg) return;
     const int p = __builtin_amdgcn_readfirstlane(A.seg_pile[sidx]);
@@ -424,7 +429,10 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
     }
     const int nch = (n_act + 63) >> 6;
     if (nch > NCHT) {  // too wide for this instance: defer
-        if (lane == 0) A.wide_list[atomicAdd(A.wide_count, 1)] = sidx;
+        if (NCHT < 8 && lane == 0) {
+            int *out = A.wide_count + (LVL + 1) * lstride;
+            out[1 + atomicAdd(out, 1)] = sidx;
+        }
         return;
     }
 
@@ -1161,8 +1169,12 @@ void fa_launch_msa_front(const FaBatchDev &b, const FaMsaDev &m, unsigned min_co
     hipLaunchKernelGGL(k_tscan, dim3(b.n_pile), dim3(64), 0, s, A);
     if (ev_tags) (void)hipEventRecord(ev_tags, s);
     if (m.n_seg > 0) {
-        (void)hipMemsetAsync(m.wide_count, 0, sizeof(int), s);
+        // (the three list heads; a wider instance's grid is the segment count because how
+        // many segments reach it is only known on the device: surplus wavefronts leave at once)
+        for (int l = 0; l < 3; l++) (void)hipMemsetAsync(m.wide_count + l * (m.n_seg + 1), 0, sizeof(int), s);
         hipLaunchKernelGGL(k_links<1>, dim3(m.n_seg), dim3(64), 0, s, A);
+        hipLaunchKernelGGL(k_links<2>, dim3(m.n_seg), dim3(64), 0, s, A);
+        hipLaunchKernelGGL(k_links<4>, dim3(m.n_seg), dim3(64), 0, s, A);
         hipLaunchKernelGGL(k_links<8>, dim3(m.n_seg), dim3(64), 0, s, A);
     }
     if (ev_links) (void)hipEventRecord(ev_links, s);
