@@ -267,6 +267,7 @@ struct fa_batch {
     HostBuf<FaAln> h_aln;
     HostBuf<FaPileOut> h_pile_out;
     HostBuf<FaTagAln> h_ta;
+    std::vector<int> pile_err, pile_err_arg;  // per pile: 0 fine, else why it has no consensus
     bool msa_static = false;  // seg lists and t_off (functions of the seed lengths) uploaded
     std::vector<int> h_out_eqv;
     std::vector<std::string> h_result;
@@ -488,6 +489,8 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
         delete b;
         return nullptr;
     }
+    b->pile_err.assign(n_pile, 0);
+    b->pile_err_arg.assign(n_pile, 0);
     b->n_seq = g;
     b->n_words = woff;
     b->ascii_bytes = aoff + 16;
@@ -857,7 +860,7 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
             }
         }
         if (b->d_seg_pile.alloc(n_seg + 1) || b->d_seg_t0.alloc(n_seg + 1) ||
-            b->d_wide.alloc(3 * (n_seg + 1) + 1) || b->d_t_off.alloc((size_t)b->n_pile + 1))
+            b->d_wide.alloc(4 * (n_seg + 1) + 1) || b->d_t_off.alloc((size_t)b->n_pile + 1))
             return -1;
         // (synchronous copies on the null stream; the context's stream is non-blocking,
         // so they do not wait for k_align)
@@ -900,6 +903,11 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
         u64 levels = (u64)pm.seed_len + 2, cols = 8;
         acc_first[p] = (u32)n_ta;
         int n_acc = 0;
+        b->pile_err[p] = 0;
+        // what the pile adds to the pools, committed below unless the pile is too deep
+        const size_t n_ta0 = n_ta;
+        const u64 desc0 = desc_tot, ins0 = ins_tot;
+        const long long sD0 = sD, sA0 = sA;
         for (int j = 1; j < pm.n_seq; j++) {
             const int g = pm.first + j;
             const FaAln &al = b->h_aln[g];
@@ -921,9 +929,14 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
             ins_tot += (u64)al.n_ins + 4;
         }
         if (n_acc > FA_CNS_MAX_ALN) {
-            set_err("falcon_amd: pile %d has %d usable reads; at most %d are supported", p, n_acc,
-                    FA_CNS_MAX_ALN);
-            return -3;
+            // deeper than the MSA kernels handle: this pile alone is reported
+            // (fa_batch_pile_error) and gets no consensus; the batch goes on without it
+            b->pile_err[p] = 2;
+            b->pile_err_arg[p] = n_acc;
+            n_ta = n_ta0; desc_tot = desc0; ins_tot = ins0; sD = sD0; sA = sA0;
+            n_acc = 0;
+            levels = (u64)pm.seed_len + 2;
+            cols = 8;
         }
         nal += n_acc;
         pm.node_off = node_off;
@@ -1008,14 +1021,20 @@ static int finish_run(fa_batch *b) {
     b->in_flight = false;
     HIP_OK(hipEventSynchronize(b->ev[6]));
     long long sO = 0;
+    int n_failed = 0;
     for (int p = 0; p < b->n_pile; p++) {
-        if (b->h_pile_out[p].err) {
-            set_err("falcon_amd: consensus of pile %d failed (code %d: %s)", p, b->h_pile_out[p].err,
-                    b->h_pile_out[p].err == 2 ? "more than 512 usable reads" : "MSA pool overflow");
-            return -3;
+        if (b->h_pile_out[p].err && !b->pile_err[p]) {  // (the MSA pools are sized from exact
+            b->pile_err[p] = 1;                         // bounds: not expected, but contained)
+            b->pile_err_arg[p] = b->h_pile_out[p].err;
+        }
+        if (b->pile_err[p]) {
+            b->h_pile_out[p].len = 0;
+            n_failed++;
+            continue;
         }
         sO += b->h_pile_out[p].len;
     }
+    b->stats.n_piles_failed = n_failed;
     fa_stats &st = b->stats;
     st.O = sO;
     (void)hipEventElapsedTime(&st.ms_index, b->ev[0], b->ev[1]);
@@ -1214,6 +1233,21 @@ extern "C" int fa_batch_result(fa_batch *b, int p, const char **seq, int *len, c
         *eqv = b->h_out_eqv.data() + b->pile[p].out_off + b->h_pile_out[p].start;
     }
     return 0;
+}
+
+extern "C" int fa_batch_pile_error(fa_batch *b, int p, char *msg, int msg_cap) {
+    if (!b || p < 0 || p >= b->n_pile) return -1;
+    const int code = b->pile_err[p];
+    if (code && msg && msg_cap > 0) {
+        if (code == 2)
+            snprintf(msg, (size_t)msg_cap, "%d usable reads; the GPU consensus stage handles at most %d per "
+                     "pile (the reference has no such limit: lower --max-n-read)", b->pile_err_arg[p],
+                     FA_CNS_MAX_ALN);
+        else
+            snprintf(msg, (size_t)msg_cap, "consensus stage failed (device code %d: MSA pool overflow)",
+                     b->pile_err_arg[p]);
+    }
+    return code;
 }
 
 extern "C" int fa_batch_stats(fa_batch *b, fa_stats *out) {

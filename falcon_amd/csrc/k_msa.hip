@@ -39,7 +39,7 @@
 #include <type_traits>
 
 #define TSEG 128       // target positions per k_links wavefront
-#define MAXACT 512     // alignments overlapping one segment
+#define MAXACT 1024    // alignments overlapping one segment (FA_CNS_MAX_ALN at most do)
 #define INL 11         // inserted bases stored inline in a tag
 #define BT_WIN 64      // levels per back-trace window
 
@@ -86,7 +86,7 @@ struct MsaArgs {
     const int *seg_pile;       // k_links work list
     const int *seg_t0;
     int n_seg;
-    int *wide_count;           // to-do lists of the wider k_links instances (3 lists of 1 + n_seg
+    int *wide_count;           // to-do lists of the wider k_links instances (4 lists of 1 + n_seg
     int *wide_list;            // ints: [count, segments...]; wide_count = first list's count)
     unsigned min_cov;
     int first_links_back;      // unitig mode (falcon.c:668-773): see k_links
@@ -381,20 +381,35 @@ __device__ __forceinline__ int tag_ins_base(const MsaArgs &A, u32 ins_off, u32 w
 // coverage); wider segments put themselves on a to-do list that the NCHT = 8
 // instance works off in a second launch (no host round trip).
 template <int NCHT>
+__device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx);
+
+// Instance NCHT works off the list the narrower one before it filled and hands what is too
+// wide for itself to the next (1 -> 2 -> 4 -> 8 -> 16 chunks of 64 alignments).  The first
+// instance is one wavefront per segment; the wider ones a fixed grid looping over their
+// list (how long it is only the device knows; usually it is empty).
+template <int NCHT>
 __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
-    __shared__ int act[MAXACT];
-    const int lane = fa_lane();
-    // instance NCHT works off the list the narrower one before it filled and hands what
-    // is too wide for itself to the next (1 -> 2 -> 4 -> 8 chunks of 64 alignments)
-    constexpr int LVL = NCHT == 1 ? -1 : NCHT == 2 ? 0 : NCHT == 4 ? 1 : 2;
-    const int lstride = A.n_seg + 1;
-    int sidx = blockIdx.x;
-    if (NCHT > 1) {
-        const int *in = A.wide_count + LVL * lstride;
-        if (sidx >= in[0]) return;
-        sidx = in[1 + sidx];
+    constexpr int LVL = NCHT == 1 ? -1 : NCHT == 2 ? 0 : NCHT == 4 ? 1 : NCHT == 8 ? 2 : 3;
+    if (NCHT == 1) {
+        if ((int)blockIdx.x < A.n_seg) links_segment<NCHT>(A, (int)blockIdx.x);
+        return;
     }
-    if (sidx >= A.n_seg) return;
+    const int *in = A.wide_count + LVL * (A.n_seg + 1);
+    const int n_in = __builtin_amdgcn_readfirstlane(in[0]);
+    for (int i = (int)blockIdx.x; i < n_in; i += (int)gridDim.x) {
+        links_segment<NCHT>(A, __builtin_amdgcn_readfirstlane(in[1 + i]));
+        __syncthreads();  // (the next segment reuses the LDS)
+    }
+}
+
+template <int NCHT>
+__device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
+    // (only what this instance can take is kept: a segment with more is handed on; LDS per
+    // wavefront decides how many of these latency-bound wavefronts a CU holds)
+    __shared__ int act[NCHT * 64];
+    const int lane = fa_lane();
+    constexpr int LVL = NCHT == 1 ? -1 : NCHT == 2 ? 0 : NCHT == 4 ? 1 : NCHT == 8 ? 2 : 3;
+    const int lstride = A.n_seg + 1;
     const int p = __builtin_amdgcn_readfirstlane(A.seg_pile[sidx]);
     const int t_lo = __builtin_amdgcn_readfirstlane(A.seg_t0[sidx]);
     const FaPile pm = A.pile[p];
@@ -419,17 +434,17 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
         }
         const u64 m = __ballot(ov);
         const int rank = __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-        if (ov && n_act + rank < MAXACT) act[n_act + rank] = (int)i;
+        if (ov && n_act + rank < NCHT * 64) act[n_act + rank] = (int)i;
         n_act += __popcll(m);
     }
     __syncthreads();
-    if (n_act > MAXACT) {  // cannot happen: <= 512 accepted alignments per pile
+    if (n_act > MAXACT) {  // cannot happen: <= FA_CNS_MAX_ALN accepted alignments per pile
         if (lane == 0) A.score_out[p].err = 2;
         return;
     }
     const int nch = (n_act + 63) >> 6;
     if (nch > NCHT) {  // too wide for this instance: defer
-        if (NCHT < 8 && lane == 0) {
+        if (NCHT < 16 && lane == 0) {
             int *out = A.wide_count + (LVL + 1) * lstride;
             out[1 + atomicAdd(out, 1)] = sidx;
         }
@@ -706,7 +721,7 @@ __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
 #define SC_LEVELS 128     // levels per block (their link counts sit in two VGPRs)
 #define SC_REG 12         // insertion levels whose scores live in registers
 #define SC_ZERO 63        // lane of the score registers that always holds 0 (start links)
-#define SC_BIAS 1024      // makes every link score positive (score >= -2 - coverage, coverage <= 512)
+#define SC_BIAS 2048      // makes every link score positive (score >= -2 - coverage, coverage <= 1023)
 
 struct ScoreAcc { int h, p, k, n; };
 
@@ -1169,13 +1184,14 @@ void fa_launch_msa_front(const FaBatchDev &b, const FaMsaDev &m, unsigned min_co
     hipLaunchKernelGGL(k_tscan, dim3(b.n_pile), dim3(64), 0, s, A);
     if (ev_tags) (void)hipEventRecord(ev_tags, s);
     if (m.n_seg > 0) {
-        // (the three list heads; a wider instance's grid is the segment count because how
-        // many segments reach it is only known on the device: surplus wavefronts leave at once)
-        for (int l = 0; l < 3; l++) (void)hipMemsetAsync(m.wide_count + l * (m.n_seg + 1), 0, sizeof(int), s);
+        // (the list heads)
+        for (int l = 0; l < 4; l++) (void)hipMemsetAsync(m.wide_count + l * (m.n_seg + 1), 0, sizeof(int), s);
         hipLaunchKernelGGL(k_links<1>, dim3(m.n_seg), dim3(64), 0, s, A);
-        hipLaunchKernelGGL(k_links<2>, dim3(m.n_seg), dim3(64), 0, s, A);
-        hipLaunchKernelGGL(k_links<4>, dim3(m.n_seg), dim3(64), 0, s, A);
-        hipLaunchKernelGGL(k_links<8>, dim3(m.n_seg), dim3(64), 0, s, A);
+        const int wide_grid = m.n_seg < 8192 ? m.n_seg : 8192;
+        hipLaunchKernelGGL(k_links<2>, dim3(wide_grid), dim3(64), 0, s, A);
+        hipLaunchKernelGGL(k_links<4>, dim3(wide_grid), dim3(64), 0, s, A);
+        hipLaunchKernelGGL(k_links<8>, dim3(wide_grid), dim3(64), 0, s, A);
+        hipLaunchKernelGGL(k_links<16>, dim3(wide_grid), dim3(64), 0, s, A);
     }
     if (ev_links) (void)hipEventRecord(ev_links, s);
 }

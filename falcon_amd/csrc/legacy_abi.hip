@@ -56,6 +56,13 @@ extern "C" consensus_data *generate_consensus(char **input_seq, unsigned int n_s
     const int *e = nullptr;
     int len = 0;
     if (fa_batch_result(b, 0, &s, &len, &e)) die("generate_consensus(result)");
+    char why[256];
+    if (fa_batch_pile_error(b, 0, why, (int)sizeof(why)) > 0) {
+        // this ABI has no error channel and the reference no such limit: loud, like its own
+        // failed allocations (DW_banded.c:100-113)
+        fprintf(stderr, "CRITICAL ERROR: falcon_amd generate_consensus: %s\n", why);
+        abort();
+    }
     consensus_data *r = (consensus_data *)calloc(1, sizeof(consensus_data));
     r->sequence = (char *)calloc((size_t)len + 1, 1);
     r->eqv = (int *)calloc((size_t)len + 1, sizeof(int));

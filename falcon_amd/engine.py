@@ -17,6 +17,16 @@ def _b(s) -> bytes:
     return s if isinstance(s, bytes) else s.encode("ascii")
 
 
+class FailedPile(str):
+    """The (empty) consensus of a pile that failed alone (fa_batch_pile_error): its batch went
+    on without it; ``reason`` says why.  Prints like a pile without usable reads: nothing."""
+
+    def __new__(cls, reason):
+        self = super().__new__(cls, "")
+        self.reason = reason
+        return self
+
+
 class PileSet:
     """Admitted piles of one ``fa_reader_next`` call: pointer arrays owned by the reader
     (valid until its next call), in exactly the shape ``fa_batch_create`` takes."""
@@ -168,6 +178,10 @@ class Batch:
                                     C.byref(eqv) if self._eqv else None):
             raise FalconAmdError(last_error())
         s = C.string_at(seq, n.value).decode("ascii")
+        if n.value == 0:
+            msg = C.create_string_buffer(256)
+            if self.lib.fa_batch_pile_error(self.h, pile, msg, 256) > 0:
+                s = FailedPile(msg.value.decode("utf-8", "replace"))
         return (s, list(eqv[:n.value])) if self._eqv else s
 
     def stats(self) -> FaStats:

@@ -28,7 +28,8 @@ class FaStats(C.Structure):
                 ("align_slots", C.c_int),
                 ("ms_tags", C.c_float), ("ms_links", C.c_float), ("ms_score", C.c_float),
                 ("ms_backtrace", C.c_float),
-                ("align_slot_cells", C.c_longlong), ("align_relaunched", C.c_int)]
+                ("align_slot_cells", C.c_longlong), ("align_relaunched", C.c_int),
+                ("n_piles_failed", C.c_int)]
 
     def b_alg(self) -> int:
         """Algorithmic bytes: L/4 + 4C + 8D + 16A + 12T + 5O."""
@@ -71,6 +72,7 @@ def load() -> C.CDLL:
     lib.fa_batch_result.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p),
                                     C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_int))]
     lib.fa_batch_stats.argtypes = [C.c_void_p, C.POINTER(FaStats)]
+    lib.fa_batch_pile_error.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
     lib.fa_batch_free.argtypes = [C.c_void_p]
     lib.fa_batch_range.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_int)] * 4 + \
         [C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.POINTER(C.c_int)]

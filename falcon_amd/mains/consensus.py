@@ -342,6 +342,21 @@ def fasta_records(seed_id, cns, output_full, output_multi):
     return "".join(text)
 
 
+# Piles fail alone (falcon_amd.h: fa_batch_pile_error -- e.g. more usable reads than the GPU
+# consensus stage handles, which takes --max-n-read above 1024): every other pile is
+# corrected and printed, the failed ones are named on stderr and make the exit status 3
+# (FALCON_AMD_SKIP_FAILED_PILES=1: status 0) -- the reference would have corrected them too.
+FAILED_PILES = []
+
+
+def note_failed_piles(ids, cns_all):
+    for sid, cns in zip(ids, cns_all):
+        reason = getattr(cns, "reason", None)
+        if reason is not None:
+            FAILED_PILES.append(sid)
+            LOG.error("seed %s is not corrected: %s", sid, reason)
+
+
 def _stream_fd(stream):
     """File descriptor behind ``stream`` when it is an OS-level stream (the native reader
     takes it over and python must not have read from it), else None (StringIO & co)."""
@@ -448,6 +463,7 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
                     want += 1
                     if stop.is_set():
                         continue
+                    note_failed_piles(ids, cns_all)
                     stdout.write("".join(fasta_records(sid, cns, args.output_full, args.output_multi)
                                          for sid, cns in zip(ids, cns_all)))
                     LOG.debug("printer: %d piles in %.3f s", len(ids), time.perf_counter() - t0)
@@ -527,6 +543,7 @@ def run(args, stdin=None, stdout=None, consensus_map=None):
         todo = gpu.trimmed(todo, cfg)
     try:
         for i, cns in enumerate(consensus_map(todo)):
+            note_failed_piles(seed_ids[i:i + 1], [cns])
             stdout.write(fasta_records(seed_ids[i], cns, args.output_full, args.output_multi))
     finally:
         if gpu is not None:
@@ -535,7 +552,14 @@ def run(args, stdin=None, stdout=None, consensus_map=None):
 
 
 def main(argv=None):
-    run(parse_args(sys.argv if argv is None else argv))
+    args = parse_args(sys.argv if argv is None else argv)
+    if args.max_n_read - 1 > 1023:
+        sys.stderr.write("falcon_amd: --max-n-read %d: piles with more than 1023 usable reads will be "
+                         "reported and left uncorrected (the GPU consensus stage's limit)\n" % args.max_n_read)
+    run(args)
+    if FAILED_PILES and not os.environ.get("FALCON_AMD_SKIP_FAILED_PILES"):
+        sys.stderr.write("falcon_amd: %d pile(s) were not corrected (see above)\n" % len(FAILED_PILES))
+        sys.exit(3)
 
 
 if __name__ == "__main__":

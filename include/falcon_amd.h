@@ -138,6 +138,7 @@ typedef struct {
      * had to be repeated with worst-case slots (some alignment outgrew the usual size) */
     long long align_slot_cells;
     int align_relaunched;
+    int n_piles_failed; /* piles of the last run without a consensus, see fa_batch_pile_error */
 } fa_stats;
 
 const char *fa_last_error(void);
@@ -167,6 +168,13 @@ int fa_batch_fetch(fa_batch *b, int want_eqv);
 /* Consensus of pile p: *seq is NUL terminated and owned by the batch. */
 int fa_batch_result(fa_batch *b, int pile, const char **seq, int *len, const int **eqv);
 int fa_batch_stats(fa_batch *b, fa_stats *out);
+/* Piles fail alone.  The consensus stage handles up to 1023 usable reads per pile (the
+ * reference, falcon.c:597-647, any number; its driver's default --max-n-read is 500); a
+ * deeper pile -- or one whose consensus stage reports a device error -- does not fail its
+ * batch: fa_batch_run succeeds, fa_batch_result gives that pile an empty consensus, and this
+ * returns why (0: the pile is fine; 2: too many usable reads; 1: device error), with a
+ * description in msg if msg != NULL. */
+int fa_batch_pile_error(fa_batch *b, int pile, char *msg, int msg_cap);
 void fa_batch_free(fa_batch *b);
 
 /* Diagnostics used by the parity tests: per-sequence stage outputs.

@@ -49,3 +49,27 @@ def test_overlay_exposes_reference_names():
             "print(fk.consensus_of(['ACGT'*300]*12, 4, 8, 0.7)[:20])")
     out = run_cmd([sys.executable, "-c", code], "", extra_path=os.path.join(ROOT, "dropin"))
     assert out.strip() == ("ACGT" * 300)[1:21]
+
+
+def test_a_pile_too_deep_for_the_gpu_fails_alone():
+    """--max-n-read 2000 lets a pile of ~1200 usable reads through: every other pile is printed
+    exactly as without it, the deep one is named on stderr, the exit status is 3 (0 with
+    FALCON_AMD_SKIP_FAILED_PILES=1) -- never a dead stream half way through."""
+    from falcon_amd.synth import make_pile, pile_to_la4falcon
+    chunks = []
+    for i in range(3):
+        seed, rd = make_pile(1300 + i, S=2500, coverage=14, min_read=500, mean_read=1500, sd_read=400)
+        chunks.append(pile_to_la4falcon("%09d" % i, seed, rd, 100000 * i + 1))
+    seed, rd = make_pile(1310, S=2500, coverage=830, e=0.08, min_read=1500, mean_read=2200, sd_read=200)
+    deep = pile_to_la4falcon("%09d" % 7, seed, rd, 700001)
+    opts = ["--output-multi", "--min-idt", "0.70", "--min-cov", "4", "--max-n-read", "2000", "--n-core", "1"]
+    cmd = [sys.executable, "-m", "falcon_amd.mains.consensus"] + opts
+    clean = run_cmd(cmd, "".join(chunks) + "- -\n")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    text = chunks[0] + deep + chunks[1] + chunks[2] + "- -\n"
+    p = subprocess.run(cmd, input=text, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert p.returncode == 3 and p.stdout == clean
+    assert "seed 000000007 is not corrected" in p.stderr and "1023" in p.stderr
+    p = subprocess.run(cmd, input=text, capture_output=True, text=True, cwd=ROOT, timeout=600,
+                       env=dict(env, FALCON_AMD_SKIP_FAILED_PILES="1"))
+    assert p.returncode == 0 and p.stdout == clean

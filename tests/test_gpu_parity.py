@@ -240,6 +240,40 @@ def test_batch_is_order_preserving_and_rerunnable(engine):
     bt.free()
 
 
+def test_deep_piles_and_failures_stay_with_their_pile(engine, port):
+    """The reference loops over any n_seq (falcon.c:597-647); its driver's default
+    --max-n-read is 500.  Piles of ~700 and ~1000 usable reads (more than 64, 128, 256 and 512
+    alignments over a segment: every k_links instance) equal the oracle; a pile past the
+    consensus stage's 1023 fails ALONE -- its neighbours in the batch are corrected as if
+    it were not there, it is reported (fa_batch_pile_error) and gets the empty consensus."""
+    from falcon_amd.engine import FailedPile
+    normal = [_synthetic(700 + i, S=3000, coverage=14, min_read=600, mean_read=1800, sd_read=500)
+              for i in range(2)]
+    deep = _synthetic(710, max_n_read=5000, S=3000, coverage=440, e=0.10, min_read=1500, mean_read=2400, sd_read=300)
+    deeper = _synthetic(711, max_n_read=5000, S=2500, coverage=690, e=0.08, min_read=1500, mean_read=2200, sd_read=200)
+    too_deep = _synthetic(712, max_n_read=5000, S=2500, coverage=830, e=0.08, min_read=1500, mean_read=2200,
+                          sd_read=200)
+    assert 650 < len(deep) < 800 and 900 < len(deeper) <= 1020 and len(too_deep) > 1150
+    piles = [normal[0], deep, too_deep, deeper, normal[1]]
+    b = engine.batch(piles)
+    try:
+        b.run(4, 8, 0.70).fetch(True)
+        got = [b.result(i) for i in range(len(piles))]
+        st = b.stats()
+    finally:
+        b.free()
+    assert st.n_piles_failed == 1
+    for i in (0, 1, 3, 4):
+        want = port.generate_consensus(piles[i], 4, 8, 0.70)
+        assert got[i][0] == want[0] and got[i][1] == want[1], i
+        assert not isinstance(got[i][0], FailedPile)
+    assert isinstance(got[2][0], FailedPile) and got[2][0] == "" and got[2][1] == []
+    assert "usable reads" in got[2][0].reason and "1023" in got[2][0].reason
+    # and alone in a batch: still no failure of the call
+    (only,) = engine.consensus([too_deep], 4, 8, 0.70)
+    assert isinstance(only, FailedPile)
+
+
 def test_pipelined_submit_wait_equals_run(engine):
     """fa_batch_submit / fa_batch_wait: two (and three) batches of one context in flight, the
     next one's throughput stages beside the previous one's score recurrence and back-trace
