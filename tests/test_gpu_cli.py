@@ -73,3 +73,44 @@ def test_a_pile_too_deep_for_the_gpu_fails_alone():
     p = subprocess.run(cmd, input=text, capture_output=True, text=True, cwd=ROOT, timeout=600,
                        env=dict(env, FALCON_AMD_SKIP_FAILED_PILES="1"))
     assert p.returncode == 0 and p.stdout == clean
+
+
+def test_length_limits_through_the_command_line():
+    """Sequences of more than 100 000 bases are cut to 99 999 (consensus.py:162,178-179) and
+    the consensus core takes seeds below 100 000 (falcon.c:343): a pile on a 99.3 kb seed
+    with a 101 kb read (cut by the reader), and a pile whose seed line itself is 100.6 kb
+    (cut to 99 999, the largest seed there can be) -- stdout equals the restated parser +
+    the CPU oracle + the output rules on the same text."""
+    import io
+    import numpy as np
+    from falcon_amd.mains import consensus as cli
+    from falcon_amd.synth import codes_to_str, noisy
+    from oracle.pyoracle import Port
+    rng = np.random.default_rng(99)
+    lines, seeds = [], []
+    for pile, (window, seed_e) in enumerate(((95000, 0.13), (98500, 0.05))):
+        genome = rng.integers(0, 4, 104000).astype(np.uint8)
+        seeds.append(codes_to_str(noisy(genome[:window], rng, seed_e)))
+        lines.append("%08d %s" % (pile, seeds[-1]))
+        k = 1
+        for start in range(0, window - 20000, 9000):
+            lines.append("%08d %s" % (1000 + 100 * pile + k,
+                                      codes_to_str(noisy(genome[start:start + 31000], rng, 0.12))))
+            k += 1
+        lines.append("%08d %s" % (1000 + 100 * pile + k, codes_to_str(noisy(genome[:100500], rng, 0.05))))
+        lines.append("+ +")
+    text = "\n".join(lines) + "\n- -\n"
+    assert 99000 < len(seeds[0]) < 100000 and len(seeds[1]) > 100000
+    assert max(len(ln) for ln in lines) > 100000 + 9
+    opts = ["--output-multi", "--min-idt", "0.70", "--min-cov", "2", "--min-cov-aln", "2", "--min-n-read", "3",
+            "--n-core", "1"]
+    out = run_cmd([sys.executable, "-m", "falcon_amd.mains.consensus"] + opts, text)
+    args = cli.parse_args(["prog"] + opts)
+    cfg = cli.settings_from(args)
+    port, want = Port(), []
+    piles = list(cli.PileReader(io.StringIO(text), cfg, args.min_n_read, args.min_len_aln))
+    assert [len(p[0]) for _, p in piles] == [len(seeds[0]), 99999]
+    assert max(len(r) for _, p in piles for r in p) == 99999
+    for sid, pile in piles:
+        want.append(cli.fasta_records(sid, port.generate_consensus(pile, 2, 8, 0.70)[0], False, True))
+    assert out == "".join(want) and out.count(">") >= 2 and len(out) > 150000

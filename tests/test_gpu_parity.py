@@ -115,6 +115,32 @@ def test_wide_band_vs_oracle(engine):
     assert widest > 1500  # rows far wider than the 190-diagonal kernel could hold
 
 
+def test_align_beyond_100kb_band_1500(engine, port):
+    """graph_to_contig.get_aln_data aligns overlapping contig ends with band 1500 over up to
+    250 kb (falcon_kit/mains/graph_to_contig.py:52-105): 120 kb at 2 % and 230 kb at 0.3 %
+    divergence through k_align_wide against the oracle -- the six numbers, and the gapped
+    strings by digest."""
+    import hashlib
+    import time
+    from falcon_amd.synth import codes_to_str, noisy
+    rng = np.random.default_rng(77)
+    pairs = []
+    for n, e in ((120000, 0.02), (230000, 0.003)):
+        t = rng.integers(0, 4, n).astype(np.uint8)
+        pairs.append((codes_to_str(noisy(t, rng, e)), codes_to_str(t)))
+    t0 = time.time()
+    got = engine.align_pairs(pairs, band=1500, want_str=True)
+    dt = time.time() - t0
+    for (q, t), r in zip(pairs, got):
+        want = port.align(q, t, 1500, 1)
+        for k in ("aln_str_size", "dist", "aln_q_s", "aln_q_e", "aln_t_s", "aln_t_e"):
+            assert r[k] == want[k], k
+        assert r["aln_str_size"] > 100000
+        for k in ("q_aln_str", "t_aln_str"):
+            assert hashlib.sha1(r[k].encode()).hexdigest() == hashlib.sha1(want[k].encode()).hexdigest(), k
+    print("align_pairs of 120 kb + 230 kb at band 1500: %.2f s (staging, kernel, strings)" % dt)
+
+
 def test_chain_ranges_golden(engine):
     """k_seed_index + k_chain vs find_kmer_pos_for_seq + find_best_aln_range."""
     cases = [c for c in F1 if c["mask"] < 0]
@@ -125,6 +151,70 @@ def test_chain_ranges_golden(engine):
         assert r["n_hit"] == c["count"], c["name"]
         assert [r["s1"], r["e1"], r["s2"], r["e2"], r["score"]] == c["range_48_5"], c["name"]
     b.free()
+
+
+def _planted(rng, runs, seed_len, query_len, homopolymer_at=()):
+    """Seed and query in which the only 8-mer matches (up to accidents, which both sides see
+    alike) are planted: `runs` = [(q0, t0, n_hits)]: n_hits consecutive probes (every 4th
+    query offset) on one diagonal.  Fillers come from disjoint alphabets."""
+    seed = [rng.choice("AC") for _ in range(seed_len)]
+    query = [rng.choice("GT") for _ in range(query_len)]
+    for q0, t0, n in runs:
+        word = [rng.choice("ACGT") for _ in range(4 * (n - 1) + 8)]
+        seed[t0:t0 + len(word)] = word
+        query[q0:q0 + len(word)] = word
+    for q0, t0, reps in homopolymer_at:   # one query 8-mer, `reps` seed positions in a row
+        seed[t0:t0 + 8 + reps - 1] = "G" * (8 + reps - 1)
+        query[q0:q0 + 8] = "G" * 8
+    return "".join(seed)[:seed_len], "".join(query)[:query_len]
+
+
+def test_chain_tie_breaks_on_planted_hits(engine, port):
+    """The tie-breaks of find_best_aln_range (kmer_lookup.c:360-366: first fullest bin in hit
+    order; :396-410: the running score resets at gaps, repeated query positions count +32
+    each) on k_chain itself: planted hit patterns in the style of tests/golden/f2_ranges_extra
+    (equal counts in two bins in both orders, gap resets, a query 8-mer hitting a run of
+    seed positions, counts around the threshold of 5), k_seed_index + k_chain against the
+    oracle's hit list and window on the same strings."""
+    import random
+    rng = random.Random(2024)
+    designs = []
+    for _ in range(12):   # two runs of equal length on different diagonals, either order
+        n = rng.choice([6, 7, 9, 12])
+        qa, qb = sorted(rng.sample(range(0, 1500, 4), 2))
+        if qb - qa < 4 * n + 40:
+            qb = qa + 4 * n + 40 + 4 * rng.randint(0, 50)
+        ta, tb = rng.sample([200, 900, 1700, 2600, 3300], 2)
+        designs.append(([(qa, ta, n), (qb, tb, n)], ()))
+    for _ in range(8):    # one diagonal broken by gaps: the score resets (:396-410)
+        n1, n2, n3 = rng.choice([3, 6, 8]), rng.choice([6, 7]), rng.choice([2, 6, 10])
+        q0, gap1, gap2 = 4 * rng.randint(0, 30), 4 * rng.randint(20, 120), 4 * rng.randint(20, 120)
+        q1 = q0 + 4 * n1 + gap1
+        q2 = q1 + 4 * n2 + gap2
+        designs.append(([(q0, q0 + 300, n1), (q1, q1 + 300, n2), (q2, q2 + 300, n3)], ()))
+    for _ in range(8):    # counts around the threshold (count_th = 5: more than 5 hits needed)
+        n = rng.choice([4, 5, 6])
+        designs.append(([(4 * rng.randint(0, 100), rng.randint(0, 2000), n)], ()))
+    for _ in range(8):    # a query 8-mer on 2..6 consecutive seed positions inside a run
+        n = rng.choice([6, 8])
+        q0, t0 = 4 * rng.randint(5, 60), rng.randint(100, 1500)
+        designs.append(([(q0, t0, n), (q0 + 4 * n + 8, t0 + 4 * n + 8 + rng.choice([0, 3]), n)],
+                        [(q0 + 4 * n, t0 + 4 * n - rng.randint(0, 2), rng.randint(2, 6))]))
+    pairs = [_planted(rng, runs, 4000, 2400, homo) for runs, homo in designs]
+    b = engine.batch([[seed, query] for seed, query in pairs])
+    try:
+        b.run(4, 8, 0.70)
+        interesting = 0
+        for i, (seed, query) in enumerate(pairs):
+            hq, ht = port.find_hits(seed, query)
+            want = list(port.best_range(hq, ht, 48, 5))
+            r = b.range(2 * i + 1)
+            assert r["n_hit"] == len(hq), i
+            assert [r["s1"], r["e1"], r["s2"], r["e2"], r["score"]] == want, (i, designs[i])
+            interesting += want != [0, 0, 0, 0, 0]
+        assert interesting >= 25   # most designs produce a window, the sub-threshold ones none
+    finally:
+        b.free()
 
 
 @pytest.mark.parametrize("case", F4, ids=[c["name"] for c in F4])
