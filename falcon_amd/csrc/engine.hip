@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -78,6 +79,14 @@ struct fa_ctx {
     hipStream_t back_stream = nullptr;
     hipStream_t dl_stream = nullptr;
     std::mutex front_mu, fetch_mu;
+    // The back stage of the batch submitted last is not queued at once: it is queued by the
+    // NEXT submit, between that batch's k_chain and k_align (or by its own fa_batch_wait /
+    // fa_batch_free, whichever comes first).  Its wavefronts then start beside k_align --
+    // which is bound by the scalar pipe and gives up three of eight wave slots for ~30 ms at
+    // little cost -- instead of beside k_seed_index / k_chain, which need the wave slots and
+    // the LDS those wavefronts hold (measured: k_chain 9.5 -> 19 ms next to k_score).
+    std::mutex back_mu;
+    fa_batch *pending_back = nullptr;
     char *h_dl = nullptr;    // pinned landing buffer of the downloads (grow only; fetch_mu)
     size_t h_dl_cap = 0;
     // alignment work-slot arena (grow only)
@@ -277,6 +286,9 @@ struct fa_batch {
     // timing events of the last run (0..7 on the front stream, 8..11 on the back stream)
     hipEvent_t ev[12] = {};
     bool in_flight = false;  // fa_batch_submit done, fa_batch_wait pending
+    bool back_queued = false;  // its k_score / k_backtrace are on the back stream
+    FaMsaDev md_saved = {};
+    unsigned min_cov_saved = 0;
     ~fa_batch() {
         for (auto &e : ev)
             if (e) (void)hipEventDestroy(e);
@@ -330,7 +342,11 @@ extern "C" fa_ctx *fa_create(int device) {
     c->n_cu = prop.multiProcessorCount;
     c->total_mem = prop.totalGlobalMem;
     HIP_OK_P(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_OK_P(hipStreamCreateWithFlags(&c->back_stream, hipStreamNonBlocking));
+    {   // the back stream's few wavefronts go first when wave slots free up
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        HIP_OK_P(hipStreamCreateWithPriority(&c->back_stream, hipStreamNonBlocking, greatest));
+    }
     HIP_OK_P(hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
     HIP_OK_P(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
     HIP_OK_P(hipMalloc((void **)&c->arena.counter, sizeof(int)));
@@ -655,7 +671,11 @@ extern "C" fa_batch *fa_batch_create(fa_ctx *ctx, int n_pile, const int *pile_n_
 extern "C" void fa_batch_free(fa_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
-    if (b->in_flight && b->ev[6]) (void)hipEventSynchronize(b->ev[6]);  // its kernels still read it
+    {
+        std::lock_guard<std::mutex> hold(b->ctx->back_mu);
+        if (b->ctx->pending_back == b) b->ctx->pending_back = nullptr;  // never queued: nothing reads it
+    }
+    if (b->in_flight && b->back_queued && b->ev[6]) (void)hipEventSynchronize(b->ev[6]);  // its kernels still read it
     // (its device and pinned buffers release themselves)
     delete b;
 }
@@ -747,7 +767,8 @@ static int fetch_aln(fa_batch *b) {
 // falcon.c:699-704).
 static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int band,
                            int force_accept_g);
-static int finish_run(fa_batch *b);
+static int finish_run(fa_batch *b, bool grace);
+static int flush_pending_back(fa_ctx *c, fa_batch *only = nullptr, hipEvent_t after = nullptr);
 
 // Front stages of a run (seed index, chaining, alignment, MSA plan, tags, links) on the
 // context's front stream -- this call returns when they are done -- then k_score and
@@ -793,6 +814,15 @@ extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double
     if (b->h_range.resize(b->n_seq)) return -1;
     HIP_OK(hipMemcpyAsync(b->h_range.data(), b->d_range.p, (size_t)b->n_seq * sizeof(FaRange),
                           hipMemcpyDeviceToHost, s));
+    // The batch before this one: its k_score / k_backtrace are queued here.  They start as
+    // soon as their own links are done -- the host runs ahead of the device -- i.e. beside
+    // this batch's k_seed_index and k_chain; FALCON_AMD_BACK_AFTER_CHAIN=1 holds them until
+    // this batch's k_chain is done, beside k_align instead.  Measured per 3072 piles
+    // [MI355X]: beside index + chain 140 ms per step (k_chain 9.5 -> 19 ms: it loses LDS and
+    // wave slots), beside k_align 144 ms (k_align 72 -> 90 ms: its throughput follows its
+    // resident wavefronts), one batch at a time 158 ms.
+    static const bool after_chain = getenv("FALCON_AMD_BACK_AFTER_CHAIN") != nullptr;
+    if (flush_pending_back(c, nullptr, after_chain ? b->ev[2] : nullptr)) return -1;
     return run_from_ranges(b, min_cov, max_diff, FA_BAND, -1);
 }
 
@@ -804,13 +834,13 @@ extern "C" int fa_batch_wait(fa_batch *b) {
         return -1;
     }
     HIP_OK(hipSetDevice(b->ctx->device));
-    return finish_run(b);
+    return finish_run(b, true);
 }
 
 extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double min_idt) {
     int rc = fa_batch_submit(b, min_cov, K, min_idt);
     if (rc) return rc;
-    return fa_batch_wait(b);
+    return finish_run(b, false);
 }
 
 static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int band,
@@ -998,17 +1028,15 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
     HIP_OK(hipEventRecord(b->ev[5], s));
     trace_stage(s, "links");
     HIP_OK(hipGetLastError());
-    // k_score + k_backtrace on the back stream, behind this batch's links
-    hipStream_t sb = c->back_stream;
-    HIP_OK(hipStreamWaitEvent(sb, b->ev[5], 0));
-    HIP_OK(hipEventRecord(b->ev[7], sb));
-    fa_launch_msa_back(d, md, min_cov, sb, b->ev[10], b->ev[11]);  // k_score | k_backtrace
-    trace_stage(sb, "consensus");
-    HIP_OK(hipGetLastError());
+    // k_score + k_backtrace: queued later, see fa_ctx::pending_back
+    b->md_saved = md;
+    b->min_cov_saved = min_cov;
+    b->back_queued = false;
     if (b->h_pile_out.resize(b->n_pile)) return -1;
-    HIP_OK(hipMemcpyAsync(b->h_pile_out.data(), b->d_pile_out.p,
-                          (size_t)b->n_pile * sizeof(FaPileOut), hipMemcpyDeviceToHost, sb));
-    HIP_OK(hipEventRecord(b->ev[6], sb));
+    {
+        std::lock_guard<std::mutex> hold(c->back_mu);
+        c->pending_back = b;
+    }
     // what the statistics need of this plan
     b->stats.C = sC; b->stats.D = sD; b->stats.A = sA; b->stats.n_aligned = nal;
     b->stats.align_slots = c->arena.n_slot;
@@ -1017,8 +1045,58 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
     return 0;
 }
 
-static int finish_run(fa_batch *b) {
+// k_score + k_backtrace of `b` on the back stream, behind its links.  Caller holds back_mu.
+static int queue_back(fa_batch *b, hipEvent_t after) {
+    fa_ctx *c = b->ctx;
+    hipStream_t sb = c->back_stream;
+    HIP_OK(hipStreamWaitEvent(sb, b->ev[5], 0));
+    // (the host runs ahead of the device: without this the stage would start as soon as
+    // its own links are done, i.e. beside the next batch's k_seed_index and k_chain)
+    if (after) HIP_OK(hipStreamWaitEvent(sb, after, 0));
+    HIP_OK(hipEventRecord(b->ev[7], sb));
+    fa_launch_msa_back(b->dev(), b->md_saved, b->min_cov_saved, sb, b->ev[10], b->ev[11]);  // k_score | k_backtrace
+    trace_stage(sb, "consensus");
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(b->h_pile_out.data(), b->d_pile_out.p,
+                          (size_t)b->n_pile * sizeof(FaPileOut), hipMemcpyDeviceToHost, sb));
+    HIP_OK(hipEventRecord(b->ev[6], sb));
+    b->back_queued = true;
+    return 0;
+}
+// Queue the context's pending back stage, if any (or only if it is `only`).
+static int flush_pending_back(fa_ctx *c, fa_batch *only, hipEvent_t after) {
+    std::lock_guard<std::mutex> hold(c->back_mu);
+    fa_batch *p = c->pending_back;
+    if (!p || (only && p != only)) return 0;
+    c->pending_back = nullptr;
+    return queue_back(p, after);
+}
+
+static int finish_run(fa_batch *b, bool grace) {
+    // Still pending: a submit of the next batch that is under way (it holds front_mu) queues
+    // this batch's back stage at the right moment, right after its own k_chain; with
+    // `grace`, one that is about to start (another thread of a worker, between two calls)
+    // gets a millisecond to do so; otherwise this call queues it itself.
+    fa_ctx *c = b->ctx;
+    for (int idle = 0;; ) {
+        {
+            std::lock_guard<std::mutex> hold(c->back_mu);
+            if (b->back_queued || c->pending_back != b) break;
+        }
+        if (c->front_mu.try_lock()) {
+            c->front_mu.unlock();
+            if (!grace || ++idle > 20) {
+                if (flush_pending_back(c, b)) return -1;
+                break;
+            }
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
     b->in_flight = false;
+    if (!b->back_queued) {
+        set_err("falcon_amd: the batch's consensus stage was never queued");
+        return -1;
+    }
     HIP_OK(hipEventSynchronize(b->ev[6]));
     long long sO = 0;
     int n_failed = 0;
@@ -1121,7 +1199,7 @@ extern "C" fa_batch *fa_utg_consensus(fa_ctx *ctx, int n_seq, const char *const 
         for (int i = 0; i < 3; i++) (void)hipEventRecord(b->ev[i], s);
         if (run_from_ranges(b, 0, 1.0 - min_idt, band, 1)) return fail(nullptr);
     }
-    if (finish_run(b)) return fail(nullptr);
+    if (finish_run(b, false)) return fail(nullptr);
     return b;
 }
 

@@ -76,7 +76,7 @@ void fa_launch_pack(const FaBatchDev &b, int *first_bad, hipStream_t s) {
 // After phase D, T[k+1] (the bucket cursor) equals the bucket end, and T[0]=0,
 // so bucket(k) = [T[k], T[k+1]).
 // --------------------------------------------------------------------------
-#define SI_NT 1024  // threads per pile: few, fat workgroups keep the tables in flight (262 KB
+#define SI_NT 512  // threads per pile: few, fat workgroups keep the tables in flight (262 KB
                     // each) within the 256 MB Infinity Cache; 256-thread ones put 537 MB in flight
 __global__ __launch_bounds__(SI_NT) void k_seed_index(const u32 *__restrict__ words,
                                                     const FaSeq *__restrict__ seq,
