@@ -111,13 +111,36 @@ def _mem_available_gb():
     return None
 
 
+def _cpu_run(kind, piles, first, cores, per):
+    """`cores` worker processes, worker w on piles[first + w * per : first + (w + 1) * per]
+    (its first pile is the untimed warm-up).  -> (result object, {pile index: string})"""
+    jobs = [(kind, piles[first + i * per:first + (i + 1) * per]) for i in range(cores)]
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - t0
+    strings = {}
+    for w, (out, _) in enumerate(res):
+        for j, s in enumerate(out):
+            strings[first + w * per + 1 + j] = s
+    bases = sum(len(s) for s in strings.values())
+    busy = max(r[1] for r in res)  # workers run concurrently: timed span of the slowest
+    return {"cores": cores, "value": round(bases / busy, 1), "piles_per_sec": round(len(strings) / busy, 3),
+            "per_core_bases_per_sec": round(bases / sum(r[1] for r in res), 1), "piles": len(strings),
+            "wall_s": round(wall, 1)}, strings
+
+
 def cpu_baseline(piles, timed_per_worker=20):
     """-> (the cpu_baseline object, {pile index: consensus string} of the timed piles).
 
-    SURVEY.md 8d "CPU baseline timing": P worker processes = the host's physical cores (never
-    more than this process may run on, nor than memory allows: the reference keeps a 0.9 GB
-    workspace per process), one untimed warm-up pile per worker, `timed_per_worker` timed
-    piles each, taken from the front of this rank's batch."""
+    SURVEY.md 8d "CPU baseline timing": the reference C path in P worker processes = the
+    host's physical cores (never more than this process may run on, nor than memory allows:
+    the reference keeps a 0.9 GB workspace per process), one untimed warm-up pile per
+    worker, `timed_per_worker` timed piles each, taken from the front of this rank's batch.
+    The reference does not scale to a big host (every process sweeps its own 0.9 GB
+    workspace per pile: 128 processes were measured SLOWER than 16), so a 16-process run is
+    timed as well and `value` is the better of the two -- both are listed."""
     from oracle.pyoracle import build, have_ref
     try:
         build()
@@ -129,22 +152,17 @@ def cpu_baseline(piles, timed_per_worker=20):
     mem = _mem_available_gb()
     if mem is not None:
         cores = max(1, min(cores, int(mem / 2.0)))  # 0.9 GB workspace + the piles + headroom
-    per = timed_per_worker + 1
-    cores = max(1, min(cores, len(piles) // per)) if len(piles) >= per else 1
-    per = min(per, len(piles))
-    jobs = [(kind, piles[i * per:(i + 1) * per]) for i in range(cores)]
-    ctx = mp.get_context("fork")
-    t0 = time.perf_counter()
-    with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, jobs)
-    wall = time.perf_counter() - t0
-    strings = {}
-    for w, (out, _) in enumerate(res):
-        for j, s in enumerate(out):
-            strings[w * per + 1 + j] = s
-    bases = sum(len(s) for s in strings.values())
-    n = len(strings)
-    busy = max(r[1] for r in res)  # workers run concurrently: timed span of the slowest
+    per = min(timed_per_worker + 1, len(piles))
+    runs, strings, first = [], {}, 0
+    for want in sorted({cores, min(cores, 16)}):
+        c = max(1, min(want, (len(piles) - first) // per))
+        if (c < want and runs) or first + per > len(piles):
+            break  # (not enough piles left for another configuration)
+        r, got = _cpu_run(kind, piles, first, c, per)
+        runs.append(r)
+        strings.update(got)
+        first += c * per
+    best = max(runs, key=lambda r: r["value"])
     cpu_model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -155,32 +173,40 @@ def cpu_baseline(piles, timed_per_worker=20):
     except OSError:
         pass
     return {
-        "value": round(bases / busy, 1), "unit": "bases/s", "cores": cores, "kind": kind,
-        "piles_per_sec": round(n / busy, 3),
-        "per_core_bases_per_sec": round(bases / sum(r[1] for r in res), 1),
+        "value": best["value"], "unit": "bases/s", "cores": best["cores"], "kind": kind,
+        "piles_per_sec": best["piles_per_sec"],
+        "per_core_bases_per_sec": best["per_core_bases_per_sec"],
         "host_cpu_count": logical, "host_physical_cores": phys, "host_cpu_model": cpu_model,
-        "sample": "%d piles of this workload (%d timed per worker process + 1 untimed warm-up "
-                  "pile each), %d worker processes = min(physical cores, cpus allowed, "
-                  "memory / 2 GB), %.1f s wall incl. warm-up" % (n, per - 1, cores, wall),
+        "runs": runs,
+        "sample": "piles of this workload from the front of the batch, %d timed per worker process + 1 "
+                  "untimed warm-up pile each; worker processes: %s (physical cores, capped by the cpus "
+                  "allowed and memory / 2 GB; and 16) -- `value` is the best of them: %d processes, %d "
+                  "piles" % (per - 1, ", ".join(str(r["cores"]) for r in runs), best["cores"], best["piles"]),
     }, strings
 
 
-def write_la4falcon(piles, f):
+def write_la4falcon(piles, f, repeats=1):
     """The LA4Falcon text a pile [seed, seed copy + reads by length] (falcon_amd.synth
     pile_to_seqs) came from: the seed line, then the reads (the reader adds the seed's copy
-    itself, consensus.py:183-190)."""
-    for i, p in enumerate(piles):
-        lines, seen_copy = [b"%09d %s" % (i, p[0])], False
-        for j, r in enumerate(p[1:]):
-            if not seen_copy and r == p[0]:
-                seen_copy = True
-                continue
-            lines.append(b"%09d %s" % (1000000 + 1000 * i + j, r))
-        f.write(b"\n".join(lines) + b"\n+ +\n")
+    itself, consensus.py:183-190).  `repeats`: the piles again under new seed ids, for a
+    stream as long as a .las block's."""
+    for rep in range(repeats):
+        for i, p in enumerate(piles):
+            lines, seen_copy = [b"%09d %s" % (rep * len(piles) + i, p[0])], False
+            for j, r in enumerate(p[1:]):
+                if not seen_copy and r == p[0]:
+                    seen_copy = True
+                    continue
+                lines.append(b"%09d %s" % (1000000 + 1000 * i + j, r))
+            f.write(b"\n".join(lines) + b"\n+ +\n")
     f.write(b"- -\n")
 
 
-def end_to_end(piles, extra_args=(), expect=None):
+E2E_REPEATS = 3  # the end-to-end stream = the step's piles this many times (start-up amortised
+                 # the way a .las block of tens of thousands of piles amortises it)
+
+
+def end_to_end(piles, extra_args=(), expect=None, repeats=E2E_REPEATS):
     """SURVEY.md 8d "end-to-end": LA4Falcon text on stdin -> FASTA on stdout through the
     consensus worker (falcon_amd.mains.consensus: native reader, staging, GPU stages,
     printing) in a process of its own, on the piles of this workload written out as text.
@@ -193,7 +219,7 @@ def end_to_end(piles, extra_args=(), expect=None):
     with tempfile.TemporaryDirectory() as tmp:
         src, dst = os.path.join(tmp, "piles.txt"), os.path.join(tmp, "cns.fasta")
         with open(src, "wb") as f:
-            write_la4falcon(piles, f)
+            write_la4falcon(piles, f, repeats)
         size = os.path.getsize(src)
         cmd = [sys.executable, "-m", "falcon_amd.mains.consensus", "--output-multi", "--min-idt",
                "0.70", "--min-cov", "4", "--max-n-read", "200", "--n-core", "1"] + list(extra_args)
@@ -208,13 +234,16 @@ def end_to_end(piles, extra_args=(), expect=None):
         with open(dst) as f:
             text = f.read()
         bases = sum(len(ln) for ln in text.split("\n") if not ln.startswith(">"))
-    out = {"piles_per_sec": round(len(piles) / wall, 1), "text_MB_per_sec": round(size / 1e6 / wall, 1),
+    n = repeats * len(piles)
+    out = {"piles_per_sec": round(n / wall, 1), "text_MB_per_sec": round(size / 1e6 / wall, 1),
            "fasta_bases_per_sec": round(bases / wall, 1), "wall_s": round(wall, 2),
-           "what": "%d piles (%.0f MB of text from the page cache) -> FASTA, one worker process on "
-                   "one GPU, process start and HIP initialisation included" % (len(piles), size / 1e6)}
+           "what": "%d piles (the step's %d, %d times; %.0f MB of text from the page cache) -> FASTA, one "
+                   "worker process on one GPU, process start and HIP initialisation included"
+                   % (n, len(piles), repeats, size / 1e6)}
     if expect is not None:
         from falcon_amd.mains.consensus import fasta_records
-        want = "".join(fasta_records("%09d" % i, c, False, True) for i, c in enumerate(expect))
+        want = "".join(fasta_records("%09d" % (rep * len(piles) + i), c, False, True)
+                       for rep in range(repeats) for i, c in enumerate(expect))
         out["fasta_identical_to_resident_batch"] = (want == text)
         out["fasta_sha1"] = hashlib.sha1(text.encode()).hexdigest()[:16]
     return out
@@ -278,8 +307,8 @@ def measured_traffic(kernel, piles, workload):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="ecoli")
     ap.add_argument("--piles", type=int, default=int(os.environ.get("FALCON_BENCH_PILES", "0")),
                     help="piles per step per GPU (default: 3072 ecoli, 1024 dmel, 1536 arab)")
