@@ -1,0 +1,33 @@
+#!/bin/bash
+# Round-2 evidence of HEAD on the GPU box: parity, bench lines (three workloads, pipelined and
+# one batch at a time), rocprofv3 kernel stats, PMC passes (HBM traffic both sides, issue/wait,
+# LDS bank conflicts), secondary entry points.  usage: scripts/r02_evidence.sh <tag>
+TAG=${1:-r02e}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/$TAG; mkdir -p $O/pmc
+cd $R
+timeout 600 python -m pytest tests -m gpu -q > $O/pytest.txt 2>&1; tail -2 $O/pytest.txt
+timeout 200 python scripts/gpu_differential_campaign.py piles 0 72 > $O/campaign.txt 2>&1
+timeout 200 python scripts/gpu_differential_campaign.py pairs 0 64 >> $O/campaign.txt 2>&1; cut -c1-160 $O/campaign.txt
+timeout 600 python bench.py > $O/bench_ecoli.json.txt 2> $O/bench_ecoli.err; cut -c1-160 $O/bench_ecoli.json.txt
+timeout 300 python bench.py --no-pipeline --no-cpu-baseline --no-end-to-end > $O/bench_ecoli_serial.json.txt 2> /dev/null; cut -c1-160 $O/bench_ecoli_serial.json.txt
+for w in dmel arab; do
+  timeout 600 python bench.py --workload $w > $O/bench_$w.json.txt 2> $O/bench_$w.err; cut -c1-160 $O/bench_$w.json.txt
+done
+timeout 200 python scripts/exp_secondary.py > $O/secondary.txt 2>&1; tail -12 $O/secondary.txt
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline --no-end-to-end > $O/kt.log 2>&1
+python $R/scripts/rocpd_summary.py $(ls $O/kt/*/*.db $O/kt/*.db 2>/dev/null | head -1) > $O/kernel_stats.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/kts -o kts -- python $R/bench.py --no-pipeline --no-cpu-baseline --no-end-to-end > $O/kts.log 2>&1
+python $R/scripts/rocpd_summary.py $(ls $O/kts/*/*.db $O/kts/*.db 2>/dev/null | head -1) > $O/kernel_stats_serial.txt 2>&1; head -14 $O/kernel_stats_serial.txt | cut -c1-140
+B="python $R/bench.py --steps 1 --warmup 0 --no-pipeline --no-cpu-baseline --no-end-to-end"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 200 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "k_align|k_pack" --output-format csv -d $O/pmc/$c -o $c -- $B > $O/pmc/$c.log 2>&1; echo "pmc $c rc=$?"
+done
+i=0
+for ctrs in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+  i=$((i+1))
+  timeout 200 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/pmc/p$i -o p$i -- $B > $O/pmc/p$i.log 2>&1; echo "pmc pass $i rc=$?"
+done
+python $R/scripts/pmc_table.py $O/pmc > $O/pmc_table.txt 2>&1
+find $O -name "*.db" -size +20M -delete
