@@ -717,7 +717,7 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
 // requested one level ahead; position records and link counts are handed out of
 // registers; node records leave with one coalesced store per position.
 // ---------------------------------------------------------------------------
-#define SC_LINKS 1280     // link words staged per block
+#define SC_LINKS 640      // link words staged per block (LDS per wavefront: what the kernels running beside this one keep)
 #define SC_LEVELS 128     // levels per block (their link counts sit in two VGPRs)
 #define SC_REG 12         // insertion levels whose scores live in registers
 #define SC_ZERO 63        // lane of the score registers that always holds 0 (start links)
