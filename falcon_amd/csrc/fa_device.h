@@ -143,6 +143,30 @@ __device__ __forceinline__ u32 snake_step(QP qL, TP tL, u32 qa, u32 ta, u32 lim)
     return min(ffbl_raw(qw ^ tw) >> 1, lim);
 }
 
+// The same for code that already runs under the band's exec mask (every executing lane
+// holds a cell): no predication by selects, and the loads only carry the band's lanes.
+template <class QP, class TP>
+__device__ __forceinline__ void snake16_band(QP qL, TP tL, int qb, int tb, int q_len, int t_len,
+                                             int &x, int &y) {
+    u32 mlast;
+    {
+        const u32 lim = min(16u, (u32)min(q_len - x, t_len - y));
+        const u32 m = snake_step(qL, tL, (u32)(qb + x), (u32)(tb + y), lim);
+        x += (int)m;
+        y += (int)m;
+        mlast = m;
+    }
+    while (fa_ballot(mlast == 16u)) {  // only lanes inside a run of >= 16 matches get here
+        if (mlast == 16u) {
+            const u32 lim = min(16u, (u32)min(q_len - x, t_len - y));
+            const u32 m = snake_step(qL, tL, (u32)(qb + x), (u32)(tb + y), lim);
+            x += (int)m;
+            y += (int)m;
+            mlast = m;
+        }
+    }
+}
+
 // act lanes hold a cell of the row: 0 <= x <= q_len, 0 <= y <= t_len (a cell that
 // reached either end finishes the alignment in its own row, DW_banded.c:220).
 template <class QP, class TP>

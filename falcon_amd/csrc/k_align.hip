@@ -278,12 +278,16 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             x = fa_sel(fa_m, a + 1, b);
             y = fa_add3(x, m2lane, nkd);  // x - k, k = kd + 2 lane: one v_add3
             PROF(1);
-            snake16(qL, tL, qb, tb, q_len, t_len, act, x, y);
+            // snake and cell store under ONE exec mask, the band's: the loads carry 27
+            // lanes instead of 64 (the vector memory pipe is the third thing this kernel
+            // leans on: an all-lane store, even with the idle lanes dropped by a buffer
+            // range check, was measured 72 -> 77 ms; idle lanes to a spare cell: 88 ms)
+            if (act) {
+                snake16_band(qL, tL, qb, tb, q_len, t_len, x, y);
+                cells[(u32)((int)row_off - lo) + (u32)lane] = fa_twice_plus(x, fa_m);  // x<<1 | from_above
+            }
             PROF(2);
             vreg = x;
-            // (storing from every lane, the idle ones to a spare cell, to save the exec-mask
-            // round trip was measured: 72 -> 88 ms, the same-address stores serialise)
-            if (act) cells[(u32)((int)row_off - lo) + (u32)lane] = fa_twice_plus(x, fa_m);  // x<<1 | from_above
             const u64 dir0 = fa_m >> lo;
             fin = (fa_ballot(x >= q_len) | fa_ballot(y >= t_len)) & act_m;  // :220
             PROF(3);
