@@ -222,7 +222,8 @@ def end_to_end(piles, extra_args=(), expect=None, repeats=E2E_REPEATS):
             write_la4falcon(piles, f, repeats)
         size = os.path.getsize(src)
         cmd = [sys.executable, "-m", "falcon_amd.mains.consensus", "--output-multi", "--min-idt",
-               "0.70", "--min-cov", "4", "--max-n-read", "200", "--n-core", "1"] + list(extra_args)
+               "0.70", "--min-cov", "4", "--max-n-read", "200", "--n-core", "1"] + list(extra_args) + \
+            os.environ.get("FALCON_BENCH_E2E_ARGS", "").split()
         t0 = time.perf_counter()
         with open(src) as fin, open(dst, "w") as fout:
             # (a profiler wrapped around this process stays with this process: the worker's

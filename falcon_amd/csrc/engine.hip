@@ -36,6 +36,31 @@ static void trace_stage(hipStream_t s, const char *name) {
     fflush(stderr);
 }
 
+// FALCON_AMD_TIMING=1: host-side wall time of the phases of fa_batch_create / fa_batch_submit
+// on stderr (where do a worker's stalls come from?)
+static bool timing_on() {
+    static int v = -1;
+    if (v < 0) v = getenv("FALCON_AMD_TIMING") ? 1 : 0;
+    return v == 1;
+}
+struct PhaseTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::string line;
+    const char *what;
+    explicit PhaseTimer(const char *w) : what(w) {}
+    void mark(const char *name) {
+        if (!timing_on()) return;
+        auto t1 = std::chrono::steady_clock::now();
+        char buf[64];
+        snprintf(buf, sizeof(buf), " %s %.1f", name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        line += buf;
+        t0 = t1;
+    }
+    ~PhaseTimer() {
+        if (timing_on() && !line.empty()) fprintf(stderr, "[falcon_amd] %s ms:%s\n", what, line.c_str());
+    }
+};
+
 static void set_err(const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -92,7 +117,9 @@ struct fa_ctx {
     // alignment work-slot arena (grow only)
     FaAlignArena arena = {};
     size_t arena_cells_bytes = 0, arena_rows_bytes = 0;  // rows and rowx have equal size
-    bool arena_full = false;  // an alignment outgrew the usual slot once: worst-case slots from now on
+    // a few worst-case slots for the alignments that outgrow the usual ones (grow only)
+    FaAlignArena arena2 = {};
+    size_t arena2_cells_bytes = 0, arena2_rows_bytes = 0;
     // staging of a batch's ASCII (grow only, one batch at a time): pinned host buffer, its
     // device twin, and a stream of their own so that the upload and pack of batch i+1 run
     // next to the kernels of batch i instead of queueing behind them
@@ -255,7 +282,7 @@ struct fa_batch {
     DevBuf<u32> d_words, d_kidx, d_kpos, d_script;
     DevBuf<FaSeq> d_seq;
     DevBuf<FaPile> d_pile;
-    DevBuf<int> d_order, d_chain_order;
+    DevBuf<int> d_order, d_chain_order, d_redo;
     // MSA stage (k_msa.hip)
     DevBuf<FaTagAln> d_ta;
     DevBuf<u32> d_acc_first, d_desc, d_links;
@@ -363,6 +390,9 @@ extern "C" void fa_destroy(fa_ctx *c) {
     if (c->arena.rows) (void)hipFree(c->arena.rows);
     if (c->arena.rowx) (void)hipFree(c->arena.rowx);
     if (c->arena.counter) (void)hipFree(c->arena.counter);
+    if (c->arena2.cells) (void)hipFree(c->arena2.cells);
+    if (c->arena2.rows) (void)hipFree(c->arena2.rows);
+    if (c->arena2.rowx) (void)hipFree(c->arena2.rowx);
     if (c->d_first_bad) (void)hipFree(c->d_first_bad);
     if (c->h_dl) (void)hipHostFree(c->h_dl);
     if (c->back_stream) (void)hipStreamDestroy(c->back_stream);
@@ -442,6 +472,7 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
         return nullptr;
     }
     HIP_OK_P(hipSetDevice(ctx->device));
+    PhaseTimer pt("fa_batch_create");
     fa_batch *b = new fa_batch();
     b->ctx = ctx;
     b->n_pile = n_pile;
@@ -560,6 +591,7 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
     // Stage the ASCII through the context's pinned buffer: sequences are copied in by a
     // few threads (one memcpy stream does not come near the PCIe rate), uploaded, packed
     // to 2 bits on the device; only the packed form stays resident.
+    pt.mark("layout");
     int rc = 0;
     rc |= b->d_ascii_off.alloc(g);
     rc |= b->d_words.alloc(b->n_words + 8);
@@ -585,12 +617,15 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
         return nullptr;
     }
     bool ok = true;
+    pt.mark("device-buffers");
     {
         std::lock_guard<std::mutex> hold(ctx->stage_mu);
+        pt.mark("stage-lock");
         if (stage_reserve(ctx, b->ascii_bytes)) {
             delete b;
             return nullptr;
         }
+        pt.mark("stage-reserve");
         uint8_t *h_ascii = ctx->h_stage;
         const u64 *aoffs = b->ascii_off.data();
         const FaSeq *sq = b->seq.data();
@@ -613,6 +648,7 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
             }
             for (auto &t : pool) t.join();
         }
+        pt.mark("host-copy");
         b->ascii_dev = ctx->d_stage;
         hipStream_t s = ctx->up_stream;
         ok &= hipMemcpyAsync(ctx->d_stage, h_ascii, b->ascii_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
@@ -637,6 +673,7 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
         // (also on the error path: nothing may still read the staging buffers)
         ok &= hipStreamSynchronize(s) == hipSuccess;
         trace_stage(s, "pack");
+        pt.mark("h2d+pack");
         b->ascii_dev = nullptr;
         if (ok && first_bad != 0x7fffffff) {
             // the reference aligns raw characters and codes other bytes specially
@@ -700,7 +737,7 @@ static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes, bool ful
     u64 rows = (u64)b->max_rows;
     int width = FA_SLOT_WIDTH;
     if (const char *e = getenv("FALCON_AMD_SLOT_WIDTH")) width = std::max(1, atoi(e));  // (tests)
-    if (full || c->arena_full || width > b->band + 1) width = b->band + 1;
+    if (full || width > b->band + 1) width = b->band + 1;
     u64 cells = std::max<u64>(rows * (u64)width, 4096);
     // slot stride = 4 KB x m + 256 B x 7: the slots' first pages (all waves start writing
     // at their slot's base) spread over the memory channels instead of piling on a few
@@ -713,6 +750,22 @@ static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes, bool ful
     u64 budget = (u64)free_b / 2 + have;
     if ((u64)n_slot * per_slot > budget) n_slot = (int)std::max<u64>(1, budget / per_slot);
     size_t need_cells = (size_t)n_slot * cells * 4, need_rows = (size_t)n_slot * rows * sizeof(FaRowRec);
+    // The slot size follows the batch's longest read, so it creeps up from batch to batch
+    // of a stream; re-allocating 13 GB for a few per cent more costs 0.4-0.8 s each time
+    // (and every other hipMalloc of the process queues behind it).  What is there is used
+    // with fewer slots as long as that loses less than an eighth of them; a real growth
+    // takes a quarter more than asked for.
+    if (need_cells > c->arena_cells_bytes || need_rows > c->arena_rows_bytes) {
+        const u64 fit = std::min<u64>(c->arena_cells_bytes / (cells * 4),
+                                      c->arena_rows_bytes / (rows * sizeof(FaRowRec)));
+        if (fit >= (u64)n_slot - (u64)n_slot / 8 && fit >= 1) {
+            n_slot = (int)fit;
+            need_cells = need_rows = 0;
+        } else {
+            need_cells += need_cells / 4;
+            need_rows += need_rows / 4;
+        }
+    }
     if (need_cells > c->arena_cells_bytes) {
         if (c->arena.cells) (void)hipFree(c->arena.cells);
         c->arena.cells = nullptr;
@@ -736,8 +789,44 @@ static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes, bool ful
     return 0;
 }
 
+// The redo arena: min(n, 512) slots of the worst case rows x (band + 1) cells, for the
+// alignments of a launch that outgrew the usual slots (a handful per batch at most: reads
+// that pass the window filter and then align badly).  Repeating the whole launch with
+// worst-case slots, as the first version did, meant a 60 GB allocation in the middle of a
+// stream (0.7 s, and the next process waits for the driver to wipe it).
+static int ensure_arena2(fa_ctx *c, const fa_batch *b, int n) {
+    const int n_slot = std::max(1, std::min(n, 512));
+    const u64 rows = (u64)b->max_rows;
+    u64 cells = std::max<u64>(rows * (u64)(b->band + 1), 4096);
+    cells = ((cells + 1023) & ~(u64)1023) + 448;
+    const size_t need_cells = (size_t)n_slot * cells * 4, need_rows = (size_t)n_slot * rows * sizeof(FaRowRec);
+    if (need_cells > c->arena2_cells_bytes) {
+        if (c->arena2.cells) (void)hipFree(c->arena2.cells);
+        c->arena2.cells = nullptr;
+        c->arena2_cells_bytes = 0;
+        HIP_OK(hipMalloc((void **)&c->arena2.cells, need_cells));
+        c->arena2_cells_bytes = need_cells;
+    }
+    if (need_rows > c->arena2_rows_bytes) {
+        if (c->arena2.rows) (void)hipFree(c->arena2.rows);
+        if (c->arena2.rowx) (void)hipFree(c->arena2.rowx);
+        c->arena2.rows = nullptr;
+        c->arena2.rowx = nullptr;
+        c->arena2_rows_bytes = 0;
+        HIP_OK(hipMalloc((void **)&c->arena2.rows, need_rows));
+        HIP_OK(hipMalloc((void **)&c->arena2.rowx, need_rows));
+        c->arena2_rows_bytes = need_rows;
+    }
+    c->arena2.cells_per_slot = cells;
+    c->arena2.rows_per_slot = rows;
+    c->arena2.n_slot = n_slot;
+    c->arena2.counter = c->arena.counter;  // (same stream, one launch after the other)
+    c->arena2.prof = c->arena.prof;
+    return 0;
+}
+
 // Alignment summaries to the host.  0: fine; 1: some alignment outgrew its work slot (the
-// caller repeats the launch with worst-case slots); < 0: error.
+// caller repeats those with worst-case slots); < 0: error.
 static int fetch_aln(fa_batch *b) {
     if (b->h_aln.resize(b->n_seq)) return -1;
     HIP_OK(hipMemcpyAsync(b->h_aln.data(), b->d_aln.p, (size_t)b->n_seq * sizeof(FaAln),
@@ -794,13 +883,16 @@ extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double
         set_err("falcon_amd: hipEventCreate failed");
         return -1;
     }
+    PhaseTimer pt("fa_batch_submit");
     std::lock_guard<std::mutex> front(c->front_mu);  // one batch at a time on the front stream
+    pt.mark("front-lock");
     hipStream_t s = c->stream;
     b->fetched = b->fetched_eqv = false;
     b->have_range = b->have_aln = false;
     const double max_diff = 1.0 - min_idt;  // falcon.c:580
     size_t lds = fa_align_lds_bytes(b->max_read_len, b->max_seed_len);
     if (ensure_arena(c, b, lds, false)) return -1;
+    pt.mark("arena");
     FaBatchDev d = b->dev();
 
     HIP_OK(hipEventRecord(b->ev[0], s));
@@ -823,7 +915,10 @@ extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double
     // resident wavefronts), one batch at a time 158 ms.
     static const bool after_chain = getenv("FALCON_AMD_BACK_AFTER_CHAIN") != nullptr;
     if (flush_pending_back(c, nullptr, after_chain ? b->ev[2] : nullptr)) return -1;
-    return run_from_ranges(b, min_cov, max_diff, FA_BAND, -1);
+    pt.mark("launch-front");
+    const int rc = run_from_ranges(b, min_cov, max_diff, FA_BAND, -1);
+    pt.mark("align-wait+plan+msa-launch");
+    return rc;
 }
 
 // The rest of a submitted run: waits for the back stream's kernels, checks every pile's
@@ -904,14 +999,20 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
     b->stats.align_relaunched = 0;
     int rc_aln = fetch_aln(b);
     if (rc_aln == 1) {
-        // some alignment outgrew its slot (written nowhere past it): worst-case slots, for
-        // this launch and for the rest of the context's life
-        c->arena_full = true;
-        if (ensure_arena(c, b, fa_align_lds_bytes(b->max_read_len, b->max_seed_len), true)) return -1;
-        launch_align();
+        // some alignments outgrew their slots (nothing was written past them): those
+        // again, alone, in worst-case slots
+        std::vector<int> redo;
+        for (int g = 0; g < b->n_seq; g++)
+            if (b->h_aln[g].err == 2) redo.push_back(g);
+        if (band + 1 > 64 * FA_ALIGN_MAXCH - 1 || ensure_arena2(c, b, (int)redo.size()) ||
+            b->d_redo.alloc(redo.size()))
+            return -1;
+        HIP_OK(hipMemcpyAsync(b->d_redo.p, redo.data(), redo.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        fa_launch_align_list(d, c->arena2, b->max_read_len, b->max_seed_len, max_diff, band, b->d_redo.p,
+                             (int)redo.size(), s);
         HIP_OK(hipEventRecord(b->ev[3], s));
         HIP_OK(hipGetLastError());
-        b->stats.align_relaunched = 1;
+        b->stats.align_relaunched = (int)redo.size();
         rc_aln = fetch_aln(b);
         if (rc_aln == 1) {
             set_err("falcon_amd: an alignment overflowed a worst-case work slot");

@@ -175,6 +175,8 @@ void fa_launch_align(const FaBatchDev &b, const FaAlignArena &a, int max_q_len, 
                      double max_diff, hipStream_t s);
 void fa_launch_align_band(const FaBatchDev &b, const FaAlignArena &a, int max_q_len,
                           int max_t_len, double max_diff, int band, hipStream_t s);
+void fa_launch_align_list(const FaBatchDev &b, const FaAlignArena &a, int max_q_len, int max_t_len,
+                          double max_diff, int band, const int *order, int n_work, hipStream_t s);
 struct FaMsaDev {
     const FaTagAln *ta;
     const u32 *acc_first;

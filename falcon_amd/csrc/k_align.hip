@@ -590,10 +590,16 @@ int fa_align_blocks_per_cu(size_t lds_bytes) {
 
 void fa_launch_align_band(const FaBatchDev &b, const FaAlignArena &a, int max_q_len,
                           int max_t_len, double max_diff, int band, hipStream_t s) {
-    if (b.n_seq == 0) return;
+    fa_launch_align_list(b, a, max_q_len, max_t_len, max_diff, band, b.order, b.n_seq, s);
+}
+
+// the alignments of the sequences order[0 .. n_work) (device array)
+void fa_launch_align_list(const FaBatchDev &b, const FaAlignArena &a, int max_q_len, int max_t_len,
+                          double max_diff, int band, const int *order, int n_work, hipStream_t s) {
+    if (n_work == 0) return;
     AlignArgs A;
-    A.words = b.words; A.seq = b.seq; A.pile = b.pile; A.range = b.range; A.order = b.order;
-    A.n_work = b.n_seq;
+    A.words = b.words; A.seq = b.seq; A.pile = b.pile; A.range = b.range; A.order = order;
+    A.n_work = n_work;
     A.counter = a.counter;
     A.cells = a.cells; A.rows = a.rows; A.rowx = a.rowx;
     A.cells_per_slot = a.cells_per_slot; A.rows_per_slot = a.rows_per_slot;
@@ -608,7 +614,7 @@ void fa_launch_align_band(const FaBatchDev &b, const FaAlignArena &a, int max_q_
     A.max_diff = max_diff;
     size_t lds = fa_align_lds_bytes(max_q_len, max_t_len);
     (void)hipMemsetAsync(a.counter, 0, sizeof(int), s);
-    int grid = a.n_slot < b.n_seq ? a.n_slot : b.n_seq;
+    int grid = a.n_slot < n_work ? a.n_slot : n_work;
     if (seq_in_lds()) {
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute((const void *)k_align<true>,

@@ -134,8 +134,8 @@ typedef struct {
     int align_slots; /* resident alignment work slots (wavefronts) */
     /* the kernels of the consensus stage (k_msa.hip), same clock */
     float ms_tags, ms_links, ms_score, ms_backtrace;
-    /* alignment work slots hold `align_slot_cells` cells each; 1 if the alignment launch
-     * had to be repeated with worst-case slots (some alignment outgrew the usual size) */
+    /* alignment work slots hold `align_slot_cells` cells each; align_relaunched = the
+     * alignments that outgrew them and were done again in worst-case slots */
     long long align_slot_cells;
     int align_relaunched;
     int n_piles_failed; /* piles of the last run without a consensus, see fa_batch_pile_error */

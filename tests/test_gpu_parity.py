@@ -451,11 +451,13 @@ def test_bench_scale_batch_properties(engine):
     assert len(digest) == 40
 
 
-def test_outgrown_alignment_slots_are_relaunched(monkeypatch, port):
+def test_outgrown_alignment_slots_are_redone(monkeypatch, port):
     """Alignment work slots are sized for what alignments use, not for the worst case
-    rows x (band + 1); an alignment that outgrows its slot is reported by the kernel and
-    the launch repeated with worst-case slots, which the context then keeps.  Forced here
-    with slots of 2 diagonals per row: same results as the oracle, one relaunch, none after."""
+    rows x (band + 1); an alignment that outgrows its slot is reported by the kernel
+    (nothing is written past the slot) and done again, alone, in one of a few worst-case
+    slots -- the usual slots stay as they are.  Forced here with slots of 2 diagonals per
+    row (nearly every alignment outgrows them): same results as the oracle, batch after
+    batch."""
     from falcon_amd.engine import Engine
     monkeypatch.setenv("FALCON_AMD_SLOT_WIDTH", "2")
     piles = [
@@ -470,14 +472,14 @@ def test_outgrown_alignment_slots_are_relaunched(monkeypatch, port):
         st = b.stats()
         got = [b.result(i) for i in range(len(piles))]
         b.free()
-        assert st.align_relaunched == 1
+        assert 40 < st.align_relaunched <= st.n_seqs
         assert [tuple(x) for x in got] == [tuple(x) for x in want]
         b = eng.batch(piles[::-1])
         b.run(4, 8, 0.70).fetch(True)
         st2 = b.stats()
         got2 = [b.result(i) for i in range(len(piles))]
         b.free()
-        assert st2.align_relaunched == 0 and st2.align_slot_cells == st.align_slot_cells  # (worst case, kept)
+        assert st2.align_relaunched == st.align_relaunched and st2.align_slot_cells == st.align_slot_cells
         assert [tuple(x) for x in got2] == [tuple(x) for x in want[::-1]]
     finally:
         eng.close()
