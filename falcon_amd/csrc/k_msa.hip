@@ -647,10 +647,35 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
             // resolves a level with one segmented scan over them) and, inside a node, in
             // lowest-lane order = the reference's first-insertion order (Q5).  The lowest
             // lane of a group (its leader) keeps the group's rank and size and stores the word.
+            int n_link = 0;
+            if constexpr (NCHT == 1) {
+                // One chunk (nearly every segment below 64x coverage).  This kernel runs at
+                // 90 % of the CU's scalar pipe, so the peeling is written for it: the group
+                // leader's rank and count go to its lane with v_writelane (no compare /
+                // select round per group), one loop test per group.
+                const int knode = key[0] >= 0 ? (key[0] & 7) : 7;
+                int myrank = -1, mycnt = 0;
+                for (int nbq = 0; nbq < 5; nbq++) {
+                    u64 rem = fa_ballot(knode == nbq);
+                    while (rem) {
+                        const int ldr = __builtin_ctzll(rem);
+                        const int kk = __builtin_amdgcn_readlane(key[0], ldr);
+                        const u64 m = fa_ballot(key[0] == kk);
+                        const int cnt = __popcll(m);
+                        rem &= ~m;
+                        asm volatile("s_mov_b32 m0, %2\n\t"
+                                     "v_writelane_b32 %0, %3, m0\n\t"
+                                     "v_writelane_b32 %1, %4, m0"
+                                     : "+v"(myrank), "+v"(mycnt)
+                                     : "s"(ldr), "s"(n_link), "s"(cnt));
+                        n_link++;
+                    }
+                }
+                if (myrank >= 0) links[out + (u32)myrank] = wv[0] | (u32)mycnt;
+            } else {
             int knode[NCHT];
 #pragma unroll
             for (int c = 0; c < NCHT; c++) knode[c] = (c < nch && key[c] >= 0) ? (key[c] & 7) : 7;
-            int n_link = 0;
             int myrank[NCHT];
 #pragma unroll
             for (int c = 0; c < NCHT; c++) myrank[c] = -1;
@@ -697,6 +722,7 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
 #pragma unroll
             for (int c = 0; c < NCHT; c++)
                 if (myrank[c] >= 0) links[out + (u32)myrank[c]] = wv[c];
+            }
             out += (u32)n_link;
             nlk[x.lvl_start + (u32)dl] = (u16)n_link;
         }
