@@ -483,6 +483,10 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
         }
     }
 
+    // (one chunk, not the unitig mode, no alignment opening with an insertion run: the
+    // branch-free key building below)
+    const bool plain_seg = NCHT == 1 && !A.first_links_back && fa_ballot(leadv[0]) == 0ull;
+
     // The segment's position records and seed bases are fetched once, lanes =
     // positions / words, and handed out with readlane; the tag words of position
     // t + 1 are requested while position t is being grouped.
@@ -592,6 +596,7 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
                 base0[c] = (wtag[c] & TAG_DEL) ? 4 : sb;
             }
         }
+        const bool plain = plain_seg && fa_ballot(nins[0] > INL) == 0ull;
         for (int dl = 0; dl < (int)x.nlev; dl++) {
             // key of every participating lane (-1 = none):
             //   node base | prev base << 3 | prev delta << 6 | start << 14
@@ -599,6 +604,30 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
             //   count | node base << 10 | prev score index (delta * 5 + base) << 13 | start << 24
             int key[NCHT];
             u32 wv[NCHT];
+            if (plain) {
+                // The falcon_sense path with runs of <= INL inserted bases (every position
+                // but a handful): the same key and word as below, by selects -- every divergent
+                // `if` costs an exec-mask round trip on the scalar pipe that bounds this kernel.
+                if (dl == 0) {
+                    const bool first = t == s2v[0];  // first column: no predecessor (falcon.c:434)
+                    const int kprev = first ? ((5 << 3) | (1 << 14)) : ((pbv[0] << 3) | (pnv[0] << 6));
+                    const u32 wprev = first ? (1u << 24) : ((u32)(pnv[0] * 5 + pbv[0]) << 13);
+                    key[0] = covd[0] ? (base0[0] | kprev) : -1;
+                    wv[0] = covd[0] ? (((u32)base0[0] << 10) | wprev) : 0u;
+                    const bool upd = covd[0] && nins[0] == 0;
+                    pbv[0] = upd ? base0[0] : pbv[0];
+                    pnv[0] = upd ? 0 : pnv[0];
+                } else {
+                    const bool part = covd[0] && nins[0] >= dl;
+                    const int b = (int)((wtag[0] >> (2 * (dl - 1))) & 3u);
+                    const int pb = dl == 1 ? base0[0] : (int)((wtag[0] >> (2 * (dl - 2))) & 3u);
+                    key[0] = part ? (b | (pb << 3) | ((dl - 1) << 6)) : -1;
+                    wv[0] = part ? (((u32)b << 10) | ((u32)((dl - 1) * 5 + pb) << 13)) : 0u;
+                    const bool upd = part && nins[0] == dl;
+                    pbv[0] = upd ? b : pbv[0];
+                    pnv[0] = upd ? dl : pnv[0];
+                }
+            } else
 #pragma unroll
             for (int c = 0; c < NCHT; c++) {
                 key[c] = -1; wv[c] = 0;
