@@ -511,46 +511,53 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
         xr[h].cov = (u16)(cn & 0xffffu);
         xr[h].nlev = (u16)(cn >> 16);
     }
+    // Up to four chunks: the tag words are fetched 16 positions at a time, four 16-byte loads
+    // per lane and chunk issued a block ahead, and handed to the positions through LDS
+    // ([chunk][position][lane]).  One word per lane and position straight from HBM (what the
+    // two widest instances still do) means a wait per position -- for the word AND, the
+    // counter being shared, for the link stores of the position before (measured on the
+    // one-chunk instance: 45 % of the wave cycles in s_waitcnt, 26 % L1 hit rate).
+    constexpr bool STG = NCHT <= 4;
     u32 wnx[NCHT];
 #pragma unroll
     for (int c = 0; c < NCHT; c++) {
         wnx[c] = 0u;
         const int u = t_lo - s2v[c];
-        if (NCHT > 1 && c < nch && u >= 0 && u < tcv[c]) wnx[c] = dptr[c][u];
+        if (!STG && c < nch && u >= 0 && u < tcv[c]) wnx[c] = dptr[c][u];
     }
-    // One chunk (the normal case): the tag words are fetched 16 positions at a time, four
-    // 16-byte loads per lane issued a block ahead, and handed to the positions through
-    // LDS ([position][lane]).  One word per lane and position straight from HBM meant a
-    // wait per position -- for the word AND, the counter being shared, for the link
-    // stores of the position before (measured: 45 % of the wave cycles in s_waitcnt,
-    // 26 % L1 hit rate).
-    __shared__ u32 tagw[NCHT == 1 ? TG_BLK * 64 : 1];
+    __shared__ u32 tagw[STG ? NCHT * TG_BLK * 64 : 1];
     typedef u32 tag_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
-    tag_u32x4 tnx[4];
-    auto request_tags = [&](int tb) {  // positions tb .. tb + 15 of my alignment
-        const int u = tb - s2v[0];
+    tag_u32x4 tnx[STG ? NCHT : 1][4];
+    auto request_tags = [&](int tb) {  // positions tb .. tb + 15 of my alignments
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            tnx[q] = (tag_u32x4){0u, 0u, 0u, 0u};
-            // (a partly covered group is loaded whole: the words beside the alignment's
-            // own belong to its neighbours or to the buffer's padding and are masked by
-            // `covd` below)
-            if (tb < t_hi && u + 4 * q + 3 >= 0 && u + 4 * q < tcv[0])
-                tnx[q] = *reinterpret_cast<const tag_u32x4 *>(dptr[0] + (u + 4 * q));
+        for (int c = 0; c < (STG ? NCHT : 1); c++) {
+            const int u = tb - s2v[c];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                tnx[c][q] = (tag_u32x4){0u, 0u, 0u, 0u};
+                // (a partly covered group is loaded whole: the words beside the alignment's
+                // own belong to its neighbours or to the buffer's padding and are masked by
+                // `covd` below)
+                if (c < nch && tb < t_hi && u + 4 * q + 3 >= 0 && u + 4 * q < tcv[c])
+                    tnx[c][q] = *reinterpret_cast<const tag_u32x4 *>(dptr[c] + (u + 4 * q));
+            }
         }
     };
-    if (NCHT == 1) request_tags(t_lo);
+    if (STG) request_tags(t_lo);
 
     for (int t = t_lo; t < t_hi; t++) {
         const int j = t - t_lo;
-        if (NCHT == 1 && (j & (TG_BLK - 1)) == 0) {  // a new block of 16 positions
+        if (STG && (j & (TG_BLK - 1)) == 0) {  // a new block of 16 positions
             __syncthreads();
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                tagw[(4 * q + 0) * 64 + lane] = tnx[q].x;
-                tagw[(4 * q + 1) * 64 + lane] = tnx[q].y;
-                tagw[(4 * q + 2) * 64 + lane] = tnx[q].z;
-                tagw[(4 * q + 3) * 64 + lane] = tnx[q].w;
+            for (int c = 0; c < (STG ? NCHT : 1); c++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    tagw[(c * TG_BLK + 4 * q + 0) * 64 + lane] = tnx[c][q].x;
+                    tagw[(c * TG_BLK + 4 * q + 1) * 64 + lane] = tnx[c][q].y;
+                    tagw[(c * TG_BLK + 4 * q + 2) * 64 + lane] = tnx[c][q].z;
+                    tagw[(c * TG_BLK + 4 * q + 3) * 64 + lane] = tnx[c][q].w;
+                }
             }
             __syncthreads();
             request_tags(t + TG_BLK);
@@ -580,7 +587,7 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
             if (c < nch) {
                 const int u = t - s2v[c];
                 covd[c] = u >= 0 && u < tcv[c];
-                if (NCHT == 1) wtag[c] = tagw[(j & (TG_BLK - 1)) * 64 + lane];
+                if (STG) wtag[c] = tagw[(c * TG_BLK + (j & (TG_BLK - 1))) * 64 + lane];
                 else if (t + 1 < t_hi && u + 1 >= 0 && u + 1 < tcv[c]) wnx[c] = dptr[c][u + 1];
             }
         }
@@ -702,12 +709,14 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
                 }
                 if (myrank >= 0) links[out + (u32)myrank] = wv[0] | (u32)mycnt;
             } else {
+            // several chunks: the same peeling, the leader found in the lowest chunk that
+            // still holds lanes of the node
             int knode[NCHT];
 #pragma unroll
             for (int c = 0; c < NCHT; c++) knode[c] = (c < nch && key[c] >= 0) ? (key[c] & 7) : 7;
-            int myrank[NCHT];
+            int myrank[NCHT], mycnt[NCHT];
 #pragma unroll
-            for (int c = 0; c < NCHT; c++) myrank[c] = -1;
+            for (int c = 0; c < NCHT; c++) { myrank[c] = -1; mycnt[c] = 0; }
             for (int nbq = 0; nbq < 5; nbq++) {
                 u64 rem[NCHT];
                 bool any = false;
@@ -716,13 +725,11 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
                     rem[c] = (c < nch) ? fa_ballot(knode[c] == nbq) : 0ull;
                     any = any || rem[c] != 0ull;
                 }
-                if (!any) continue;
-                for (;;) {
-                    int c0 = -1;
+                while (any) {
+                    int c0 = 0;
 #pragma unroll
                     for (int c = NCHT - 1; c >= 0; c--)
                         if (rem[c]) c0 = c;
-                    if (c0 < 0) break;
                     int kk = 0, ldr = 0;
 #pragma unroll
                     for (int c = 0; c < NCHT; c++)
@@ -731,26 +738,30 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
                             kk = __builtin_amdgcn_readlane(key[c], ldr);
                         }
                     int cnt = 0;
+                    any = false;
 #pragma unroll
                     for (int c = 0; c < NCHT; c++) {
                         if (c < nch) {
                             const u64 m = fa_ballot(key[c] == kk);
                             cnt += __popcll(m);
                             rem[c] &= ~m;
+                            any = any || rem[c] != 0ull;
                         }
                     }
 #pragma unroll
                     for (int c = 0; c < NCHT; c++)
-                        if (c == c0 && lane == ldr) {
-                            myrank[c] = n_link;
-                            wv[c] |= (u32)cnt;
-                        }
+                        if (c == c0)
+                            asm volatile("s_mov_b32 m0, %2\n\t"
+                                         "v_writelane_b32 %0, %3, m0\n\t"
+                                         "v_writelane_b32 %1, %4, m0"
+                                         : "+v"(myrank[c]), "+v"(mycnt[c])
+                                         : "s"(ldr), "s"(n_link), "s"(cnt));
                     n_link++;
                 }
             }
 #pragma unroll
             for (int c = 0; c < NCHT; c++)
-                if (myrank[c] >= 0) links[out + (u32)myrank[c]] = wv[c];
+                if (myrank[c] >= 0) links[out + (u32)myrank[c]] = wv[c] | (u32)mycnt[c];
             }
             out += (u32)n_link;
             nlk[x.lvl_start + (u32)dl] = (u16)n_link;
