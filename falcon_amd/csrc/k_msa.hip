@@ -483,9 +483,11 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
         }
     }
 
-    // (one chunk, not the unitig mode, no alignment opening with an insertion run: the
-    // branch-free key building below)
-    const bool plain_seg = NCHT == 1 && !A.first_links_back && fa_ballot(leadv[0]) == 0ull;
+    // (not the unitig mode, no alignment opening with an insertion run: the branch-free key
+    // building below)
+    bool plain_seg = !A.first_links_back;
+#pragma unroll
+    for (int c = 0; c < NCHT; c++) plain_seg = plain_seg && fa_ballot(leadv[c]) == 0ull;
 
     // The segment's position records and seed bases are fetched once, lanes =
     // positions / words, and handed out with readlane; the tag words of position
@@ -603,7 +605,9 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
                 base0[c] = (wtag[c] & TAG_DEL) ? 4 : sb;
             }
         }
-        const bool plain = plain_seg && fa_ballot(nins[0] > INL) == 0ull;
+        bool plain = plain_seg;
+#pragma unroll
+        for (int c = 0; c < NCHT; c++) plain = plain && fa_ballot(nins[c] > INL) == 0ull;
         for (int dl = 0; dl < (int)x.nlev; dl++) {
             // key of every participating lane (-1 = none):
             //   node base | prev base << 3 | prev delta << 6 | start << 14
@@ -615,24 +619,28 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
                 // The falcon_sense path with runs of <= INL inserted bases (every position
                 // but a handful): the same key and word as below, by selects -- every divergent
                 // `if` costs an exec-mask round trip on the scalar pipe that bounds this kernel.
-                if (dl == 0) {
-                    const bool first = t == s2v[0];  // first column: no predecessor (falcon.c:434)
-                    const int kprev = first ? ((5 << 3) | (1 << 14)) : ((pbv[0] << 3) | (pnv[0] << 6));
-                    const u32 wprev = first ? (1u << 24) : ((u32)(pnv[0] * 5 + pbv[0]) << 13);
-                    key[0] = covd[0] ? (base0[0] | kprev) : -1;
-                    wv[0] = covd[0] ? (((u32)base0[0] << 10) | wprev) : 0u;
-                    const bool upd = covd[0] && nins[0] == 0;
-                    pbv[0] = upd ? base0[0] : pbv[0];
-                    pnv[0] = upd ? 0 : pnv[0];
-                } else {
-                    const bool part = covd[0] && nins[0] >= dl;
-                    const int b = (int)((wtag[0] >> (2 * (dl - 1))) & 3u);
-                    const int pb = dl == 1 ? base0[0] : (int)((wtag[0] >> (2 * (dl - 2))) & 3u);
-                    key[0] = part ? (b | (pb << 3) | ((dl - 1) << 6)) : -1;
-                    wv[0] = part ? (((u32)b << 10) | ((u32)((dl - 1) * 5 + pb) << 13)) : 0u;
-                    const bool upd = part && nins[0] == dl;
-                    pbv[0] = upd ? b : pbv[0];
-                    pnv[0] = upd ? dl : pnv[0];
+                // (covd is false in the chunks beyond nch.)
+#pragma unroll
+                for (int c = 0; c < NCHT; c++) {
+                    if (dl == 0) {
+                        const bool first = t == s2v[c];  // first column: no predecessor (falcon.c:434)
+                        const int kprev = first ? ((5 << 3) | (1 << 14)) : ((pbv[c] << 3) | (pnv[c] << 6));
+                        const u32 wprev = first ? (1u << 24) : ((u32)(pnv[c] * 5 + pbv[c]) << 13);
+                        key[c] = covd[c] ? (base0[c] | kprev) : -1;
+                        wv[c] = covd[c] ? (((u32)base0[c] << 10) | wprev) : 0u;
+                        const bool upd = covd[c] && nins[c] == 0;
+                        pbv[c] = upd ? base0[c] : pbv[c];
+                        pnv[c] = upd ? 0 : pnv[c];
+                    } else {
+                        const bool part = covd[c] && nins[c] >= dl;
+                        const int b = (int)((wtag[c] >> (2 * (dl - 1))) & 3u);
+                        const int pb = dl == 1 ? base0[c] : (int)((wtag[c] >> (2 * (dl - 2))) & 3u);
+                        key[c] = part ? (b | (pb << 3) | ((dl - 1) << 6)) : -1;
+                        wv[c] = part ? (((u32)b << 10) | ((u32)((dl - 1) * 5 + pb) << 13)) : 0u;
+                        const bool upd = part && nins[c] == dl;
+                        pbv[c] = upd ? b : pbv[c];
+                        pnv[c] = upd ? dl : pnv[c];
+                    }
                 }
             } else
 #pragma unroll
