@@ -169,10 +169,15 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
     int fin_d = -1, fin_k = 0, fin_x = 0, fin_y = 0;
     // the last <= 64 row records live in registers, lane (d & 63) holds row d;
     // they are flushed to the arena 64 at a time with one coalesced 16-byte store
+    // A record says where bit 0 of the row's from_above bits sits: its cell (`off`) and its
+    // diagonal, NEGATED (`-k0`; bit i <-> diagonal k0 + 2 i <-> cell off + i).  Register-mode
+    // rows store the lane mask as it is -- bit = lane, k0 = kd, off = row_off - lo -- so that
+    // the hot loop does no shifting or min_k arithmetic on the scalar pipe; ring-mode rows
+    // bit = cell index in the row, k0 = min_k, off = row_off.
     u32 rc_off = 0, rc_mink = 0, rc_dlo = 0, rc_dhi = 0;
     // WRITE_ROW_RECORD: row d's record into lane d & 63 (v_writelane; lane select in M0:
     // a VOP3 may read only one SGPR besides it).  FLUSH_ROW_RECORDS: rows d - (d & 63) .. d.
-#define WRITE_ROW_RECORD(dir0_, min_k_expr)                                       \
+#define WRITE_ROW_RECORD(off_expr, dir0_, neg_k0_expr)                            \
     do {                                                                          \
         const u64 dw_ = (dir0_);                                                  \
         asm volatile("s_mov_b32 m0, %8\n\t"                                       \
@@ -181,7 +186,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
                      "v_writelane_b32 %2, %6, m0\n\t"                             \
                      "v_writelane_b32 %3, %7, m0"                                 \
                      : "+v"(rc_off), "+v"(rc_mink), "+v"(rc_dlo), "+v"(rc_dhi)    \
-                     : "s"(row_off), "s"((u32)(min_k_expr)), "s"((u32)dw_),       \
+                     : "s"((u32)(off_expr)), "s"((u32)(neg_k0_expr)), "s"((u32)dw_), \
                        "s"((u32)(dw_ >> 32)), "s"(d & 63));                       \
     } while (0)
 #define FLUSH_ROW_RECORDS()                                                       \
@@ -194,7 +199,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
     } while (0)
 #define PUT_ROW_RECORD(dir0_, finished_)                                          \
     do {                                                                          \
-        WRITE_ROW_RECORD(dir0_, min_k);                                           \
+        WRITE_ROW_RECORD(row_off, dir0_, -min_k);                                 \
         if ((d & 63) == 63 || (finished_)) FLUSH_ROW_RECORDS();                   \
     } while (0)
 
@@ -282,16 +287,16 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             // lanes instead of 64 (the vector memory pipe is the third thing this kernel
             // leans on: an all-lane store, even with the idle lanes dropped by a buffer
             // range check, was measured 72 -> 77 ms; idle lanes to a spare cell: 88 ms)
+            const u32 off0 = row_off - (u32)lo;  // the cell lane 0 would have: record and store address
             if (act) {
                 snake16_band(qL, tL, qb, tb, q_len, t_len, x, y);
-                cells[(u32)((int)row_off - lo) + (u32)lane] = fa_twice_plus(x, fa_m);  // x<<1 | from_above
+                cells[off0 + (u32)lane] = fa_twice_plus(x, fa_m);  // x<<1 | from_above
             }
             PROF(2);
             vreg = x;
-            const u64 dir0 = fa_m >> lo;
             fin = (fa_ballot(x >= q_len) | fa_ballot(y >= t_len)) & act_m;  // :220
             PROF(3);
-            WRITE_ROW_RECORD(dir0, 2 * lo - nkd);
+            WRITE_ROW_RECORD(off0, fa_m, nkd);
             if (fin) break;  // (its records are flushed below)
             // (an LDS ds_max on one word instead of the DPP reduction was measured 2x
             // slower: 64 same-address atomics serialise)
@@ -442,7 +447,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
         const bool have = r >= 0;
         u32x4 rv = {0u, 0u, 0u, 0u};
         if (have) rv = rows[r];
-        tb_rec[4 * lane + 0] = rv.y;  // min_k
+        tb_rec[4 * lane + 0] = 0u - rv.y;  // k0 (stored negated)
         tb_rec[4 * lane + 1] = rv.z;  // dlo
         tb_rec[4 * lane + 2] = rv.w;  // dhi
         const int n_rows = min(64, hi + 1);
@@ -467,7 +472,7 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
         k_cur = __builtin_amdgcn_readfirstlane(kv);
         // x2 of my row on the path
         int x2 = 0;
-        if (have) x2 = (int)(cells[rv.x + (u32)((my_k - (int)rv.y) >> 1)] >> 1);
+        if (have) x2 = (int)(cells[rv.x + (u32)((my_k + (int)rv.y) >> 1)] >> 1);
         int x2_prev = __shfl_down(x2, 1);  // row r-1 sits in lane+1
         const bool emit = have && (lane < 63 || hi < 63);
         if (emit) {
