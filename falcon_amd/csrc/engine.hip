@@ -914,7 +914,8 @@ extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double
     // wave slots), beside k_align 144 ms (k_align 72 -> 90 ms: its throughput follows its
     // resident wavefronts), one batch at a time 158 ms.
     static const bool after_chain = getenv("FALCON_AMD_BACK_AFTER_CHAIN") != nullptr;
-    if (flush_pending_back(c, nullptr, after_chain ? b->ev[2] : nullptr)) return -1;
+    static const bool after_align = getenv("FALCON_AMD_BACK_AFTER_ALIGN") != nullptr;
+    if (!after_align && flush_pending_back(c, nullptr, after_chain ? b->ev[2] : nullptr)) return -1;
     pt.mark("launch-front");
     const int rc = run_from_ranges(b, min_cov, max_diff, FA_BAND, -1);
     pt.mark("align-wait+plan+msa-launch");
@@ -1020,6 +1021,9 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
         }
     }
     if (rc_aln) return rc_aln;
+    // (FALCON_AMD_BACK_AFTER_ALIGN: the previous batch's back stage starts here, beside this
+    // batch's tags and links and the next one's index and chain)
+    if (getenv("FALCON_AMD_BACK_AFTER_ALIGN") && flush_pending_back(c)) return -1;
     b->have_range = true;  // its copy was queued ahead of k_align
     if (force_accept_g >= 0 && b->h_aln[force_accept_g].aligned) b->h_aln[force_accept_g].accept = 1;
     // ---- plan the MSA stage from the alignment summaries (host, O(#reads))
