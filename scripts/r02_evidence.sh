@@ -7,8 +7,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG; mkdir -p $O/pmc
 cd $R
 timeout 600 python -m pytest tests -m gpu -q > $O/pytest.txt 2>&1; tail -2 $O/pytest.txt
-timeout 200 python scripts/gpu_differential_campaign.py piles 0 72 > $O/campaign.txt 2>&1
-timeout 200 python scripts/gpu_differential_campaign.py pairs 0 64 >> $O/campaign.txt 2>&1; cut -c1-160 $O/campaign.txt
+timeout 200 python scripts/gpu_differential_campaign.py piles 0 300 > $O/campaign.txt 2>&1
+timeout 200 python scripts/gpu_differential_campaign.py pairs 0 256 >> $O/campaign.txt 2>&1; cut -c1-160 $O/campaign.txt
 timeout 600 python bench.py > $O/bench_ecoli.json.txt 2> $O/bench_ecoli.err; cut -c1-160 $O/bench_ecoli.json.txt
 timeout 300 python bench.py --no-pipeline --no-cpu-baseline --no-end-to-end > $O/bench_ecoli_serial.json.txt 2> /dev/null; cut -c1-160 $O/bench_ecoli_serial.json.txt
 for w in dmel arab; do
@@ -25,9 +25,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "k_align|k_pack" --output-format csv -d $O/pmc/$c -o $c -- $B > $O/pmc/$c.log 2>&1; echo "pmc $c rc=$?"
 done
 i=0
-for ctrs in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+for ctrs in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   i=$((i+1))
   timeout 200 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/pmc/p$i -o p$i -- $B > $O/pmc/p$i.log 2>&1; echo "pmc pass $i rc=$?"
 done
 python $R/scripts/pmc_table.py $O/pmc > $O/pmc_table.txt 2>&1
 find $O -name "*.db" -size +20M -delete
+# instruction counts by class: restricted to the kernels of the path (an unrestricted pass hung once)
+cd /tmp
+timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --kernel-include-regex "k_align|k_links|k_score|k_tags|k_chain|k_backtrace|k_seed_index" --output-format csv -d $O/pmc/p9 -o p9 -- python $R/bench.py --steps 1 --warmup 0 --no-pipeline --no-cpu-baseline --no-end-to-end > $O/pmc/p9.log 2>&1; echo "pmc insts rc=$?"
+python $R/scripts/pmc_table.py $O/pmc > $O/pmc_table.txt 2>&1
