@@ -1127,6 +1127,7 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
     md.n_seg = (int)n_seg;
     md.wide_count = b->d_wide.p; md.wide_list = b->d_wide.p + 1;
     md.first_links_back = force_accept_g >= 0 ? 1 : 0;
+    md.force_generic = getenv("FALCON_AMD_SCORE_GENERIC") ? 1 : 0;  // (tests: pins the generic path of k_score)
     d = b->dev();
     HIP_OK(hipEventRecord(b->ev[4], s));
     fa_launch_msa_front(d, md, min_cov, s, b->ev[8], b->ev[9]);  // k_tags + k_tscan | k_links

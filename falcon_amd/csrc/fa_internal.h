@@ -115,6 +115,8 @@ struct FaScoreOut { // per pile
     int n_levels;
     int n_links;
     int err;
+    int wide;       // 1: scores may outgrow the fast path's key (k_score takes the generic path)
+    int pad;
 };
 
 // ---- launcher prototypes (each .hip file owns its kernels) ----
@@ -198,6 +200,7 @@ struct FaMsaDev {
     const int *seg_t0;
     int n_seg;
     int first_links_back;  // unitig mode: a read's first column links back to (s2 - 1, 0, '-')
+    int force_generic;     // k_score: every level through the generic path (tests)
     int *wide_count;
     int *wide_list;
 };

@@ -54,6 +54,9 @@
 #define TG_WIN 1024    // target positions per k_tags LDS window
 #define TG_BLK 16      // positions per k_links tag block
 #define TCOV_LEAD 0x40000000  // tcov flag: the alignment opens with an insertion run (see k_tags)
+// scores are bounded by the sum over levels of the coverage; beyond this bound the 25-bit
+// score field of k_score's fast-path keys could overflow and the pile takes the generic path
+#define SC_FAST_SCORE_MAX 33000000ll
 
 struct MsaArgs {
     const u32 *words;
@@ -90,6 +93,7 @@ struct MsaArgs {
     int *wide_list;            // ints: [count, segments...]; wide_count = first list's count)
     unsigned min_cov;
     int first_links_back;      // unitig mode (falcon.c:668-773): see k_links
+    int force_generic;         // k_score: every level through the generic path (tests)
 };
 
 // ---------------------------------------------------------------------------
@@ -324,6 +328,7 @@ __global__ __launch_bounds__(64) void k_tscan(MsaArgs A) {
     FaTInfo *ti = A.tinfo + A.t_off[p];
     int c_cov = 0;
     u32 c_lvl = 0, c_link = 0;
+    long long score_bound = 0;  // no score exceeds the sum over levels of the coverage
     for (int t0 = 0; t0 < T; t0 += 64) {
         const int t = t0 + lane;
         const bool have = t < T;
@@ -346,12 +351,15 @@ __global__ __launch_bounds__(64) void k_tscan(MsaArgs A) {
         c_cov = __shfl(cov, 63);
         c_lvl += (u32)__shfl(ls, 63);
         c_link += (u32)__shfl(ps, 63);
+        score_bound += (long long)__shfl(wave_incl_sum(min(cov, 65535) * nlev, lane), 63);
     }
     FaScoreOut so;
     so.g_node = -1; so.g_ck = 0; so.g_h = -2;
     so.n_levels = (int)c_lvl;
     so.n_links = (int)c_link;
     so.err = ((u64)c_lvl * 5 > pm.node_cap || (u64)c_link > A.link_cap[p]) ? 1 : 0;
+    so.wide = score_bound >= SC_FAST_SCORE_MAX ? 1 : 0;
+    so.pad = 0;
     A.score_out[p] = so;  // every lane stores the same record
 }
 
@@ -921,6 +929,19 @@ __device__ __noinline__ ScoreSlowIo score_level_slow(ScoreSlowIo io, int prev_h,
     return io;
 }
 
+// prefix maximum of unsigned keys inside each row of 16 lanes, in place: 4 VALU
+// (lanes without a source lane keep their value; s_nop 1: a VGPR written by VALU needs 2
+// wait states before a DPP read)
+__device__ __forceinline__ u32 row_prefix_max_u32(u32 v) {
+    asm volatile("s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
+                 : "+v"(v));
+    return v;
+}
+
 __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
     __shared__ u32 s_links[SC_LINKS + 64];
     const int lane = fa_lane();
@@ -941,6 +962,9 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
     int *s_deep = A.score_ovf + (u64)p * (2 * 256 * 5);
     const int ldl = lane / 5;
     const int h_init = (lane == SC_ZERO) ? 0 : -2;
+    // (the fast path's key holds a score in 25 bits: piles whose scores could outgrow them,
+    // or every level when the tests ask for it, take the generic path)
+    const bool fast_pile = so.wide == 0 && A.force_generic == 0;
 
     ScoreAcc cur;
     cur.h = h_init; cur.p = 0; cur.k = 0; cur.n = 0;
@@ -1014,7 +1038,7 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
             u32 lk = y_link;
             // no level of this position and no predecessor of one lies beyond the
             // register-resident levels: the per-level test of the fast path is one compare
-            const bool shallow = nlev <= SC_REG && prev_nlev <= SC_REG;
+            const bool shallow = fast_pile && nlev <= SC_REG && prev_nlev <= SC_REG;
             const u32 next_rel = (u32)__builtin_amdgcn_readlane((int)x_link, (j + 1) & 63) - lnk0;
             for (int dl = 0; dl < nlev; dl++) {
                 const u32 slot = y_lvl + (u32)dl;
@@ -1045,42 +1069,37 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                 const bool start = (w >> 24) & 1u;
                 if (shallow && n_link <= 16) {
                     // ---- the usual level: <= 16 links in lanes 0..15, node-major (k_links).
-                    // One segmented max-scan resolves all five nodes; no loop, no branch.
-                    // Independent of the scores (issued while the gather below is in flight):
+                    // ONE unsegmented prefix maximum resolves all five nodes -- the node's base
+                    // sits on top of the key, so a later node's links beat any link of an
+                    // earlier node and every node's winner ends up on its last link; no loop,
+                    // no branch, no masks.  Independent of the scores (issued while the gather
+                    // below is in flight):
                     const u64 have_m = (1ull << n_link) - 1ull;
                     const int nbp = have ? nbase + 1 : 0;  // 0: no link in this lane
                     const int n1 = __builtin_amdgcn_mov_dpp(nbp, 0x111, 0xf, 0xf, true);  // row_shr:1
-                    const int n2 = __builtin_amdgcn_mov_dpp(nbp, 0x112, 0xf, 0xf, true);
-                    const int n4 = __builtin_amdgcn_mov_dpp(nbp, 0x114, 0xf, 0xf, true);
-                    const int n8 = __builtin_amdgcn_mov_dpp(nbp, 0x118, 0xf, 0xf, true);
                     const int nx = __builtin_amdgcn_mov_dpp(nbp, 0x101, 0xf, 0xf, true);  // row_shl:1
-                    const u64 m1 = fa_ballot(n1 == nbp) & have_m, m2 = fa_ballot(n2 == nbp) & have_m;
-                    const u64 m4 = fa_ballot(n4 == nbp) & have_m, m8 = fa_ballot(n8 == nbp) & have_m;
-                    const u64 tail_m = fa_ballot(nx != nbp) & have_m;  // last link of its node
-                    int ss = fa_sel(have_m & ~m1, 0, lane);            // first lane of my node:
-                    ss = max(ss, __builtin_amdgcn_update_dpp(0, ss, 0x111, 0xf, 0xf, true));
-                    ss = max(ss, __builtin_amdgcn_update_dpp(0, ss, 0x112, 0xf, 0xf, true));
-                    ss = max(ss, __builtin_amdgcn_update_dpp(0, ss, 0x114, 0xf, 0xf, true));
-                    ss = max(ss, __builtin_amdgcn_update_dpp(0, ss, 0x118, 0xf, 0xf, true));
+                    const u64 first_m = fa_ballot(n1 != nbp) & have_m;  // first link of its node
+                    const u64 tail_m = fa_ballot(nx != nbp) & have_m;   // last link of its node
+                    // first lane of my node: prefix maximum of the first links' lane numbers
+                    const int ss = (int)row_prefix_max_u32((u32)fa_sel(first_m, 0, lane));
                     const int cv = 2 * cnt - cov;
                     const int lidx = start ? SC_ZERO : pidx;
                     const int pidv = start ? -1 : (int)(plvl5 + (u32)pidx);
                     const int dst = fa_sel(tail_m, 62, dl * 5 + nbase);  // 62: a lane nobody reads
+                    const u32 kfix = have ? (((u32)nbase << 29) | (u32)(15 - lane)) : 0u;
                     // The dependent chain: previous scores -> link scores -> per node the first
                     // maximum (falcon.c:440-447: strict '>', links in insertion order) -> the
-                    // node's score lane.  key = (score, 15 - lane): the larger score wins, among
-                    // equals the lower lane.
+                    // node's score lane.  key = (node, score, 15 - lane): inside a node the
+                    // larger score wins, among equals the lower lane.  (Scores fit the key's 25
+                    // bits: SC_FAST_SCORE_MAX, k_tscan.)
                     const int ph = __builtin_amdgcn_ds_bpermute(lidx << 2, dl == 0 ? prev_h : cur.h);
                     const int h = ph + cv;
-                    u32 key = have ? (((u32)(h + SC_BIAS) << 4) | (u32)(15 - lane)) : 0u;
-                    key = (u32)fa_sel(m1, (int)key, (int)max(key, (u32)__builtin_amdgcn_update_dpp(0, (int)key, 0x111, 0xf, 0xf, true)));
-                    key = (u32)fa_sel(m2, (int)key, (int)max(key, (u32)__builtin_amdgcn_update_dpp(0, (int)key, 0x112, 0xf, 0xf, true)));
-                    key = (u32)fa_sel(m4, (int)key, (int)max(key, (u32)__builtin_amdgcn_update_dpp(0, (int)key, 0x114, 0xf, 0xf, true)));
-                    key = (u32)fa_sel(m8, (int)key, (int)max(key, (u32)__builtin_amdgcn_update_dpp(0, (int)key, 0x118, 0xf, 0xf, true)));
+                    u32 key = have ? (((u32)(h + SC_BIAS) << 4) | kfix) : 0u;
+                    key = row_prefix_max_u32(key);
                     const int wl = 15 - (int)(key & 15u);  // lane of my node's winning link
                     const int pidw = __builtin_amdgcn_ds_bpermute(wl << 2, pidv);
                     const u32 pp = ((u32)(pidw + 1) << 4) | (u32)ss;
-                    const u32 r_key = (u32)__builtin_amdgcn_ds_permute(dst << 2, fa_sel(tail_m, 0, (int)key));
+                    const u32 r_key = (u32)__builtin_amdgcn_ds_permute(dst << 2, fa_sel(tail_m, 0, (int)key)) & 0x1fffffffu;
                     const u32 r_pp = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)pp);
                     // a node of this level landed on my lane, with a link above the floor: a
                     // node keeps -1 (-2 half units) and the zero back pointer unless some link
@@ -1244,6 +1263,7 @@ static MsaArgs msa_args(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov
     A.seg_pile = m.seg_pile; A.seg_t0 = m.seg_t0; A.n_seg = m.n_seg; A.min_cov = min_cov;
     A.wide_count = m.wide_count; A.wide_list = m.wide_list;
     A.first_links_back = m.first_links_back;
+    A.force_generic = m.force_generic;
     return A;
 }
 

@@ -364,6 +364,21 @@ def test_deep_piles_and_failures_stay_with_their_pile(engine, port):
     assert isinstance(only, FailedPile)
 
 
+def test_score_generic_path_alone(engine, monkeypatch):
+    """k_score's generic path (what levels of more than 16 links, levels beyond the
+    register-resident ones and piles whose scores could outgrow the fast path's 25-bit key
+    take) on EVERY level of the golden piles: same strings and eqv as the fast path and the
+    reference (FALCON_AMD_SCORE_GENERIC pins it)."""
+    class Impl:
+        def generate_consensus(self, seqs, min_cov, K, min_idt):
+            return engine.consensus([seqs], min_cov, K, min_idt, want_eqv=True)[0]
+    fast = [Impl().generate_consensus(c["seqs"], c["min_cov"], c["K"], c["min_idt"]) for c in F4]
+    monkeypatch.setenv("FALCON_AMD_SCORE_GENERIC", "1")
+    for c, f in zip(F4, fast):
+        check_pile_case(Impl(), c)
+        assert Impl().generate_consensus(c["seqs"], c["min_cov"], c["K"], c["min_idt"]) == f
+
+
 def test_pipelined_submit_wait_equals_run(engine):
     """fa_batch_submit / fa_batch_wait: two (and three) batches of one context in flight, the
     next one's throughput stages beside the previous one's score recurrence and back-trace
