@@ -427,6 +427,17 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
 
     stream_gbs = measured_stream_rate(plumb.torch) if plumb.cuda else None
 
+    # the dominant kernel with the device to itself (outside the timed region): in the
+    # pipelined steps its launches share the CUs with the previous step's sequential stages
+    alone_ms = {}
+    if pipelined and rank == 0:
+        for _ in range(2):
+            batch.run(MIN_COV, K, MIN_IDT)
+        s1 = batch.stats()
+        alone_ms = {"k_seed_index": s1.ms_index, "k_chain": s1.ms_chain, "k_align": s1.ms_align,
+                    "k_tags": s1.ms_tags, "k_links": s1.ms_links, "k_score": s1.ms_score,
+                    "k_backtrace": s1.ms_backtrace}
+
     st = batch.stats()
     # whole-job aggregate: units summed over ranks, time = slowest rank
     from falcon_amd.multigpu import reduce_measurement
@@ -499,6 +510,13 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
                 "frac_of_measured": round(ach / stream_gbs, 5) if stream_gbs else None,
                 "algorithmic_bytes_per_launch": int(kalg[domk]),
                 "avg_launch_ms": round(kernel_ms[domk], 4),
+                # the same kernel launched with nothing beside it (two extra unpipelined
+                # passes after the timed region); null when the steps are not pipelined,
+                # where avg_launch_ms already is that number
+                "alone": ({"avg_launch_ms": round(alone_ms[domk], 4),
+                           "achieved": round(kalg[domk] / (alone_ms[domk] * 1e-3) / 1e9, 2),
+                           "frac": round(kalg[domk] / (alone_ms[domk] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                          if alone_ms.get(domk) else None),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
             },
