@@ -19,15 +19,20 @@
 // No HIP in this file: it is usable (and tested) without a GPU.
 #include <algorithm>
 #include <cerrno>
+#include <chrono>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_set>
 #include <vector>
 
 #include <fcntl.h>
+#include <poll.h>
 #include <sys/mman.h>
 #include <emmintrin.h>
 #include <unistd.h>
@@ -53,6 +58,10 @@ inline bool is_space(unsigned char c) {
 struct fa_reader {
     int fd = -1;
     int min_n_read = 0, min_len_aln = 0, min_cov_aln = 0, max_n_read = 0, max_cov_aln = 0;
+    // time inside read() (helper thread), inside fa_reader_next, and of the latter waiting
+    // for the former (FALCON_AMD_TIMING)
+    double read_s = 0, next_s = 0, wait_s = 0, scan_s = 0;
+    size_t read_bytes = 0;
     bool eof = false;        // read() returned 0
     bool finished = false;   // "- -" seen or eof reached and the buffer drained
     std::string err;
@@ -61,14 +70,53 @@ struct fa_reader {
     // closed (it may grow), pointers afterwards
     char *text = nullptr;    // (mmap'ed: grown by remapping, never copied or zero-filled by us)
     size_t text_cap = 0;
+    // What a call hands out stays valid through the NEXT call (so that one thread can
+    // stage a batch while another reads the following one): two text buffers and two sets
+    // of pointer arrays alternate; `text` is the one being filled, `shelf` holds the
+    // other between calls.
+    struct Shelf {
+        char *text = nullptr;
+        size_t text_cap = 0;
+        std::vector<int> pile_n_seq, out_len;
+        std::vector<const char *> out_seqs, out_ids;
+    } shelf[2];
+    int cur = 0;             // shelf[cur]: arrays of the batch handed out last (its text is
+                             // `text`, shelf[cur].text is null); shelf[cur ^ 1]: the batch before
     size_t parsed = 0;       // start of the line being scanned (all lines before it are split)
     size_t scanned = 0;      // bytes of `text` the scanner has looked at (>= parsed)
     size_t filled = 0;       // bytes of `text` holding stream data
     // white-space bytes (<= 0x20) seen so far in the line being scanned
     size_t line_low = 0, line_first_low = 0;
     ~fa_reader() {
+        if (ahead.th.joinable()) {
+            {
+                std::lock_guard<std::mutex> g(ahead.mu);
+                ahead.quit = true;
+            }
+            ahead.cv.notify_all();
+            ahead.th.join();
+        }
         if (text) munmap(text, text_cap);
+        for (const Shelf &o : shelf)
+            if (o.text) munmap(o.text, o.text_cap);
     }
+
+    // Read-ahead: while the scanner works through one 4 MB piece, a helper thread has the
+    // next read() under way (the copy out of the page cache or the pipe is 2/3 of the
+    // reader's time).  One request at a time, always behind `filled`; the buffer only
+    // grows or changes hands while no request is in flight.
+    struct Ahead {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        enum { IDLE, REQUESTED, DONE } state = IDLE;
+        char *dst = nullptr;
+        size_t want = 0;
+        ssize_t n = 0;       // read()'s result, -1 with `err` = errno
+        int err = 0;
+        bool quit = false;
+    } ahead;
+    bool in_flight = false;  // a request is out (scanner's side of ahead.state)
 
     // pile in progress
     std::vector<Tok> pile;                  // seed, then reads in stream order
@@ -82,44 +130,119 @@ struct fa_reader {
     std::vector<Tok> sel_name;              // seed name per pile
     long long batch_bases = 0;
 
-    // what fa_reader_next() hands out
-    std::vector<const char *> out_seqs, out_ids;
-    std::vector<int> out_len;
 };
 
-static bool fill(fa_reader *r) {
-    // make room and read more of the stream; false at end of file.  Reads are capped so
-    // that what is read is scanned while it is still in the cache, and so that the tail a
-    // closed batch leaves behind (moved to the front by the next call) stays small.
-    if (r->eof) return false;
+static char *map_text(char *old, size_t old_cap, size_t cap) {
+    void *t = old ? mremap(old, old_cap, cap, MREMAP_MAYMOVE)
+                  : mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (t == MAP_FAILED) return nullptr;
+#ifdef MADV_HUGEPAGE
+    (void)madvise(t, cap, MADV_HUGEPAGE);  // hundreds of MB touched once: fewer faults
+#endif
+    return (char *)t;
+}
+
+// the helper thread: one read() per request.  It polls first (in slices, looking at `quit`),
+// so that closing the reader never waits for a producer that went silent.
+static void ahead_main(fa_reader *r) {
+    fa_reader::Ahead &a = r->ahead;
+    std::unique_lock<std::mutex> lk(a.mu);
+    for (;;) {
+        a.cv.wait(lk, [&] { return a.quit || a.state == fa_reader::Ahead::REQUESTED; });
+        if (a.quit) return;
+        char *dst = a.dst;
+        const size_t want = a.want;
+        lk.unlock();
+        ssize_t n = -1;
+        int err = 0;
+        for (;;) {
+            struct pollfd pfd = {r->fd, POLLIN, 0};
+            const int pr = poll(&pfd, 1, 50);
+            if (pr == 0 || (pr < 0 && errno == EINTR)) {
+                std::lock_guard<std::mutex> g(a.mu);
+                if (a.quit) return;
+                continue;
+            }
+            // (pr < 0 otherwise: not pollable -- just read)
+            const auto t0 = std::chrono::steady_clock::now();
+            n = read(r->fd, dst, want);
+            err = errno;
+            r->read_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (n < 0 && (err == EINTR || err == EAGAIN)) continue;
+            break;
+        }
+        lk.lock();
+        a.n = n;
+        a.err = err;
+        a.state = fa_reader::Ahead::DONE;
+        a.cv.notify_all();
+    }
+}
+
+// ask for the next piece of the stream, behind `filled` (no request may be in flight)
+static bool request_ahead(fa_reader *r) {
     const size_t want = 4u << 20;
     if (r->text_cap < r->filled + want) {
         const size_t cap = (std::max(r->text_cap * 2, r->filled + want) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
-        void *t = r->text ? mremap(r->text, r->text_cap, cap, MREMAP_MAYMOVE)
-                          : mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-        if (t == MAP_FAILED) {
+        char *t = map_text(r->text, r->text_cap, cap);
+        if (!t) {
             r->err = "falcon_amd: out of memory while reading the pile stream";
             r->eof = true;
             return false;
         }
-        r->text = (char *)t;
+        r->text = t;
         r->text_cap = cap;
     }
-    for (;;) {
-        ssize_t n = read(r->fd, r->text + r->filled, want);
-        if (n > 0) {
-            r->filled += (size_t)n;
-            return true;
-        }
-        if (n == 0) {
-            r->eof = true;
-            return false;
-        }
-        if (errno == EINTR) continue;
-        r->err = std::string("falcon_amd: read() of the pile stream failed: ") + strerror(errno);
-        r->eof = true;
-        return false;
+    fa_reader::Ahead &a = r->ahead;
+    if (!a.th.joinable()) a.th = std::thread(ahead_main, r);
+    {
+        std::lock_guard<std::mutex> g(a.mu);
+        a.dst = r->text + r->filled;
+        a.want = want;
+        a.state = fa_reader::Ahead::REQUESTED;
     }
+    r->in_flight = true;
+    a.cv.notify_all();
+    return true;
+}
+
+// wait for the request in flight (if any) and take its bytes in; false: nothing came
+// (end of file or an error, see r->eof / r->err)
+static bool settle_ahead(fa_reader *r) {
+    if (!r->in_flight) return true;
+    r->in_flight = false;
+    fa_reader::Ahead &a = r->ahead;
+    ssize_t n;
+    int err;
+    {
+        std::unique_lock<std::mutex> lk(a.mu);
+        const auto t0 = std::chrono::steady_clock::now();
+        a.cv.wait(lk, [&] { return a.state == fa_reader::Ahead::DONE; });
+        r->wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        n = a.n;
+        err = a.err;
+        a.state = fa_reader::Ahead::IDLE;
+    }
+    if (n > 0) {
+        r->filled += (size_t)n;
+        r->read_bytes += (size_t)n;
+        return true;
+    }
+    r->eof = true;
+    if (n < 0) r->err = std::string("falcon_amd: read() of the pile stream failed: ") + strerror(err);
+    return false;
+}
+
+static bool fill(fa_reader *r) {
+    // More of the stream behind `filled`; false at end of file.  Pieces are 4 MB so that what
+    // is read is scanned while it is still in the cache, and so that the tail a closed batch
+    // leaves behind (copied over by the next call) stays small.  The piece after the one
+    // returned is requested before the scanner gets this one.
+    if (r->eof) return false;
+    if (!r->in_flight && !request_ahead(r)) return false;
+    const size_t before = r->filled;
+    if (!settle_ahead(r) || r->filled == before) return false;
+    return request_ahead(r);
 }
 
 // get_longest_reads (consensus.py:26-45) on the pile in progress -> r->sel
@@ -223,7 +346,13 @@ extern "C" fa_reader *fa_reader_open(int fd, int min_n_read, int min_len_aln, in
     return r;
 }
 
-extern "C" void fa_reader_close(fa_reader *r) { delete r; }
+extern "C" void fa_reader_close(fa_reader *r) {
+    if (r && getenv("FALCON_AMD_TIMING"))
+        fprintf(stderr, "[falcon_amd] reader: %.1f MB, %.1f ms in fa_reader_next (%.1f ms of them waiting "
+                "for data, %.1f ms scanning and splitting), %.1f ms in read()\n",
+                r->read_bytes / 1e6, 1e3 * r->next_s, 1e3 * r->wait_s, 1e3 * r->scan_s, 1e3 * r->read_s);
+    delete r;
+}
 
 extern "C" const char *fa_reader_error(const fa_reader *r) { return r ? r->err.c_str() : ""; }
 
@@ -231,14 +360,49 @@ extern "C" int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, 
                               const char *const **seqs, const int **seq_len,
                               const char *const **seed_ids) {
     if (!r) return -1;
-    // drop the previous batch: keep the unparsed tail and the lines of the pile in progress
+    struct Clock {
+        fa_reader *r;
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~Clock() { r->next_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    } clock{r};
+    if (r->finished) {  // (nothing is asked of the stream any more; a request in flight stays)
+        r->pile_n_seq.clear();
+        r->sel.clear();
+        r->sel_name.clear();
+        return r->err.empty() ? 0 : -1;
+    }
+    // a piece requested during the previous call lands in the old buffer: take it along
+    if (!settle_ahead(r) && !r->err.empty()) return -1;
+    // The batch handed out last stays where it is (its pointers live through this call);
+    // the unparsed tail and the lines of the pile in progress move over to the other text
+    // buffer, the one of the batch before it, and the stream continues there.
     {
         size_t keep_from = r->parsed;
         for (const Tok &t : r->pile) keep_from = std::min(keep_from, t.off);
         if (!r->pile.empty()) keep_from = std::min(keep_from, r->seed_name.off);
         // (names of the pile in progress are owned copies)
         if (keep_from > 0) {
-            memmove(r->text, r->text + keep_from, r->filled - keep_from);
+            const size_t tail = r->filled - keep_from;
+            fa_reader::Shelf &mine = r->shelf[r->cur], &other = r->shelf[r->cur ^ 1];
+            if (other.text_cap < tail) {
+                const size_t cap = std::max(r->text_cap,  // (untouched pages cost nothing)
+                                            (tail + (4u << 20) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1));
+                char *t = map_text(other.text, other.text_cap, cap);
+                if (!t) {
+                    r->err = "falcon_amd: out of memory while reading the pile stream";
+                    return -1;
+                }
+                other.text = t;
+                other.text_cap = cap;
+            }
+            memcpy(other.text, r->text + keep_from, tail);
+            mine.text = r->text;
+            mine.text_cap = r->text_cap;
+            r->text = other.text;
+            r->text_cap = other.text_cap;
+            other.text = nullptr;
+            other.text_cap = 0;
+            r->cur ^= 1;
             r->filled -= keep_from;
             r->parsed -= keep_from;
             r->scanned -= keep_from;
@@ -294,6 +458,7 @@ extern "C" int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, 
             r->finished = true;
             break;
         }
+        const auto ts0 = std::chrono::steady_clock::now();
         const char *t = r->text;
         size_t i = r->scanned;
         bool go = true;
@@ -310,24 +475,27 @@ extern "C" int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, 
         for (; go && i < end; i++)
             if ((unsigned char)t[i] <= 0x20 && !event(i)) go = false;
         if (go) r->scanned = end;  // (a stop left `scanned` just behind its line feed)
+        r->scan_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
     }
     // the batch is closed: offsets become pointers, tokens become C strings
     const size_t n_sel = r->sel.size(), n_pile = r->pile_n_seq.size();
     char *t = r->text;
-    r->out_seqs.resize(n_sel);
-    r->out_len.resize(n_sel);
-    r->out_ids.resize(n_pile);
+    fa_reader::Shelf &out = r->shelf[r->cur];  // (last used by the batch before the previous one)
+    out.pile_n_seq = r->pile_n_seq;
+    out.out_seqs.resize(n_sel);
+    out.out_len.resize(n_sel);
+    out.out_ids.resize(n_pile);
     for (size_t i = 0; i < n_sel; i++) {
-        r->out_seqs[i] = t + r->sel[i].off;
-        r->out_len[i] = r->sel[i].len;
+        out.out_seqs[i] = t + r->sel[i].off;
+        out.out_len[i] = r->sel[i].len;
     }
     for (size_t i = 0; i < n_pile; i++) {
         t[r->sel_name[i].off + (size_t)r->sel_name[i].len] = '\0';  // the separator after the name
-        r->out_ids[i] = t + r->sel_name[i].off;
+        out.out_ids[i] = t + r->sel_name[i].off;
     }
-    if (pile_n_seq) *pile_n_seq = r->pile_n_seq.data();
-    if (seqs) *seqs = r->out_seqs.data();
-    if (seq_len) *seq_len = r->out_len.data();
-    if (seed_ids) *seed_ids = r->out_ids.data();
+    if (pile_n_seq) *pile_n_seq = out.pile_n_seq.data();
+    if (seqs) *seqs = out.out_seqs.data();
+    if (seq_len) *seq_len = out.out_len.data();
+    if (seed_ids) *seed_ids = out.out_ids.data();
     return (int)n_pile;
 }

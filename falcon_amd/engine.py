@@ -29,11 +29,12 @@ class FailedPile(str):
 
 class PileSet:
     """Admitted piles of one ``fa_reader_next`` call: pointer arrays owned by the reader
-    (valid until its next call), in exactly the shape ``fa_batch_create`` takes."""
+    (valid through its next call, not the one after), in exactly the shape
+    ``fa_batch_create`` takes."""
 
     def __init__(self, n_pile, pile_n_seq, seqs, seq_len, seed_ids):
         self.n_pile = n_pile
-        self.pile_n_seq, self.seqs, self.seq_len = pile_n_seq, seqs, seq_len
+        self.pile_n_seq, self.seqs, self.seq_len, self.raw_ids = pile_n_seq, seqs, seq_len, seed_ids
         self.seed_ids = [seed_ids[i].decode("ascii", "replace") for i in range(n_pile)]
         self.first = [0] * (n_pile + 1)
         for p in range(n_pile):

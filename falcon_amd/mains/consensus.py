@@ -28,6 +28,12 @@ import time
 from collections import namedtuple
 
 LOG = logging.getLogger("falcon_amd.consensus")
+_T0 = time.perf_counter()  # (debug lines carry seconds since the module was loaded)
+
+
+def _clock():
+    return time.perf_counter() - _T0
+
 
 KMER = 8              # consensus.py:270 hard-wires K = 8
 MAX_SEQ_LEN = 100000  # consensus.py:162: longer sequences are cut to MAX_SEQ_LEN - 1
@@ -379,8 +385,9 @@ NATIVE_BATCH_BASES = 400_000_000
 def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
     """The worker's pipeline, records leaving in input order:
 
-      ingest thread    native reader -> the next batch (``batch_bases`` bases) staged on the
-                       device with the least work queued (``gpu.stage``)
+      ingest thread    native reader -> the next batch (``batch_bases`` bases) of the stream
+      staging thread   that batch onto the device with the least work queued (``gpu.stage``),
+                       while the ingest thread reads the one behind it
       runner threads   ``gpu.parallel`` of them (two per engine): a batch's GPU stages
                        (``gpu.finish``: throughput stages under the engine's lock, then the
                        per-pile sequential stages beside the next batch's) and the download
@@ -405,22 +412,52 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
         failed.append(exc)
         stop.set()
 
+    # What the reader hands out lives through one further reader.next() (two text buffers
+    # alternate): `lease` counts the buffers the stager has not finished with.
+    raw = queue.Queue(maxsize=1)
+    lease = threading.Semaphore(2)
+
     def ingest():
         seq = 0
         try:
             while not stop.is_set():
+                while not lease.acquire(timeout=0.1):
+                    if stop.is_set():
+                        return
                 t0 = time.perf_counter()
                 ps = reader.next(0, batch_bases)
                 if ps is None:
                     break
-                t1 = time.perf_counter()
-                item = (seq, ps.seed_ids, gpu.stage(ps))
-                LOG.debug("ingest: batch %d, %d piles read in %.3f s, staged in %.3f s", seq, ps.n_pile,
-                          t1 - t0, time.perf_counter() - t1)
+                LOG.debug("t=%.3f ingest: batch %d, %d piles read in %.3f s", _clock(), seq, ps.n_pile,
+                          time.perf_counter() - t0)
+                raw.put((seq, ps))
                 seq += 1
-                staged.put(item)
         except Exception as exc:
             fail(exc)
+        finally:
+            raw.put(END)
+
+    def stager():
+        try:
+            while True:
+                item = raw.get()
+                if item is END:
+                    return
+                seq, ps = item
+                try:
+                    if stop.is_set():
+                        continue
+                    t0 = time.perf_counter()
+                    out = (seq, ps.seed_ids, gpu.stage(ps))
+                    LOG.debug("t=%.3f stager: batch %d staged in %.3f s", _clock(), seq,
+                              time.perf_counter() - t0)
+                finally:
+                    lease.release()
+                staged.put(out)
+        except Exception as exc:
+            fail(exc)
+            while raw.get() is not END:  # (the reader never blocks on a full queue)
+                lease.release()
         finally:
             staged.put(END)
 
@@ -437,7 +474,8 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
                     continue
                 t0 = time.perf_counter()
                 cns_all = gpu.finish(handle)
-                LOG.debug("runner: batch %d, GPU stages + download %.3f s", seq, time.perf_counter() - t0)
+                LOG.debug("t=%.3f runner: batch %d, GPU stages + download %.3f s", _clock(), seq,
+                          time.perf_counter() - t0)
                 done.put((seq, ids, cns_all))
         except Exception as exc:
             fail(exc)
@@ -466,16 +504,18 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
                     note_failed_piles(ids, cns_all)
                     stdout.write("".join(fasta_records(sid, cns, args.output_full, args.output_multi)
                                          for sid, cns in zip(ids, cns_all)))
-                    LOG.debug("printer: %d piles in %.3f s", len(ids), time.perf_counter() - t0)
+                    LOG.debug("t=%.3f printer: %d piles in %.3f s", _clock(), len(ids),
+                              time.perf_counter() - t0)
         except Exception as exc:  # (a closed stdout, say): stop the pipeline, report below
             fail(exc)
             while done.get() is not END:
                 pass
 
     t_in = threading.Thread(target=ingest, daemon=True)
+    t_stage = threading.Thread(target=stager, daemon=True)
     t_run = [threading.Thread(target=runner, daemon=True) for _ in range(n_run)]
     t_out = threading.Thread(target=printer, daemon=True)
-    for t in [t_in, t_out] + t_run:
+    for t in [t_in, t_stage, t_out] + t_run:
         t.start()
     try:
         for t in t_run:
@@ -487,9 +527,9 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
         done.put(END)   # (behind everything the runners delivered)
         t_out.join()
         stop.set()
-        # the reader may only be closed once the ingest thread has left it; what it had
-        # staged meanwhile is released
-        while t_in.is_alive():
+        # the reader may only be closed once the ingest and staging threads have left it;
+        # what they had staged meanwhile is released
+        while t_in.is_alive() or t_stage.is_alive():
             try:
                 item = staged.get(timeout=0.05)
             except queue.Empty:
@@ -497,6 +537,7 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
             if item is not END:
                 getattr(item[2], "free", lambda: None)()
         reader.close()
+    LOG.debug("t=%.3f stream finished", _clock())
     if failed:
         raise failed[0]
 
@@ -517,15 +558,16 @@ def run(args, stdin=None, stdout=None, consensus_map=None):
     if consensus_map is None:
         gpu = GpuConsensus(args.min_cov, args.min_idt)
         consensus_map = gpu.imap
-        LOG.info("falcon_amd consensus on %d engine(s)", len(gpu.engines))
+        LOG.info("falcon_amd consensus on %d engine(s) (t=%.3f)", len(gpu.engines), _clock())
 
     fd = _stream_fd(stdin)
     if gpu is not None and not args.trim and fd is not None:
         try:
             _run_native(args, cfg, fd, gpu, stdout)
         finally:
+            stdout.flush()
             gpu.close()
-        stdout.flush()
+            LOG.debug("t=%.3f engines closed", _clock())
         return
 
     if args.trim and gpu is None:

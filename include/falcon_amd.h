@@ -223,7 +223,8 @@ fa_reader *fa_reader_open(int fd, int min_n_read, int min_len_aln, int min_cov_a
  *   seed_ids[p]              NUL-terminated name of the pile's seed (a name holding a
  *                            NUL byte therefore ends there);
  * exactly the arguments of fa_batch_create().  The arrays and what they point to stay
- * valid until the next fa_reader_next() / fa_reader_close() on this reader. */
+ * valid through ONE further fa_reader_next() on this reader (a thread may stage batch n
+ * while another reads batch n + 1), until the call after that or fa_reader_close(). */
 int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, const int **pile_n_seq,
                    const char *const **seqs, const int **seq_len, const char *const **seed_ids);
 const char *fa_reader_error(const fa_reader *r);

@@ -87,6 +87,38 @@ def test_batch_limits_do_not_change_the_piles():
     assert c1 == 1 and c3 == -(-len(want) // 3) and cb > 1
 
 
+def test_a_batch_outlives_one_further_call():
+    """include/falcon_amd.h: what fa_reader_next hands out stays valid through one further
+    call (the worker stages batch n while it reads batch n + 1)."""
+    rng = random.Random(78)
+    text = _rand_stream(rng, 60, with_noise=True)
+    opts = (2, 0, 0, 500, 0)
+    want = _python(text, *opts)
+    with tempfile.NamedTemporaryFile("wb", delete=False) as f:
+        f.write(text.encode("ascii"))
+        path = f.name
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        for limits in ((1, 0), (4, 0), (0, 900)):
+            os.lseek(fd, 0, os.SEEK_SET)
+            r = Reader(fd, *opts)
+            got, prev = [], None
+            while True:
+                ps = r.next(*limits)
+                if prev is not None:  # read only now, after the call that followed it
+                    got.extend(zip(prev.seed_ids, prev.piles()))
+                    assert [prev.seed_ids[i] for i in range(prev.n_pile)] == \
+                           [prev.raw_ids[i].decode("ascii") for i in range(prev.n_pile)]
+                if ps is None:
+                    break
+                prev = ps
+            r.close()
+            assert got == want
+    finally:
+        os.close(fd)
+        os.unlink(path)
+
+
 def test_pipe_with_ragged_writes_and_control_bytes():
     """The scanner keeps its per-line state across short reads (a pipe fed in odd-sized
     pieces), across 16-byte compare blocks and across batch boundaries; control bytes that
