@@ -100,8 +100,13 @@ struct fa_ctx {
     // sequence, latency-bound at a few wavefronts per SIMD: they run next to the NEXT
     // batch's front stages (fa_batch_submit / fa_batch_wait).  `dl_stream`: result
     // download, so that a fetch never queues behind another batch's kernels.
+    // Two back streams take turns: a back stage lasts as long for 500 piles as for 3000 (one
+    // wavefront per pile, each walking its own levels), so a worker's small batches would
+    // otherwise queue up behind one another there while most wave slots are free.
+    static constexpr int N_BACK = 2;
     hipStream_t stream = nullptr;
-    hipStream_t back_stream = nullptr;
+    hipStream_t back_stream[N_BACK] = {};
+    unsigned back_turn = 0;  // (back_mu)
     hipStream_t dl_stream = nullptr;
     std::mutex front_mu, fetch_mu;
     // The back stage of the batch submitted last is not queued at once: it is queued by the
@@ -372,7 +377,8 @@ extern "C" fa_ctx *fa_create(int device) {
     {   // the back stream's few wavefronts go first when wave slots free up
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        HIP_OK_P(hipStreamCreateWithPriority(&c->back_stream, hipStreamNonBlocking, greatest));
+        for (hipStream_t &sb : c->back_stream)
+            HIP_OK_P(hipStreamCreateWithPriority(&sb, hipStreamNonBlocking, greatest));
     }
     HIP_OK_P(hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
     HIP_OK_P(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
@@ -395,7 +401,8 @@ extern "C" void fa_destroy(fa_ctx *c) {
     if (c->arena2.rowx) (void)hipFree(c->arena2.rowx);
     if (c->d_first_bad) (void)hipFree(c->d_first_bad);
     if (c->h_dl) (void)hipHostFree(c->h_dl);
-    if (c->back_stream) (void)hipStreamDestroy(c->back_stream);
+    for (hipStream_t sb : c->back_stream)
+        if (sb) (void)hipStreamDestroy(sb);
     if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->d_stage) (void)hipFree(c->d_stage);
@@ -1154,7 +1161,7 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
 // k_score + k_backtrace of `b` on the back stream, behind its links.  Caller holds back_mu.
 static int queue_back(fa_batch *b, hipEvent_t after) {
     fa_ctx *c = b->ctx;
-    hipStream_t sb = c->back_stream;
+    hipStream_t sb = c->back_stream[c->back_turn++ % fa_ctx::N_BACK];
     HIP_OK(hipStreamWaitEvent(sb, b->ev[5], 0));
     // (the host runs ahead of the device: without this the stage would start as soon as
     // its own links are done, i.e. beside the next batch's k_seed_index and k_chain)

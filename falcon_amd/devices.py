@@ -33,7 +33,7 @@ class Device:
 class DevicePool:
     # batches staged (resident in HBM, ~5 GB each at the default size) but not finished, per
     # device: enough to keep the device busy, bounded however many producers there are
-    MAX_QUEUED = 4
+    MAX_QUEUED = 5
 
     def __init__(self, engines):
         self.devices = [Device(e, i) for i, e in enumerate(engines)]
@@ -117,8 +117,10 @@ class SharedGpu:
     def __init__(self, pool: DevicePool, backend):
         self.pool, self.backend = pool, backend
         self.engines = tuple(d.engine for d in pool.devices)
-        # batches this worker may have between submit and collect: two per engine
-        self.parallel = 2 * len(pool.devices)
+        # batches this worker may have between submit and collect, per engine: one in the
+        # throughput stages (they take turns: the device's run_lock), two in the sequential
+        # stages and the download (FALCON_AMD_RUNNERS_PER_ENGINE)
+        self.parallel = max(1, int(os.environ.get("FALCON_AMD_RUNNERS_PER_ENGINE", "3"))) * len(pool.devices)
 
     def stage(self, ps):
         dev = self.pool.take()

@@ -114,7 +114,7 @@ def test_jobs_share_devices_and_print_what_the_single_worker_prints(tmp_path, mo
 def test_single_stream_worker_on_several_engines(tmp_path):
     """falcon_amd.mains.consensus on a node with several GPUs: GpuConsensus with
     three stand-in engines behind the worker's pipeline -- batches go to the engine with the
-    least work queued (no contiguous split ahead of time, no per-batch join), two batches per
+    least work queued (no contiguous split ahead of time, no per-batch join), three batches per
     engine in flight (one in the throughput stages), records printed in input order; the
     python-parser path (``imap``, e.g. --trim) shares the same queues."""
     rng = random.Random(21)
@@ -141,7 +141,7 @@ def test_single_stream_worker_on_several_engines(tmp_path):
     engines = [Named("dev%d" % i) for i in range(3)]
     backend = SlowFirst()
     gpu = single.GpuConsensus(args.min_cov, args.min_idt, engines=engines, backend=backend)
-    assert gpu.parallel == 6 and len(gpu.engines) == 3
+    assert gpu.parallel == 9 and len(gpu.engines) == 3
     rd, wr = os.pipe()
     t = threading.Thread(target=lambda: (os.write(wr, text.encode()), os.close(wr)))
     t.start()
