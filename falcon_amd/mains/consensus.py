@@ -394,16 +394,15 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
       printer thread   batches back in input order -> FASTA text
 
     ``gpu``: ``stage(pileset) -> handle`` (``handle.free()`` drops it), ``finish(handle) ->
-    consensus strings``, optionally ``parallel``."""
+    consensus strings``, optionally ``parallel`` -- or a function without arguments that
+    returns such an object: it is called once the ingest thread is reading, so that opening
+    the devices (HIP start-up) and the first two batches of the stream overlap."""
     import queue
     from falcon_amd.engine import Reader
     reader = Reader(fd, args.min_n_read, args.min_len_aln, cfg.min_cov_aln, cfg.max_n_read,
                     cfg.max_cov_aln)
     if batch_bases is None:
         batch_bases = int(os.environ.get("FALCON_AMD_BATCH_BASES", NATIVE_BATCH_BASES))
-    n_run = max(1, int(getattr(gpu, "parallel", 1)))
-    staged = queue.Queue(maxsize=n_run)
-    done = queue.Queue(maxsize=2 * n_run + 2)
     failed = []
     stop = threading.Event()
     END = object()
@@ -512,10 +511,26 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
                 pass
 
     t_in = threading.Thread(target=ingest, daemon=True)
+    t_in.start()
+    if callable(gpu):
+        try:
+            gpu = gpu()
+        except BaseException:
+            stop.set()
+            while t_in.is_alive() or not raw.empty():  # (the reader's batches are its own)
+                try:
+                    raw.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            reader.close()
+            raise
+    n_run = max(1, int(getattr(gpu, "parallel", 1)))
+    staged = queue.Queue(maxsize=n_run)
+    done = queue.Queue(maxsize=2 * n_run + 2)
     t_stage = threading.Thread(target=stager, daemon=True)
     t_run = [threading.Thread(target=runner, daemon=True) for _ in range(n_run)]
     t_out = threading.Thread(target=printer, daemon=True)
-    for t in [t_in, t_stage, t_out] + t_run:
+    for t in [t_stage, t_out] + t_run:
         t.start()
     try:
         for t in t_run:
@@ -555,20 +570,26 @@ def run(args, stdin=None, stdout=None, consensus_map=None):
     cfg = settings_from(args)
     kup = None
     gpu = None
-    if consensus_map is None:
-        gpu = GpuConsensus(args.min_cov, args.min_idt)
-        consensus_map = gpu.imap
-        LOG.info("falcon_amd consensus on %d engine(s) (t=%.3f)", len(gpu.engines), _clock())
+    opened = []
+
+    def open_gpu():
+        opened.append(GpuConsensus(args.min_cov, args.min_idt))
+        LOG.info("falcon_amd consensus on %d engine(s) (t=%.3f)", len(opened[0].engines), _clock())
+        return opened[0]
 
     fd = _stream_fd(stdin)
-    if gpu is not None and not args.trim and fd is not None:
+    if consensus_map is None and not args.trim and fd is not None:
         try:
-            _run_native(args, cfg, fd, gpu, stdout)
+            _run_native(args, cfg, fd, open_gpu, stdout)
         finally:
             stdout.flush()
-            gpu.close()
+            for g in opened:
+                g.close()
             LOG.debug("t=%.3f engines closed", _clock())
         return
+    if consensus_map is None:
+        gpu = open_gpu()
+        consensus_map = gpu.imap
 
     if args.trim and gpu is None:
         from falcon_amd import falcon_kit as fk
