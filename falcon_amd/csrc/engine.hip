@@ -7,6 +7,7 @@
 // stage together.
 #include "../../include/falcon_amd.h"
 #include "fa_internal.h"
+#include "fa_host.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -312,6 +313,7 @@ struct fa_batch {
     bool msa_static = false;  // seg lists and t_off (functions of the seed lengths) uploaded
     std::vector<int> h_out_eqv;
     std::vector<std::string> h_result;
+    std::string fasta;  // fa_batch_fasta's text
     bool have_range = false, have_aln = false, fetched = false, fetched_eqv = false;
     u64 out_slots = 0;
     fa_stats stats = {};
@@ -1423,6 +1425,25 @@ extern "C" int fa_batch_result(fa_batch *b, int p, const char **seq, int *len, c
         }
         *eqv = b->h_out_eqv.data() + b->pile[p].out_off + b->h_pile_out[p].start;
     }
+    return 0;
+}
+
+extern "C" int fa_batch_fasta(fa_batch *b, const char *const *seed_ids, int mode, const char **text,
+                              long long *len) {
+    if (!b || !b->fetched || !seed_ids || mode < 0 || mode > 2) {
+        set_err("falcon_amd: fa_batch_fasta: no fetched batch, or bad arguments");
+        return -1;
+    }
+    std::string &out = b->fasta;
+    out.clear();
+    size_t total = 0;
+    for (int p = 0; p < b->n_pile; p++) total += b->h_result[p].size();
+    out.reserve(total + total / 64 + 64 * (size_t)b->n_pile);
+    for (int p = 0; p < b->n_pile; p++)
+        if (!b->pile_err[p])
+            fa_fasta_append(out, seed_ids[p], b->h_result[p].data(), (long long)b->h_result[p].size(), mode);
+    if (text) *text = out.data();
+    if (len) *len = (long long)out.size();
     return 0;
 }
 

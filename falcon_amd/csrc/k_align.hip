@@ -317,7 +317,6 @@ __device__ __noinline__ void align_one(int band_v, u64 rows_per_slot_v, double m
             kd = -nkd;
             if (fin) break;
         }
-    reg_rows_finished:
         min_k = kd + 2 * lo;
         if (fin) {  // row d finished the alignment on its first (lowest) such diagonal
             FLUSH_ROW_RECORDS();

@@ -106,6 +106,16 @@ class EngineBackend:
         finally:
             batch.free()
 
+    def collect_fasta(self, batch, seed_ids, mode):
+        """The same, straight to the FASTA text of the batch (native output rules):
+        (bytes, [(pile, reason)] of failed piles); frees the batch."""
+        try:
+            batch.wait()
+            batch.fetch(False)
+            return batch.fasta(seed_ids, mode), batch.failures()
+        finally:
+            batch.free()
+
     def release(self, batch):
         batch.free()
 
@@ -130,7 +140,9 @@ class SharedGpu:
             self.pool.give_back(dev)
             raise
 
-    def finish(self, st):
+    def finish(self, st, fasta=None):
+        """Consensus strings of a staged batch -- or, with ``fasta=(seed_ids, mode)`` and a
+        backend that formats natively, (FASTA bytes, failed piles)."""
         try:
             try:
                 with st.dev.run_lock:
@@ -139,9 +151,15 @@ class SharedGpu:
             except BaseException:
                 self.backend.release(st.batch)
                 raise
+            if fasta is not None:
+                return self.backend.collect_fasta(st.batch, *fasta)
             return self.backend.collect(st.batch)
         finally:
             self.pool.give_back(st.dev)
+
+    @property
+    def native_fasta(self):
+        return hasattr(self.backend, "collect_fasta")
 
 
 class Staged:

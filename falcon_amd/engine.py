@@ -35,7 +35,8 @@ class PileSet:
     def __init__(self, n_pile, pile_n_seq, seqs, seq_len, seed_ids):
         self.n_pile = n_pile
         self.pile_n_seq, self.seqs, self.seq_len, self.raw_ids = pile_n_seq, seqs, seq_len, seed_ids
-        self.seed_ids = [seed_ids[i].decode("ascii", "replace") for i in range(n_pile)]
+        self.seed_ids_raw = [seed_ids[i] for i in range(n_pile)]  # (bytes, copied out of the reader)
+        self.seed_ids = [b.decode("ascii", "replace") for b in self.seed_ids_raw]
         self.first = [0] * (n_pile + 1)
         for p in range(n_pile):
             self.first[p + 1] = self.first[p] + pile_n_seq[p]
@@ -184,6 +185,27 @@ class Batch:
             if self.lib.fa_batch_pile_error(self.h, pile, msg, 256) > 0:
                 s = FailedPile(msg.value.decode("utf-8", "replace"))
         return (s, list(eqv[:n.value])) if self._eqv else s
+
+    def fasta(self, seed_ids, mode: int) -> bytes:
+        """FASTA text of the fetched batch under the worker's output rules (consensus.py:275-299;
+        mode 0 default, 1 --output-multi, 2 --output-full), failed piles left out.
+        ``seed_ids``: bytes (or str), one per pile."""
+        ids = (C.c_char_p * self.n_pile)(*[s if isinstance(s, bytes) else s.encode("utf-8") for s in seed_ids])
+        text = C.c_void_p()
+        n = C.c_longlong()
+        if self.lib.fa_batch_fasta(self.h, ids, mode, C.byref(text), C.byref(n)):
+            raise FalconAmdError(last_error())
+        return C.string_at(text, n.value)
+
+    def failures(self):
+        """[(pile, reason)] of the piles without a consensus (fa_batch_pile_error)."""
+        out = []
+        if self.stats().n_piles_failed:
+            msg = C.create_string_buffer(256)
+            for p in range(self.n_pile):
+                if self.lib.fa_batch_pile_error(self.h, p, msg, 256) > 0:
+                    out.append((p, msg.value.decode("utf-8", "replace")))
+        return out
 
     def stats(self) -> FaStats:
         st = FaStats()

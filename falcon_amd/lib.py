@@ -67,6 +67,11 @@ def load() -> C.CDLL:
     lib.fa_batch_run.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_double]
     lib.fa_batch_submit.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_double]
     lib.fa_batch_wait.argtypes = [C.c_void_p]
+    lib.fa_batch_fasta.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_void_p),
+                                   C.POINTER(C.c_longlong)]
+    lib.fa_batch_fasta.restype = C.c_int
+    lib.fa_fasta_records.argtypes = [C.c_char_p, C.c_char_p, C.c_longlong, C.c_int, C.c_char_p, C.c_longlong]
+    lib.fa_fasta_records.restype = C.c_longlong
     lib.fa_batch_fetch.argtypes = [C.c_void_p, C.c_int]
     lib.fa_batch_trim_windows.argtypes = [C.c_void_p, C.c_uint, C.c_int]
     lib.fa_batch_result.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p),

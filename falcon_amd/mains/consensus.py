@@ -307,9 +307,14 @@ class GpuConsensus:
         2-bit pack).  The PileSet may be recycled by its reader once this returns."""
         return self.shared.stage(ps)
 
-    def finish(self, staged):
-        """Run a staged batch and return its consensus strings in pile order."""
-        return self.shared.finish(staged)
+    def finish(self, staged, fasta=None):
+        """Run a staged batch and return its consensus strings in pile order (or, with
+        ``fasta=(seed ids, mode)``, its FASTA text and failed piles: SharedGpu.finish)."""
+        return self.shared.finish(staged, fasta)
+
+    @property
+    def native_fasta(self):
+        return self.shared.native_fasta
 
     def close(self):
         self.pool.close()
@@ -447,7 +452,7 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
                     if stop.is_set():
                         continue
                     t0 = time.perf_counter()
-                    out = (seq, ps.seed_ids, gpu.stage(ps))
+                    out = (seq, (ps.seed_ids, ps.seed_ids_raw), gpu.stage(ps))
                     LOG.debug("t=%.3f stager: batch %d staged in %.3f s", _clock(), seq,
                               time.perf_counter() - t0)
                 finally:
@@ -467,15 +472,18 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
                 if item is END:
                     staged.put(END)  # the other runners see it too
                     return
-                seq, ids, handle = item
+                seq, (ids, ids_raw), handle = item
                 if stop.is_set():
                     getattr(handle, "free", lambda: None)()
                     continue
                 t0 = time.perf_counter()
-                cns_all = gpu.finish(handle)
+                if native_fasta:  # (text, [(pile, reason)]): no per-pile python object
+                    res = gpu.finish(handle, (ids_raw, fasta_mode))
+                else:
+                    res = gpu.finish(handle)
                 LOG.debug("t=%.3f runner: batch %d, GPU stages + download %.3f s", _clock(), seq,
                           time.perf_counter() - t0)
-                done.put((seq, ids, cns_all))
+                done.put((seq, ids, res))
         except Exception as exc:
             fail(exc)
             # keep draining so that the ingest thread never blocks on a full queue
@@ -496,10 +504,18 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
                 waiting[item[0]] = item
                 while want in waiting:
                     t0 = time.perf_counter()
-                    _, ids, cns_all = waiting.pop(want)
+                    _, ids, res = waiting.pop(want)
                     want += 1
                     if stop.is_set():
                         continue
+                    if native_fasta:
+                        text, bad = res
+                        for p, reason in bad:
+                            FAILED_PILES.append(ids[p])
+                            LOG.error("seed %s is not corrected: %s", ids[p], reason)
+                        write_bytes(text)
+                        continue
+                    cns_all = res
                     note_failed_piles(ids, cns_all)
                     stdout.write("".join(fasta_records(sid, cns, args.output_full, args.output_multi)
                                          for sid, cns in zip(ids, cns_all)))
@@ -525,6 +541,18 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
             reader.close()
             raise
     n_run = max(1, int(getattr(gpu, "parallel", 1)))
+    # the output rules in native code (fa_batch_fasta) when the engine offers them
+    native_fasta = bool(getattr(gpu, "native_fasta", False)) and not os.environ.get("FALCON_AMD_PY_PRINTER")
+    fasta_mode = 2 if args.output_full else 1 if args.output_multi else 0
+    raw_out = getattr(stdout, "buffer", None)
+
+    def write_bytes(text):
+        if raw_out is not None:
+            stdout.flush()
+            raw_out.write(text)
+        else:
+            stdout.write(text.decode("utf-8", "replace"))
+
     staged = queue.Queue(maxsize=n_run)
     done = queue.Queue(maxsize=2 * n_run + 2)
     t_stage = threading.Thread(target=stager, daemon=True)

@@ -175,6 +175,20 @@ int fa_batch_stats(fa_batch *b, fa_stats *out);
  * returns why (0: the pile is fine; 2: too many usable reads; 1: device error), with a
  * description in msg if msg != NULL. */
 int fa_batch_pile_error(fa_batch *b, int pile, char *msg, int msg_cap);
+/* The worker's output rules (falcon_kit/mains/consensus.py:275-299): the FASTA text the
+ * reference prints for a consensus string -- nothing if it is shorter than 500; default:
+ * ">seed_id" and the longest run of [ACGT] (the last of equally long ones); --output-multi:
+ * every run >= 500, at most 10, ">prolog/<seed_id><i>/0_<len>", wrapped at 80 columns;
+ * --output-full: ">seed_id_f" and the raw string. */
+enum { FA_FASTA_DEFAULT = 0, FA_FASTA_MULTI = 1, FA_FASTA_FULL = 2 };
+/* One string (host only, no device needed): up to cap bytes are written to out, the
+ * return value is the length of the whole text (< 0: bad arguments). */
+long long fa_fasta_records(const char *seed_id, const char *cns, long long len, int mode, char *out,
+                           long long cap);
+/* All piles of a fetched batch, in pile order, seed_ids[p] NUL-terminated; piles that
+ * failed contribute nothing (fa_batch_pile_error / fa_stats.n_piles_failed tell).  *text is
+ * owned by the batch and valid until the next call or fa_batch_free. */
+int fa_batch_fasta(fa_batch *b, const char *const *seed_ids, int mode, const char **text, long long *len);
 void fa_batch_free(fa_batch *b);
 
 /* Diagnostics used by the parity tests: per-sequence stage outputs.

@@ -98,3 +98,39 @@ def test_dropin_overlay_falls_through_to_the_reference_package(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 0, r.stderr
     assert r.stdout.split("\n")[:3] == ["reference task reference io", "reference io", "True True True False"]
+
+
+def test_native_output_rules_equal_the_python_ones():
+    """fa_fasta_records (falcon_amd/csrc/fasta.cpp, what fa_batch_fasta applies to every pile
+    of a batch) against fasta_records, which tests/golden/f5_cli pins to the reference's own
+    driver (consensus.py:275-299): short strings, no solid run, ties between longest runs,
+    more than ten runs, runs of exactly 499/500 and of multiples of 80, lower-case and
+    foreign characters as separators."""
+    import ctypes as C
+    import random
+    from falcon_amd.lib import load
+    lib = load()
+    rng = random.Random(9)
+
+    def run_of(n):
+        return "".join(rng.choice("ACGT") for _ in range(n))
+
+    cases = ["", "ACGT" * 10, "acgt" * 300, run_of(499), run_of(500), run_of(560) + "a" + run_of(560),
+             run_of(700) + "n" + run_of(800) + "c" + run_of(800) + "N-" + run_of(30),
+             "a".join(run_of(500 + 80 * (i % 3)) for i in range(14)),
+             "g".join(run_of(rng.choice([3, 499, 500, 501, 640, 641])) for _ in range(30)),
+             run_of(100) + "t" * 450, "x" + run_of(1600) + "y", run_of(480) + "a" + run_of(480)]
+    for _ in range(60):
+        n_piece = rng.randint(1, 25)
+        cases.append("".join(run_of(rng.choice([1, 7, 80, 160, 499, 500, 503, 1200])) +
+                             rng.choice(["", "a", "ac", "N", "-", "tg"]) for _ in range(n_piece)))
+    buf = C.create_string_buffer(1 << 20)
+    n_out = 0
+    for cns in cases:
+        for mode, (full, multi) in enumerate([(False, False), (False, True), (True, False)]):
+            want = cli.fasta_records("000123", cns, full, multi).encode("ascii")
+            n = lib.fa_fasta_records(b"000123", cns.encode("ascii"), len(cns), mode, buf, len(buf))
+            assert n == len(want) and buf.raw[:n] == want, (mode, len(cns))
+            n_out += bool(want)
+    assert n_out > 100
+    assert lib.fa_fasta_records(b"x", b"ACGT", 4, 3, buf, 10) < 0  # unknown mode

@@ -75,6 +75,32 @@ def test_a_pile_too_deep_for_the_gpu_fails_alone():
     assert p.returncode == 0 and p.stdout == clean
 
 
+def test_native_and_python_printers_agree():
+    """The worker formats a batch's FASTA text in native code (fa_batch_fasta);
+    FALCON_AMD_PY_PRINTER=1 takes the per-pile python path (fasta_records, pinned to the
+    reference's driver by f5_cli): same bytes in the three output modes, also around a pile
+    that fails alone, with batches of a few piles each."""
+    from falcon_amd.synth import make_pile, pile_to_la4falcon
+    chunks = []
+    for i in range(7):
+        seed, rd = make_pile(1500 + i, S=2400 + 300 * i, coverage=16, e=0.10 + 0.01 * i, min_read=500,
+                             mean_read=1500, sd_read=400)
+        chunks.append(pile_to_la4falcon("%09d" % i, seed, rd, 100000 * i + 1))
+    seed, rd = make_pile(1310, S=2500, coverage=830, e=0.08, min_read=1500, mean_read=2200, sd_read=200)
+    chunks.insert(3, pile_to_la4falcon("%09d" % 77, seed, rd, 700001))
+    text = "".join(chunks) + "- -\n"
+    env = dict(os.environ, PYTHONPATH=ROOT, FALCON_AMD_BATCH_BASES="150000")
+    for mode in ([], ["--output-multi"], ["--output-full"]):
+        cmd = [sys.executable, "-m", "falcon_amd.mains.consensus"] + mode + \
+              ["--min-idt", "0.70", "--min-cov", "1", "--max-n-read", "2000", "--n-core", "1"]
+        nat = subprocess.run(cmd, input=text, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+        py = subprocess.run(cmd, input=text, capture_output=True, text=True, cwd=ROOT, timeout=600,
+                            env=dict(env, FALCON_AMD_PY_PRINTER="1"))
+        assert nat.returncode == 3 and py.returncode == 3
+        assert nat.stdout == py.stdout and nat.stdout.count(">") >= 7
+        assert "seed 000000077 is not corrected" in nat.stderr and "seed 000000077 is not corrected" in py.stderr
+
+
 def test_length_limits_through_the_command_line():
     """Sequences of more than 100 000 bases are cut to 99 999 (consensus.py:162,178-179) and
     the consensus core takes seeds below 100 000 (falcon.c:343): a pile on a 99.3 kb seed
