@@ -953,6 +953,7 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
     fa_ctx *c = b->ctx;
     hipStream_t s = c->stream;
     FaBatchDev d = b->dev();
+    PhaseTimer pt("align + msa plan");
     auto launch_align = [&]() {
         if (band + 1 > 64 * FA_ALIGN_MAXCH - 1)
             fa_launch_align_wide(d, c->arena, max_diff, band, s);
@@ -1005,9 +1006,11 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
         b->msa_static = true;
     }
     if (b->h_ta.resize((size_t)b->n_seq + 1)) return -1;
+    pt.mark("launch+static-plan");
     // alignment summaries bound the MSA node pools (levels <= seed + insertions)
     b->stats.align_relaunched = 0;
     int rc_aln = fetch_aln(b);
+    pt.mark("align-wait+summaries");
     if (rc_aln == 1) {
         // some alignments outgrew their slots (nothing was written past them): those
         // again, alone, in worst-case slots
@@ -1091,6 +1094,7 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
         link_tot += cols;
     }
     acc_first[b->n_pile] = (u32)n_ta;
+    pt.mark("plan");
     if (ins_tot >= 0xffffffffull || link_tot >= 0xffffffffull * 4) {
         set_err("falcon_amd: batch too large for the MSA stage");
         return -1;
@@ -1113,6 +1117,7 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
     rc2 |= need(b->d_score_out, (size_t)b->n_pile);
     rc2 |= need(b->d_nodes, (size_t)node_off + 8);
     if (rc2) return -1;
+    pt.mark("buffers");
     auto up = [&](void *dst, const void *src, size_t bytes) {
         return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s) == hipSuccess;
     };
@@ -1138,9 +1143,11 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
     md.first_links_back = force_accept_g >= 0 ? 1 : 0;
     md.force_generic = getenv("FALCON_AMD_SCORE_GENERIC") ? 1 : 0;  // (tests: pins the generic path of k_score)
     d = b->dev();
+    pt.mark("upload");
     HIP_OK(hipEventRecord(b->ev[4], s));
     fa_launch_msa_front(d, md, min_cov, s, b->ev[8], b->ev[9]);  // k_tags + k_tscan | k_links
     HIP_OK(hipEventRecord(b->ev[5], s));
+    pt.mark("msa-launch");
     trace_stage(s, "links");
     HIP_OK(hipGetLastError());
     // k_score + k_backtrace: queued later, see fa_ctx::pending_back
