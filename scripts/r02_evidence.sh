@@ -31,6 +31,14 @@ for ctrs in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
 done
 python $R/scripts/pmc_table.py $O/pmc > $O/pmc_table.txt 2>&1
 find $O -name "*.db" -size +20M -delete
+# kernel timeline of pipelined steps (every dispatch with its queue, duration, gaps)
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/tl -o tl -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/tl.log 2>&1
+python $R/scripts/timeline.py $(find $O/tl -name "*kernel_trace.csv" | head -1) $(find $O/tl -name "*memory_copy_trace.csv" | head -1) > $O/timeline_pipelined.txt 2>&1; head -18 $O/timeline_pipelined.txt
+# the worker end to end on a long stream (text in -> FASTA out, one process)
+cd $R
+FALCON_AMD_TIMING=1 timeout 600 python scripts/exp_e2e.py 3072 3 FALCON_AMD_NOTHING=1 > $O/e2e.txt 2>&1; tail -2 $O/e2e.txt
+cp /tmp/e2e_stream.txt.err $O/e2e_last.err 2>/dev/null
 # instruction counts by class: restricted to the kernels of the path (an unrestricted pass hung once)
 cd /tmp
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --kernel-include-regex "k_align|k_links|k_score|k_tags|k_chain|k_backtrace|k_seed_index" --output-format csv -d $O/pmc/p9 -o p9 -- python $R/bench.py --steps 1 --warmup 0 --no-pipeline --no-cpu-baseline --no-end-to-end > $O/pmc/p9.log 2>&1; echo "pmc insts rc=$?"
