@@ -831,30 +831,40 @@ __device__ __forceinline__ void score_links(ScoreAcc &acc, int src_h, int nbv, i
 
 // ---- the unusual levels, out of line -----------------------------------------------
 // More than 16 links, a level beyond the register-resident ones, or a predecessor there.
-// Kept out of the hot loop as a by-value call: inlined, its control flow joins cost the
-// fast path a dozen register copies per level (measured: 32 -> 28 ms without them).
+// Kept out of the hot loop as a call whose per-lane state travels through LDS (the caller
+// parks its score lanes there and takes them back): inlined, or with the state passed and
+// returned in registers, its control flow joins cost the fast path dozens of register
+// copies per position.
 struct ScoreSlowIo {
     int cur_h, cur_p, cur_k;   // score lanes of the position being scored
     int dg_h, dg_slot, dg_ck;  // best deep node so far (lanes 0..4)
 };
+#define SC_IO_WORDS (3 * 64 + 3 * 8 + 2)  // cur_h, cur_p, cur_k per lane; dg_h, dg_slot, dg_ck of lanes 0..4; plvl5, adjacent
 typedef u32 sc_u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __noinline__ ScoreSlowIo score_level_slow(ScoreSlowIo io, int prev_h, u32 w_first, int dl_v,
-                                                     int n_link_v, u32 lk_v, u32 plvl5_v, u32 slot_v,
-                                                     int cov_v, int upper_v, int adjacent_v,
+__device__ __noinline__ void score_level_slow(int *s_io_v, int prev_h, u32 w_first, int dl_v,
+                                                     int n_link_v, u32 lk_v, u32 slot_v,
+                                                     int cov_v, int upper_v,
                                                      int curbuf_v, const u32 *links_v,
                                                      const u32 *s_links_v, int *s_deep_v,
                                                      sc_u32x2 *nodes_v) {
     // every scalar argument is wave-uniform; pin it (arguments arrive in VGPRs)
     const int dl = fa_uni(dl_v), n_link = fa_uni(n_link_v), cov = fa_uni(cov_v);
     const int upper = fa_uni(upper_v), curbuf = fa_uni(curbuf_v);
-    const bool adjacent = fa_uni(adjacent_v) != 0;
-    const u32 lk = fa_uni(lk_v), plvl5 = fa_uni(plvl5_v), slot = fa_uni(slot_v);
+    const u32 lk = fa_uni(lk_v), slot = fa_uni(slot_v);
     const u32 *links = fa_uni(links_v);        // the level's words in HBM ...
     const u32 *s_links = fa_uni(s_links_v);    // ... or staged in LDS (then links is unused): generic pointer
     int *s_deep = fa_uni(s_deep_v);
     sc_u32x2 *nodes = fa_uni(nodes_v);
+    int *s_io = fa_uni(s_io_v);
+    // (these two depend on the previous position: as register arguments they would pull the
+    // caller's loop-carried scalars into vector registers)
+    const u32 plvl5 = (u32)fa_uni(s_io[216]);
+    const bool adjacent = fa_uni(s_io[217]) != 0;
     const int lane = fa_lane();
+    ScoreSlowIo io;
+    io.cur_h = s_io[lane]; io.cur_p = s_io[64 + lane]; io.cur_k = s_io[128 + lane];
+    io.dg_h = s_io[192 + (lane & 7)]; io.dg_slot = s_io[200 + (lane & 7)]; io.dg_ck = s_io[208 + (lane & 7)];
     const bool have = lane < n_link;
     const u32 w = w_first;
     const int cnt = (int)(w & 0x3ffu), nbase = (int)((w >> 10) & 7u);
@@ -873,8 +883,8 @@ __device__ __noinline__ ScoreSlowIo score_level_slow(ScoreSlowIo io, int prev_h,
         const int lane_rel = lane - dl * 5;
         if (dl == 0) score_links<false>(acc, prev_h, nbase, cv, lidx, pidv, n_link, lane_rel);
         else score_links<true>(acc, 0, nbase, cv, lidx, pidv, n_link, lane_rel);
-        io.cur_h = acc.h; io.cur_p = acc.p; io.cur_k = acc.k;
-        return io;
+        s_io[lane] = acc.h; s_io[64 + lane] = acc.p; s_io[128 + lane] = acc.k;
+        return;
     }
     // generic level: any number of links, predecessors and/or the level itself beyond
     // the register-resident ones; accumulators in lanes 0..4
@@ -924,9 +934,9 @@ __device__ __noinline__ ScoreSlowIo score_level_slow(ScoreSlowIo io, int prev_h,
         sc_u32x2 r;
         r.x = (u32)d.h; r.y = (u32)(((d.p + 1) << 1) | upper);
         nodes[slot * 5u + (u32)lane] = r;
-        if (d.h > io.dg_h) { io.dg_h = d.h; io.dg_slot = (int)slot; io.dg_ck = d.k; }
+        if (d.h > io.dg_h) { s_io[192 + lane] = d.h; s_io[200 + lane] = (int)slot; s_io[208 + lane] = d.k; }
     }
-    return io;
+    s_io[lane] = io.cur_h; s_io[64 + lane] = io.cur_p; s_io[128 + lane] = io.cur_k;
 }
 
 // prefix maximum of unsigned keys inside each row of 16 lanes, in place: 4 VALU
@@ -944,11 +954,17 @@ __device__ __forceinline__ u32 row_prefix_max_u32(u32 v) {
 
 __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
     __shared__ u32 s_links[SC_LINKS + 64];
+    __shared__ int s_io[SC_IO_WORDS];  // score_level_slow's state (and the deep levels' best nodes)
     const int lane = fa_lane();
     const int p = blockIdx.x;
     if (p >= A.n_pile) return;
     const FaPile pm = A.pile[p];
     FaScoreOut so = A.score_out[p];
+    // (this kernel also writes score_out, so the record arrives by vector loads: pin what
+    // steers the control flow, or every branch on it counts as divergent and the values
+    // merged behind it move to vector registers)
+    so.err = fa_uni(so.err); so.wide = fa_uni(so.wide);
+    so.n_levels = fa_uni(so.n_levels); so.n_links = fa_uni(so.n_links);
     if (so.err) return;
     const int T = pm.seed_len;
     const u32 *tiw = reinterpret_cast<const u32 *>(A.tinfo + A.t_off[p]);  // 3 words per position
@@ -970,7 +986,8 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
     cur.h = h_init; cur.p = 0; cur.k = 0; cur.n = 0;
     int prev_h = h_init;
     int gl_h = -2, gl_slot = 0, gl_ck = 0;  // best node of this lane's (delta, base) class
-    int dg_h = -2, dg_slot = 0, dg_ck = 0;  // same for the deep levels (lanes 0..4)
+    // (the same for the deep levels, lanes 0..4: s_io[192..], [200..], [208..])
+    if (lane < 8) { s_io[192 + lane] = -2; s_io[200 + lane] = 0; s_io[208 + lane] = 0; }
     int curbuf = 0;     // which half of s_deep belongs to the position being scored
     int prev_nlev = 0;  // its number of levels
     int prev_t = -2;    // last scored target position
@@ -1023,13 +1040,15 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
         // is being scored (bulk blocks; a position's first level continues where the
         // capacity of the position before it ends, uncovered positions have none)
         u32 w_nx = BULK ? s_links[lane] : 0u;
-        for (int j = 0; j < nb; j++) {
+        // (covered positions only: a `continue` for the others is a second way to the loop
+        // latch and costs every position a round of register copies)
+        for (u64 todo = fa_ballot((x_cn & 0xffffu) != 0u) & ((1ull << nb) - 1ull); todo; todo &= todo - 1) {
+            const int j = (int)__builtin_ctzll(todo);
             const int t = t0 + j;
             const u32 y_lvl = (u32)__builtin_amdgcn_readlane((int)x_lvl, j);
             const u32 y_link = (u32)__builtin_amdgcn_readlane((int)x_link, j);
             const u32 y_cn = (u32)__builtin_amdgcn_readlane((int)x_cn, j);
             const int cov = (int)(y_cn & 0xffffu), nlev = (int)(y_cn >> 16);
-            if (cov == 0) continue;
             const int upper = cov > min_cov ? 1 : 0;  // falcon.c:498 (Q7)
             const bool adjacent = (prev_t == t - 1);
             prev_h = adjacent ? cur.h : h_init;
@@ -1109,32 +1128,39 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                     cur.p = got ? (int)(r_pp >> 4) - 1 : cur.p;
                     cur.k = got ? 15 - (int)(r_key & 15u) - (int)(r_pp & 15u) : cur.k;
                 } else {
-                    ScoreSlowIo io;
-                    io.cur_h = cur.h; io.cur_p = cur.p; io.cur_k = cur.k;
-                    io.dg_h = dg_h; io.dg_slot = dg_slot; io.dg_ck = dg_ck;
+                    s_io[lane] = cur.h; s_io[64 + lane] = cur.p; s_io[128 + lane] = cur.k;
+                    // (scalar -> vector here and nowhere else: the "s" operands keep the
+                    // loop-carried scalars they derive from in scalar registers)
+                    int plvl5_v, adj_v, curbuf_v;
+                    asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5"
+                                 : "=&v"(plvl5_v), "=&v"(adj_v), "=&v"(curbuf_v)
+                                 : "s"(plvl5), "s"(adjacent ? 1 : 0), "s"(curbuf));
+                    s_io[216] = plvl5_v; s_io[217] = adj_v;
                     const u32 *staged = nullptr;
                     if constexpr (BULK) staged = s_links + (lk - lnk0);
-                    io = score_level_slow(io, prev_h, w, dl, n_link, lk, plvl5, slot, cov, upper,
-                                          adjacent ? 1 : 0, curbuf, links, staged, s_deep,
-                                          (sc_u32x2 *)nodes);
-                    cur.h = io.cur_h; cur.p = io.cur_p; cur.k = io.cur_k;
-                    dg_h = io.dg_h; dg_slot = io.dg_slot; dg_ck = io.dg_ck;
+                    score_level_slow(s_io, prev_h, w, dl, n_link, lk, slot, cov, upper,
+                                     curbuf_v, links, staged, s_deep, (sc_u32x2 *)nodes);
+                    cur.h = s_io[lane]; cur.p = s_io[64 + lane]; cur.k = s_io[128 + lane];
                 }
                 lk += (u32)n_link;
             }
             // the register-resident levels of the position: node records + lane bests
-            if (lane < min(nlev, SC_REG) * 5) {
-                u32x2 r;
-                r.x = (u32)cur.h; r.y = (u32)(((cur.p + 1) << 1) | upper);
-                nodes[y_lvl * 5u + (u32)lane] = r;
-                if (cur.h > gl_h) {  // strict: the lane's first maximum
-                    gl_h = cur.h;
-                    gl_slot = (int)y_lvl + ldl;
-                    gl_ck = cur.k;
+            {
+                const bool in = lane < min(nlev, SC_REG) * 5;
+                if (in) {
+                    u32x2 r;
+                    r.x = (u32)cur.h; r.y = (u32)(((cur.p + 1) << 1) | upper);
+                    nodes[y_lvl * 5u + (u32)lane] = r;
                 }
+                // strict: the lane's first maximum (selects, in place: a masked block costs
+                // copies in and out of it)
+                const bool better = in && cur.h > gl_h;
+                gl_h = better ? cur.h : gl_h;
+                gl_slot = better ? (int)y_lvl + ldl : gl_slot;
+                gl_ck = better ? cur.k : gl_ck;
             }
-            prev_t = t;
-            prev_lvl = y_lvl;
+            // (defined by scalar instructions, so that the loop keeps them in scalar registers)
+            asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=&s"(prev_t), "=&s"(prev_lvl) : "s"(t), "s"(y_lvl));
             prev_nlev = nlev;
         }
         };
@@ -1147,9 +1173,9 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
     for (int i = 0; i < SC_REG * 5 + 5; i++) {
         const bool dp = i >= SC_REG * 5;
         const int src = dp ? i - SC_REG * 5 : i;
-        const int hv = dp ? __builtin_amdgcn_readlane(dg_h, src) : __builtin_amdgcn_readlane(gl_h, src);
-        const int sv = dp ? __builtin_amdgcn_readlane(dg_slot, src) : __builtin_amdgcn_readlane(gl_slot, src);
-        const int kv = dp ? __builtin_amdgcn_readlane(dg_ck, src) : __builtin_amdgcn_readlane(gl_ck, src);
+        const int hv = dp ? fa_uni(s_io[192 + src]) : __builtin_amdgcn_readlane(gl_h, src);
+        const int sv = dp ? fa_uni(s_io[200 + src]) : __builtin_amdgcn_readlane(gl_slot, src);
+        const int kv = dp ? fa_uni(s_io[208 + src]) : __builtin_amdgcn_readlane(gl_ck, src);
         if (hv > g_h || (hv == g_h && hv > -2 && sv < g_slot)) {
             g_h = hv;
             g_slot = sv;
