@@ -800,7 +800,7 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
 // registers; node records leave with one coalesced store per position.
 // ---------------------------------------------------------------------------
 #define SC_LINKS 640      // link words staged per block (LDS per wavefront: what the kernels running beside this one keep)
-#define SC_LEVELS 128     // levels per block (their link counts sit in two VGPRs)
+#define SC_LEVELS 64      // levels per block (their link counts sit in one VGPR: one readlane per level)
 #define SC_REG 12         // insertion levels whose scores live in registers
 #define SC_ZERO 63        // lane of the score registers that always holds 0 (start links)
 #define SC_BIAS 2048      // makes every link score positive (score >= -2 - coverage, coverage <= 1023)
@@ -977,6 +977,7 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
     // HBM -- LDS here would cost occupancy (one wave per pile must all be resident)
     int *s_deep = A.score_ovf + (u64)p * (2 * 256 * 5);
     const int ldl = lane / 5;
+    const u32 le_lane_mask = lane < 31 ? (2u << lane) - 1u : 0xffffffffu;  // bits 0 .. lane
     const int h_init = (lane == SC_ZERO) ? 0 : -2;
     // (the fast path's key holds a score in 25 bits: piles whose scores could outgrow them,
     // or every level when the tests ask for it, take the generic path)
@@ -1016,18 +1017,16 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
         int nb = __popcll(__ballot(fits));  // prefix sums are monotone, so is `fits`
         const bool bulk = nb > 0;
         if (!bulk) nb = 1;  // one oversized position: read straight from HBM
-        int nlk0 = 0, nlk1 = 0;
+        int nlk0 = 0;
         __syncthreads();
         if (bulk) {
             const u32 n_l = (u32)__builtin_amdgcn_readlane((int)end_l, nb) - lvl0;
             const u32 n_k = (u32)__builtin_amdgcn_readlane((int)end_k, nb) - lnk0;
             for (u32 i = lane; i < n_k; i += 64) s_links[i] = links[lnk0 + i];
             if ((u32)lane < n_l) nlk0 = (int)nlk[lvl0 + (u32)lane];
-            if ((u32)lane + 64u < n_l) nlk1 = (int)nlk[lvl0 + 64u + (u32)lane];
         }
         __syncthreads();
         nlk0 = (int)settled((u32)nlk0);
-        nlk1 = (int)settled((u32)nlk1);
         x_lvl = settled(x_lvl);
         x_link = settled(x_link);
         x_cn = settled(x_cn);
@@ -1063,10 +1062,7 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                 const u32 slot = y_lvl + (u32)dl;
                 int n_link;
                 if constexpr (BULK) {
-                    const int li = (int)(slot - lvl0);
-                    const int a0 = __builtin_amdgcn_readlane(nlk0, li & 63);
-                    const int a1 = __builtin_amdgcn_readlane(nlk1, li & 63);
-                    n_link = li < 64 ? a0 : a1;
+                    n_link = __builtin_amdgcn_readlane(nlk0, (int)(slot - lvl0));
                 } else {
                     n_link = __builtin_amdgcn_readfirstlane((int)nlk[slot]);
                 }
@@ -1097,10 +1093,19 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                     const int nbp = have ? nbase + 1 : 0;  // 0: no link in this lane
                     const int n1 = __builtin_amdgcn_mov_dpp(nbp, 0x111, 0xf, 0xf, true);  // row_shr:1
                     const int nx = __builtin_amdgcn_mov_dpp(nbp, 0x101, 0xf, 0xf, true);  // row_shl:1
-                    const u64 first_m = fa_ballot(n1 != nbp) & have_m;  // first link of its node
+                    // (first link of its node; also flags the lane behind the last link, which no
+                    // lane with a link looks at)
+                    const u64 first_raw = fa_ballot(n1 != nbp);
                     const u64 tail_m = fa_ballot(nx != nbp) & have_m;   // last link of its node
-                    // first lane of my node: prefix maximum of the first links' lane numbers
-                    const int ss = (int)row_prefix_max_u32((u32)fa_sel(first_m, 0, lane));
+                    // first lane of my node: the highest first link at or below my lane
+                    // (lane 0 is one whenever the level has links; lanes without a link read 0
+                    // or garbage that nobody uses)
+                    int ss;  // (v_ffbh_u32 as the hardware defines it: -1 for 0, which only lanes without a link see)
+                    // (the AND stays with the compiler: the mask may sit in VCC, written by the
+                    // v_cmp just before, and reading VCC by its SGPR number right behind an
+                    // implicit write needs a wait state that nobody inserts inside an asm block)
+                    const u32 first_le = (u32)first_raw & le_lane_mask;
+                    asm("v_ffbh_u32 %0, %1\n\tv_sub_u32 %0, 31, %0" : "=v"(ss) : "v"(first_le));
                     const int cv = 2 * cnt - cov;
                     const int lidx = start ? SC_ZERO : pidx;
                     const int pidv = start ? -1 : (int)(plvl5 + (u32)pidx);
@@ -1117,16 +1122,18 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                     key = row_prefix_max_u32(key);
                     const int wl = 15 - (int)(key & 15u);  // lane of my node's winning link
                     const int pidw = __builtin_amdgcn_ds_bpermute(wl << 2, pidv);
-                    const u32 pp = ((u32)(pidw + 1) << 4) | (u32)ss;
+                    const u32 pp = ((u32)pidw << 4) | (u32)ss;  // (-1, a start link, stays -1 under >> 4)
                     const u32 r_key = (u32)__builtin_amdgcn_ds_permute(dst << 2, fa_sel(tail_m, 0, (int)key)) & 0x1fffffffu;
                     const u32 r_pp = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)pp);
                     // a node of this level landed on my lane, with a link above the floor: a
                     // node keeps -1 (-2 half units) and the zero back pointer unless some link
                     // scores strictly more (falcon.c:420,447; Q4)
-                    const bool got = r_key > (((u32)(SC_BIAS - 2) << 4) | 15u);
-                    cur.h = got ? (int)(r_key >> 4) - SC_BIAS : cur.h;
-                    cur.p = got ? (int)(r_pp >> 4) - 1 : cur.p;
-                    cur.k = got ? 15 - (int)(r_key & 15u) - (int)(r_pp & 15u) : cur.k;
+                    // (selects by the lane mask: as `got ? .. : ..` the compiler branches around
+                    // the three updates, three scalar instructions per level for nothing)
+                    const u64 got = fa_ballot(r_key > (((u32)(SC_BIAS - 2) << 4) | 15u));
+                    cur.h = fa_sel(got, cur.h, (int)(r_key >> 4) - SC_BIAS);
+                    cur.p = fa_sel(got, cur.p, (int)r_pp >> 4);
+                    cur.k = fa_sel(got, cur.k, 15 - (int)(r_key & 15u) - (int)(r_pp & 15u));
                 } else {
                     s_io[lane] = cur.h; s_io[64 + lane] = cur.p; s_io[128 + lane] = cur.k;
                     // (scalar -> vector here and nowhere else: the "s" operands keep the

@@ -69,3 +69,40 @@ def test_legacy_table_functions_match_golden(lib):
         check_hits_case(impl, c)
     for c in load_golden("f2_ranges_extra")["cases"]:
         assert list(impl.best_range(c["q"], c["t"], c["bin"], c["th"])) == c["range"]
+
+
+def test_no_asm_block_names_vcc():
+    """Inline asm is opaque to the compiler's hazard recognizer.  One hazard it would otherwise
+    cover: VCC written implicitly (v_cmp e32) and read by its SGPR number in the next
+    instruction needs a wait state ("mixed use of VCC", CDNA3 ISA 4.5) -- which is what an
+    asm block with an "s" operand does if the register allocator hands it VCC (seen once:
+    two piles of the differential campaign off by a link index).  The kernels keep such
+    operands out of asm blocks or behind a compiler-visible instruction; this checks the ISA
+    the current sources compile to."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src_dir = os.path.join(ROOT, "falcon_amd", "csrc")
+    bad = []
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = []
+        for src in sorted(glob.glob(os.path.join(src_dir, "k_*.hip"))):
+            out = os.path.join(tmp, os.path.basename(src) + ".s")
+            procs.append((src, out, subprocess.Popen(
+                [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
+                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
+        for src, out, proc in procs:
+            assert proc.wait() == 0, src
+            inside = False
+            for n, line in enumerate(open(out), 1):
+                if "#ASMSTART" in line:
+                    inside = True
+                elif "#ASMEND" in line:
+                    inside = False
+                elif inside and "vcc" in line:
+                    bad.append("%s:%d: %s" % (os.path.basename(out), n, line.strip()))
+    assert not bad, bad
