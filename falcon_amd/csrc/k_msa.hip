@@ -982,6 +982,7 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
     // (the fast path's key holds a score in 25 bits: piles whose scores could outgrow them,
     // or every level when the tests ask for it, take the generic path)
     const bool fast_pile = so.wide == 0 && A.force_generic == 0;
+    const int reg_max = fa_uni(fast_pile ? SC_REG : -1);  // most levels a position of the fast path may have
 
     ScoreAcc cur;
     cur.h = h_init; cur.p = 0; cur.k = 0; cur.n = 0;
@@ -1031,6 +1032,13 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
         x_link = settled(x_link);
         x_cn = settled(x_cn);
 
+        // (what the position loop carries from position to position is wave-uniform; pinned once
+        // per block, the loop keeps it in scalar registers instead of following the vector
+        // copies the other instance's joins hand it)
+        prev_t = fa_uni(prev_t);
+        prev_lvl = fa_uni(prev_lvl);
+        prev_nlev = fa_uni(prev_nlev);
+        curbuf = fa_uni(curbuf);
         // the block's positions; two instances of the code so that the oversized-position
         // case (links read straight from HBM) costs the normal one no branches
         auto run_block = [&](auto bulk_c) {
@@ -1048,15 +1056,24 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
             const u32 y_link = (u32)__builtin_amdgcn_readlane((int)x_link, j);
             const u32 y_cn = (u32)__builtin_amdgcn_readlane((int)x_cn, j);
             const int cov = (int)(y_cn & 0xffffu), nlev = (int)(y_cn >> 16);
-            const int upper = cov > min_cov ? 1 : 0;  // falcon.c:498 (Q7)
+            // falcon.c:498 (Q7): cov > min_cov -- as scalar integer arithmetic the compiler cannot
+            // turn back into a compare: a uniform bool lives as a lane mask, and its `? 1 : 0`
+            // is a vector select in every position, wanted or not
+            int upper;
+            asm("s_sub_i32 %0, %1, %2\n\ts_lshr_b32 %0, %0, 31" : "=s"(upper) : "s"(min_cov), "s"(cov) : "scc");
             const bool adjacent = (prev_t == t - 1);
+            int adjacent_i;  // (the same, as an integer: see upper; t - 1 - prev_t >= 0)
+            asm("s_sub_i32 %0, %1, %2\n\ts_min_u32 %0, %0, 1\n\ts_xor_b32 %0, %0, 1"
+                : "=s"(adjacent_i) : "s"(t - 1), "s"(prev_t) : "scc");
             prev_h = adjacent ? cur.h : h_init;
             cur.h = h_init; cur.p = 0; cur.k = 0;
             curbuf ^= 1;
             u32 lk = y_link;
             // no level of this position and no predecessor of one lies beyond the
             // register-resident levels: the per-level test of the fast path is one compare
-            const bool shallow = fast_pile && nlev <= SC_REG && prev_nlev <= SC_REG;
+            int fast_lim;  // 16 if so, else -1 (scalar arithmetic instead of lane-mask algebra)
+            asm("s_max_i32 %0, %1, %2\n\ts_cmp_le_i32 %0, %3\n\ts_cselect_b32 %0, 16, -1"
+                : "=&s"(fast_lim) : "s"(nlev), "s"(prev_nlev), "s"(reg_max) : "scc");
             const u32 next_rel = (u32)__builtin_amdgcn_readlane((int)x_link, (j + 1) & 63) - lnk0;
             for (int dl = 0; dl < nlev; dl++) {
                 const u32 slot = y_lvl + (u32)dl;
@@ -1082,7 +1099,7 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                 const int cnt = (int)(w & 0x3ffu), nbase = (int)((w >> 10) & 7u);
                 const int pidx = (int)((w >> 13) & 0x7ffu);
                 const bool start = (w >> 24) & 1u;
-                if (shallow && n_link <= 16) {
+                if (__builtin_expect(n_link <= fast_lim, 1)) {
                     // ---- the usual level: <= 16 links in lanes 0..15, node-major (k_links).
                     // ONE unsegmented prefix maximum resolves all five nodes -- the node's base
                     // sits on top of the key, so a later node's links beat any link of an
@@ -1138,14 +1155,15 @@ __global__ __launch_bounds__(64) void k_score(MsaArgs A) {
                     s_io[lane] = cur.h; s_io[64 + lane] = cur.p; s_io[128 + lane] = cur.k;
                     // (scalar -> vector here and nowhere else: the "s" operands keep the
                     // loop-carried scalars they derive from in scalar registers)
-                    int plvl5_v, adj_v, curbuf_v;
-                    asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5"
-                                 : "=&v"(plvl5_v), "=&v"(adj_v), "=&v"(curbuf_v)
-                                 : "s"(plvl5), "s"(adjacent ? 1 : 0), "s"(curbuf));
+                    int plvl5_v, adj_v, curbuf_v, upper_v, cov_v;
+                    asm volatile("v_mov_b32 %0, %5\n\tv_mov_b32 %1, %6\n\tv_mov_b32 %2, %7\n\t"
+                                 "v_mov_b32 %3, %8\n\tv_mov_b32 %4, %9"
+                                 : "=&v"(plvl5_v), "=&v"(adj_v), "=&v"(curbuf_v), "=&v"(upper_v), "=&v"(cov_v)
+                                 : "s"(plvl5), "s"(adjacent_i), "s"(curbuf), "s"(upper), "s"(cov));
                     s_io[216] = plvl5_v; s_io[217] = adj_v;
                     const u32 *staged = nullptr;
                     if constexpr (BULK) staged = s_links + (lk - lnk0);
-                    score_level_slow(s_io, prev_h, w, dl, n_link, lk, slot, cov, upper,
+                    score_level_slow(s_io, prev_h, w, dl, n_link, lk, slot, cov_v, upper_v,
                                      curbuf_v, links, staged, s_deep, (sc_u32x2 *)nodes);
                     cur.h = s_io[lane]; cur.p = s_io[64 + lane]; cur.k = s_io[128 + lane];
                 }
