@@ -27,7 +27,8 @@ done
 i=0
 for ctrs in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/pmc/p$i -o p$i -- $B > $O/pmc/p$i.log 2>&1; echo "pmc pass $i rc=$?"
+  # (restricted to the kernels of the path: unrestricted passes hang rocprofv3 on this pool every other time)
+  timeout 120 rocprofv3 --kernel-trace --pmc $ctrs --kernel-include-regex "k_align|k_links|k_score|k_tags|k_chain|k_backtrace|k_seed_index|k_pack" --output-format csv -d $O/pmc/p$i -o p$i -- $B > $O/pmc/p$i.log 2>&1; echo "pmc pass $i rc=$?"
 done
 python $R/scripts/pmc_table.py $O/pmc > $O/pmc_table.txt 2>&1
 find $O -name "*.db" -size +20M -delete
