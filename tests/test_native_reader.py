@@ -119,6 +119,30 @@ def test_a_batch_outlives_one_further_call():
         os.unlink(path)
 
 
+def test_closing_the_reader_does_not_wait_for_a_silent_producer():
+    """The reader keeps one read() ahead of the scanner on a helper thread (reader.cpp).  A
+    producer that has delivered a batch and then says nothing (the pipe stays open) must not
+    hold up that batch, nor the close that follows while the read-ahead is still waiting."""
+    import time
+    rng = random.Random(6)
+    text = _rand_stream(rng, 30, with_noise=False).split("- -")[0]  # (no end marker, no EOF)
+    opts = (2, 0, 0, 500, 0)
+    want = _python(text + "- -\n", *opts)
+    rd, wr = os.pipe()
+    try:
+        os.write(wr, text.encode("ascii"))
+        r = Reader(rd, *opts)
+        t0 = time.perf_counter()
+        ps = r.next(len(want), 0)  # exactly what has been written: no need to wait for more
+        got = list(zip(ps.seed_ids, ps.piles()))
+        r.close()
+        assert time.perf_counter() - t0 < 2.0
+        assert got == want
+    finally:
+        os.close(wr)
+        os.close(rd)
+
+
 def test_pipe_with_ragged_writes_and_control_bytes():
     """The scanner keeps its per-line state across short reads (a pipe fed in odd-sized
     pieces), across 16-byte compare blocks and across batch boundaries; control bytes that
