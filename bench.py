@@ -224,20 +224,27 @@ def end_to_end(piles, extra_args=(), expect=None, repeats=E2E_REPEATS):
         cmd = [sys.executable, "-m", "falcon_amd.mains.consensus", "--output-multi", "--min-idt",
                "0.70", "--min-cov", "4", "--max-n-read", "200", "--n-core", "1"] + list(extra_args) + \
             os.environ.get("FALCON_BENCH_E2E_ARGS", "").split()
-        t0 = time.perf_counter()
-        with open(src) as fin, open(dst, "w") as fout:
-            # (a profiler wrapped around this process stays with this process: the worker's
-            # launches are at another batch size and would blur its per-kernel averages)
-            env = {k: v for k, v in os.environ.items()
-                   if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTRACER", "HSA_TOOLS"))}
-            subprocess.run(cmd, stdin=fin, stdout=fout, check=True, cwd=root, timeout=600, env=env)
-        wall = time.perf_counter() - t0
+        # (a profiler wrapped around this process stays with this process: the worker's
+        # launches are at another batch size and would blur its per-kernel averages)
+        env = {k: v for k, v in os.environ.items()
+               if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTRACER", "HSA_TOOLS"))}
+        # twice, the better run counts: the first worker starts while the text it reads is
+        # still being written back and beside this process's resident batches, and its wall
+        # time moves by a factor of two with that (both are listed)
+        walls = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            with open(src) as fin, open(dst, "w") as fout:
+                subprocess.run(cmd, stdin=fin, stdout=fout, check=True, cwd=root, timeout=600, env=env)
+            walls.append(time.perf_counter() - t0)
+        wall = min(walls)
         with open(dst) as f:
             text = f.read()
         bases = sum(len(ln) for ln in text.split("\n") if not ln.startswith(">"))
     n = repeats * len(piles)
     out = {"piles_per_sec": round(n / wall, 1), "text_MB_per_sec": round(size / 1e6 / wall, 1),
            "fasta_bases_per_sec": round(bases / wall, 1), "wall_s": round(wall, 2),
+           "runs_wall_s": [round(w, 2) for w in walls],
            "what": "%d piles (the step's %d, %d times; %.0f MB of text from the page cache) -> FASTA, one "
                    "worker process on one GPU, process start and HIP initialisation included"
                    % (n, len(piles), repeats, size / 1e6)}
