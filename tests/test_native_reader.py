@@ -280,6 +280,26 @@ def test_cli_native_path_orders_and_prints(tmp_path):
     finally:
         os.close(fd)
 
+    # the devices are opened while the ingest thread is already reading (gpu given as a
+    # factory): one that fails -- no HIP device -- ends the run with its error, the reader
+    # is left and closed, nothing hangs; one that succeeds is used like the object itself
+    def no_device():
+        raise RuntimeError("no HIP device visible")
+
+    for factory, error in ((no_device, RuntimeError), (FakeGpu, None)):
+        fd = os.open(str(path), os.O_RDONLY)
+        out = io.StringIO()
+        try:
+            if error is not None:
+                with pytest.raises(error):
+                    _run_native(args, cfg, fd, factory, out, batch_bases=900)
+                assert out.getvalue() == ""
+            else:
+                _run_native(args, cfg, fd, factory, out, batch_bases=900)
+                assert out.getvalue() == want
+        finally:
+            os.close(fd)
+
 
 def test_bench_end_to_end_text_rebuilds_the_bench_piles(tmp_path):
     """bench.py's end-to-end leg writes its piles out as LA4Falcon text: the reader hands
