@@ -514,6 +514,8 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
                             FAILED_PILES.append(ids[p])
                             LOG.error("seed %s is not corrected: %s", ids[p], reason)
                         write_bytes(text)
+                        LOG.debug("t=%.3f printer: %d piles in %.3f s", _clock(), len(ids),
+                                  time.perf_counter() - t0)
                         continue
                     cns_all = res
                     note_failed_piles(ids, cns_all)
