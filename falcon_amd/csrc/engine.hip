@@ -320,6 +320,10 @@ struct fa_batch {
     // timing events of the last run (0..7 on the front stream, 8..11 on the back stream)
     hipEvent_t ev[12] = {};
     bool in_flight = false;  // fa_batch_submit done, fa_batch_wait pending
+    // kernels of this batch were launched on the context's front stream (submit, pair and
+    // unitig runs, also ones that failed half-way): fa_batch_free waits for that stream
+    // before the batch's blocks go back to the cache, where another thread may take them
+    bool front_launched = false;
     bool back_queued = false;  // its k_score / k_backtrace are on the back stream
     FaMsaDev md_saved = {};
     unsigned min_cov_saved = 0;
@@ -719,9 +723,17 @@ extern "C" void fa_batch_free(fa_batch *b) {
     (void)hipSetDevice(b->ctx->device);
     {
         std::lock_guard<std::mutex> hold(b->ctx->back_mu);
-        if (b->ctx->pending_back == b) b->ctx->pending_back = nullptr;  // never queued: nothing reads it
+        if (b->ctx->pending_back == b) b->ctx->pending_back = nullptr;  // its back stage is never queued
     }
-    if (b->in_flight && b->back_queued && b->ev[6]) (void)hipEventSynchronize(b->ev[6]);  // its kernels still read it
+    // Its buffers go to the per-device block cache, from where another thread's batch_build
+    // may take them at once (hipFree used to wait for the device; the cache does not):
+    // nothing of this batch may still be running.  Front stages (also of a submit that
+    // failed half-way: k_index / k_chain / k_align / k_tags / k_links and the async copies
+    // are only queued) run on the context's front stream, the back stage signals ev[6].
+    // (no front_mu here: callers may hold it, and waiting for a little more than this
+    // batch's own work -- whatever another thread queued since -- is harmless)
+    if (b->front_launched) (void)hipStreamSynchronize(b->ctx->stream);
+    if (b->back_queued && b->ev[6]) (void)hipEventSynchronize(b->ev[6]);
     // (its device and pinned buffers release themselves)
     delete b;
 }
@@ -736,6 +748,18 @@ extern "C" void fa_batch_free(fa_batch *b) {
 // amdgpu wipes released VRAM, and the next process on the device waits for that (a 60 GB
 // arena cost the next worker ~4 s).
 static const int FA_SLOT_WIDTH = 32;
+
+// hipMalloc for the context-owned arenas: what is missing may sit in the device's block
+// cache (freed batches), so a failure is retried once after dropping the cache
+static hipError_t arena_malloc(void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        cache_of_current_device()->drop_all();
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
 
 static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes, bool full) {
     int per_cu = fa_align_blocks_per_cu(lds_bytes);
@@ -770,8 +794,8 @@ static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes, bool ful
         if (fit >= (u64)n_slot - (u64)n_slot / 8 && fit >= 1) {
             n_slot = (int)fit;
             need_cells = need_rows = 0;
-        } else {
-            need_cells += need_cells / 4;
+        } else if (((u64)need_cells + 2 * (u64)need_rows) * 5 / 4 <= budget) {
+            need_cells += need_cells / 4;  // (headroom only while it stays inside the budget)
             need_rows += need_rows / 4;
         }
     }
@@ -779,7 +803,7 @@ static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes, bool ful
         if (c->arena.cells) (void)hipFree(c->arena.cells);
         c->arena.cells = nullptr;
         c->arena_cells_bytes = 0;
-        HIP_OK(hipMalloc((void **)&c->arena.cells, need_cells));
+        HIP_OK(arena_malloc((void **)&c->arena.cells, need_cells));
         c->arena_cells_bytes = need_cells;
     }
     if (need_rows > c->arena_rows_bytes) {
@@ -788,8 +812,8 @@ static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes, bool ful
         c->arena.rows = nullptr;
         c->arena.rowx = nullptr;
         c->arena_rows_bytes = 0;
-        HIP_OK(hipMalloc((void **)&c->arena.rows, need_rows));
-        HIP_OK(hipMalloc((void **)&c->arena.rowx, need_rows));
+        HIP_OK(arena_malloc((void **)&c->arena.rows, need_rows));
+        HIP_OK(arena_malloc((void **)&c->arena.rowx, need_rows));
         c->arena_rows_bytes = need_rows;
     }
     c->arena.cells_per_slot = cells;
@@ -804,16 +828,24 @@ static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes, bool ful
 // worst-case slots, as the first version did, meant a 60 GB allocation in the middle of a
 // stream (0.7 s, and the next process waits for the driver to wipe it).
 static int ensure_arena2(fa_ctx *c, const fa_batch *b, int n) {
-    const int n_slot = std::max(1, std::min(n, 512));
+    int n_slot = std::max(1, std::min(n, 512));
     const u64 rows = (u64)b->max_rows;
     u64 cells = std::max<u64>(rows * (u64)(b->band + 1), 4096);
     cells = ((cells + 1023) & ~(u64)1023) + 448;
+    {   // worst-case slots are MBs each: never more of them than half of the free memory holds
+        // (fewer slots only mean more trips of the persistent kernel)
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const u64 per_slot = cells * 4 + rows * (sizeof(FaRowRec) + sizeof(FaRowExt));
+        const u64 budget = (u64)free_b / 2 + (u64)c->arena2_cells_bytes + 2 * (u64)c->arena2_rows_bytes;
+        if ((u64)n_slot * per_slot > budget) n_slot = (int)std::max<u64>(1, budget / per_slot);
+    }
     const size_t need_cells = (size_t)n_slot * cells * 4, need_rows = (size_t)n_slot * rows * sizeof(FaRowRec);
     if (need_cells > c->arena2_cells_bytes) {
         if (c->arena2.cells) (void)hipFree(c->arena2.cells);
         c->arena2.cells = nullptr;
         c->arena2_cells_bytes = 0;
-        HIP_OK(hipMalloc((void **)&c->arena2.cells, need_cells));
+        HIP_OK(arena_malloc((void **)&c->arena2.cells, need_cells));
         c->arena2_cells_bytes = need_cells;
     }
     if (need_rows > c->arena2_rows_bytes) {
@@ -822,8 +854,8 @@ static int ensure_arena2(fa_ctx *c, const fa_batch *b, int n) {
         c->arena2.rows = nullptr;
         c->arena2.rowx = nullptr;
         c->arena2_rows_bytes = 0;
-        HIP_OK(hipMalloc((void **)&c->arena2.rows, need_rows));
-        HIP_OK(hipMalloc((void **)&c->arena2.rowx, need_rows));
+        HIP_OK(arena_malloc((void **)&c->arena2.rows, need_rows));
+        HIP_OK(arena_malloc((void **)&c->arena2.rowx, need_rows));
         c->arena2_rows_bytes = need_rows;
     }
     c->arena2.cells_per_slot = cells;
@@ -869,9 +901,10 @@ static int finish_run(fa_batch *b, bool grace);
 static int flush_pending_back(fa_ctx *c, fa_batch *only = nullptr, hipEvent_t after = nullptr);
 
 // Front stages of a run (seed index, chaining, alignment, MSA plan, tags, links) on the
-// context's front stream -- this call returns when they are done -- then k_score and
-// k_backtrace are queued on the back stream and the call returns without waiting for
-// them: the next batch's fa_batch_submit overlaps their latency-bound walk.
+// context's front stream.  The call waits for k_align (the MSA plan is sized from the
+// alignment summaries) and returns with k_tags / k_tscan / k_links only QUEUED; k_score and
+// k_backtrace are queued on a back stream by the next submit (or by this batch's own wait):
+// the next batch's fa_batch_submit overlaps their latency-bound walk.
 extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double min_idt) {
     if (!b || b->pair_mode) {
         set_err("falcon_amd: fa_batch_submit on an invalid batch");
@@ -896,6 +929,7 @@ extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double
     std::lock_guard<std::mutex> front(c->front_mu);  // one batch at a time on the front stream
     pt.mark("front-lock");
     hipStream_t s = c->stream;
+    b->front_launched = true;
     b->fetched = b->fetched_eqv = false;
     b->have_range = b->have_aln = false;
     const double max_diff = 1.0 - min_idt;  // falcon.c:580
@@ -1017,9 +1051,12 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
         std::vector<int> redo;
         for (int g = 0; g < b->n_seq; g++)
             if (b->h_aln[g].err == 2) redo.push_back(g);
-        if (band + 1 > 64 * FA_ALIGN_MAXCH - 1 || ensure_arena2(c, b, (int)redo.size()) ||
-            b->d_redo.alloc(redo.size()))
+        if (band + 1 > 64 * FA_ALIGN_MAXCH - 1) {
+            // (k_align_wide runs in worst-case slots from the start: not expected)
+            set_err("falcon_amd: %zu alignments overflowed their work slots at band %d", redo.size(), band);
             return -1;
+        }
+        if (ensure_arena2(c, b, (int)redo.size()) || b->d_redo.alloc(redo.size())) return -1;
         HIP_OK(hipMemcpyAsync(b->d_redo.p, redo.data(), redo.size() * sizeof(int), hipMemcpyHostToDevice, s));
         fa_launch_align_list(d, c->arena2, b->max_read_len, b->max_seed_len, max_diff, band, b->d_redo.p,
                              (int)redo.size(), s);
@@ -1309,6 +1346,7 @@ extern "C" fa_batch *fa_utg_consensus(fa_ctx *ctx, int n_seq, const char *const 
     fa_ctx *c = ctx;
     if (hipSetDevice(c->device) != hipSuccess) return fail("hipSetDevice failed");
     hipStream_t s = c->stream;
+    b->front_launched = true;
     if (hipMemcpyAsync(b->d_range.p, rg, (size_t)b->n_seq * sizeof(FaRange), hipMemcpyHostToDevice, s) !=
         hipSuccess)
         return fail("range upload failed");
@@ -1317,6 +1355,9 @@ extern "C" fa_batch *fa_utg_consensus(fa_ctx *ctx, int n_seq, const char *const 
     if (b->ensure_events()) return fail("hipEventCreate failed");
     {
         std::lock_guard<std::mutex> front(c->front_mu);
+        b->front_launched = true;
+        // (a batch submitted on this context and not yet waited for keeps its back stage)
+        if (flush_pending_back(c)) return fail(nullptr);
         if (ensure_arena(c, b, fa_align_lds_bytes(b->max_read_len, b->max_seed_len), true)) return fail(nullptr);
         for (int i = 0; i < 3; i++) (void)hipEventRecord(b->ev[i], s);
         if (run_from_ranges(b, 0, 1.0 - min_idt, band, 1)) return fail(nullptr);
@@ -1558,6 +1599,7 @@ extern "C" int fa_align_pairs(fa_ctx *ctx, int n, const char *const *q, const in
         fa_batch_free(b);
         return code;
     };
+    b->front_launched = true;
     if (hipMemcpyAsync(b->d_range.p, rg.data(), rg.size() * sizeof(FaRange), hipMemcpyHostToDevice,
                        s) != hipSuccess) {
         set_err("falcon_amd: range upload failed");

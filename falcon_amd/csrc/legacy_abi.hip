@@ -298,71 +298,86 @@ extern "C" aln_range *find_best_aln_range(kmer_match *km, seq_coor_t K, seq_coor
     return r;
 }
 
+// find_best_aln_range2 (kmer_lookup.c:429-585), host form of what k_trimwin.hip does per read
+// on the device, in the same four steps:
+//   1. fold over the hits for max_q and the reference's `max_t` (which takes max_q when the
+//      running value already exceeds the hit's target position -- its typo at :458, kept);
+//   2. the diagonals q - t, sorted;
+//   3. the densest diagonal window of width delta = 0.05 (max_q + max_t): the reference's
+//      two-pointer sweep is monotone, so the window end of start s is a lower bound search
+//      for ds[s] + delta (capped at the last hit); the first start with the widest span wins;
+//   4. the hits inside that window, compacted in list order, chained: a hit's predecessor is
+//      the earlier in-window hit with the smallest x + y gap among those within 320 bases
+//      on both axes (looking back until the query distance exceeds 320; ties: the nearest
+//      one), score 64 - gap per link with a floor at 0; the best-scoring hit ends the range,
+//      its chain's head starts it.
 extern "C" aln_range *find_best_aln_range2(kmer_match *km, seq_coor_t K, seq_coor_t bin_width,
-                                           seq_coor_t count_th) {  // :429-585
+                                           seq_coor_t count_th) {
     (void)K; (void)bin_width; (void)count_th;  // unused by the reference as well
-    aln_range *r = (aln_range *)calloc(1, sizeof(aln_range));
+    aln_range *out = (aln_range *)calloc(1, sizeof(aln_range));
     const int n = km->count;
-    if (n <= 0) return r;
-    std::vector<int> ds((size_t)n);
+    if (n <= 0) return out;
+    const seq_coor_t *qp = km->query_pos, *tp = km->target_pos;
+    // 1 + 2
     int max_q = -1, max_t = -1;
+    std::vector<int> diag((size_t)n);
     for (int i = 0; i < n; i++) {
-        ds[i] = km->query_pos[i] - km->target_pos[i];
-        max_q = std::max(max_q, km->query_pos[i]);
-        max_t = (max_t > km->target_pos[i]) ? max_q : km->target_pos[i];  // sic, :458
+        max_q = std::max(max_q, (int)qp[i]);
+        max_t = (max_t > (int)tp[i]) ? max_q : (int)tp[i];
+        diag[i] = (int)qp[i] - (int)tp[i];
     }
-    std::sort(ds.begin(), ds.end());
+    std::sort(diag.begin(), diag.end());
     const int delta = (int)(long)(0.05 * (max_q + max_t));
-    int s = 0, e = 0, bs = -1, be = -1, span = -1;
-    for (;;) {
-        const int d_s = ds[s];
-        int d_e = ds[e];
-        while (d_e < d_s + delta && e < n - 1) d_e = ds[++e];
-        if (span == -1 || e - s > span) {
-            span = e - s;
-            bs = s;
-            be = e;
+    // 3
+    int win_s = 0, win_e = 0, widest = -1 - n;
+    for (int s = 0; s < n; s++) {
+        const int e = (int)std::min<ptrdiff_t>(
+            n - 1, std::lower_bound(diag.begin(), diag.end(), diag[s] + delta) - diag.begin());
+        if (s == 0 || e - s > widest) {
+            widest = e - s;
+            win_s = s;
+            win_e = e;
         }
-        if (++s == n || e == n) break;
     }
-    if (bs == -1 || be == -1 || be - bs < 32) return r;
-    const int lo = ds[bs], hi = ds[be];
-    std::vector<int> prev((size_t)n, -1), score((size_t)n, 0), links((size_t)n, 0);
-    int top = -1, top_score = 0, top_links = 0;
+    if (win_e - win_s < 32) return out;
+    const int d_lo = diag[win_s], d_hi = diag[win_e];
+    // 4
+    struct Hit { int x, y, head, score, links; };
+    std::vector<Hit> hit;
+    hit.reserve((size_t)n);
+    int best = -1, best_score = 0;
     for (int i = 0; i < n; i++) {
-        const int cx = km->query_pos[i], cy = km->target_pos[i];
-        if (cx - cy < lo || cx - cy > hi) continue;
-        int cand = -1, gap = 65535;
-        for (int j = i - 1; j >= 0; j--) {
-            const int px = km->query_pos[j], py = km->target_pos[j];
-            if (px - py < lo || px - py > hi) continue;
-            if (cx - px > 320) break;
-            if (cy > py && cx - px + cy - py < gap && cy - py <= 320) {
-                gap = cx - px + cy - py;
-                cand = j;
+        const int x = qp[i], y = tp[i];
+        if (x - y < d_lo || x - y > d_hi) continue;
+        Hit h = {x, y, (int)hit.size(), 0, 0};
+        int from = -1, gap = 65535;
+        for (int j = (int)hit.size() - 1; j >= 0 && x - hit[j].x <= 320; j--) {
+            const int dy = y - hit[j].y, g = x - hit[j].x + dy;
+            if (dy > 0 && dy <= 320 && g < gap) {
+                gap = g;
+                from = j;
             }
         }
-        if (cand != -1) {
-            prev[i] = cand;
-            score[i] = score[cand] + (64 - gap);
-            links[i] = links[cand] + 1;
-            if (score[i] < 0) score[i] = links[i] = 0;
+        if (from >= 0) {
+            h.head = hit[from].head;
+            h.score = hit[from].score + 64 - gap;
+            h.links = hit[from].links + 1;
+            // (a chain whose score falls below 0 keeps its head but starts counting afresh)
+            if (h.score < 0) h.score = h.links = 0;
         }
-        if (score[i] > top_score) {
-            top_score = score[i];
-            top_links = links[i];
-            top = i;
+        hit.push_back(h);
+        if (h.score > best_score) {
+            best_score = h.score;
+            best = (int)hit.size() - 1;
         }
     }
-    if (top == -1) return r;
-    r->score = top_links + 1;
-    r->e1 = km->query_pos[top];
-    r->e2 = km->target_pos[top];
-    int i = top;
-    while (prev[i] != -1) i = prev[i];
-    r->s1 = km->query_pos[i];
-    r->s2 = km->target_pos[i];
-    return r;
+    if (best < 0) return out;
+    out->score = hit[best].links + 1;
+    out->s1 = hit[hit[best].head].x;
+    out->s2 = hit[hit[best].head].y;
+    out->e1 = hit[best].x;
+    out->e2 = hit[best].y;
+    return out;
 }
 
 extern "C" void free_aln_range(aln_range *r) { free(r); }

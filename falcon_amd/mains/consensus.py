@@ -360,11 +360,15 @@ def fasta_records(seed_id, cns, output_full, output_multi):
 FAILED_PILES = []
 
 
-def note_failed_piles(ids, cns_all):
+def note_failed_piles(ids, cns_all, failed_piles=None):
+    """``failed_piles``: the list the seeds go to (one per stream in the multi-stream worker);
+    default: the process-wide one ``main`` looks at."""
+    if failed_piles is None:
+        failed_piles = FAILED_PILES
     for sid, cns in zip(ids, cns_all):
         reason = getattr(cns, "reason", None)
         if reason is not None:
-            FAILED_PILES.append(sid)
+            failed_piles.append(sid)
             LOG.error("seed %s is not corrected: %s", sid, reason)
 
 
@@ -387,8 +391,9 @@ def _stream_fd(stream):
 NATIVE_BATCH_BASES = 400_000_000
 
 
-def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
-    """The worker's pipeline, records leaving in input order:
+def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None):
+    """The worker's pipeline, records leaving in input order (``failed_piles``: where the
+    seeds of piles that failed alone are collected, default the process-wide list):
 
       ingest thread    native reader -> the next batch (``batch_bases`` bases) of the stream
       staging thread   that batch onto the device with the least work queued (``gpu.stage``),
@@ -511,14 +516,14 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None):
                     if native_fasta:
                         text, bad = res
                         for p, reason in bad:
-                            FAILED_PILES.append(ids[p])
+                            (FAILED_PILES if failed_piles is None else failed_piles).append(ids[p])
                             LOG.error("seed %s is not corrected: %s", ids[p], reason)
                         write_bytes(text)
                         LOG.debug("t=%.3f printer: %d piles in %.3f s", _clock(), len(ids),
                                   time.perf_counter() - t0)
                         continue
                     cns_all = res
-                    note_failed_piles(ids, cns_all)
+                    note_failed_piles(ids, cns_all, failed_piles)
                     stdout.write("".join(fasta_records(sid, cns, args.output_full, args.output_multi)
                                          for sid, cns in zip(ids, cns_all)))
                     LOG.debug("t=%.3f printer: %d piles in %.3f s", _clock(), len(ids),

@@ -88,12 +88,19 @@ def run_job(args, cfg, pool, backend, src, out_path):
     """One job: stream in, FASTA out (``<out>.tmp`` renamed on completion)."""
     fd, close = _open_source(src)
     tmp = out_path + ".tmp"
+    not_corrected = []  # this job's piles that failed alone (named on stderr by the worker)
     try:
         try:
             with open(tmp, "w") as out:
-                single._run_native(args, cfg, fd, SharedGpu(pool, backend), out)
+                single._run_native(args, cfg, fd, SharedGpu(pool, backend), out,
+                                   failed_piles=not_corrected)
         finally:
             close()  # (a producer that failed fails the job)
+        # A FASTA that lacks reads the reference would have corrected is not a complete
+        # output: the job fails like the single-stream worker exits 3 (same opt-out).
+        if not_corrected and not os.environ.get("FALCON_AMD_SKIP_FAILED_PILES"):
+            raise RuntimeError("%d pile(s) were not corrected: %s" % (
+                len(not_corrected), ", ".join(not_corrected[:8]) + (" ..." if len(not_corrected) > 8 else "")))
     except BaseException:
         if os.path.exists(tmp):
             os.unlink(tmp)

@@ -106,3 +106,38 @@ def test_no_asm_block_names_vcc():
                 elif inside and "vcc" in line:
                     bad.append("%s:%d: %s" % (os.path.basename(out), n, line.strip()))
     assert not bad, bad
+
+
+def test_legacy_window_functions_vs_reference_random(lib, ref):
+    """find_best_aln_range / find_best_aln_range2 of the product library (host code written in
+    this repo's own formulation: sorted diagonals, per-start lower-bound search, compacted
+    in-window hits) against the compiled reference on random hit lists -- real k-mer hits of
+    noisy sequence pairs, masked and unmasked, and synthetic lists with ties and gaps."""
+    import numpy as np
+    from falcon_amd.synth import codes_to_str, noisy
+    from oracle.pyoracle import LegacyABI
+    impl = LegacyABI(SO)
+    rng = np.random.default_rng(77)
+    n_checked = 0
+    for it in range(40):
+        n = int(rng.integers(200, 4000))
+        g = rng.integers(0, 4, n, dtype=np.uint8)
+        if it % 5 == 0:  # low complexity: monster buckets, many ties
+            g = np.tile(g[: int(rng.integers(3, 40))], n)[:n]
+        e = float(rng.choice([0.0, 0.03, 0.1, 0.2]))
+        q, t = codes_to_str(noisy(g, rng, e)), codes_to_str(noisy(g, rng, e))
+        for mask in (-1, 16):
+            h = ref.find_hits(t, q, mask=mask)
+            assert impl.find_hits(t, q, mask=mask) == h
+            if not h[0]:
+                continue
+            assert impl.best_range2(*h) == ref.best_range2(*h), (it, mask)
+            assert impl.best_range(*h) == ref.best_range(*h), (it, mask)
+            n_checked += 1
+    for it in range(200):  # synthetic hit lists (query positions ascending as the table emits them)
+        n = int(rng.integers(1, 400))
+        qp = np.sort(rng.integers(0, int(rng.integers(50, 5000)), n)).tolist()
+        tp = (np.array(qp) + rng.integers(-int(rng.integers(1, 600)), 600, n)).clip(0).tolist()
+        assert impl.best_range2(qp, tp) == ref.best_range2(qp, tp), it
+        n_checked += 1
+    assert n_checked > 200

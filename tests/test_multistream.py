@@ -272,3 +272,47 @@ def test_multi_stream_worker_on_the_gpu(tmp_path):
         single.run(single.parse_args(["prog"] + opts), stdin=open(path), stdout=out)
         got = (tmp_path / ("cns_%d.fasta" % j)).read_text()
         assert got == out.getvalue() and got.count(">") >= 3
+
+
+def test_a_job_with_an_uncorrected_pile_fails_alone(tmp_path, monkeypatch):
+    """Piles fail alone (fa_batch_pile_error); the multi-stream worker must not deliver a
+    FASTA that silently lacks them: that job is reported failed and leaves no output file,
+    the other jobs are untouched, FALCON_AMD_SKIP_FAILED_PILES=1 accepts the gap (the
+    single-stream worker's exit status 3 and its opt-out)."""
+    from falcon_amd.engine import FailedPile
+    monkeypatch.setenv("FALCON_AMD_BATCH_BASES", "900")
+    rng = random.Random(5)
+    texts = [_rand_stream(rng, 12, with_noise=False) for _ in range(3)]
+    marker = texts[1].split("\n")[0].split()[0]  # first seed of job 1: the pile that "fails"
+
+    class Backend(FakeBackend):
+        def stage(self, engine, ps):
+            with self.lock:
+                self.staged += 1
+            return (engine, ps.piles(), list(ps.seed_ids))
+
+        def submit(self, batch):
+            pass
+
+        def collect(self, batch):
+            engine, piles, ids = batch
+            return [FailedPile("too deep") if i == marker else (p[0] * 20)[:600] for i, p in zip(ids, piles)]
+
+    def go():
+        argv = ["prog"] + OPTS
+        for i, text in enumerate(texts):
+            path = tmp_path / ("in_%d.txt" % i)
+            path.write_text(text)
+            argv += ["--job", str(path), str(tmp_path / ("out_%d.fasta" % i))]
+        args = multi.parse_args(argv)
+        return multi.run(args, pool=multi.DevicePool([FakeEngine()]), backend=Backend())
+
+    res = go()
+    assert res[0][2] is None and res[2][2] is None
+    assert isinstance(res[1][2], RuntimeError) and marker in str(res[1][2])
+    assert (tmp_path / "out_0.fasta").exists() and (tmp_path / "out_2.fasta").exists()
+    assert not (tmp_path / "out_1.fasta").exists() and not (tmp_path / "out_1.fasta.tmp").exists()
+    monkeypatch.setenv("FALCON_AMD_SKIP_FAILED_PILES", "1")
+    res = go()
+    assert [r[2] for r in res] == [None] * 3
+    assert marker not in (tmp_path / "out_1.fasta").read_text()
