@@ -22,54 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef uint32_t u32;
-typedef uint64_t u64;
-typedef uint16_t u16;
-
-#define FA_K 8                 // k-mer size (consensus.py:270 hard-wires 8)
-#define FA_NKMER 65536         // 4^8
-#define FA_IDX_STRIDE 65540    // u32 per pile for the CSR table (65537 used, padded)
-#define FA_BAND 150            // falcon.c:624 INDEL_ALLOWENCE_2
-#define FA_ALIGN_MAXCH 3       // 64-lane chunks per band row (<= 191 diagonals)
-#define FA_CNS_MAX_ALN 1023    // accepted alignments per pile the MSA kernels handle (10-bit link counts,
-                               // 16 lane chunks in k_links); a deeper pile is reported, alone
-
-struct FaSeq {
-    u32 woff;   // offset into words[]
-    int len;    // bases
-    int pile;   // pile id
-    int idx;    // index in pile, 0 = seed
-};
-
-struct FaPile {
-    int first;      // global index of the seed
-    int n_seq;
-    int seed_len;
-    int pad0;
-    u64 kidx_off;   // u32 offset of this pile's CSR table
-    u64 kpos_off;   // u32 offset of this pile's position list
-    u64 node_off;   // node offset in nodes[] (set after the alignment stage)
-    u64 node_cap;   // nodes available (multiple of 5)
-    u64 out_off;    // char/int offset into out_seq / out_eqv (2*T+2 slots)
-};
-
-struct FaRange {
-    int s1, e1, s2, e2;
-    int ok;         // 1 = passed the falcon.c:613-619 sanity filter
-    int n_hit;      // diagnostic: k-mer hits
-    long long score;
-};
-
-struct FaAln {
-    int dist;
-    int q_e, t_e;
-    int size;       // alignment columns (aln_str_size)
-    int accept;     // falcon.c:629 verdict
-    int n_ins;      // query-only edit rows (bounds the number of MSA levels)
-    int aligned;    // 1 = the O(ND) search reached a sequence end
-    int err;        // 1 = resource overflow (must not happen; checked on host)
-    long long cells;// (d,k) cells evaluated
-};
+#include "fa_types.h"
 
 struct FaRowRec {   // one per edit row d of an alignment in flight (16 B)
     u32 off;        // first cell of the row in the slot's cell arena
@@ -158,6 +111,24 @@ struct FaAlignArena {
     int *counter;      // work-queue head
     u64 *prof;         // 8 debug counters (FA_ALIGN_PROF builds)
 };
+
+// k_align2.hip: two alignments per wavefront over an iteration tape (one-byte cells)
+struct FaAlign2Arena {
+    u32 *mem;          // n_slot * slot_words
+    u64 slot_words;    // fa_align2_slot_words(ring)
+    u32 ring;          // tape iterations per slot (a power of two)
+    int n_slot;
+    int *counter;      // work-queue head
+    unsigned long long *stats;  // 8 counters (optional): pair / single iterations, placements, parkings, hand-backs, -, wide episodes, alignments
+};
+u64 fa_align2_slot_words(u32 ring);
+u32 fa_align2_ring_for(int max_rows);
+size_t fa_align2_lds_bytes();
+int fa_align2_blocks_per_cu();
+// alignments whose band tolerance is >= 64 and whose packed words fit 2^32 bases; what it
+// cannot hold on its tape comes back with FaAln.err = 2 (repeat with fa_launch_align_list)
+void fa_launch_align2(const FaBatchDev &b, const FaAlign2Arena &a, double max_diff, int band,
+                      const int *order, int n_work, hipStream_t s);
 
 // first_bad: device int, preset to INT_MAX; receives the lowest sequence index holding a byte
 // other than upper-case A, C, G, T

@@ -1,0 +1,160 @@
+// fa_wave.h -- the wave64 primitive layer k_align2_core.h is written against (gfx950).
+//
+// The core of k_align2 uses per-lane values (`vi` / `vu`), lane masks (u64) and the
+// cross-lane operations below, nothing else.  In the product they are plain registers and
+// single instructions.  tests/emu/ holds a twin of this header that implements the same
+// names on 64-element arrays, so that the kernel's control logic (two alignments per
+// wavefront, band placement, parking, the iteration tape, the trace-back) runs against the
+// CPU oracle in the `-m "not gpu"` suite; that twin is test infrastructure and is never
+// compiled into the library.
+#pragma once
+#include "fa_device.h"
+
+typedef int vi;    // one int per lane
+typedef u32 vu;    // one u32 per lane
+typedef bool vb;   // one predicate per lane (feed ONE comparison to w_ballot)
+
+#define W_FN __device__ __forceinline__
+#define W_NOINLINE __device__ __noinline__
+// the lanes of mask `m` execute the block (the others keep their values)
+#define W_WHERE(m) if (__builtin_amdgcn_inverse_ballot_w64(m))
+
+W_FN vi w_lane() { return fa_lane(); }
+W_FN u64 w_ballot(vb p) { return fa_ballot(p); }
+// lane in m ? b : a
+// (the predicate straight from the scalar mask: v_cndmask on an SGPR pair, no v_cmp)
+W_FN vi w_sel(u64 m, vi a, vi b) { return __builtin_amdgcn_inverse_ballot_w64(m) ? b : a; }
+W_FN vu w_selu(u64 m, vu a, vu b) { return __builtin_amdgcn_inverse_ballot_w64(m) ? b : a; }
+// lane l takes the value of lane l - 1 (lane 0: 0) / of lane l + 1 (lane 63: 0)
+W_FN vi w_from_below(vi v) { return __builtin_amdgcn_mov_dpp(v, 0x138, 0xf, 0xf, true); }  // wave_shr:1
+W_FN vi w_from_above(vi v) { return __builtin_amdgcn_mov_dpp(v, 0x130, 0xf, 0xf, true); }  // wave_shl:1
+// wave-uniform value of lane l (l wave-uniform)
+W_FN int w_readlane(vi v, int l) { return __builtin_amdgcn_readlane(v, l); }
+W_FN u32 w_readlaneu(vu v, int l) { return (u32)__builtin_amdgcn_readlane((int)v, l); }
+// two registers, one lane select (M0 written once)
+W_FN void w_writelane2(vu &a, vu &b, u32 sa, u32 sb, int l) {
+    asm volatile("s_mov_b32 m0, %4\n\t"
+                 "v_writelane_b32 %0, %2, m0\n\t"
+                 "v_writelane_b32 %1, %3, m0"
+                 : "+v"(a), "+v"(b)
+                 : "s"(sa), "s"(sb), "s"(l));
+}
+// lane l takes v of lane src (per-lane src, 0..63)
+W_FN vi w_gather_lanes(vi v, vi src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
+W_FN int w_uni(int v) { return fa_uni(v); }
+W_FN u32 w_uniu(u32 v) { return fa_uni(v); }
+
+// inclusive prefix maximum over the lanes, unsigned: 4 in-row DPP steps, then the two row
+// broadcasts (lanes without a source keep their value)
+W_FN vu w_prefix_max(vu v) {
+    asm volatile("s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(v));
+    return v;
+}
+
+W_FN vi w_min(vi a, vi b) { return min(a, b); }
+W_FN vi w_max(vi a, vi b) { return max(a, b); }
+W_FN vu w_minu(vu a, vu b) { return min(a, b); }
+// find-first-set as the hardware defines it: 0xffffffff for 0
+W_FN vu w_ffbl(vu x) { return ffbl_raw(x); }
+// (hi:lo) >> (sh & 31), low word
+W_FN vu w_alignbit(vu hi, vu lo, vu sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+// (x << 1) | (lane in m)
+W_FN vu w_twice_plus(vi x, u64 m) { return fa_twice_plus(x, m); }
+
+// scalar mask helpers
+W_FN u64 w_lanes(int lo, int n) { return fa_lane_range(lo, n); }       // n lanes from lo; 0 < n <= 63
+W_FN u64 w_bit_clr(u64 m, int b) {
+    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(b));
+    return m;
+}
+W_FN u64 w_bit_set(u64 m, int b) {
+    asm("s_bitset1_b64 %0, %1" : "+s"(m) : "s"(b));
+    return m;
+}
+W_FN int w_lowest(u64 m) { return __builtin_ctzll(m); }                 // m != 0
+W_FN int w_highest(u64 m) { return 63 - __builtin_clzll(m); }           // m != 0
+W_FN int w_popc(u64 m) { return __builtin_popcountll(m); }
+// per lane: the number of set bits of m below the lane
+W_FN vi w_rank_in(u64 m) {
+    return (vi)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+}
+// acc with byte J replaced by the low byte of m (v_perm_b32; the other bytes of m do not matter)
+template <int J>
+W_FN vu w_put_byte(vu acc, vu m) {
+    return __builtin_amdgcn_perm(m, acc, 0x03020100u + ((4u - (u32)J) << (8 * J)));
+}
+// a register whose content does not matter yet (no instruction)
+W_FN vu w_undef() {
+    vu v;
+    asm volatile("" : "=v"(v));
+    return v;
+}
+
+// ---- memory (global pointers are address space 1: SGPR base + VGPR offset forms) ----
+typedef u32 w_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u32 w_gu32;
+typedef __attribute__((address_space(1))) uint8_t w_gu8;
+typedef __attribute__((address_space(1))) w_u32x4 w_gu32x4;
+typedef __attribute__((address_space(1))) u64 w_gu64;
+
+// words base[i], base[i + 1] (i per lane)
+W_FN void w_load_pair(const u32 *base, vu i, vu &lo, vu &hi) {
+    const w_gu32 *p = (const w_gu32 *)base;
+    lo = p[i];
+    hi = p[i + 1u];
+}
+W_FN vu w_load32(const u32 *base, vu i) { return ((const w_gu32 *)base)[i]; }
+W_FN void w_store32(u32 *base, vu i, vu v) { ((w_gu32 *)base)[i] = v; }
+W_FN vu w_load8(const uint8_t *base, vu i) { return (vu)((const w_gu8 *)base)[i]; }
+W_FN void w_store64(u64 *base, vu i, vu lo, vu hi) { ((w_gu64 *)base)[i] = ((u64)hi << 32) | lo; }
+W_FN void w_load64(const u64 *base, vu i, vu &lo, vu &hi) {
+    const u64 v = ((const w_gu64 *)base)[i];
+    lo = (vu)v;
+    hi = (vu)(v >> 32);
+}
+// 16-byte records
+W_FN void w_store_x4(u32 *base16, vu i, vu a, vu b, vu c, vu d) {
+    const w_u32x4 r = {a, b, c, d};
+    ((w_gu32x4 *)base16)[i] = r;
+}
+W_FN void w_load_x4(const u32 *base16, vu i, vu &a, vu &b, vu &c, vu &d) {
+    const w_u32x4 r = ((const w_gu32x4 *)base16)[i];
+    a = r.x; b = r.y; c = r.z; d = r.w;
+}
+// the same value from every lane (results, counters)
+W_FN int w_atomic_add_lane0(int *p, int v) {
+    // (no `if (lane == 0)`: hipcc 7.2 jump-threads such blocks across loop back edges)
+    return w_uni(atomicAdd(p, fa_lane() == 0 ? v : 0));
+}
+W_FN void w_fence_block() { __threadfence_block(); }
+// an alignment summary, the same record from every lane
+W_FN void w_store_aln(FaAln *dst, const FaAln &r) {
+    static_assert(sizeof(FaAln) == 40, "layout");
+    typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(1))) u32x2 g_u32x2;
+    const w_u32x4 a = {(u32)r.dist, (u32)r.q_e, (u32)r.t_e, (u32)r.size};
+    const w_u32x4 b = {(u32)r.accept, (u32)r.n_ins, (u32)r.aligned, (u32)r.err};
+    const u32x2 c = {(u32)(u64)r.cells, (u32)((u64)r.cells >> 32)};
+    ((w_gu32x4 *)dst)[0] = a;
+    ((w_gu32x4 *)dst)[1] = b;
+    ((g_u32x2 *)dst)[4] = c;
+}
+W_FN void w_stat_add(unsigned long long *p, unsigned long long v) {
+    if (p) atomicAdd(p, fa_lane() == 0 ? v : 0ull);
+}
+
+// LDS words of the wavefront (the kernel's dynamic __shared__ array)
+W_FN u32 *w_lds() {
+    extern __shared__ __attribute__((aligned(16))) u32 smem[];
+    return smem;
+}
+W_FN void w_lds_store(u32 *l, vu i, vu v) { l[i] = v; }
+W_FN vu w_lds_bcast(const u32 *l, int i) { return l[i]; }   // every lane reads word i
+W_FN vu w_lds_load(const u32 *l, vu i) { return l[i]; }          // per-lane word

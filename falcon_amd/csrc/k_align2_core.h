@@ -1,0 +1,977 @@
+// k_align2_core.h -- banded O(ND) alignment with trace-back, TWO alignments per wavefront.
+//
+// Restates align() of the reference (src/c/DW_banded.c:115-330) like k_align.hip does; what
+// is different is how the work sits on the machine.  A band row of the falcon_sense
+// workload holds ~27 diagonals, so one alignment per wavefront leaves 37 of 64 lanes (and
+// the same share of every instruction issued) idle.  Here a wavefront carries two
+// alignments ("tracks"): track 0 in the low lanes, track 1 in the high lanes, the boundary
+// (`split`) movable.  One instruction stream advances both by one row per iteration; all
+// lane sets are 64-bit scalar masks that simply hold both tracks' bits.
+//
+//   lanes      lane l of a track holds diagonal Kc + 2 l of the row it computed last.  Rows
+//              alternate between two phases so that a band does not climb the lanes: an
+//              even iteration computes diagonals Kc - 1 + 2 l (V[k-1] comes from lane l - 1,
+//              V[k+1] is the lane's own value), an odd one Kc + 1 + 2 l (V[k-1] own,
+//              V[k+1] from lane l + 1).  A band only moves when the alignment's diagonal
+//              drifts; when a band reaches the edge of its share of the wave, or the two
+//              bands no longer fit together, the wave re-places them (`a2_place`) -- or
+//              parks the narrower track (its last row waits in a spare register) and runs
+//              the wider one alone until they fit again.
+//   tape       the wavefront writes ONE record per iteration, shared by both tracks, into a
+//              ring in its arena slot: 64 one-byte cells (the snake length of each lane's
+//              cell, 255 = "look it up in the escape list"), the 64 from_above bits, and per
+//              track the diagonal of lane 0 (or "took no part").  4 bytes per DP cell
+//              became 1: the trace-back never needed x, only the snake length and the
+//              direction of the cells on the path (the edit script IS that list).
+//   trace      (DW_banded.c:264-319) walks a track's iterations backwards, 64 at a time:
+//              the diagonal chain is resolved from the from_above bits, then all 64 rows
+//              fetch their cell byte in parallel and emit `(snake << 1) | from_above`.
+//
+// Anything outside the common case -- a band wider than 60 diagonals, an alignment too
+// long for the tape ring, too many snakes of >= 255 bases -- is handed back (FaAln.err = 2)
+// and repeated by the general one-alignment-per-wavefront kernel (k_align.hip) in a
+// worst-case slot, the same way alignments that outgrew their slot always were.
+//
+// Written against fa_wave.h only (per-lane values, masks, cross-lane primitives), so that
+// tests/emu can run this very source on 64-element arrays against the CPU oracle.
+#pragma once
+#ifndef W_FN
+#error "include fa_wave.h (the product's, or the lane emulator's twin under tests/emu) before k_align2_core.h"
+#endif
+
+#define A2_INVALID 0x80000000u  // tape record: the track computed no row in this iteration
+#define A2_CONT 0x80000001u     // ... or: cells 64.. of the row the iteration before began (wide rows)
+#define A2_WIDE_RING 256        // LDS ring of a wide row's V values, per row parity (<= 191 live diagonals)
+#define A2_LDS_WORDS (256 + 2 * A2_WIDE_RING)  // trace-back staging + the two rings
+#ifndef A2_FREE_MIN
+#define A2_FREE_MIN 8           // free lanes two running tracks need to stay paired
+#endif
+#ifndef A2_FREE_JOIN
+#define A2_FREE_JOIN 14         // ... and to (re)join a parked or a new track
+#endif
+#define A2_MAX_N 60             // widest band a track may have (alone in the wave)
+#ifndef A2_LOOK_EVERY
+#define A2_LOOK_EVERY 32        // iterations a track runs alone before the wave checks whether its parked neighbour fits again
+#endif
+#define A2_ESC_CAP 1024         // escape entries per slot (snakes of >= 255 bases)
+#define A2_WIDE_PATIENCE 128    // wide rows a track may take while its neighbour waits
+
+struct A2Args {
+    const u32 *words;
+    const FaSeq *seq;
+    const FaPile *pile;
+    const FaRange *range;
+    const int *order;
+    int n_work;
+    int *counter;
+    u32 *cells;        // per slot: ring x 64 bytes, as words: ((it >> 2) & (ring/4 - 1)) * 64 + lane
+    u32 *recs;         // per slot: ring x 16 bytes {mask lo, mask hi, K track 0, K track 1}
+    u64 *esc;          // per slot: A2_ESC_CAP entries {(it << 6 | lane), snake length}
+    u64 slot_words;    // u32 words between two slots' cells
+    u32 ring;          // iterations per slot, a power of two >= 256
+    u32 *script;
+    const u64 *script_off;
+    FaAln *aln;
+    int band;
+    double max_diff;
+    unsigned long long *stats;  // 8 counters (see A2_STAT_*)
+};
+enum { A2_STAT_PAIR_IT = 0, A2_STAT_SINGLE_IT, A2_STAT_PLACE, A2_STAT_PARK, A2_STAT_BAIL,
+       A2_STAT_ESC, A2_STAT_EXT, A2_STAT_TRACKS };
+
+enum { A2_IDLE = 0, A2_RUN = 1, A2_PARKED = 2 };
+
+struct A2Track {
+    int state;
+    int g;              // sequence index
+    int q_len, t_len;
+    int max_d;
+    int d;              // rows computed
+    int kc;             // diagonal of lane 0 of the last computed row (in v_x or v_park)
+    int li, hin;        // lanes of the band hull of the last computed row (what passed the band filter)
+    int best;           // best x + y so far (DW_banded.c best_m); -1 before row 0
+    u32 it0;            // tape iteration of row 0
+    u32 cells;          // DP cells evaluated
+    u32 qb, tb;         // base index (into words[], 16 per word) of the two windows' first bases
+    u32 script_lo, script_hi;  // word offset of its script
+};
+
+// ---------------------------------------------------------------------------------------
+// the snake past its first 16 bases (rare: ~2 % of the rows): out of line, so that its
+// loop and registers stay out of the row loop
+// ---------------------------------------------------------------------------------------
+struct A2Snake { vi x, y; vu m; };
+
+template <class DUMMY>
+W_NOINLINE A2Snake a2_snake_more(const u32 *words, vu vqb, vu vtb, vi vqlen, vi vtlen, vi x, vi y, vu m) {
+    vu last = m;
+    for (;;) {
+        const u64 go = w_ballot(last == 16u);
+        if (!go) break;
+        W_WHERE(go) {
+            const vu qa = vqb + (vu)x, ta = vtb + (vu)y;
+            vu qlo, qhi, tlo, thi;
+            w_load_pair(words, qa >> 4, qlo, qhi);
+            w_load_pair(words, ta >> 4, tlo, thi);
+            const vu qw = w_alignbit(qhi, qlo, qa << 1), tw = w_alignbit(thi, tlo, ta << 1);
+            const vu lim = (vu)w_min(vqlen - x, vtlen - y);
+            const vu s = w_minu(w_minu(w_ffbl(qw ^ tw) >> 1, lim), 16u);
+            x = x + (vi)s;
+            y = y + (vi)s;
+            m = m + s;
+            last = s;
+        }
+    }
+    A2Snake r;
+    r.x = x; r.y = y; r.m = m;
+    return r;
+}
+
+// snakes of >= 255 bases do not fit the cell byte: (iteration, lane, length) of the lanes
+// `big` go to the slot's escape list; returns the new entry count (A2_ESC_CAP + 1: the list
+// is full).  Called outside any W_WHERE: a wave-uniform value assigned under a lane mask
+// would count as divergent from there on.
+template <class DUMMY>
+W_NOINLINE int a2_escape(u64 *esc, int n_esc, u32 it, vu m, u32 big_lo, u32 big_hi) {
+    const u64 big = ((u64)w_uniu(big_hi) << 32) | w_uniu(big_lo);
+    n_esc = w_uni(n_esc);
+    it = w_uniu(it);
+    const int n_new = w_popc(big);
+    if (n_esc + n_new > A2_ESC_CAP) return A2_ESC_CAP + 1;
+    const vi lane = w_lane();
+    const vu rank = (vu)w_rank_in(big);  // among the escaping lanes
+    W_WHERE(big) { w_store64(esc, (vu)n_esc + rank, m, (vu)(it << 6) | (vu)lane); }
+    return n_esc + n_new;
+}
+
+// ---------------------------------------------------------------------------------------
+// one band row of up to two tracks.  P: phase (iteration parity), J: byte of the cell word
+// ---------------------------------------------------------------------------------------
+// (Per-lane and wave-uniform state live in SEPARATE structs, here and for the wavefront's
+// state below: SROA merges neighbouring fields of one struct into vector values, and a
+// vector with one per-lane element makes every scalar in it count as divergent -- the whole
+// row loop then lands on the vector unit.)
+struct A2HotV {   // per lane
+    vi vx;            // x of the last computed row (lane l: diagonal Kc + 2 l)
+    vi vnegk;         // -(diagonal the lane computes in an even iteration)
+    vu vqb, vtb;      // window starts
+    vi vqlen, vtlen;
+    vu vtop;          // 0x80000000 in track 1's lanes (PAIR), else 0
+    vu vacc;          // the cell bytes of up to 4 iterations
+    vu rc_mlo, rc_mhi;  // ring of the last <= 64 iterations' from_above masks (lane = it & 63)
+};
+struct A2Hot {    // wave-uniform
+    u64 act;          // lanes holding a cell in the next row
+    int lo0, hi0, lo1, hi1;  // the two bands of the next row
+    int best0, best1; // best_m per track (track 1's carries the key's top bit)
+    u32 cells0, cells1;
+    int split;        // PAIR: first lane of track 1
+    u64 zone1;        // PAIR: lanes >= split
+    u64 forbid_to0, forbid_to1;  // lanes the band hull may not reach before an even / odd row
+    u64 fin;          // lanes whose cell reached an end of a sequence (this row)
+    u64 ev;           // fin | hull on a forbidden lane
+    u64 act_row;      // the lanes of the row that raised `ev`
+    u32 it;
+    int n_esc;
+    u32 kb0, kb1;     // what the tape records say about the two tracks (lane-0 diagonal | A2_INVALID)
+};
+
+// Returns the lanes that held a cell in this row.
+template <int P, int J, bool PAIR>
+W_FN u64 a2_row(A2Hot &h, A2HotV &hv, const u32 *words, u64 *esc, int band) {
+    const u64 act = h.act;
+    // V[k-1] + 1 and V[k+1] of the previous row (DW_banded.c:190-196)
+    vi a1, b;
+    if (P == 0) {
+        a1 = w_from_below(hv.vx) + 1;
+        b = hv.vx;
+    } else {
+        a1 = hv.vx + 1;
+        b = w_from_above(hv.vx);
+    }
+    // from_above: k == min_k, or k != max_k and V[k-1] < V[k+1]
+    u64 fa = w_ballot(a1 <= b);
+    fa = w_bit_clr(fa, h.hi0);
+    if (PAIR) fa = w_bit_clr(fa, h.hi1);
+    fa = w_bit_set(fa, h.lo0);
+    if (PAIR) fa = w_bit_set(fa, h.lo1);
+    fa &= act;
+    h.cells0 += (u32)(h.hi0 - h.lo0 + 1);
+    if (PAIR) h.cells1 += (u32)(h.hi1 - h.lo1 + 1);
+    vi x = w_sel(fa, a1, b);
+    vi y = (P == 0) ? x + hv.vnegk : x + hv.vnegk - 1;
+    vu m = w_undef();  // (idle lanes: whatever -- their cell bytes are never read)
+    W_WHERE(act) {
+        // the snake (:203-206), 16 bases per step on 2-bit packed words
+        const vu qa = hv.vqb + (vu)x, ta = hv.vtb + (vu)y;
+        vu qlo, qhi, tlo, thi;
+        w_load_pair(words, qa >> 4, qlo, qhi);
+        w_load_pair(words, ta >> 4, tlo, thi);
+        const vu qw = w_alignbit(qhi, qlo, qa << 1), tw = w_alignbit(thi, tlo, ta << 1);
+        const vu lim = (vu)w_min(hv.vqlen - x, hv.vtlen - y);
+        m = w_minu(w_minu(w_ffbl(qw ^ tw) >> 1, lim), 16u);
+        x = x + (vi)m;
+        y = y + (vi)m;
+        if (w_ballot(m == 16u)) {
+            const A2Snake r = a2_snake_more<void>(words, hv.vqb, hv.vtb, hv.vqlen, hv.vtlen, x, y, m);
+            x = r.x; y = r.y; m = r.m;
+        }
+    }
+    {
+        const u64 big = w_ballot(m >= 255u) & act;
+        if (big) {  // (a call's result arrives in a VGPR: w_uni)
+            h.n_esc = w_uni(a2_escape<void>(esc, h.n_esc, h.it, m, (u32)big, (u32)(big >> 32)));
+            m = w_minu(m, 255u);
+        }
+    }
+    // the cell byte: the snake length
+    hv.vacc = w_put_byte<J>(hv.vacc, m);
+    hv.vx = x;
+    const u64 fin = (w_ballot(x >= hv.vqlen) | w_ballot(y >= hv.vtlen)) & act;  // :220
+    w_writelane2(hv.rc_mlo, hv.rc_mhi, (u32)fa, (u32)(fa >> 32), (int)(h.it & 63u));
+    // band (:228-243): keep the hull of the cells with x + y >= best_m - band.  One prefix
+    // maximum serves both tracks: track 1's keys carry the top bit.
+    const vu key = w_selu(act, 0u, (vu)(x + y) + hv.vtop);
+    const vu pm = w_prefix_max(key);
+    u64 in;
+    if (PAIR) {
+        h.best0 = max(h.best0, (int)w_readlaneu(pm, h.split - 1));
+        h.best1 = (int)max((u32)h.best1, w_readlaneu(pm, 63));
+        const vu vbest = w_selu(h.zone1, (vu)h.best0, (vu)h.best1);
+        in = w_ballot(key + (vu)band >= vbest) & act;
+    } else {
+        h.best0 = max(h.best0, (int)w_readlaneu(pm, 63));
+        in = w_ballot(key + (vu)band >= (vu)h.best0) & act;
+    }
+    // the next row's bands: the hull, one diagonal wider on either side -- in lanes: one
+    // lane up before an even row, one lane down before an odd one
+    if (PAIR) {
+        const u64 in0 = in & ~h.zone1, in1 = in & h.zone1;
+        if (P == 0) {  // next: odd
+            h.lo0 = w_lowest(in0) - 1; h.hi0 = w_highest(in0);
+            h.lo1 = w_lowest(in1) - 1; h.hi1 = w_highest(in1);
+        } else {
+            h.lo0 = w_lowest(in0); h.hi0 = w_highest(in0) + 1;
+            h.lo1 = w_lowest(in1); h.hi1 = w_highest(in1) + 1;
+        }
+        h.act = w_lanes(h.lo0 & 63, h.hi0 - h.lo0 + 1) | w_lanes(h.lo1 & 63, h.hi1 - h.lo1 + 1);
+    } else {
+        if (P == 0) { h.lo0 = w_lowest(in) - 1; h.hi0 = w_highest(in); }
+        else        { h.lo0 = w_lowest(in); h.hi0 = w_highest(in) + 1; }
+        h.act = w_lanes(h.lo0 & 63, h.hi0 - h.lo0 + 1);
+    }
+    h.fin = fin;
+    h.ev = fin | (in & (P == 0 ? h.forbid_to1 : h.forbid_to0));
+    h.it++;
+    return act;
+}
+
+// ---------------------------------------------------------------------------------------
+// the wavefront's state between two runs of the row loop
+// ---------------------------------------------------------------------------------------
+struct A2Lanes {   // per lane
+    vi vx, vpark;
+    vu vacc, rc_mlo, rc_mhi, rc_k0, rc_k1;
+    vi vnegk, vqlen, vtlen;
+    vu vqb, vtb, vtop;
+};
+struct A2Wave {    // wave-uniform
+    A2Track T0, T1;
+    u32 it;            // the next tape iteration
+    int pair;          // the current placement runs both tracks
+    int split;
+    int n_esc;
+    bool more;         // the work queue may hold more
+    // the slot
+    u32 *cells, *recs;
+    u64 *esc;
+    // statistics of this wavefront
+    u32 st_pair, st_single, st_place, st_park, st_bail, st_tracks, st_wide, st_wide_rows;
+};
+
+W_FN void a2_result(const A2Args &A, int g, int err, int aligned, int dist, int q_e, int t_e, int n_ins,
+                    long long cells) {
+    FaAln r;
+    r.dist = dist; r.q_e = q_e; r.t_e = t_e;
+    r.size = aligned ? (q_e + t_e + dist) / 2 : 0;  // DW_banded.c:248
+    r.accept = (aligned && r.size > 500 && (double)r.dist / (double)r.size < A.max_diff) ? 1 : 0;  // falcon.c:629
+    r.n_ins = n_ins; r.aligned = aligned; r.err = err; r.cells = cells;
+    w_store_aln(A.aln + g, r);
+}
+
+// The next alignment of the work queue into `t` (state A2_RUN, no row computed yet); false
+// when the queue is empty.  Sequences that take no part (seeds, reads the window filter
+// dropped) get their empty summary here.
+W_FN bool a2_fetch(const A2Args &A, A2Track &t) {
+    for (;;) {
+        const int wi = w_atomic_add_lane0(A.counter, 1);
+        if (wi >= A.n_work) return false;
+        const int g = w_uni(A.order[wi]);
+        const int q_idx = w_uni(A.seq[g].idx);
+        const u32 q_woff = w_uniu(A.seq[g].woff);
+        const int pile_id = w_uni(A.seq[g].pile);
+        const int s1 = w_uni(A.range[g].s1), e1 = w_uni(A.range[g].e1);
+        const int s2 = w_uni(A.range[g].s2), e2 = w_uni(A.range[g].e2);
+        const int rg_ok = w_uni(A.range[g].ok);
+        if (q_idx == 0 || !rg_ok) {
+            a2_result(A, g, 0, 0, 0, 0, 0, 0, 0);
+            continue;
+        }
+        const int seed_g = w_uni(A.pile[pile_id].first);
+        const u32 t_woff = w_uniu(A.seq[seed_g].woff);
+        const int q_len = e1 - s1, t_len = e2 - s2;  // falcon.c:626-627
+        const int max_d = w_uni((int)(0.3 * (double)(q_len + t_len)));  // DW_banded.c:149
+        if (max_d <= 0) {  // no row is ever computed (:183)
+            a2_result(A, g, 0, 0, 0, 0, 0, 0, 0);
+            continue;
+        }
+        if ((u32)max_d + 192u > A.ring) {  // its rows would not fit the tape: the general kernel's
+            a2_result(A, g, 2, 0, 0, 0, 0, 0, 0);
+            continue;
+        }
+        t.state = A2_RUN;
+        t.g = g;
+        t.q_len = q_len; t.t_len = t_len;
+        t.max_d = max_d;
+        t.d = 0;
+        t.kc = 0; t.li = 0; t.hin = 0;
+        t.best = -1;
+        t.it0 = 0;
+        t.cells = 0;
+        t.qb = q_woff * 16u + (u32)s1;
+        t.tb = t_woff * 16u + (u32)s2;
+        const u64 so = A.script_off[g];
+        t.script_lo = w_uniu((u32)so);
+        t.script_hi = w_uniu((u32)(so >> 32));
+        return true;
+    }
+}
+
+// the band of a track's next row in its current lane coordinates, given the phase of the
+// next iteration (a track without rows: one cell, wherever it will be put)
+W_FN void a2_next_band(const A2Track &t, int p, int &lo, int &hi) {
+    if (t.d == 0) { lo = 0; hi = 0; return; }
+    if (p == 0) { lo = t.li; hi = t.hin + 1; }
+    else        { lo = t.li - 1; hi = t.hin; }
+}
+
+// Place the tracks in the wave for the iterations to come: both side by side when they fit
+// (with room to drift), else the wider one alone and the other parked.  Returns 0, or 1 + t
+// when track t cannot run even alone (the caller hands it back).
+W_FN int a2_place(A2Wave &w, A2Lanes &wl) {
+    const int p = (int)(w.it & 1u);
+    const bool have0 = w.T0.state != A2_IDLE, have1 = w.T1.state != A2_IDLE;
+    int lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+    if (have0) a2_next_band(w.T0, p, lo0, hi0);
+    if (have1) a2_next_band(w.T1, p, lo1, hi1);
+    const int n0 = hi0 - lo0 + 1, n1 = hi1 - lo1 + 1;
+#ifdef A2_HOOK_PLACE
+    A2_HOOK_PLACE(have0, n0, have1, n1);
+#endif
+    bool run0 = have0, run1 = have1;
+    if (have0 && have1) {
+        const int free_lanes = 64 - n0 - n1;
+        const bool paired_now = w.pair && w.T0.state == A2_RUN && w.T1.state == A2_RUN;
+        if (free_lanes < (paired_now ? A2_FREE_MIN : A2_FREE_JOIN)) {
+            if (n1 > n0) run0 = false; else run1 = false;   // the wider one goes on alone
+        }
+    }
+    if (run0 && !run1 && n0 > A2_MAX_N) return 1;
+    if (run1 && !run0 && n1 > A2_MAX_N) return 2;
+    const bool pair = run0 && run1;
+    int nl0 = 0, nl1 = 0, split;
+    if (pair) {
+        const int free_lanes = 64 - n0 - n1;
+        const int g0 = free_lanes / 4, mid = free_lanes / 2;
+        nl0 = g0;
+        nl1 = g0 + n0 + mid;
+        split = g0 + n0 + mid / 2;
+    } else if (run0) {
+        nl0 = (64 - n0) / 2;
+        split = 64;
+    } else {
+        nl1 = (64 - n1) / 2;
+        split = 0;
+    }
+    const vi lane = w_lane();
+    const u64 zone1 = split >= 64 ? 0ull : (split <= 0 ? ~0ull : (~0ull << split));
+    // the rows the tracks computed last, into their new lanes (a track without rows: zeros,
+    // the reference's calloc'ed V, DW_banded.c:153)
+    const int sh0 = lo0 - nl0, sh1 = lo1 - nl1;
+    vi nx = 0;
+    if (run0 && w.T0.d > 0) {
+        const vi src = w.T0.state == A2_PARKED ? wl.vpark : wl.vx;
+        nx = w_sel(zone1, w_gather_lanes(src, (lane + sh0) & 63), nx);
+    }
+    if (run1 && w.T1.d > 0) {
+        const vi src = w.T1.state == A2_PARKED ? wl.vpark : wl.vx;
+        nx = w_sel(zone1, nx, w_gather_lanes(src, (lane + sh1) & 63));
+    }
+    // a running track that stops here waits in vpark, in the lanes it has
+    if ((have0 && !run0 && w.T0.state == A2_RUN) || (have1 && !run1 && w.T1.state == A2_RUN)) {
+        wl.vpark = wl.vx;
+        w.st_park++;
+    }
+    wl.vx = nx;
+    if (run0) {
+        if (w.T0.d == 0) {  // its first row: one cell, diagonal 0, on lane nl0
+            w.T0.kc = -2 * nl0 - (p ? 1 : -1);
+            w.T0.it0 = w.it;
+        } else {
+            w.T0.kc += 2 * sh0;
+            w.T0.li -= sh0;
+            w.T0.hin -= sh0;
+        }
+        w.T0.state = A2_RUN;
+    } else if (have0) {
+        w.T0.state = A2_PARKED;
+    }
+    if (run1) {
+        if (w.T1.d == 0) {
+            w.T1.kc = -2 * nl1 - (p ? 1 : -1);
+            w.T1.it0 = w.it;
+        } else {
+            w.T1.kc += 2 * sh1;
+            w.T1.li -= sh1;
+            w.T1.hin -= sh1;
+        }
+        w.T1.state = A2_RUN;
+    } else if (have1) {
+        w.T1.state = A2_PARKED;
+    }
+    w.pair = pair ? 1 : 0;
+    w.split = split;
+    // per-lane constants of the lanes' track
+    const int kb0 = w.T0.kc + p, kb1 = w.T1.kc + p;  // lane-0 diagonal of an odd iteration's row
+    wl.vnegk = w_sel(zone1, -(kb0 - 1), -(kb1 - 1)) - 2 * lane;
+    wl.vqlen = w_sel(zone1, w.T0.q_len, w.T1.q_len);
+    wl.vtlen = w_sel(zone1, w.T0.t_len, w.T1.t_len);
+    wl.vqb = w_selu(zone1, w.T0.qb, w.T1.qb);
+    wl.vtb = w_selu(zone1, w.T0.tb, w.T1.tb);
+    wl.vtop = pair ? w_selu(zone1, 0u, 0x80000000u) : (vu)0u;
+    // the tape says from here on which tracks take part and where their lane 0 is
+    const u64 ahead = ~0ull << (w.it & 63u);
+    wl.rc_k0 = w_selu(ahead, wl.rc_k0, run0 ? (u32)kb0 : A2_INVALID);
+    wl.rc_k1 = w_selu(ahead, wl.rc_k1, run1 ? (u32)kb1 : A2_INVALID);
+    w.st_place++;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// trace-back of a finished track (DW_banded.c:264-319): its rows, newest first, 64 tape
+// iterations at a time.  TI: which of the two K fields of the tape records is the track's.
+// Returns the number of query-only rows (FaAln.n_ins).
+// ---------------------------------------------------------------------------------------
+template <int TI>
+W_FN int a2_trace(const A2Args &A, A2Wave &w, A2Lanes &wl, const A2Track &t, u32 it_f, int k_f, int fin_d) {
+    u32 *lds = w_lds();
+    const u32 ring_mask = A.ring - 1u, chunk_mask = (A.ring >> 2) - 1u;
+    u32 *script = A.script + (((u64)t.script_hi << 32) | t.script_lo);
+    const vi lane = w_lane();
+    vi kvv = k_f;       // the path's diagonal at the newest row not yet resolved (same in every lane)
+    int r_top = fin_d;  // its row
+    int n_ins = 0;
+    for (u32 ih = it_f;; ih -= 64u) {
+        const vu itj = ih - (vu)lane;  // lane j looks at iteration ih - j
+        const u64 have = w_ballot((vi)(itj - t.it0) >= 0);
+        vu ra = 0u, rb = 0u, rc = 0u, rd = 0u;
+        W_WHERE(have) { w_load_x4(w.recs, itj & ring_mask, ra, rb, rc, rd); }
+        const vu kb = TI ? rd : rc;
+        const u64 valid = have & w_ballot((vi)kb > (vi)A2_CONT);  // (neither A2_INVALID nor A2_CONT)
+        const vi kc = (vi)kb - 1 + (vi)(itj & 1u);  // lane-0 diagonal of that iteration's row
+        w_lds_store(lds, (vu)lane * 4u + 0u, (vu)kc);
+        w_lds_store(lds, (vu)lane * 4u + 1u, ra);
+        w_lds_store(lds, (vu)lane * 4u + 2u, rb);
+        w_lds_store(lds, (vu)lane * 4u + 3u, w_selu(valid, 0u, 0xffffffffu));
+        w_fence_block();
+        // the chain of diagonals through the block, one iteration after the other
+        vi my_lane = 0, my_dir = 0;
+        const int n_it = w_popc(have);  // (`have` is a run of lanes from 0)
+        for (int l = 0; l < n_it; l++) {
+            const vi kc_l = (vi)w_lds_bcast(lds, 4 * l + 0);
+            const vu mlo = w_lds_bcast(lds, 4 * l + 1), mhi = w_lds_bcast(lds, 4 * l + 2);
+            const vu vm = w_lds_bcast(lds, 4 * l + 3);
+            const vi j = (kvv - kc_l) >> 1;
+            vu word = w_selu(w_ballot(j >= 32), mlo, mhi);
+            if (w_ballot(j >= 64) & w_ballot(vm != 0u)) {
+                // a wide row: cells 64.. and their bits are in the iterations behind it
+                const vu at = ((ih - (u32)l) + ((vu)j >> 6)) & ring_mask;
+                vu xa, xb, xc, xd;
+                w_load_x4(w.recs, at, xa, xb, xc, xd);
+                word = w_selu(w_ballot((j & 63) >= 32), xa, xb);
+            }
+            const vi bit = (vi)((word >> ((vu)j & 31u)) & 1u);
+            const u64 me = 1ull << l;
+            my_lane = w_sel(me, my_lane, j);
+            my_dir = w_sel(me, my_dir, bit);
+            kvv = kvv + ((2 * bit - 1) & (vi)vm);  // from_above: pre_k = k + 1 (:190-196)
+        }
+        w_fence_block();
+        const vi r = r_top - w_rank_in(valid);
+        W_WHERE(valid) {
+            const vu itc = itj + ((vu)my_lane >> 6);  // (a wide row's cell 64 c + l: c iterations on)
+            const vu word = w_load32(w.cells, ((itc >> 2) & chunk_mask) * 64u + ((vu)my_lane & 63u));
+            vu m = (word >> ((itc & 3u) * 8u)) & 255u;
+            const u64 long_one = w_ballot(m == 255u);
+            if (long_one) {
+                const vu want = (itc << 6) | ((vu)my_lane & 63u);
+                for (int e = 0; e < w.n_esc; e++) {
+                    vu elo, ehi;
+                    w_load64(w.esc, (vu)e, elo, ehi);
+                    m = w_selu(w_ballot(ehi == want) & long_one, m, elo);
+                }
+            }
+            const vi dir = w_sel(w_ballot(r == 0), my_dir, 0);  // row 0 starts at (0, 0): no edit
+            w_store32(script, (vu)r, (m << 1) | (vu)dir);
+        }
+        n_ins += w_popc(valid & w_ballot(my_dir == 0) & w_ballot(r > 0));
+        r_top -= w_popc(valid);
+        if (r_top < 0 || (int)(ih - t.it0) < 64) break;
+    }
+    return n_ins;
+}
+
+// the records of the current (incomplete) block of 64 iterations, and the cell word of the
+// current (incomplete) group of 4, to the tape: a trace-back is about to read them
+W_FN void a2_flush_partial(const A2Args &A, A2Wave &w, A2Lanes &wl) {
+    const vi lane = w_lane();
+    const int n = (int)(w.it & 63u);
+    if (n > 0) {
+        W_WHERE(w_lanes(0, n)) {
+            w_store_x4(w.recs, (w.it - (u32)n + (vu)lane) & (A.ring - 1u), wl.rc_mlo, wl.rc_mhi, wl.rc_k0, wl.rc_k1);
+        }
+    }
+    if (w.it & 3u) w_store32(w.cells, ((w.it >> 2) & ((A.ring >> 2) - 1u)) * 64u + (vu)lane, wl.vacc);
+    w_fence_block();
+}
+
+// ---------------------------------------------------------------------------------------
+// the row loop: runs until a row finishes a track, a band hull reaches a forbidden lane,
+// or `budget` iterations are done
+// ---------------------------------------------------------------------------------------
+template <bool PAIR>
+W_FN void a2_after_row(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV &hv) {
+    // (h.it is the iteration after the row)
+    const vi lane = w_lane();
+    if ((h.it & 3u) == 0u)
+        w_store32(w.cells, (((h.it >> 2) - 1u) & ((A.ring >> 2) - 1u)) * 64u + (vu)lane, hv.vacc);
+    if ((h.it & 63u) == 0u) {
+        w_store_x4(w.recs, ((h.it - 64u) & (A.ring - 1u)) + (vu)lane, hv.rc_mlo, hv.rc_mhi, wl.rc_k0, wl.rc_k1);
+        wl.rc_k0 = h.kb0;
+        wl.rc_k1 = h.kb1;
+    }
+}
+
+template <bool PAIR>
+W_FN void a2_rows(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV &hv, int budget) {
+    const u32 it_end = h.it + (u32)budget;
+#define A2_ROW(P, J)                                                              \
+    {                                                                             \
+        const u64 lanes_ = a2_row<P, J, PAIR>(h, hv, A.words, w.esc, A.band);         \
+        if (h.ev) { h.act_row = lanes_; }                                         \
+    }
+    for (;;) {
+        if (h.ev || (int)(it_end - h.it) <= 0) break;
+        if ((h.it & 3u) == 0u && (int)(it_end - h.it) >= 4) {
+            // whole groups of four iterations
+            for (;;) {
+                A2_ROW(0, 0);
+                if (h.ev) break;
+                A2_ROW(1, 1);
+                if (h.ev) break;
+                A2_ROW(0, 2);
+                if (h.ev) break;
+                A2_ROW(1, 3);
+                a2_after_row<PAIR>(A, w, wl, h, hv);
+                if (h.ev || (int)(it_end - h.it) < 4) break;
+            }
+        } else {
+            switch (h.it & 3u) {
+                case 0: A2_ROW(0, 0); break;
+                case 1: A2_ROW(1, 1); break;
+                case 2: A2_ROW(0, 2); break;
+                default: A2_ROW(1, 3); break;
+            }
+            a2_after_row<PAIR>(A, w, wl, h, hv);
+        }
+    }
+#undef A2_ROW
+}
+
+W_FN u64 a2_zone(const A2Wave &w, int ti) {
+    const u64 zone1 = w.split >= 64 ? 0ull : (w.split <= 0 ? ~0ull : (~0ull << w.split));
+    return ti ? zone1 : ~zone1;
+}
+
+// a track whose row reached an end of one of its sequences: summary, trace-back, script
+template <int TI>
+W_FN void a2_finish(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Track &t, u64 fin_t, u64 act_row) {
+    // the finishing cell: the first such diagonal in ascending order (DW_banded.c:220-224)
+    const int fl = w_lowest(fin_t);
+    const int fin_x = w_readlane(wl.vx, fl);
+    const int k_f = t.kc + 2 * fl;
+    const int fin_y = fin_x - k_f;
+    const int fin_d = t.d - 1;
+    // cells evaluated: the reference stops its row at the finishing cell
+    const u64 above = fl >= 63 ? 0ull : (~0ull << (fl + 1));
+    const long long cells = (long long)t.cells - w_popc(act_row & a2_zone(w, TI) & above);
+    a2_flush_partial(A, w, wl);
+    const int n_ins = a2_trace<TI>(A, w, wl, t, w.it - 1u, k_f, fin_d);
+    a2_result(A, t.g, 0, 1, fin_d, fin_x, fin_y, n_ins, cells);
+    t.state = A2_IDLE;
+}
+
+// ---------------------------------------------------------------------------------------
+// wide rows (61..191 diagonals; < 0.1 % of the rows, but a fifth of the alignments meet
+// one): the track runs alone, one row at a time, 64 cells per pass, the previous row in an
+// LDS ring indexed by diagonal -- the scheme of k_align.hip's ring mode.  On the tape a wide
+// row is its first 64 cells as an ordinary iteration plus one continuation iteration
+// (A2_CONT) per further 64 cells.
+// ---------------------------------------------------------------------------------------
+// one iteration's cells, bits and K fields onto the tape (any byte position)
+W_FN void a2_emit(const A2Args &A, A2Wave &w, A2Lanes &wl, u64 fa, vu m, u32 k0, u32 k1) {
+    const vi lane = w_lane();
+    switch (w.it & 3u) {
+        case 0: wl.vacc = w_put_byte<0>(wl.vacc, m); break;
+        case 1: wl.vacc = w_put_byte<1>(wl.vacc, m); break;
+        case 2: wl.vacc = w_put_byte<2>(wl.vacc, m); break;
+        default: wl.vacc = w_put_byte<3>(wl.vacc, m); break;
+    }
+    const int slot = (int)(w.it & 63u);
+    w_writelane2(wl.rc_mlo, wl.rc_mhi, (u32)fa, (u32)(fa >> 32), slot);
+    w_writelane2(wl.rc_k0, wl.rc_k1, k0, k1, slot);
+    w.it++;
+    if ((w.it & 3u) == 0u)
+        w_store32(w.cells, (((w.it >> 2) - 1u) & ((A.ring >> 2) - 1u)) * 64u + (vu)lane, wl.vacc);
+    if ((w.it & 63u) == 0u)
+        w_store_x4(w.recs, ((w.it - 64u) & (A.ring - 1u)) + (vu)lane, wl.rc_mlo, wl.rc_mhi, wl.rc_k0, wl.rc_k1);
+}
+
+// Runs track `t` (TI: its K field) through its wide rows, at most `row_budget` of them: with
+// a neighbour waiting, a track that stays wide (reads that passed the window filter and then
+// align badly widen the band for good) is handed back rather than holding the wave.  In: its last row in `from`
+// (lane l: diagonal t.kc + 2 l, hull t.li .. t.hin).  Out: finished, dead (state A2_IDLE),
+// handed back, or narrow again with its last row in wl.vx (state A2_RUN; the caller places it).
+template <int TI>
+W_FN void a2_wide(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Track &t, vi from, int row_budget) {
+    u32 *ring = w_lds() + 256;
+    const vi lane = w_lane();
+    int min_k = t.kc + 2 * t.li - 1, n = t.hin - t.li + 2;
+    int d = t.d;
+    {   // the last row into the ring of its parity
+        const vi kp = t.kc + 2 * lane;
+        w_lds_store(ring, (vu)(((d - 1) & 1) * A2_WIDE_RING) + ((vu)(kp >> 1) & (A2_WIDE_RING - 1u)), (vu)from);
+        w_fence_block();
+    }
+    bool done = false, dead = false, back = false;
+    int fin_x = 0, fin_k = 0, fin_j = 0, n_chunk_fin = 0;
+    u32 it_row = 0;
+    while (!done && !dead && !back) {
+        if (d >= t.max_d || n - 1 > A.band) { dead = true; break; }  // DW_banded.c:183-186
+        if (n > 191 || (int)(w.it - t.it0) + 4 > (int)A.ring - 192 || row_budget-- <= 0) { back = true; break; }
+        if (n <= A2_MAX_N - 12) break;
+        const int par = d & 1, max_k = min_k + 2 * (n - 1);
+        u32 *Vcur = ring + par * A2_WIDE_RING;
+        const u32 *Vprev = ring + (par ^ 1) * A2_WIDE_RING;
+        it_row = w.it;
+        int best_row = -1;
+        for (int c = 0; c * 64 < n && !done; c++) {
+            const vi j = c * 64 + lane;
+            const u64 act = w_ballot(j < n);
+            const vi k = min_k + 2 * j;
+            const vi a = (vi)w_lds_load(Vprev, (vu)((k - 1) >> 1) & (A2_WIDE_RING - 1u));
+            const vi b = (vi)w_lds_load(Vprev, (vu)((k + 1) >> 1) & (A2_WIDE_RING - 1u));
+            // from_above: k == min_k, or k != max_k and V[k-1] < V[k+1]   (:190)
+            const u64 fa = (w_ballot(j == 0) | (w_ballot(a < b) & ~w_ballot(k == max_k))) & act;
+            vi x = w_sel(fa, a + 1, b);
+            vi y = x - k;
+            vu m = 0u;
+            W_WHERE(act) {
+                // (the snake from its first base: "16 matched so far" makes the helper start)
+                const A2Snake r = a2_snake_more<void>(A.words, (vu)t.qb, (vu)t.tb, (vi)t.q_len, (vi)t.t_len,
+                                                      x, y, (vu)16u);
+                m = r.m - 16u;
+                x = r.x; y = r.y;
+                w_lds_store(Vcur, (vu)(k >> 1) & (A2_WIDE_RING - 1u), (vu)x);
+            }
+            {
+                const u64 big = w_ballot(m >= 255u) & act;
+                if (big) {
+                    w.n_esc = w_uni(a2_escape<void>(w.esc, w.n_esc, w.it, m, (u32)big, (u32)(big >> 32)));
+                    m = w_minu(m, 255u);
+                }
+            }
+            t.cells += (u32)w_popc(act);
+            const u64 fin = (w_ballot(x >= t.q_len) | w_ballot(y >= t.t_len)) & act;  // :220
+            const vi u = w_sel(act, -1, x + y);
+            best_row = max(best_row, (int)w_readlaneu(w_prefix_max((vu)(u + 1)), 63) - 1);
+            const u32 kfield = c == 0 ? (u32)(min_k + 1 - (int)(w.it & 1u)) : A2_CONT;
+            a2_emit(A, w, wl, fa, m, TI == 0 ? kfield : A2_INVALID, TI == 0 ? A2_INVALID : kfield);
+            if (fin) {  // the first finishing diagonal in ascending order
+                const int fl = w_lowest(fin);
+                fin_j = c * 64 + fl;
+                fin_k = min_k + 2 * fin_j;
+                fin_x = w_readlane(x, fl);
+                t.cells -= (u32)w_popc(act & (fl >= 63 ? 0ull : (~0ull << (fl + 1))));
+                n_chunk_fin = c + 1;
+                done = true;
+            }
+        }
+        d++;
+        w.st_wide_rows++;
+        if (done || w.n_esc > A2_ESC_CAP) break;
+        w_fence_block();
+        t.best = max(t.best, best_row);
+        // band (:228-243) over the whole row
+        int jlo = -1, jhi = -1;
+        for (int c = 0; c * 64 < n; c++) {
+            const vi j = c * 64 + lane;
+            const vi k = min_k + 2 * j;
+            const vi x = (vi)w_lds_load(Vcur, (vu)(k >> 1) & (A2_WIDE_RING - 1u));
+            const u64 in = w_ballot(2 * x - k >= t.best - A.band) & w_ballot(j < n);
+            if (in) {
+                if (jlo < 0) jlo = c * 64 + w_lowest(in);
+                jhi = c * 64 + w_highest(in);
+            }
+        }
+        min_k = min_k + 2 * jlo - 1;  // (jlo >= 0: best_m is attained inside the row)
+        n = jhi - jlo + 2;
+    }
+    t.d = d;
+    if (w.n_esc > A2_ESC_CAP) return;  // (the caller hands everybody back)
+    if (done) {
+        (void)n_chunk_fin; (void)fin_j;
+        a2_flush_partial(A, w, wl);
+        const int n_ins = a2_trace<TI>(A, w, wl, t, it_row, fin_k, d - 1);
+        a2_result(A, t.g, 0, 1, d - 1, fin_x, fin_x - fin_k, n_ins, (long long)t.cells);
+        t.state = A2_IDLE;
+        return;
+    }
+    if (dead) {
+        a2_result(A, t.g, 0, 0, 0, 0, 0, 0, (long long)t.cells);
+        t.state = A2_IDLE;
+        return;
+    }
+    if (back) {
+        a2_result(A, t.g, 2, 0, 0, 0, 0, 0, 0);
+        t.state = A2_IDLE;
+        w.st_bail++;
+        return;
+    }
+    // narrow again: the last row back into registers, its hull around the middle of the wave
+    {
+        const int hull_n = n - 1;  // the hull's cells: diagonals min_k + 1, min_k + 3, ..
+        const int li = max(2, (64 - hull_n) / 2);
+        t.kc = (min_k + 1) - 2 * li;
+        t.li = li;
+        t.hin = li + hull_n - 1;
+        const vi kp = t.kc + 2 * lane;
+        wl.vx = (vi)w_lds_load(ring + ((d - 1) & 1) * A2_WIDE_RING, (vu)(kp >> 1) & (A2_WIDE_RING - 1u));
+        t.state = A2_RUN;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// one wavefront: alignments from the work queue, two at a time, until the queue is empty
+// ---------------------------------------------------------------------------------------
+W_FN void a2_hand_back(const A2Args &A, A2Wave &w, A2Track &t) {
+    a2_result(A, t.g, 2, 0, 0, 0, 0, 0, 0);  // err 2: the engine repeats it with the general kernel
+    t.state = A2_IDLE;
+    w.st_bail++;
+}
+
+W_FN void a2_wave(const A2Args &A, int slot) {
+    A2Wave w;
+    A2Lanes wl;
+    w.T0.state = A2_IDLE; w.T1.state = A2_IDLE;
+    w.T0.d = 0; w.T1.d = 0;
+    w.T0.g = 0; w.T1.g = 0; w.T0.q_len = w.T0.t_len = w.T1.q_len = w.T1.t_len = 0;
+    w.T0.max_d = w.T1.max_d = 0; w.T0.kc = w.T1.kc = 0; w.T0.li = w.T0.hin = w.T1.li = w.T1.hin = 0;
+    w.T0.best = w.T1.best = -1; w.T0.it0 = w.T1.it0 = 0; w.T0.cells = w.T1.cells = 0;
+    w.T0.qb = w.T0.tb = w.T1.qb = w.T1.tb = 0; w.T0.script_lo = w.T0.script_hi = w.T1.script_lo = w.T1.script_hi = 0;
+    w.it = 0;
+    w.pair = 0;
+    w.split = 64;
+    w.n_esc = 0;
+    w.more = true;
+    wl.vx = 0; wl.vpark = 0;
+    wl.vacc = 0u; wl.rc_mlo = 0u; wl.rc_mhi = 0u; wl.rc_k0 = A2_INVALID; wl.rc_k1 = A2_INVALID;
+    wl.vnegk = 0; wl.vqlen = 0; wl.vtlen = 0; wl.vqb = 0u; wl.vtb = 0u; wl.vtop = 0u;
+    w.cells = A.cells + (u64)slot * A.slot_words;
+    w.recs = w.cells + (u64)A.ring * 16u;
+    w.esc = (u64 *)(w.recs + (u64)A.ring * 4u);
+    w.st_pair = w.st_single = w.st_place = w.st_park = w.st_bail = w.st_tracks = w.st_wide = w.st_wide_rows = 0;
+    for (;;) {
+        // ---- fill the free tracks
+        if (w.T0.state == A2_IDLE && w.more) { w.more = a2_fetch(A, w.T0); if (w.more) w.st_tracks++; }
+        if (w.T1.state == A2_IDLE && w.more) { w.more = a2_fetch(A, w.T1); if (w.more) w.st_tracks++; }
+        if (w.T0.state == A2_IDLE && w.T1.state == A2_IDLE) break;
+        // (escape entries of tracks long gone: start over when nobody can refer to them, and
+        // drop the ones older than every track in flight when the list is half full -- they
+        // are in tape order)
+        if (w.n_esc > 0 && (w.T0.state == A2_IDLE || w.T0.d == 0) && (w.T1.state == A2_IDLE || w.T1.d == 0))
+            w.n_esc = 0;
+        if (w.n_esc > A2_ESC_CAP / 2) {
+            const bool live0 = w.T0.state != A2_IDLE && w.T0.d > 0, live1 = w.T1.state != A2_IDLE && w.T1.d > 0;
+            u32 oldest = live0 ? w.T0.it0 : w.T1.it0;
+            if (live0 && live1 && (int)(w.T1.it0 - w.T0.it0) < 0) oldest = w.T1.it0;
+            const vi lane = w_lane();
+            int kept = 0;
+            for (int base = 0; base < w.n_esc; base += 64) {
+                const u64 have = w_ballot(base + lane < w.n_esc);
+                vu elo = 0u, ehi = 0u;
+                W_WHERE(have) { w_load64(w.esc, (vu)(base + lane), elo, ehi); }
+                // (26 bits of the iteration are kept in an entry: compare modulo 2^26)
+                const u64 alive = have & w_ballot((vi)(((ehi >> 6) - oldest) << 6) >= 0);
+                const vu to = (vu)kept + (vu)w_rank_in(alive);
+                w_fence_block();
+                W_WHERE(alive) { w_store64(w.esc, to, elo, ehi); }
+                w_fence_block();
+                kept += w_popc(alive);
+            }
+            w.n_esc = kept;
+        }
+        // ---- the tape must keep every row of the tracks in flight: whoever has been on it
+        // for too long (parked while its neighbour ran) is handed back
+        {
+            const int span0 = (w.T0.state != A2_IDLE && w.T0.d > 0) ? (int)(w.it - w.T0.it0) + (w.T0.max_d - w.T0.d) : 0;
+            const int span1 = (w.T1.state != A2_IDLE && w.T1.d > 0) ? (int)(w.it - w.T1.it0) + (w.T1.max_d - w.T1.d) : 0;
+            const int lim = (int)A.ring - 128;
+            if (span0 > lim && span0 >= span1) { a2_hand_back(A, w, w.T0); continue; }
+            if (span1 > lim) { a2_hand_back(A, w, w.T1); continue; }
+        }
+        const int rc = a2_place(w, wl);
+        if (rc) {
+            // a band too wide for the lanes: that track goes through its wide rows alone (its
+            // neighbour, if it was running, waits in vpark)
+            if (rc == 1) {
+                const vi from = w.T0.state == A2_PARKED ? wl.vpark : wl.vx;
+                if (w.T1.state == A2_RUN) { wl.vpark = wl.vx; w.T1.state = A2_PARKED; w.st_park++; }
+                a2_wide<0>(A, w, wl, w.T0, from, w.T1.state == A2_IDLE ? 0x7fffffff : A2_WIDE_PATIENCE);
+            } else {
+                const vi from = w.T1.state == A2_PARKED ? wl.vpark : wl.vx;
+                if (w.T0.state == A2_RUN) { wl.vpark = wl.vx; w.T0.state = A2_PARKED; w.st_park++; }
+                a2_wide<1>(A, w, wl, w.T1, from, w.T0.state == A2_IDLE ? 0x7fffffff : A2_WIDE_PATIENCE);
+            }
+            w.st_wide++;
+            w.pair = 0;
+            if (w.n_esc > A2_ESC_CAP) {
+                if (w.T0.state != A2_IDLE) a2_hand_back(A, w, w.T0);
+                if (w.T1.state != A2_IDLE) a2_hand_back(A, w, w.T1);
+                w.n_esc = 0;
+            }
+            continue;
+        }
+        // ---- rows until something happens
+        const bool run0 = w.T0.state == A2_RUN, run1 = w.T1.state == A2_RUN;
+        const int p = (int)(w.it & 1u);
+        A2Hot h;
+        A2HotV hv;
+        hv.vx = wl.vx; hv.vnegk = wl.vnegk; hv.vqb = wl.vqb; hv.vtb = wl.vtb; hv.vqlen = wl.vqlen; hv.vtlen = wl.vtlen;
+        hv.vtop = wl.vtop; hv.vacc = wl.vacc; hv.rc_mlo = wl.rc_mlo; hv.rc_mhi = wl.rc_mhi;
+        h.split = w.split;
+        h.zone1 = a2_zone(w, 1);
+        h.it = w.it;
+        h.n_esc = w.n_esc;
+        h.fin = 0ull; h.ev = 0ull; h.act_row = 0ull;
+        h.kb0 = run0 ? (u32)(w.T0.kc + p) : A2_INVALID;
+        h.kb1 = run1 ? (u32)(w.T1.kc + p) : A2_INVALID;
+        int budget;
+        const u32 it_in = w.it;
+        if (w.pair) {
+            a2_next_band(w.T0, p, h.lo0, h.hi0);
+            a2_next_band(w.T1, p, h.lo1, h.hi1);
+            if (w.T0.d == 0) h.lo0 = h.hi0 = -(w.T0.kc + (p ? 1 : -1)) / 2;  // diagonal 0's lane
+            if (w.T1.d == 0) h.lo1 = h.hi1 = -(w.T1.kc + (p ? 1 : -1)) / 2;
+            h.best0 = w.T0.best;
+            h.best1 = (int)((u32)w.T1.best + 0x80000000u);
+            h.cells0 = w.T0.cells; h.cells1 = w.T1.cells;
+            h.act = w_lanes(h.lo0, h.hi0 - h.lo0 + 1) | w_lanes(h.lo1, h.hi1 - h.lo1 + 1);
+            h.forbid_to1 = 1ull | (1ull << w.split);
+            h.forbid_to0 = (1ull << (w.split - 1)) | (1ull << 63);
+            budget = min(w.T0.max_d - w.T0.d, w.T1.max_d - w.T1.d);
+            a2_rows<true>(A, w, wl, h, hv, budget);
+        } else {
+            // the running track plays "track 0" of the row loop, whichever it is.  (Its fields
+            // are picked value by value: a reference chosen at run time would force both
+            // track records into scratch memory, and everything read back from there counts
+            // as divergent.)
+            const int t_d = run0 ? w.T0.d : w.T1.d, t_kc = run0 ? w.T0.kc : w.T1.kc;
+            const int t_li = run0 ? w.T0.li : w.T1.li, t_hin = run0 ? w.T0.hin : w.T1.hin;
+            if (t_d == 0) {
+                h.lo0 = h.hi0 = -(t_kc + (p ? 1 : -1)) / 2;
+            } else if (p == 0) {
+                h.lo0 = t_li; h.hi0 = t_hin + 1;
+            } else {
+                h.lo0 = t_li - 1; h.hi0 = t_hin;
+            }
+            h.lo1 = h.hi1 = 0;
+            h.best0 = run0 ? w.T0.best : w.T1.best; h.best1 = 0;
+            h.cells0 = run0 ? w.T0.cells : w.T1.cells; h.cells1 = 0;
+            h.act = w_lanes(h.lo0, h.hi0 - h.lo0 + 1);
+            // (both edge lanes, whatever the phase: the band then never spans all 64 lanes)
+            h.forbid_to1 = h.forbid_to0 = 1ull | (1ull << 63);
+            budget = (run0 ? w.T0.max_d : w.T1.max_d) - t_d;
+            // (a parked neighbour waits for a look at the bands every now and then)
+            const bool waiting = (w.T0.state == A2_PARKED) || (w.T1.state == A2_PARKED);
+            if (waiting) budget = min(budget, A2_LOOK_EVERY);
+            a2_rows<false>(A, w, wl, h, hv, budget);
+        }
+        // ---- back from the row loop
+        const int done_it = (int)(h.it - it_in);
+        if (w.pair) w.st_pair += (u32)done_it; else w.st_single += (u32)done_it;
+        wl.vx = hv.vx; wl.vacc = hv.vacc; wl.rc_mlo = hv.rc_mlo; wl.rc_mhi = hv.rc_mhi;
+        w.it = h.it;
+        w.n_esc = h.n_esc;
+        const int p_next = (int)(w.it & 1u), p_last = p_next ^ 1;
+        // the hulls of the last row, from the bands computed for the next iteration's phase
+        if (w.pair) {
+            w.T0.d += done_it; w.T1.d += done_it;
+            w.T0.kc = (int)h.kb0 - 1 + p_last; w.T1.kc = (int)h.kb1 - 1 + p_last;
+            if (p_next == 0) { w.T0.li = h.lo0; w.T0.hin = h.hi0 - 1; w.T1.li = h.lo1; w.T1.hin = h.hi1 - 1; }
+            else             { w.T0.li = h.lo0 + 1; w.T0.hin = h.hi0; w.T1.li = h.lo1 + 1; w.T1.hin = h.hi1; }
+            w.T0.best = h.best0;
+            w.T1.best = (int)((u32)h.best1 - 0x80000000u);
+            w.T0.cells = h.cells0; w.T1.cells = h.cells1;
+        } else {
+            const int n_li = p_next == 0 ? h.lo0 : h.lo0 + 1, n_hin = p_next == 0 ? h.hi0 - 1 : h.hi0;
+            if (run0) {
+                w.T0.d += done_it; w.T0.kc = (int)h.kb0 - 1 + p_last; w.T0.li = n_li; w.T0.hin = n_hin;
+                w.T0.best = h.best0; w.T0.cells = h.cells0;
+            } else {
+                w.T1.d += done_it; w.T1.kc = (int)h.kb1 - 1 + p_last; w.T1.li = n_li; w.T1.hin = n_hin;
+                w.T1.best = h.best0; w.T1.cells = h.cells0;
+            }
+        }
+        if (w.n_esc > A2_ESC_CAP) {  // the escape list is full: everybody on the tape goes back
+            if (w.T0.state != A2_IDLE) a2_hand_back(A, w, w.T0);
+            if (w.T1.state != A2_IDLE) a2_hand_back(A, w, w.T1);
+            w.n_esc = 0;
+            continue;
+        }
+        if (done_it > 0) {
+            const u64 fin0 = h.fin & a2_zone(w, 0), fin1 = h.fin & a2_zone(w, 1);
+            if (run0 && fin0) a2_finish<0>(A, w, wl, w.T0, fin0, h.act_row);
+            if (run1 && fin1) a2_finish<1>(A, w, wl, w.T1, fin1, h.act_row);
+        }
+        // rows exhausted without reaching an end: unaligned (DW_banded.c:183, :171)
+        if (w.T0.state == A2_RUN && w.T0.d >= w.T0.max_d) {
+            a2_result(A, w.T0.g, 0, 0, 0, 0, 0, 0, (long long)w.T0.cells);
+            w.T0.state = A2_IDLE;
+        }
+        if (w.T1.state == A2_RUN && w.T1.d >= w.T1.max_d) {
+            a2_result(A, w.T1.g, 0, 0, 0, 0, 0, 0, (long long)w.T1.cells);
+            w.T1.state = A2_IDLE;
+        }
+    }
+    if (A.stats) {
+        w_stat_add(A.stats + A2_STAT_PAIR_IT, w.st_pair);
+        w_stat_add(A.stats + A2_STAT_SINGLE_IT, w.st_single);
+        w_stat_add(A.stats + A2_STAT_PLACE, w.st_place);
+        w_stat_add(A.stats + A2_STAT_PARK, w.st_park);
+        w_stat_add(A.stats + A2_STAT_BAIL, w.st_bail);
+        w_stat_add(A.stats + A2_STAT_TRACKS, w.st_tracks);
+        w_stat_add(A.stats + A2_STAT_EXT, w.st_wide);
+        w_stat_add(A.stats + A2_STAT_ESC, w.st_wide_rows);
+    }
+}

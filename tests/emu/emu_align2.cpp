@@ -1,0 +1,80 @@
+// tests/emu/emu_align2.cpp -- TEST INFRASTRUCTURE: runs the source of the k_align2 kernel
+// (falcon_amd/csrc/k_align2_core.h) on the host, one emulated wavefront after the other,
+// through the lane emulator of tests/emu/fa_wave.h.  Built by tests/emu/Makefile into
+// tests/emu/libemu_align2.so and driven by tests/test_emu_align2.py against the CPU oracle;
+// the product never loads it.
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#include "fa_wave.h"  // (tests/emu's twin: this directory comes first on the include path)
+
+namespace emu {
+thread_local uint64_t exec = ~0ull;
+thread_local Region regions[16];
+thread_local int n_regions = 0;
+thread_local u32 lds[1024];
+void check(const void *p, size_t bytes, bool write, const char *what) {
+    const char *c = (const char *)p;
+    for (int i = 0; i < n_regions; i++) {
+        const char *b = (const char *)regions[i].p;
+        if (c >= b && c + bytes <= b + regions[i].bytes) {
+            if (write && !regions[i].writable) break;
+            return;
+        }
+    }
+    fprintf(stderr, "emu: %s of %zu bytes at %p is outside every registered buffer\n", what, bytes, p);
+    abort();
+}
+static void reg(const void *p, size_t bytes, bool writable) {
+    regions[n_regions].p = p;
+    regions[n_regions].bytes = bytes;
+    regions[n_regions].writable = writable;
+    n_regions++;
+}
+}  // namespace emu
+
+#ifdef EMU_HIST
+static long hist_sum[130], hist_one[70];
+#define A2_HOOK_PLACE(h0, n0, h1, n1) do { if ((h0) && (h1)) hist_sum[std::min(129, (n0) + (n1))]++; if (h0) hist_one[std::min(69,(n0))]++; if (h1) hist_one[std::min(69,(n1))]++; } while (0)
+extern "C" void emu_hist(long *sum, long *one) { memcpy(sum, hist_sum, sizeof(hist_sum)); memcpy(one, hist_one, sizeof(hist_one)); }
+#endif
+#include "k_align2_core.h"
+
+// words per arena slot for a tape of `ring` iterations (must match the engine's sizing)
+static u64 slot_words_for(u32 ring) { return (u64)ring * 16u + (u64)ring * 4u + (u64)A2_ESC_CAP * 2u; }
+
+extern "C" int emu_align2(const u32 *words, u64 n_words, const FaSeq *seq, int n_seq, const FaPile *pile,
+                          int n_pile, const FaRange *range, const int *order, int n_work, u32 ring,
+                          int n_wave, int band, double max_diff, u32 *script, u64 script_words,
+                          const u64 *script_off, FaAln *aln, unsigned long long *stats) {
+    if (ring < 256 || (ring & (ring - 1))) return -1;
+    if (n_wave < 1) n_wave = 1;
+    std::vector<u32> arena((size_t)slot_words_for(ring) * (size_t)n_wave, 0xA5A5A5A5u);
+    int counter = 0;
+    emu::n_regions = 0;
+    emu::reg(words, n_words * 4, false);
+    emu::reg(arena.data(), arena.size() * 4, true);
+    emu::reg(script, script_words * 4, true);
+    emu::reg(aln, (size_t)n_seq * sizeof(FaAln), true);
+    (void)n_pile;
+    A2Args A;
+    A.words = words; A.seq = seq; A.pile = pile; A.range = range; A.order = order;
+    A.n_work = n_work; A.counter = &counter;
+    A.cells = arena.data(); A.recs = nullptr; A.esc = nullptr;
+    A.slot_words = slot_words_for(ring);
+    A.ring = ring;
+    A.script = script; A.script_off = script_off; A.aln = aln;
+    A.band = band; A.max_diff = max_diff;
+    A.stats = stats;
+    // the wavefronts of a launch run at the same time on the device and take work as they
+    // go; here they run one after the other, wave w taking every n_wave-th chunk of the
+    // queue is not needed for correctness -- any split of the queue is a legal schedule
+    for (int w = 0; w < n_wave; w++) {
+        emu::exec = ~0ull;
+        // (wave w works until the queue is empty; with n_wave > 1 the first takes it all --
+        // the parameter exists to exercise slot addressing)
+        a2_wave(A, w);
+    }
+    return 0;
+}

@@ -1,0 +1,184 @@
+"""The k_align2 kernel's SOURCE (falcon_amd/csrc/k_align2_core.h: two alignments per wavefront,
+band placement and parking, the iteration tape with 1-byte cells, the trace-back) run on the
+host through the lane emulator of tests/emu, against the CPU oracle: summaries, DP-cell
+counts and gapped strings must be identical.  The GPU parity tests (tests/test_gpu_*.py) run
+the same source compiled for gfx950; this suite is where its control logic is exercised
+without a GPU -- many more shapes than a GPU box's minutes allow, and under a bounds
+checker."""
+import numpy as np
+import pytest
+
+from emu_driver import align_pairs
+from falcon_amd.synth import codes_to_str, noisy
+
+KEYS = ["dist", "aln_q_e", "aln_t_e", "aln_str_size", "q_aln_str", "t_aln_str", "cells"]
+
+
+def _pair(rng, n, e, e2=None):
+    g = rng.integers(0, 4, n, dtype=np.uint8)
+    return codes_to_str(noisy(g, rng, e)), codes_to_str(noisy(g, rng, e if e2 is None else e2))
+
+
+def _check(port, pairs, res, allow_handback=False, windows=None):
+    n_back = 0
+    for i, ((q, t), r) in enumerate(zip(pairs, res)):
+        if windows:
+            s1, e1, s2, e2 = windows[i]
+            q, t = q[s1:e1], t[s2:e2]
+        if r["err"] == 2 and allow_handback:
+            n_back += 1
+            continue
+        assert r["err"] == 0, (i, r["err"])
+        o = port.align(q, t, 150, 1)
+        if not r["aligned"]:
+            assert o["aln_str_size"] == 0 and o["dist"] == 0, i
+            assert r["cells"] == o["cells"], i
+            continue
+        for k in KEYS:
+            assert r[k] == o[k], (i, k, len(q), len(t))
+        assert r["n_ins"] == r["n_ins_script"], i
+        size = (o["aln_q_e"] + o["aln_t_e"] + o["dist"]) // 2
+        assert r["accept"] == int(size > 500 and o["dist"] / size < 2.0)
+    return n_back
+
+
+def test_pairs_of_many_shapes(port):
+    """Lengths 30..6000, divergence 0..35 %, in queue order and shuffled (different pairings in
+    the wave): every alignment identical to the oracle's, both tracks used."""
+    rng = np.random.default_rng(11)
+    pairs, err = [], []
+    for _ in range(60):
+        err.append(float(rng.choice([0.0, 0.02, 0.08, 0.13, 0.2, 0.35])))
+        pairs.append(_pair(rng, int(rng.integers(30, 6000)), err[-1]))
+    res, st = align_pairs(pairs)
+    _check(port, pairs, res, allow_handback=True)
+    # what the falcon_sense regime produces (<= 13 % per read) never needs the general kernel
+    assert all(r["err"] == 0 for r, e in zip(res, err) if e <= 0.13)
+    assert st[0] > 0 and st[1] > 0  # paired and single iterations both occurred
+    order = rng.permutation(2 * len(pairs)).astype(np.int32)
+    res2, _ = align_pairs(pairs, order=order)
+    _check(port, pairs, res2, allow_handback=True)
+    assert all(r["err"] == 0 for r, e in zip(res2, err) if e <= 0.13)
+
+
+def test_windows_inside_longer_sequences(port):
+    """The falcon_sense case: (s1, e1) x (s2, e2) windows inside reads and seeds (bases before
+    and behind the windows are real bases, not padding)."""
+    rng = np.random.default_rng(5)
+    pairs, wins = [], []
+    for _ in range(24):
+        n = int(rng.integers(1500, 5000))
+        q, t = _pair(rng, n, 0.13)
+        s1 = int(rng.integers(0, 300))  # (windows open on a k-mer match: about the same place)
+        s2 = max(0, s1 + int(rng.integers(-8, 9)))
+        e1, e2 = len(q) - int(rng.integers(0, 300)), len(t) - int(rng.integers(0, 300))
+        pairs.append((q, t))
+        wins.append((s1, e1, s2, e2))
+    res, _ = align_pairs(pairs, windows=wins)
+    assert _check(port, pairs, res, windows=wins) == 0
+
+
+def test_long_snakes_take_the_escape_list(port):
+    """Identical and nearly identical sequences: snakes of hundreds to thousands of bases do
+    not fit the one-byte cell and go through the escape list."""
+    rng = np.random.default_rng(3)
+    pairs = []
+    for n in (40, 255, 256, 300, 1000, 5000):
+        g = codes_to_str(rng.integers(0, 4, n, dtype=np.uint8))
+        pairs.append((g, g))
+    for n in (2000, 4000, 6000):
+        pairs.append(_pair(rng, n, 0.002))
+        pairs.append(_pair(rng, n, 0.0, 0.01))
+    res, _ = align_pairs(pairs)
+    assert _check(port, pairs, res) == 0
+    assert any(len(r["q_aln_str"]) > 3000 and r["dist"] < 20 for r in res)
+
+
+def test_unrelated_and_unbalanced_sequences(port):
+    """Rows run out (DW_banded.c:183) or one sequence ends early: unaligned summaries and DP
+    cell counts match; a neighbour in the same wave is not disturbed.  (Long unrelated
+    sequences open the band beyond 60 diagonals and are handed back.)"""
+    rng = np.random.default_rng(8)
+    pairs, short = [], []
+    for _ in range(10):
+        n1, n2 = (int(rng.integers(40, 100)), int(rng.integers(40, 100)))  # max_d <= 59 rows
+        pairs.append((codes_to_str(rng.integers(0, 4, n1, dtype=np.uint8)),
+                      codes_to_str(rng.integers(0, 4, n2, dtype=np.uint8))))
+        short.append(True)
+        pairs.append(_pair(rng, int(rng.integers(500, 3000)), 0.13))
+        short.append(True)
+    for _ in range(4):
+        pairs.append((codes_to_str(rng.integers(0, 4, 1500, dtype=np.uint8)),
+                      codes_to_str(rng.integers(0, 4, 1400, dtype=np.uint8))))
+        short.append(False)
+    q, t = _pair(rng, 3000, 0.1)
+    pairs.append((q[:700], t))   # the query ends first
+    pairs.append((q, t[:900]))
+    pairs.append(("ACGT", "ACGT"))
+    pairs.append(("A", "C"))     # max_d = 0: no row at all
+    pairs.append(("ACGTACGTAC", "ACGTTCGTAC"))
+    short += [True] * 5
+    res, _ = align_pairs(pairs)
+    _check(port, pairs, res, allow_handback=True)
+    assert all(r["err"] == 0 for r, s in zip(res, short) if s)
+    assert sum(1 for r in res if r["err"] == 0 and not r["aligned"]) >= 2
+
+
+def test_wide_bands_park_a_track_or_hand_it_back(port):
+    """High divergence widens the band: tracks take turns (parking), and a band beyond 60
+    diagonals, or an alignment that does not fit a short tape ring, is handed back (err 2 --
+    the engine repeats those with the general kernel) without touching its neighbour."""
+    rng = np.random.default_rng(21)
+    pairs = [_pair(rng, int(rng.integers(2000, 5000)), float(rng.choice([0.25, 0.3, 0.35, 0.4]))) for _ in range(16)]
+    res, st = align_pairs(pairs)
+    n_back = _check(port, pairs, res, allow_handback=True)
+    assert st[3] > 0, "no track was ever parked"
+    assert n_back == st[4]
+    # a ring too short for the longer alignments
+    pairs = [_pair(rng, n, 0.13) for n in (500, 3000, 600, 3200, 700, 2900, 400)]
+    res, st = align_pairs(pairs, ring=1024)
+    n_back = _check(port, pairs, res, allow_handback=True)
+    assert n_back == 3  # (refused at the queue: max_d + 192 > ring)
+    assert all(r["err"] == 0 for r, (q, _) in zip(res, pairs) if len(q) < 1000)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_campaign(port, seed):
+    """The shapes of oracle/campaign_cases.py's pair generator (band 150 cases), plus the
+    bench workload's regime: 8-14 kb at 13 % error."""
+    rng = np.random.default_rng(1000 + seed)
+    pairs = []
+    for _ in range(10):
+        n = int(rng.integers(100, 4000))
+        e1, e2 = float(rng.choice([0.0, 0.05, 0.13, 0.2])), float(rng.choice([0.0, 0.05, 0.13, 0.2]))
+        pairs.append(_pair(rng, n, e1, e2))
+    if seed == 0:
+        pairs += [_pair(rng, n, 0.13) for n in (9000, 12000, 14000, 10000)]
+    order = rng.permutation(2 * len(pairs)).astype(np.int32)
+    res, _ = align_pairs(pairs, order=order, ring=16384)
+    _check(port, pairs, res, allow_handback=True)
+
+
+def test_wide_rows_run_in_the_kernel(port):
+    """Bands of 61..191 diagonals (a fifth of real alignments meets one for a few rows): the
+    track goes through them alone, 64 cells per pass with continuation records on the tape;
+    alone in the wave it is never handed back -- aligned results, rows that run out and the
+    band-too-wide exit (DW_banded.c:184) all match the oracle."""
+    rng = np.random.default_rng(77)
+    wide = 0
+    for i in range(24):
+        if i % 4 == 3:  # unrelated: the band opens until it exceeds the tolerance
+            q = codes_to_str(rng.integers(0, 4, int(rng.integers(200, 2500)), dtype=np.uint8))
+            t = codes_to_str(rng.integers(0, 4, int(rng.integers(200, 2500)), dtype=np.uint8))
+        else:
+            q, t = _pair(rng, int(rng.integers(400, 3000)), float(rng.choice([0.18, 0.2, 0.22, 0.25, 0.3])))
+        res, st = align_pairs([(q, t)], ring=16384)
+        assert _check(port, [(q, t)], res) == 0
+        wide += int(st[6])
+    assert wide > 20
+    # with a neighbour waiting, a track that stays wide is handed back after A2_WIDE_PATIENCE rows
+    pairs = [_pair(rng, 3000, 0.13), (codes_to_str(rng.integers(0, 4, 2000, dtype=np.uint8)),
+                                      codes_to_str(rng.integers(0, 4, 2000, dtype=np.uint8)))]
+    res, st = align_pairs(pairs)
+    assert res[0]["err"] == 0 and res[1]["err"] == 2
+    assert _check(port, pairs, res, allow_handback=True) == 1
