@@ -530,6 +530,18 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
             "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},
             "kernel_ms": {n: round(v, 4) for n, v in kernel_ms.items()},
             "host_plan_gap_ms": round(host_gap, 3),
+            # the alignment stage about itself (fa_stats): arena bytes, resident wavefronts, and
+            # k_align2's iterations with two / one alignment running, band placements,
+            # parkings, alignments handed to the general kernel, wide rows
+            "align": {"arena_bytes": int(getattr(st, "align_arena_bytes", 0)), "slots": int(getattr(st, "align_slots", 0)),
+                      "pair_iterations": int(getattr(st, "align_pair_iterations", 0)),
+                      "single_iterations": int(getattr(st, "align_single_iterations", 0)),
+                      "placements": int(getattr(st, "align_placements", 0)),
+                      "parkings": int(getattr(st, "align_parkings", 0)),
+                      "handed_back": int(getattr(st, "align_handed_back", 0)),
+                      "relaunched": int(getattr(st, "align_relaunched", 0)),
+                      "wide_rows": int(getattr(st, "align_wide_rows", 0)),
+                      "band_rows": int(st.D)},
             # the counts B_alg = L/4 + 4C + 8D + 16A + 12T + 5O is made of, per step and GPU
             "work": {"L": int(st.L), "C": int(st.C), "D": int(st.D), "A": int(st.A), "T": int(st.T),
                      "O": int(st.O)},

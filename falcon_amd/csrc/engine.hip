@@ -126,6 +126,9 @@ struct fa_ctx {
     // a few worst-case slots for the alignments that outgrow the usual ones (grow only)
     FaAlignArena arena2 = {};
     size_t arena2_cells_bytes = 0, arena2_rows_bytes = 0;
+    // k_align2 (two alignments per wavefront): one tape ring per resident wavefront (grow only)
+    FaAlign2Arena a2 = {};
+    size_t a2_bytes = 0;
     // staging of a batch's ASCII (grow only, one batch at a time): pinned host buffer, its
     // device twin, and a stream of their own so that the upload and pack of batch i+1 run
     // next to the kernels of batch i instead of queueing behind them
@@ -337,6 +340,7 @@ struct fa_batch {
         return 0;
     }
 
+    const int *order_dev() const { return d_order.p; }
     FaBatchDev dev() const {
         FaBatchDev b;
         b.ascii = ascii_dev; b.ascii_off = d_ascii_off.p; b.words = d_words.p;
@@ -392,6 +396,9 @@ extern "C" fa_ctx *fa_create(int device) {
     HIP_OK_P(hipMalloc((void **)&c->d_first_bad, sizeof(int)));
     HIP_OK_P(hipMalloc((void **)&c->arena.prof, 8 * sizeof(u64)));
     HIP_OK_P(hipMemset(c->arena.prof, 0, 8 * sizeof(u64)));
+    HIP_OK_P(hipMalloc((void **)&c->a2.stats, 8 * sizeof(unsigned long long)));
+    HIP_OK_P(hipMemset(c->a2.stats, 0, 8 * sizeof(unsigned long long)));
+    c->a2.counter = c->arena.counter;  // (the front stream runs one alignment launch at a time)
     return c;
 }
 
@@ -405,6 +412,8 @@ extern "C" void fa_destroy(fa_ctx *c) {
     if (c->arena2.cells) (void)hipFree(c->arena2.cells);
     if (c->arena2.rows) (void)hipFree(c->arena2.rows);
     if (c->arena2.rowx) (void)hipFree(c->arena2.rowx);
+    if (c->a2.mem) (void)hipFree(c->a2.mem);
+    if (c->a2.stats) (void)hipFree(c->a2.stats);
     if (c->d_first_bad) (void)hipFree(c->d_first_bad);
     if (c->h_dl) (void)hipHostFree(c->h_dl);
     for (hipStream_t sb : c->back_stream)
@@ -866,6 +875,57 @@ static int ensure_arena2(fa_ctx *c, const fa_batch *b, int n) {
     return 0;
 }
 
+// k_align2 takes the falcon_sense alignments (band tolerance 150) and every other band it is
+// built for: >= 64 (a band row never ends an alignment by its width inside a wavefront's
+// lanes) and <= 190 (what the general kernel, which takes what k_align2 hands back, handles);
+// base indices into the packed words are 32 bits.  FALCON_AMD_ALIGN1=1: the one alignment
+// per wavefront kernel for everything (A/B and tests).
+static bool use_align2(const fa_batch *b, int band) {
+    static const bool off = getenv("FALCON_AMD_ALIGN1") != nullptr;
+    return !off && band >= 64 && band + 1 <= 64 * FA_ALIGN_MAXCH - 1 && b->n_words < (1ull << 28);
+}
+
+// The tape arena of k_align2: one ring per resident wavefront, sized for the batch's
+// longest alignment (twice its rows: a track may wait while its neighbour runs), at most
+// 32768 iterations -- what does not fit is handed back by the kernel.  80 bytes per
+// iteration: ~0.65 MB per wavefront for reads of 12 kb, 5 GB per device, where the 4-byte
+// cells of k_align took 13 GB.
+static int ensure_arena_a2(fa_ctx *c, const fa_batch *b) {
+    u32 ring = fa_align2_ring_for(b->max_rows);
+    if (const char *e = getenv("FALCON_AMD_RING")) ring = (u32)std::max(256, atoi(e));  // (tests: a power of two)
+    ring = std::min<u32>(ring, 32768u);
+    int per_cu = std::max(1, std::min(fa_align2_blocks_per_cu(), 32));
+    int n_slot = c->n_cu * per_cu;
+    n_slot = std::max(1, std::min(n_slot, (b->n_seq + 1) / 2));
+    if (const char *e = getenv("FALCON_AMD_SLOTS")) n_slot = std::max(1, std::min(n_slot, atoi(e)));
+    const u64 slot_words = fa_align2_slot_words(ring);
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const u64 budget = (u64)free_b / 2 + (u64)c->a2_bytes;
+    if ((u64)n_slot * slot_words * 4 > budget) n_slot = (int)std::max<u64>(1, budget / (slot_words * 4));
+    size_t need = (size_t)n_slot * slot_words * 4;
+    if (need > c->a2_bytes) {
+        // fewer slots in what is there rather than a new allocation for a few per cent more
+        // (ensure_arena's rule: re-allocating GBs in the middle of a stream costs 0.5 s)
+        const u64 fit = c->a2_bytes / (slot_words * 4);
+        if (fit >= (u64)n_slot - (u64)n_slot / 8 && fit >= 1) {
+            n_slot = (int)fit;
+        } else {
+            if (need + need / 4 <= budget) need += need / 4;
+            if (c->a2.mem) (void)hipFree(c->a2.mem);
+            c->a2.mem = nullptr;
+            c->a2_bytes = 0;
+            HIP_OK(arena_malloc((void **)&c->a2.mem, need));
+            c->a2_bytes = need;
+            n_slot = (int)std::min<u64>((u64)n_slot + (u64)n_slot / 4, need / (slot_words * 4));
+        }
+    }
+    c->a2.slot_words = slot_words;
+    c->a2.ring = ring;
+    c->a2.n_slot = n_slot;
+    return 0;
+}
+
 // Alignment summaries to the host.  0: fine; 1: some alignment outgrew its work slot (the
 // caller repeats those with worst-case slots); < 0: error.
 static int fetch_aln(fa_batch *b) {
@@ -888,6 +948,36 @@ static int fetch_aln(fa_batch *b) {
         return 1;
     }
     return 0;
+}
+
+// Alignments that came back with FaAln.err == 2 -- they outgrew their work slot, or k_align2
+// handed them back (a band that stayed wide, an alignment too long for the tape ring) -- are
+// done again, alone, by the general one-alignment-per-wavefront kernel in worst-case slots
+// (nothing was written past a slot).  Returns fetch_aln's verdict after the second launch.
+static int redo_handed_back(fa_batch *b, double max_diff, int band) {
+    fa_ctx *c = b->ctx;
+    hipStream_t s = c->stream;
+    std::vector<int> redo;
+    for (int g = 0; g < b->n_seq; g++)
+        if (b->h_aln[g].err == 2) redo.push_back(g);
+    if (band + 1 > 64 * FA_ALIGN_MAXCH - 1) {
+        // (k_align_wide runs in worst-case slots from the start: not expected)
+        set_err("falcon_amd: %zu alignments overflowed their work slots at band %d", redo.size(), band);
+        return -1;
+    }
+    if (ensure_arena2(c, b, (int)redo.size()) || b->d_redo.alloc(redo.size())) return -1;
+    HIP_OK(hipMemcpyAsync(b->d_redo.p, redo.data(), redo.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    fa_launch_align_list(b->dev(), c->arena2, b->max_read_len, b->max_seed_len, max_diff, band, b->d_redo.p,
+                         (int)redo.size(), s);
+    HIP_OK(hipGetLastError());
+    b->stats.align_relaunched = (int)redo.size();
+    // (the list must outlive the copy: fetch_aln synchronises the stream)
+    int rc = fetch_aln(b);
+    if (rc == 1) {
+        set_err("falcon_amd: an alignment overflowed a worst-case work slot");
+        return -2;
+    }
+    return rc;
 }
 
 // Stages after the windows are known (d_range on the device, h_range on the host or on
@@ -933,8 +1023,12 @@ extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double
     b->fetched = b->fetched_eqv = false;
     b->have_range = b->have_aln = false;
     const double max_diff = 1.0 - min_idt;  // falcon.c:580
-    size_t lds = fa_align_lds_bytes(b->max_read_len, b->max_seed_len);
-    if (ensure_arena(c, b, lds, false)) return -1;
+    if (use_align2(b, FA_BAND)) {
+        if (ensure_arena_a2(c, b)) return -1;
+    } else {
+        size_t lds = fa_align_lds_bytes(b->max_read_len, b->max_seed_len);
+        if (ensure_arena(c, b, lds, false)) return -1;
+    }
     pt.mark("arena");
     FaBatchDev d = b->dev();
 
@@ -988,13 +1082,15 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
     hipStream_t s = c->stream;
     FaBatchDev d = b->dev();
     PhaseTimer pt("align + msa plan");
-    auto launch_align = [&]() {
-        if (band + 1 > 64 * FA_ALIGN_MAXCH - 1)
-            fa_launch_align_wide(d, c->arena, max_diff, band, s);
-        else
-            fa_launch_align_band(d, c->arena, b->max_read_len, b->max_seed_len, max_diff, band, s);
-    };
-    launch_align();
+    const bool two_per_wave = use_align2(b, band);
+    if (two_per_wave) {
+        (void)hipMemsetAsync(c->a2.stats, 0, 8 * sizeof(unsigned long long), s);
+        fa_launch_align2(d, c->a2, max_diff, band, b->order_dev(), b->n_seq, s);
+    } else if (band + 1 > 64 * FA_ALIGN_MAXCH - 1) {
+        fa_launch_align_wide(d, c->arena, max_diff, band, s);
+    } else {
+        fa_launch_align_band(d, c->arena, b->max_read_len, b->max_seed_len, max_diff, band, s);
+    }
     HIP_OK(hipEventRecord(b->ev[3], s));
     trace_stage(s, "align");
     if (getenv("FALCON_AMD_PROF")) {  // only meaningful in -DFA_ALIGN_PROF builds
@@ -1046,28 +1142,8 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
     int rc_aln = fetch_aln(b);
     pt.mark("align-wait+summaries");
     if (rc_aln == 1) {
-        // some alignments outgrew their slots (nothing was written past them): those
-        // again, alone, in worst-case slots
-        std::vector<int> redo;
-        for (int g = 0; g < b->n_seq; g++)
-            if (b->h_aln[g].err == 2) redo.push_back(g);
-        if (band + 1 > 64 * FA_ALIGN_MAXCH - 1) {
-            // (k_align_wide runs in worst-case slots from the start: not expected)
-            set_err("falcon_amd: %zu alignments overflowed their work slots at band %d", redo.size(), band);
-            return -1;
-        }
-        if (ensure_arena2(c, b, (int)redo.size()) || b->d_redo.alloc(redo.size())) return -1;
-        HIP_OK(hipMemcpyAsync(b->d_redo.p, redo.data(), redo.size() * sizeof(int), hipMemcpyHostToDevice, s));
-        fa_launch_align_list(d, c->arena2, b->max_read_len, b->max_seed_len, max_diff, band, b->d_redo.p,
-                             (int)redo.size(), s);
+        rc_aln = redo_handed_back(b, max_diff, band);
         HIP_OK(hipEventRecord(b->ev[3], s));
-        HIP_OK(hipGetLastError());
-        b->stats.align_relaunched = (int)redo.size();
-        rc_aln = fetch_aln(b);
-        if (rc_aln == 1) {
-            set_err("falcon_amd: an alignment overflowed a worst-case work slot");
-            return -2;
-        }
     }
     if (rc_aln) return rc_aln;
     // (FALCON_AMD_BACK_AFTER_ALIGN: the previous batch's back stage starts here, beside this
@@ -1198,8 +1274,28 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
     }
     // what the statistics need of this plan
     b->stats.C = sC; b->stats.D = sD; b->stats.A = sA; b->stats.n_aligned = nal;
-    b->stats.align_slots = c->arena.n_slot;
-    b->stats.align_slot_cells = (long long)c->arena.cells_per_slot;
+    if (two_per_wave) {
+        unsigned long long st[8];
+        HIP_OK(hipMemcpyAsync(st, c->a2.stats, sizeof(st), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));  // (k_align is long done: fetch_aln waited for it)
+        b->stats.align_slots = c->a2.n_slot;
+        b->stats.align_slot_cells = (long long)c->a2.ring * 64;
+        b->stats.align_arena_bytes = (long long)c->a2_bytes + (long long)c->arena2_cells_bytes +
+                                     2 * (long long)c->arena2_rows_bytes;
+        b->stats.align_pair_iterations = (long long)st[0];
+        b->stats.align_single_iterations = (long long)st[1];
+        b->stats.align_placements = (long long)st[2];
+        b->stats.align_parkings = (long long)st[3];
+        b->stats.align_handed_back = (long long)st[4];
+        b->stats.align_wide_rows = (long long)st[5];
+    } else {
+        b->stats.align_slots = c->arena.n_slot;
+        b->stats.align_slot_cells = (long long)c->arena.cells_per_slot;
+        b->stats.align_arena_bytes = (long long)c->arena_cells_bytes + 2 * (long long)c->arena_rows_bytes +
+                                     (long long)c->arena2_cells_bytes + 2 * (long long)c->arena2_rows_bytes;
+        b->stats.align_pair_iterations = b->stats.align_single_iterations = b->stats.align_placements = 0;
+        b->stats.align_parkings = b->stats.align_handed_back = b->stats.align_wide_rows = 0;
+    }
     b->in_flight = true;
     return 0;
 }
@@ -1611,21 +1707,24 @@ extern "C" int fa_align_pairs(fa_ctx *ctx, int n, const char *const *q, const in
         return fail(-1);
     }
     trace_stage(s, "pair-range");
-    if (ensure_arena(c, b, lds, true)) return fail(-1);
-    trace_stage(s, "pair-arena");
     FaBatchDev d = b->dev();
-    FaAlignArena ar = c->arena;
-    if (wide) fa_launch_align_wide(d, ar, 2.0, band_tolerance, s);
-    else fa_launch_align_band(d, ar, max_q, max_t, 2.0, band_tolerance, s);
+    b->stats.align_relaunched = 0;
+    if (use_align2(b, band_tolerance)) {
+        if (ensure_arena_a2(c, b)) return fail(-1);
+        fa_launch_align2(d, c->a2, 2.0, band_tolerance, b->d_order.p, b->n_seq, s);
+    } else {
+        if (ensure_arena(c, b, lds, true)) return fail(-1);
+        if (wide) fa_launch_align_wide(d, c->arena, 2.0, band_tolerance, s);
+        else fa_launch_align_band(d, c->arena, max_q, max_t, 2.0, band_tolerance, s);
+    }
     trace_stage(s, "pair-align");
     if (hipGetLastError() != hipSuccess) {
         set_err("falcon_amd: k_align launch failed");
         return fail(-1);
     }
-    if ((rc = fetch_aln(b))) {
-        if (rc == 1) set_err("falcon_amd: an alignment overflowed a worst-case work slot");
-        return fail(rc == 1 ? -2 : rc);
-    }
+    rc = fetch_aln(b);
+    if (rc == 1) rc = redo_handed_back(b, 2.0, band_tolerance);
+    if (rc) return fail(rc);
     std::vector<u32> script;
     if (get_aln_str > 0) {
         script.resize(b->script_words + 8);

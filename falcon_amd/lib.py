@@ -29,7 +29,11 @@ class FaStats(C.Structure):
                 ("ms_tags", C.c_float), ("ms_links", C.c_float), ("ms_score", C.c_float),
                 ("ms_backtrace", C.c_float),
                 ("align_slot_cells", C.c_longlong), ("align_relaunched", C.c_int),
-                ("n_piles_failed", C.c_int)]
+                ("n_piles_failed", C.c_int),
+                ("align_arena_bytes", C.c_longlong),
+                ("align_pair_iterations", C.c_longlong), ("align_single_iterations", C.c_longlong),
+                ("align_placements", C.c_longlong), ("align_parkings", C.c_longlong),
+                ("align_handed_back", C.c_longlong), ("align_wide_rows", C.c_longlong)]
 
     def b_alg(self) -> int:
         """Algorithmic bytes: L/4 + 4C + 8D + 16A + 12T + 5O."""

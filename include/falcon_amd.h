@@ -139,6 +139,12 @@ typedef struct {
     long long align_slot_cells;
     int align_relaunched;
     int n_piles_failed; /* piles of the last run without a consensus, see fa_batch_pile_error */
+    /* the alignment arena the run used, in bytes (k_align2: tape rings, one-byte cells), and
+     * what the two-alignments-per-wavefront kernel reports about itself: iterations with
+     * both tracks / one track running, band placements, parkings, alignments handed back */
+    long long align_arena_bytes;
+    long long align_pair_iterations, align_single_iterations, align_placements, align_parkings,
+        align_handed_back, align_wide_rows;
 } fa_stats;
 
 const char *fa_last_error(void);

@@ -177,8 +177,9 @@ def test_wide_rows_run_in_the_kernel(port):
         wide += int(st[6])
     assert wide > 20
     # with a neighbour waiting, a track that stays wide is handed back after A2_WIDE_PATIENCE rows
-    pairs = [_pair(rng, 3000, 0.13), (codes_to_str(rng.integers(0, 4, 2000, dtype=np.uint8)),
-                                      codes_to_str(rng.integers(0, 4, 2000, dtype=np.uint8)))]
+    pairs = [_pair(rng, 5000, 0.13), _pair(rng, 5000, 0.3)]
     res, st = align_pairs(pairs)
     assert res[0]["err"] == 0 and res[1]["err"] == 2
     assert _check(port, pairs, res, allow_handback=True) == 1
+    res, st = align_pairs(pairs[1:])  # ... and alone it is not
+    assert _check(port, pairs[1:], res) == 0
