@@ -537,6 +537,7 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
                       "pair_iterations": int(getattr(st, "align_pair_iterations", 0)),
                       "single_iterations": int(getattr(st, "align_single_iterations", 0)),
                       "placements": int(getattr(st, "align_placements", 0)),
+                      "replacements_in_loop": int(getattr(st, "align_replacements", 0)),
                       "parkings": int(getattr(st, "align_parkings", 0)),
                       "handed_back": int(getattr(st, "align_handed_back", 0)),
                       "relaunched": int(getattr(st, "align_relaunched", 0)),

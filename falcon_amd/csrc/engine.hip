@@ -881,7 +881,7 @@ static int ensure_arena2(fa_ctx *c, const fa_batch *b, int n) {
 // base indices into the packed words are 32 bits.  FALCON_AMD_ALIGN1=1: the one alignment
 // per wavefront kernel for everything (A/B and tests).
 static bool use_align2(const fa_batch *b, int band) {
-    static const bool off = getenv("FALCON_AMD_ALIGN1") != nullptr;
+    const bool off = getenv("FALCON_AMD_ALIGN1") != nullptr;  // (read every time: tests switch it)
     return !off && band >= 64 && band + 1 <= 64 * FA_ALIGN_MAXCH - 1 && b->n_words < (1ull << 28);
 }
 
@@ -1288,6 +1288,7 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
         b->stats.align_parkings = (long long)st[3];
         b->stats.align_handed_back = (long long)st[4];
         b->stats.align_wide_rows = (long long)st[5];
+        b->stats.align_replacements = (long long)st[7];
     } else {
         b->stats.align_slots = c->arena.n_slot;
         b->stats.align_slot_cells = (long long)c->arena.cells_per_slot;
@@ -1295,6 +1296,7 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
                                      (long long)c->arena2_cells_bytes + 2 * (long long)c->arena2_rows_bytes;
         b->stats.align_pair_iterations = b->stats.align_single_iterations = b->stats.align_placements = 0;
         b->stats.align_parkings = b->stats.align_handed_back = b->stats.align_wide_rows = 0;
+        b->stats.align_replacements = 0;
     }
     b->in_flight = true;
     return 0;

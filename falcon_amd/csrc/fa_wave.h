@@ -47,15 +47,19 @@ W_FN u32 w_uniu(u32 v) { return fa_uni(v); }
 // inclusive prefix maximum over the lanes, unsigned: 4 in-row DPP steps, then the two row
 // broadcasts (lanes without a source keep their value)
 W_FN vu w_prefix_max(vu v) {
+    // (the first step writes a fresh register -- lanes without a source read 0, the identity
+    // of an unsigned maximum -- so the argument survives without a copy)
+    vu t;
     asm volatile("s_nop 1\n\t"
-                 "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
                  "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
                  "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
                  "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
                  "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
                  "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
-                 : "+v"(v));
-    return v;
+                 : "=&v"(t)
+                 : "v"(v));
+    return t;
 }
 
 W_FN vi w_min(vi a, vi b) { return min(a, b); }
@@ -90,6 +94,18 @@ template <int J>
 W_FN vu w_put_byte(vu acc, vu m) {
     return __builtin_amdgcn_perm(m, acc, 0x03020100u + ((4u - (u32)J) << (8 * J)));
 }
+// the same with the byte position in a wave-uniform selector (see a2_fast)
+W_FN vu w_put_byte_sel(vu acc, vu m, u32 selector) { return __builtin_amdgcn_perm(m, acc, selector); }
+// wave-uniform values travel through calls in the lanes of a register (an out-of-line
+// device function takes and returns its arguments in VGPRs): lane I of p := s / is read
+template <int I>
+W_FN void w_pack_put(vu &p, u32 s) {
+    // (the compiler keeps some uniform values on the vector unit: readfirstlane is free for
+    // the ones that are in SGPRs already)
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(p) : "s"(fa_uni(s)), "n"(I));
+}
+template <int I>
+W_FN u32 w_pack_get(vu p) { return (u32)__builtin_amdgcn_readlane((int)p, I); }
 // a register whose content does not matter yet (no instruction)
 W_FN vu w_undef() {
     vu v;

@@ -29,11 +29,14 @@ int fa_align2_blocks_per_cu() {
     return nb;
 }
 
-// the tape ring for alignments of up to `max_rows` rows: the smallest power of two that
-// holds one alignment's rows twice (a track may wait, parked, while its neighbour runs)
+// The tape ring for a batch whose longest alignment may take `max_rows` rows (the bound of
+// DW_banded.c:149, 0.3 (q + t); alignments that end up accepted walk ~0.2 (q + t)): the
+// smallest power of two that holds 0.6 x that bound.  An alignment is admitted when its
+// own bound fits the ring outright, or 0.6 x it does with room to wait parked; the few that
+// then do outgrow the tape are handed back.
 u32 fa_align2_ring_for(int max_rows) {
     u32 r = 1024;
-    while (r < 2u * (u32)max_rows + 256u && r < (1u << 20)) r <<= 1;
+    while (r < (u32)((u64)max_rows * 6 / 10) + 512u && r < (1u << 20)) r <<= 1;
     return r;
 }
 

@@ -44,14 +44,14 @@
 #define A2_WIDE_RING 256        // LDS ring of a wide row's V values, per row parity (<= 191 live diagonals)
 #define A2_LDS_WORDS (256 + 2 * A2_WIDE_RING)  // trace-back staging + the two rings
 #ifndef A2_FREE_MIN
-#define A2_FREE_MIN 8           // free lanes two running tracks need to stay paired
+#define A2_FREE_MIN 4           // free lanes two running tracks need to stay paired
 #endif
 #ifndef A2_FREE_JOIN
-#define A2_FREE_JOIN 14         // ... and to (re)join a parked or a new track
+#define A2_FREE_JOIN 6          // ... and to (re)join a parked or a new track
 #endif
 #define A2_MAX_N 60             // widest band a track may have (alone in the wave)
 #ifndef A2_LOOK_EVERY
-#define A2_LOOK_EVERY 32        // iterations a track runs alone before the wave checks whether its parked neighbour fits again
+#define A2_LOOK_EVERY 16        // iterations a track runs alone before the wave checks whether its parked neighbour fits again
 #endif
 #define A2_ESC_CAP 1024         // escape entries per slot (snakes of >= 255 bases)
 #define A2_WIDE_PATIENCE 128    // wide rows a track may take while its neighbour waits
@@ -76,6 +76,7 @@ struct A2Args {
     double max_diff;
     unsigned long long *stats;  // 8 counters (see A2_STAT_*)
 };
+// pair / single iterations, placements, parkings, hand-backs, wide rows, wide episodes, recenterings
 enum { A2_STAT_PAIR_IT = 0, A2_STAT_SINGLE_IT, A2_STAT_PLACE, A2_STAT_PARK, A2_STAT_BAIL,
        A2_STAT_ESC, A2_STAT_EXT, A2_STAT_TRACKS };
 
@@ -178,7 +179,7 @@ struct A2Hot {    // wave-uniform
 
 // Returns the lanes that held a cell in this row.
 template <int P, int J, bool PAIR>
-W_FN u64 a2_row(A2Hot &h, A2HotV &hv, const u32 *words, u64 *esc, int band) {
+W_FN u64 a2_row(A2Hot &h, A2HotV &hv, const u32 *words, u64 *esc, int band, u32 byte_sel = 0u) {
     const u64 act = h.act;
     // V[k-1] + 1 and V[k+1] of the previous row (DW_banded.c:190-196)
     vi a1, b;
@@ -225,7 +226,8 @@ W_FN u64 a2_row(A2Hot &h, A2HotV &hv, const u32 *words, u64 *esc, int band) {
         }
     }
     // the cell byte: the snake length
-    hv.vacc = w_put_byte<J>(hv.vacc, m);
+    if (J >= 0) hv.vacc = w_put_byte<(J >= 0 ? J : 0)>(hv.vacc, m);
+    else hv.vacc = w_put_byte_sel(hv.vacc, m, byte_sel);  // (J < 0: the position comes as a v_perm selector)
     hv.vx = x;
     const u64 fin = (w_ballot(x >= hv.vqlen) | w_ballot(y >= hv.vtlen)) & act;  // :220
     w_writelane2(hv.rc_mlo, hv.rc_mhi, (u32)fa, (u32)(fa >> 32), (int)(h.it & 63u));
@@ -254,11 +256,11 @@ W_FN u64 a2_row(A2Hot &h, A2HotV &hv, const u32 *words, u64 *esc, int band) {
             h.lo0 = w_lowest(in0); h.hi0 = w_highest(in0) + 1;
             h.lo1 = w_lowest(in1); h.hi1 = w_highest(in1) + 1;
         }
-        h.act = w_lanes(h.lo0 & 63, h.hi0 - h.lo0 + 1) | w_lanes(h.lo1 & 63, h.hi1 - h.lo1 + 1);
+        h.act = w_lanes(h.lo0, h.hi0 - h.lo0 + 1) | w_lanes(h.lo1, h.hi1 - h.lo1 + 1);  // (s_bfm takes both modulo 64)
     } else {
         if (P == 0) { h.lo0 = w_lowest(in) - 1; h.hi0 = w_highest(in); }
         else        { h.lo0 = w_lowest(in); h.hi0 = w_highest(in) + 1; }
-        h.act = w_lanes(h.lo0 & 63, h.hi0 - h.lo0 + 1);
+        h.act = w_lanes(h.lo0, h.hi0 - h.lo0 + 1);
     }
     h.fin = fin;
     h.ev = fin | (in & (P == 0 ? h.forbid_to1 : h.forbid_to0));
@@ -286,7 +288,7 @@ struct A2Wave {    // wave-uniform
     u32 *cells, *recs;
     u64 *esc;
     // statistics of this wavefront
-    u32 st_pair, st_single, st_place, st_park, st_bail, st_tracks, st_wide, st_wide_rows;
+    u32 st_pair, st_single, st_place, st_park, st_bail, st_tracks, st_wide, st_wide_rows, st_recenter;
 };
 
 W_FN void a2_result(const A2Args &A, int g, int err, int aligned, int dist, int q_e, int t_e, int n_ins,
@@ -325,7 +327,10 @@ W_FN bool a2_fetch(const A2Args &A, A2Track &t) {
             a2_result(A, g, 0, 0, 0, 0, 0, 0, 0);
             continue;
         }
-        if ((u32)max_d + 192u > A.ring) {  // its rows would not fit the tape: the general kernel's
+        // its rows must fit the tape: by their bound, or -- alignments that succeed walk two
+        // thirds of it at most -- by half the bound with an eighth of the ring to spare (one
+        // that then goes on and on is handed back when the tape is used up)
+        if ((u32)max_d + 192u > A.ring && (u32)max_d / 2u + A.ring / 8u > A.ring) {
             a2_result(A, g, 2, 0, 0, 0, 0, 0, 0);
             continue;
         }
@@ -549,53 +554,203 @@ W_FN void a2_flush_partial(const A2Args &A, A2Wave &w, A2Lanes &wl) {
 // the row loop: runs until a row finishes a track, a band hull reaches a forbidden lane,
 // or `budget` iterations are done
 // ---------------------------------------------------------------------------------------
-template <bool PAIR>
-W_FN void a2_after_row(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV &hv) {
-    // (h.it is the iteration after the row)
-    const vi lane = w_lane();
-    if ((h.it & 3u) == 0u)
-        w_store32(w.cells, (((h.it >> 2) - 1u) & ((A.ring >> 2) - 1u)) * 64u + (vu)lane, hv.vacc);
-    if ((h.it & 63u) == 0u) {
-        w_store_x4(w.recs, ((h.it - 64u) & (A.ring - 1u)) + (vu)lane, hv.rc_mlo, hv.rc_mhi, wl.rc_k0, wl.rc_k1);
-        wl.rc_k0 = h.kb0;
-        wl.rc_k1 = h.kb1;
-    }
-}
+
+// ---------------------------------------------------------------------------------------
+// The row loop proper, OUT OF LINE: inlined into the wavefront's event loop, hipcc folds it
+// into that loop's state machine and every row pays for the copies at its joins (k_align.hip
+// met the same).  Its state travels by value: the per-lane registers as they are, the
+// wave-uniform ones in the lanes of one more register (a device function takes and returns
+// everything in VGPRs).  Runs rows -- pairs of an even and an odd iteration -- until a row
+// raises an event or iteration `it_end` is reached.
+// ---------------------------------------------------------------------------------------
+struct A2Regs {
+    vi vx, vnegk, vqlen, vtlen;
+    vu vqb, vtb, vtop, vacc, rc_mlo, rc_mhi, rc_k0, rc_k1;
+    vu sc;  // lane i: the i-th wave-uniform value (A2_SC_*)
+};
+enum { A2_SC_ACT_LO = 0, A2_SC_ACT_HI, A2_SC_LO0, A2_SC_HI0, A2_SC_LO1, A2_SC_HI1, A2_SC_BEST0, A2_SC_BEST1,
+       A2_SC_CELLS0, A2_SC_CELLS1, A2_SC_SPLIT, A2_SC_IT, A2_SC_NESC, A2_SC_KB0, A2_SC_KB1, A2_SC_IT_END,
+       A2_SC_FIN_LO, A2_SC_FIN_HI, A2_SC_EV_LO, A2_SC_EV_HI, A2_SC_ROW_LO, A2_SC_ROW_HI,
+       A2_SC_WORDS_LO, A2_SC_WORDS_HI, A2_SC_CELLS_LO, A2_SC_CELLS_HI, A2_SC_RECS_LO, A2_SC_RECS_HI,
+       A2_SC_ESC_LO, A2_SC_ESC_HI, A2_SC_RING, A2_SC_BAND };
 
 template <bool PAIR>
-W_FN void a2_rows(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV &hv, int budget) {
-    const u32 it_end = h.it + (u32)budget;
-#define A2_ROW(P, J)                                                              \
-    {                                                                             \
-        const u64 lanes_ = a2_row<P, J, PAIR>(h, hv, A.words, w.esc, A.band);         \
-        if (h.ev) { h.act_row = lanes_; }                                         \
+W_NOINLINE A2Regs a2_fast(A2Regs r) {
+    A2HotV hv;
+    hv.vx = r.vx; hv.vnegk = r.vnegk; hv.vqlen = r.vqlen; hv.vtlen = r.vtlen;
+    hv.vqb = r.vqb; hv.vtb = r.vtb; hv.vtop = r.vtop; hv.vacc = r.vacc;
+    hv.rc_mlo = r.rc_mlo; hv.rc_mhi = r.rc_mhi;
+    vu rc_k0 = r.rc_k0, rc_k1 = r.rc_k1;
+    A2Hot h;
+    h.act = ((u64)w_pack_get<A2_SC_ACT_HI>(r.sc) << 32) | w_pack_get<A2_SC_ACT_LO>(r.sc);
+    h.lo0 = (int)w_pack_get<A2_SC_LO0>(r.sc); h.hi0 = (int)w_pack_get<A2_SC_HI0>(r.sc);
+    h.lo1 = (int)w_pack_get<A2_SC_LO1>(r.sc); h.hi1 = (int)w_pack_get<A2_SC_HI1>(r.sc);
+    h.best0 = (int)w_pack_get<A2_SC_BEST0>(r.sc); h.best1 = (int)w_pack_get<A2_SC_BEST1>(r.sc);
+    h.cells0 = w_pack_get<A2_SC_CELLS0>(r.sc); h.cells1 = w_pack_get<A2_SC_CELLS1>(r.sc);
+    h.split = (int)w_pack_get<A2_SC_SPLIT>(r.sc);
+    h.it = w_pack_get<A2_SC_IT>(r.sc);
+    h.n_esc = (int)w_pack_get<A2_SC_NESC>(r.sc);
+    h.kb0 = w_pack_get<A2_SC_KB0>(r.sc); h.kb1 = w_pack_get<A2_SC_KB1>(r.sc);
+    const u32 it_end = w_pack_get<A2_SC_IT_END>(r.sc);
+    const u32 *words = (const u32 *)(((u64)w_pack_get<A2_SC_WORDS_HI>(r.sc) << 32) | w_pack_get<A2_SC_WORDS_LO>(r.sc));
+    u32 *cells = (u32 *)(((u64)w_pack_get<A2_SC_CELLS_HI>(r.sc) << 32) | w_pack_get<A2_SC_CELLS_LO>(r.sc));
+    u32 *recs = (u32 *)(((u64)w_pack_get<A2_SC_RECS_HI>(r.sc) << 32) | w_pack_get<A2_SC_RECS_LO>(r.sc));
+    u64 *esc = (u64 *)(((u64)w_pack_get<A2_SC_ESC_HI>(r.sc) << 32) | w_pack_get<A2_SC_ESC_LO>(r.sc));
+    const u32 ring = w_pack_get<A2_SC_RING>(r.sc);
+    const int band = (int)w_pack_get<A2_SC_BAND>(r.sc);
+    if (PAIR) {
+        h.zone1 = ~0ull << h.split;
+        h.forbid_to1 = 1ull | (1ull << h.split);
+        h.forbid_to0 = (1ull << (h.split - 1)) | (1ull << 63);
+    } else {
+        h.zone1 = 0ull;
+        h.forbid_to1 = h.forbid_to0 = 1ull | (1ull << 63);
     }
+    h.fin = 0ull; h.ev = 0ull; h.act_row = 0ull;
+    const vi lane = w_lane();
+    // the cell byte of an iteration is byte it & 3 of the lane's word: v_perm selectors that
+    // put it there, alternating between (0, 1) and (2, 3) with every pair of rows
+    u32 sel_even = (h.it & 2u) ? 0x03040100u : 0x03020104u;
+    u32 sel_odd = (h.it & 2u) ? 0x04020100u : 0x03020400u;
     for (;;) {
-        if (h.ev || (int)(it_end - h.it) <= 0) break;
-        if ((h.it & 3u) == 0u && (int)(it_end - h.it) >= 4) {
-            // whole groups of four iterations
-            for (;;) {
-                A2_ROW(0, 0);
-                if (h.ev) break;
-                A2_ROW(1, 1);
-                if (h.ev) break;
-                A2_ROW(0, 2);
-                if (h.ev) break;
-                A2_ROW(1, 3);
-                a2_after_row<PAIR>(A, w, wl, h, hv);
-                if (h.ev || (int)(it_end - h.it) < 4) break;
-            }
-        } else {
-            switch (h.it & 3u) {
-                case 0: A2_ROW(0, 0); break;
-                case 1: A2_ROW(1, 1); break;
-                case 2: A2_ROW(0, 2); break;
-                default: A2_ROW(1, 3); break;
-            }
-            a2_after_row<PAIR>(A, w, wl, h, hv);
+        if ((h.it & 1u) == 0u) {  // (a call may begin at an odd iteration: then with the odd row)
+            const u64 lanes_ = a2_row<0, -1, PAIR>(h, hv, words, esc, band, sel_even);
+            if (h.ev) { h.act_row = lanes_; break; }
+            if (h.it == it_end) break;
         }
+        const u64 lanes_ = a2_row<1, -1, PAIR>(h, hv, words, esc, band, sel_odd);
+        if ((h.it & 3u) == 0u)
+            w_store32(cells, (((h.it >> 2) - 1u) & ((ring >> 2) - 1u)) * 64u + (vu)lane, hv.vacc);
+        if ((h.it & 63u) == 0u) {
+            w_store_x4(recs, ((h.it - 64u) & (ring - 1u)) + (vu)lane, hv.rc_mlo, hv.rc_mhi, rc_k0, rc_k1);
+            rc_k0 = h.kb0;
+            rc_k1 = h.kb1;
+        }
+        sel_even ^= 0x03040100u ^ 0x03020104u;
+        sel_odd ^= 0x04020100u ^ 0x03020400u;
+        if (h.ev) { h.act_row = lanes_; break; }
+        if (h.it == it_end) break;
     }
-#undef A2_ROW
+    r.vx = hv.vx; r.vacc = hv.vacc; r.rc_mlo = hv.rc_mlo; r.rc_mhi = hv.rc_mhi;
+    r.rc_k0 = rc_k0; r.rc_k1 = rc_k1;
+    w_pack_put<A2_SC_ACT_LO>(r.sc, (u32)h.act); w_pack_put<A2_SC_ACT_HI>(r.sc, (u32)(h.act >> 32));
+    w_pack_put<A2_SC_LO0>(r.sc, (u32)h.lo0); w_pack_put<A2_SC_HI0>(r.sc, (u32)h.hi0);
+    w_pack_put<A2_SC_LO1>(r.sc, (u32)h.lo1); w_pack_put<A2_SC_HI1>(r.sc, (u32)h.hi1);
+    w_pack_put<A2_SC_BEST0>(r.sc, (u32)h.best0); w_pack_put<A2_SC_BEST1>(r.sc, (u32)h.best1);
+    w_pack_put<A2_SC_CELLS0>(r.sc, h.cells0); w_pack_put<A2_SC_CELLS1>(r.sc, h.cells1);
+    w_pack_put<A2_SC_IT>(r.sc, h.it);
+    w_pack_put<A2_SC_NESC>(r.sc, (u32)h.n_esc);
+    w_pack_put<A2_SC_FIN_LO>(r.sc, (u32)h.fin); w_pack_put<A2_SC_FIN_HI>(r.sc, (u32)(h.fin >> 32));
+    w_pack_put<A2_SC_EV_LO>(r.sc, (u32)h.ev); w_pack_put<A2_SC_EV_HI>(r.sc, (u32)(h.ev >> 32));
+    w_pack_put<A2_SC_ROW_LO>(r.sc, (u32)h.act_row); w_pack_put<A2_SC_ROW_HI>(r.sc, (u32)(h.act_row >> 32));
+    return r;
+}
+
+// the call: marshal, run, take the state back
+template <bool PAIR>
+W_FN void a2_fast_call(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV &hv, u32 it_end) {
+    A2Regs r;
+    r.vx = hv.vx; r.vnegk = hv.vnegk; r.vqlen = hv.vqlen; r.vtlen = hv.vtlen;
+    r.vqb = hv.vqb; r.vtb = hv.vtb; r.vtop = hv.vtop; r.vacc = hv.vacc;
+    r.rc_mlo = hv.rc_mlo; r.rc_mhi = hv.rc_mhi; r.rc_k0 = wl.rc_k0; r.rc_k1 = wl.rc_k1;
+    r.sc = w_undef();
+    w_pack_put<A2_SC_ACT_LO>(r.sc, (u32)h.act); w_pack_put<A2_SC_ACT_HI>(r.sc, (u32)(h.act >> 32));
+    w_pack_put<A2_SC_LO0>(r.sc, (u32)h.lo0); w_pack_put<A2_SC_HI0>(r.sc, (u32)h.hi0);
+    w_pack_put<A2_SC_LO1>(r.sc, (u32)h.lo1); w_pack_put<A2_SC_HI1>(r.sc, (u32)h.hi1);
+    w_pack_put<A2_SC_BEST0>(r.sc, (u32)h.best0); w_pack_put<A2_SC_BEST1>(r.sc, (u32)h.best1);
+    w_pack_put<A2_SC_CELLS0>(r.sc, h.cells0); w_pack_put<A2_SC_CELLS1>(r.sc, h.cells1);
+    w_pack_put<A2_SC_SPLIT>(r.sc, (u32)h.split);
+    w_pack_put<A2_SC_IT>(r.sc, h.it);
+    w_pack_put<A2_SC_NESC>(r.sc, (u32)h.n_esc);
+    w_pack_put<A2_SC_KB0>(r.sc, h.kb0); w_pack_put<A2_SC_KB1>(r.sc, h.kb1);
+    w_pack_put<A2_SC_IT_END>(r.sc, it_end);
+    w_pack_put<A2_SC_WORDS_LO>(r.sc, (u32)(u64)A.words); w_pack_put<A2_SC_WORDS_HI>(r.sc, (u32)((u64)A.words >> 32));
+    w_pack_put<A2_SC_CELLS_LO>(r.sc, (u32)(u64)w.cells); w_pack_put<A2_SC_CELLS_HI>(r.sc, (u32)((u64)w.cells >> 32));
+    w_pack_put<A2_SC_RECS_LO>(r.sc, (u32)(u64)w.recs); w_pack_put<A2_SC_RECS_HI>(r.sc, (u32)((u64)w.recs >> 32));
+    w_pack_put<A2_SC_ESC_LO>(r.sc, (u32)(u64)w.esc); w_pack_put<A2_SC_ESC_HI>(r.sc, (u32)((u64)w.esc >> 32));
+    w_pack_put<A2_SC_RING>(r.sc, A.ring);
+    w_pack_put<A2_SC_BAND>(r.sc, (u32)A.band);
+    r = a2_fast<PAIR>(r);
+    hv.vx = r.vx; hv.vacc = r.vacc; hv.rc_mlo = r.rc_mlo; hv.rc_mhi = r.rc_mhi;
+    wl.rc_k0 = r.rc_k0; wl.rc_k1 = r.rc_k1;
+    h.act = ((u64)w_pack_get<A2_SC_ACT_HI>(r.sc) << 32) | w_pack_get<A2_SC_ACT_LO>(r.sc);
+    h.lo0 = (int)w_pack_get<A2_SC_LO0>(r.sc); h.hi0 = (int)w_pack_get<A2_SC_HI0>(r.sc);
+    h.lo1 = (int)w_pack_get<A2_SC_LO1>(r.sc); h.hi1 = (int)w_pack_get<A2_SC_HI1>(r.sc);
+    h.best0 = (int)w_pack_get<A2_SC_BEST0>(r.sc); h.best1 = (int)w_pack_get<A2_SC_BEST1>(r.sc);
+    h.cells0 = w_pack_get<A2_SC_CELLS0>(r.sc); h.cells1 = w_pack_get<A2_SC_CELLS1>(r.sc);
+    h.it = w_pack_get<A2_SC_IT>(r.sc);
+    h.n_esc = (int)w_pack_get<A2_SC_NESC>(r.sc);
+    h.fin = ((u64)w_pack_get<A2_SC_FIN_HI>(r.sc) << 32) | w_pack_get<A2_SC_FIN_LO>(r.sc);
+    h.ev = ((u64)w_pack_get<A2_SC_EV_HI>(r.sc) << 32) | w_pack_get<A2_SC_EV_LO>(r.sc);
+    h.act_row = ((u64)w_pack_get<A2_SC_ROW_HI>(r.sc) << 32) | w_pack_get<A2_SC_ROW_LO>(r.sc);
+}
+
+// A band hull reached the edge of its track's lanes and no track finished: lay the running
+// tracks out again without leaving the row loop -- both side by side with the free lanes
+// shared out afresh (the boundary between them moves), or the single running track back to
+// the middle of the wave.  A few dozen instructions; what it cannot do (the two bands no
+// longer fit together: one has to be parked) is a2_place's business.  Returns true when the
+// rows can go on.
+template <bool PAIR>
+W_FN bool a2_replace(A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV &hv) {
+    if (h.fin) return false;
+    const vi lane = w_lane();
+    const u64 ahead = ~0ull << (h.it & 63u);  // the tape from this iteration on
+    const int n0 = h.hi0 - h.lo0 + 1;
+    if (PAIR) {
+        const int n1 = h.hi1 - h.lo1 + 1, free_lanes = 64 - n0 - n1;
+        if (free_lanes < A2_FREE_MIN) return false;
+        const int g0 = free_lanes / 4, mid = free_lanes / 2;
+        const int sh0 = h.lo0 - g0, sh1 = h.lo1 - (g0 + n0 + mid);
+        h.split = g0 + n0 + mid / 2;
+        h.zone1 = ~0ull << h.split;
+        h.forbid_to1 = 1ull | (1ull << h.split);
+        h.forbid_to0 = (1ull << (h.split - 1)) | (1ull << 63);
+        w.split = h.split;
+        const vi vsh = w_sel(h.zone1, sh0, sh1);
+        hv.vx = w_gather_lanes(hv.vx, (lane + vsh) & 63);  // new lane l: what lane l + sh held
+        h.lo0 -= sh0; h.hi0 -= sh0; h.lo1 -= sh1; h.hi1 -= sh1;
+        h.kb0 += (u32)(2 * sh0); h.kb1 += (u32)(2 * sh1);  // (the diagonals go with the rows)
+        hv.vnegk = w_sel(h.zone1, 1 - (int)h.kb0, 1 - (int)h.kb1) - 2 * lane;
+        hv.vqlen = w_sel(h.zone1, w.T0.q_len, w.T1.q_len);
+        hv.vtlen = w_sel(h.zone1, w.T0.t_len, w.T1.t_len);
+        hv.vqb = w_selu(h.zone1, w.T0.qb, w.T1.qb);
+        hv.vtb = w_selu(h.zone1, w.T0.tb, w.T1.tb);
+        hv.vtop = w_selu(h.zone1, 0u, 0x80000000u);
+        wl.rc_k0 = w_selu(ahead, wl.rc_k0, h.kb0);
+        wl.rc_k1 = w_selu(ahead, wl.rc_k1, h.kb1);
+        h.act = w_lanes(h.lo0, n0) | w_lanes(h.lo1, n1);
+    } else {
+        if (n0 > A2_MAX_N) return false;
+        const int sh0 = h.lo0 - (64 - n0) / 2;
+        hv.vx = w_gather_lanes(hv.vx, (lane + sh0) & 63);
+        hv.vnegk = hv.vnegk - 2 * sh0;
+        h.lo0 -= sh0; h.hi0 -= sh0;
+        if (h.kb0 != A2_INVALID) { h.kb0 += (u32)(2 * sh0); wl.rc_k0 = w_selu(ahead, wl.rc_k0, h.kb0); }
+        else                     { h.kb1 += (u32)(2 * sh0); wl.rc_k1 = w_selu(ahead, wl.rc_k1, h.kb1); }
+        h.act = w_lanes(h.lo0, n0);
+    }
+    h.ev = 0ull;
+    w.st_recenter++;
+    return true;
+}
+
+// `budget`: iterations at most (the rows the tracks have left).  `join_at` (single mode with
+// a parked neighbour; else 0): every A2_LOOK_EVERY iterations the loop looks at the running
+// band, and leaves when it has become narrow enough (<= join_at lanes) for the neighbour to
+// join again.
+template <bool PAIR>
+W_FN void a2_rows(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV &hv, int budget, int join_at) {
+    const u32 it_last = h.it + (u32)budget;
+    u32 it_end = (!PAIR && join_at > 0 && budget > A2_LOOK_EVERY) ? h.it + A2_LOOK_EVERY : it_last;
+    for (;;) {
+        if (h.ev && !a2_replace<PAIR>(w, wl, h, hv)) break;
+        if ((int)(it_end - h.it) <= 0) {
+            if (PAIR || it_end == it_last || h.hi0 - h.lo0 + 1 <= join_at) break;
+            it_end = ((int)(it_last - it_end) > A2_LOOK_EVERY) ? it_end + A2_LOOK_EVERY : it_last;
+        }
+        a2_fast_call<PAIR>(A, w, wl, h, hv, it_end);
+    }
 }
 
 W_FN u64 a2_zone(const A2Wave &w, int ti) {
@@ -800,7 +955,7 @@ W_FN void a2_wave(const A2Args &A, int slot) {
     w.cells = A.cells + (u64)slot * A.slot_words;
     w.recs = w.cells + (u64)A.ring * 16u;
     w.esc = (u64 *)(w.recs + (u64)A.ring * 4u);
-    w.st_pair = w.st_single = w.st_place = w.st_park = w.st_bail = w.st_tracks = w.st_wide = w.st_wide_rows = 0;
+    w.st_pair = w.st_single = w.st_place = w.st_park = w.st_bail = w.st_tracks = w.st_wide = w.st_wide_rows = w.st_recenter = 0;
     for (;;) {
         // ---- fill the free tracks
         if (w.T0.state == A2_IDLE && w.more) { w.more = a2_fetch(A, w.T0); if (w.more) w.st_tracks++; }
@@ -832,13 +987,14 @@ W_FN void a2_wave(const A2Args &A, int slot) {
             w.n_esc = kept;
         }
         // ---- the tape must keep every row of the tracks in flight: whoever has been on it
-        // for too long (parked while its neighbour ran) is handed back
-        {
-            const int span0 = (w.T0.state != A2_IDLE && w.T0.d > 0) ? (int)(w.it - w.T0.it0) + (w.T0.max_d - w.T0.d) : 0;
-            const int span1 = (w.T1.state != A2_IDLE && w.T1.d > 0) ? (int)(w.it - w.T1.it0) + (w.T1.max_d - w.T1.d) : 0;
-            const int lim = (int)A.ring - 128;
-            if (span0 > lim && span0 >= span1) { a2_hand_back(A, w, w.T0); continue; }
-            if (span1 > lim) { a2_hand_back(A, w, w.T1); continue; }
+        // for nearly a whole ring (parked for long while its neighbour ran, or longer than
+        // the ring to begin with) is handed back; the rows below never run past what is left
+        const int span0 = (w.T0.state != A2_IDLE && w.T0.d > 0) ? (int)(w.it - w.T0.it0) : 0;
+        const int span1 = (w.T1.state != A2_IDLE && w.T1.d > 0) ? (int)(w.it - w.T1.it0) : 0;
+        const int tape_left = (int)A.ring - 192 - max(span0, span1);
+        if (tape_left < 64) {
+            if (span0 >= span1) a2_hand_back(A, w, w.T0); else a2_hand_back(A, w, w.T1);
+            continue;
         }
         const int rc = a2_place(w, wl);
         if (rc) {
@@ -889,8 +1045,8 @@ W_FN void a2_wave(const A2Args &A, int slot) {
             h.act = w_lanes(h.lo0, h.hi0 - h.lo0 + 1) | w_lanes(h.lo1, h.hi1 - h.lo1 + 1);
             h.forbid_to1 = 1ull | (1ull << w.split);
             h.forbid_to0 = (1ull << (w.split - 1)) | (1ull << 63);
-            budget = min(w.T0.max_d - w.T0.d, w.T1.max_d - w.T1.d);
-            a2_rows<true>(A, w, wl, h, hv, budget);
+            budget = min(min(w.T0.max_d - w.T0.d, w.T1.max_d - w.T1.d), tape_left);
+            a2_rows<true>(A, w, wl, h, hv, budget, 0);
         } else {
             // the running track plays "track 0" of the row loop, whichever it is.  (Its fields
             // are picked value by value: a reference chosen at run time would force both
@@ -911,11 +1067,15 @@ W_FN void a2_wave(const A2Args &A, int slot) {
             h.act = w_lanes(h.lo0, h.hi0 - h.lo0 + 1);
             // (both edge lanes, whatever the phase: the band then never spans all 64 lanes)
             h.forbid_to1 = h.forbid_to0 = 1ull | (1ull << 63);
-            budget = (run0 ? w.T0.max_d : w.T1.max_d) - t_d;
-            // (a parked neighbour waits for a look at the bands every now and then)
-            const bool waiting = (w.T0.state == A2_PARKED) || (w.T1.state == A2_PARKED);
-            if (waiting) budget = min(budget, A2_LOOK_EVERY);
-            a2_rows<false>(A, w, wl, h, hv, budget);
+            budget = min((run0 ? w.T0.max_d : w.T1.max_d) - t_d, tape_left);
+            // (a parked neighbour joins again when the two bands fit with room to spare)
+            int join_at = 0;
+            if (w.T0.state == A2_PARKED || w.T1.state == A2_PARKED) {
+                int plo, phi;
+                if (w.T0.state == A2_PARKED) a2_next_band(w.T0, 0, plo, phi); else a2_next_band(w.T1, 0, plo, phi);
+                join_at = max(1, 64 - A2_FREE_JOIN - (phi - plo + 1));
+            }
+            a2_rows<false>(A, w, wl, h, hv, budget, join_at);
         }
         // ---- back from the row loop
         const int done_it = (int)(h.it - it_in);
@@ -970,7 +1130,7 @@ W_FN void a2_wave(const A2Args &A, int slot) {
         w_stat_add(A.stats + A2_STAT_PLACE, w.st_place);
         w_stat_add(A.stats + A2_STAT_PARK, w.st_park);
         w_stat_add(A.stats + A2_STAT_BAIL, w.st_bail);
-        w_stat_add(A.stats + A2_STAT_TRACKS, w.st_tracks);
+        w_stat_add(A.stats + A2_STAT_TRACKS, w.st_recenter);
         w_stat_add(A.stats + A2_STAT_EXT, w.st_wide);
         w_stat_add(A.stats + A2_STAT_ESC, w.st_wide_rows);
     }

@@ -144,7 +144,7 @@ typedef struct {
      * both tracks / one track running, band placements, parkings, alignments handed back */
     long long align_arena_bytes;
     long long align_pair_iterations, align_single_iterations, align_placements, align_parkings,
-        align_handed_back, align_wide_rows;
+        align_handed_back, align_wide_rows, align_replacements /* inside the row loop */;
 } fa_stats;
 
 const char *fa_last_error(void);

@@ -131,6 +131,19 @@ W_FN vu w_put_byte(const vu &acc, const vu &m) {
     return r;
 }
 
+W_FN vu w_put_byte_sel(const vu &acc, const vu &m, u32 selector) {
+    vu r;  // v_perm_b32: result byte i = byte (selector byte i) of {m (4..7), acc (0..3)}
+    for (int l = 0; l < 64; l++) {
+        const uint64_t both = ((uint64_t)m.v[l] << 32) | acc.v[l];
+        u32 o = 0;
+        for (int i = 0; i < 4; i++) o |= (u32)((both >> (8 * ((selector >> (8 * i)) & 7u))) & 0xffu) << (8 * i);
+        r.v[l] = o;
+    }
+    return r;
+}
+template <int I> W_FN void w_pack_put(vu &p, u32 s) { p.v[I] = s; }
+template <int I> W_FN u32 w_pack_get(const vu &p) { return p.v[I]; }
+
 // ---- memory: loads and stores of the executing lanes; every access is bounds-checked
 // against the buffers the harness registered
 namespace emu {

@@ -38,10 +38,11 @@ def test_campaign_piles_on_the_gpu():
     from falcon_amd.engine import Engine
     eng = Engine(0)
     try:
-        n, bad, stale = camp.run_piles(eng, 0, 9, load_golden("f9_campaign"))
+        # the WHOLE frozen campaign: 300 pile seeds x 12 shapes (11 s on the GPU box)
+        n, bad, stale = camp.run_piles(eng, 0, 300, load_golden("f9_campaign"))
     finally:
         eng.close()
-    assert n == 108 and not stale and not bad, (bad, stale)
+    assert n == 3600 and not stale and not bad, (bad, stale)
 
 
 @pytest.mark.gpu
@@ -50,7 +51,8 @@ def test_campaign_pairs_on_the_gpu():
     from falcon_amd.engine import Engine
     eng = Engine(0)
     try:
-        n, bad, stale = camp.run_pairs(eng, 0, 8, load_golden("f9_campaign"))
+        # ... and all 256 pair seeds x 40 shapes over bands 10..1500 (7 s)
+        n, bad, stale = camp.run_pairs(eng, 0, 256, load_golden("f9_campaign"))
     finally:
         eng.close()
-    assert n == 320 and not stale and not bad, (bad, stale)
+    assert n == 10240 and not stale and not bad, (bad, stale)

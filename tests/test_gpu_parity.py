@@ -455,8 +455,11 @@ def test_bench_scale_batch_properties(engine):
         bt.free()
     assert r1 == r2                                     # rerunnable, deterministic
     assert st.n_piles == len(piles) and st.n_aligned > 60 * len(piles)
-    # the usual work slots (32 diagonals per row, not the worst case 151) hold this workload
-    assert st.align_relaunched == 0 and st.align_slot_cells * 4 < 3 * 1024 * 1024
+    # the tape arena (one-byte cells, 80 bytes per iteration) holds this workload: nothing is
+    # handed to the general kernel, and a wavefront's slot stays under 3 MB
+    assert st.align_relaunched == 0 and st.align_handed_back == 0
+    assert st.align_slot_cells // 64 * 80 < 3 * 1024 * 1024
+    assert st.align_pair_iterations > st.align_single_iterations // 4  # two tracks do run side by side
     assert all(len(c) > 19000 for c, _ in r1)           # every seed corrected end to end
     rev = engine.consensus(list(reversed(piles)), 4, 8, 0.70, want_eqv=True)
     assert rev == list(reversed(r1))                    # order of piles is irrelevant
@@ -466,19 +469,29 @@ def test_bench_scale_batch_properties(engine):
     assert len(digest) == 40
 
 
-def test_outgrown_alignment_slots_are_redone(monkeypatch, port):
-    """Alignment work slots are sized for what alignments use, not for the worst case
-    rows x (band + 1); an alignment that outgrows its slot is reported by the kernel
-    (nothing is written past the slot) and done again, alone, in one of a few worst-case
-    slots -- the usual slots stay as they are.  Forced here with slots of 2 diagonals per
-    row (nearly every alignment outgrows them): same results as the oracle, batch after
-    batch."""
+@pytest.mark.parametrize("kernel", ["two_per_wave", "one_per_wave"])
+def test_outgrown_alignment_slots_are_redone(monkeypatch, port, kernel):
+    """The alignment arena is sized for what alignments use, not for the worst case: an
+    alignment that outgrows what it was given is reported by the kernel (nothing is written
+    past a slot) and done again, alone, by the general kernel in one of a few worst-case
+    slots.  Forced here: k_align2 with a tape ring of 1024 iterations (alignments of more
+    than ~1700 rows are refused at the queue or handed back when their tape is used up),
+    k_align (FALCON_AMD_ALIGN1) with slots of 2 diagonals per row.  Same results as the
+    oracle, batch after batch."""
     from falcon_amd.engine import Engine
-    monkeypatch.setenv("FALCON_AMD_SLOT_WIDTH", "2")
-    piles = [
-        _synthetic(32, S=8000, coverage=25, min_read=1000, mean_read=5000, sd_read=2000),
-        _synthetic(34, S=6000, coverage=20, e=0.20, min_read=1000, mean_read=4000, sd_read=1500),
-    ]
+    if kernel == "two_per_wave":
+        monkeypatch.setenv("FALCON_AMD_RING", "1024")
+        piles = [
+            _synthetic(32, S=12000, coverage=25, min_read=1000, mean_read=7000, sd_read=3000),
+            _synthetic(34, S=9000, coverage=20, e=0.20, min_read=1000, mean_read=6000, sd_read=2500),
+        ]
+    else:
+        monkeypatch.setenv("FALCON_AMD_ALIGN1", "1")
+        monkeypatch.setenv("FALCON_AMD_SLOT_WIDTH", "2")
+        piles = [
+            _synthetic(32, S=8000, coverage=25, min_read=1000, mean_read=5000, sd_read=2000),
+            _synthetic(34, S=6000, coverage=20, e=0.20, min_read=1000, mean_read=4000, sd_read=1500),
+        ]
     want = [port.generate_consensus(p, 4, 8, 0.70) for p in piles]
     eng = Engine(0)
     try:
@@ -487,7 +500,7 @@ def test_outgrown_alignment_slots_are_redone(monkeypatch, port):
         st = b.stats()
         got = [b.result(i) for i in range(len(piles))]
         b.free()
-        assert 40 < st.align_relaunched <= st.n_seqs
+        assert 10 < st.align_relaunched <= st.n_seqs
         assert [tuple(x) for x in got] == [tuple(x) for x in want]
         b = eng.batch(piles[::-1])
         b.run(4, 8, 0.70).fetch(True)
