@@ -85,6 +85,7 @@ W_FN u64 w_bit_set(u64 m, int b) {
 W_FN int w_lowest(u64 m) { return __builtin_ctzll(m); }                 // m != 0
 W_FN int w_highest(u64 m) { return 63 - __builtin_clzll(m); }           // m != 0
 W_FN int w_popc(u64 m) { return __builtin_popcountll(m); }
+W_FN int w_span(u64 m) { return 64 - (__builtin_clzll(m) + __builtin_ctzll(m)); }  // highest - lowest + 1; m != 0
 // per lane: the number of set bits of m below the lane
 W_FN vi w_rank_in(u64 m) {
     return (vi)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));

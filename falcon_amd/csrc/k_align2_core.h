@@ -39,6 +39,7 @@
 #error "include fa_wave.h (the product's, or the lane emulator's twin under tests/emu) before k_align2_core.h"
 #endif
 
+#define A2_NEG (-(1 << 29))      // "x" of the lanes outside a band's hull: loses every comparison
 #define A2_INVALID 0x80000000u  // tape record: the track computed no row in this iteration
 #define A2_CONT 0x80000001u     // ... or: cells 64.. of the row the iteration before began (wide rows)
 #define A2_WIDE_RING 256        // LDS ring of a wide row's V values, per row parity (<= 191 live diagonals)
@@ -163,7 +164,8 @@ struct A2HotV {   // per lane
 };
 struct A2Hot {    // wave-uniform
     u64 act;          // lanes holding a cell in the next row
-    int lo0, hi0, lo1, hi1;  // the two bands of the next row
+    u64 in;           // lanes of the last row inside the band filter (their hulls: what the next bands grow from)
+    int lo0, hi0, lo1, hi1;  // the two bands of the next row (set where the rows begin and end, not by the rows)
     int best0, best1; // best_m per track (track 1's carries the key's top bit)
     u32 cells0, cells1;
     int split;        // PAIR: first lane of track 1
@@ -175,6 +177,7 @@ struct A2Hot {    // wave-uniform
     u32 it;
     int n_esc;
     u32 kb0, kb1;     // what the tape records say about the two tracks (lane-0 diagonal | A2_INVALID)
+    u32 n_replace;    // in-loop re-placements (statistics)
 };
 
 // Returns the lanes that held a cell in this row.
@@ -190,18 +193,16 @@ W_FN u64 a2_row(A2Hot &h, A2HotV &hv, const u32 *words, u64 *esc, int band, u32 
         a1 = hv.vx + 1;
         b = w_from_above(hv.vx);
     }
-    // from_above: k == min_k, or k != max_k and V[k-1] < V[k+1]
-    u64 fa = w_ballot(a1 <= b);
-    fa = w_bit_clr(fa, h.hi0);
-    if (PAIR) fa = w_bit_clr(fa, h.hi1);
-    fa = w_bit_set(fa, h.lo0);
-    if (PAIR) fa = w_bit_set(fa, h.lo1);
-    fa &= act;
-    h.cells0 += (u32)(h.hi0 - h.lo0 + 1);
-    if (PAIR) h.cells1 += (u32)(h.hi1 - h.lo1 + 1);
+    // from_above: k == min_k, or k != max_k and V[k-1] < V[k+1] -- the lanes outside the
+    // hull of the previous row hold A2_NEG, so the two edges of a band decide themselves:
+    // at min_k V[k-1] is A2_NEG (from above), at max_k V[k+1] is (from below)
+    const u64 fa = w_ballot(a1 <= b) & act;
     vi x = w_sel(fa, a1, b);
     vi y = (P == 0) ? x + hv.vnegk : x + hv.vnegk - 1;
     vu m = w_undef();  // (idle lanes: whatever -- their cell bytes are never read)
+#ifdef A2_HOOK_ROW
+    A2_HOOK_ROW(P, PAIR, h, hv, a1, b, x, y, act, fa);
+#endif
     W_WHERE(act) {
         // the snake (:203-206), 16 bases per step on 2-bit packed words
         const vu qa = hv.vqb + (vu)x, ta = hv.vtb + (vu)y;
@@ -228,7 +229,6 @@ W_FN u64 a2_row(A2Hot &h, A2HotV &hv, const u32 *words, u64 *esc, int band, u32 
     // the cell byte: the snake length
     if (J >= 0) hv.vacc = w_put_byte<(J >= 0 ? J : 0)>(hv.vacc, m);
     else hv.vacc = w_put_byte_sel(hv.vacc, m, byte_sel);  // (J < 0: the position comes as a v_perm selector)
-    hv.vx = x;
     const u64 fin = (w_ballot(x >= hv.vqlen) | w_ballot(y >= hv.vtlen)) & act;  // :220
     w_writelane2(hv.rc_mlo, hv.rc_mhi, (u32)fa, (u32)(fa >> 32), (int)(h.it & 63u));
     // band (:228-243): keep the hull of the cells with x + y >= best_m - band.  One prefix
@@ -245,23 +245,28 @@ W_FN u64 a2_row(A2Hot &h, A2HotV &hv, const u32 *words, u64 *esc, int band, u32 
         h.best0 = max(h.best0, (int)w_readlaneu(pm, 63));
         in = w_ballot(key + (vu)band >= (vu)h.best0) & act;
     }
-    // the next row's bands: the hull, one diagonal wider on either side -- in lanes: one
-    // lane up before an even row, one lane down before an odd one
+    // the next row's bands: the hulls, one diagonal wider on either side -- in lanes: one
+    // lane down before an odd row, one lane up before an even one.  (Lane numbers never
+    // become registers here: masks only; the band's cells are counted as it is laid out.)
+    u64 hull;
     if (PAIR) {
         const u64 in0 = in & ~h.zone1, in1 = in & h.zone1;
-        if (P == 0) {  // next: odd
-            h.lo0 = w_lowest(in0) - 1; h.hi0 = w_highest(in0);
-            h.lo1 = w_lowest(in1) - 1; h.hi1 = w_highest(in1);
-        } else {
-            h.lo0 = w_lowest(in0); h.hi0 = w_highest(in0) + 1;
-            h.lo1 = w_lowest(in1); h.hi1 = w_highest(in1) + 1;
-        }
-        h.act = w_lanes(h.lo0, h.hi0 - h.lo0 + 1) | w_lanes(h.lo1, h.hi1 - h.lo1 + 1);  // (s_bfm takes both modulo 64)
+        const int span0 = w_span(in0), span1 = w_span(in1);
+        hull = w_lanes(w_lowest(in0), span0) | w_lanes(w_lowest(in1), span1);
+        h.cells0 += (u32)(span0 + 1);
+        h.cells1 += (u32)(span1 + 1);
     } else {
-        if (P == 0) { h.lo0 = w_lowest(in) - 1; h.hi0 = w_highest(in); }
-        else        { h.lo0 = w_lowest(in); h.hi0 = w_highest(in) + 1; }
-        h.act = w_lanes(h.lo0, h.hi0 - h.lo0 + 1);
+        const int span0 = w_span(in);
+        hull = w_lanes(w_lowest(in), span0);
+        h.cells0 += (u32)(span0 + 1);
     }
+    // (the two hulls keep a lane's distance from the boundary between the tracks, so one
+    // shift of the whole mask widens both; a hull on the wave's first or last lane loses the
+    // bit that falls off -- the row raises an event then, and its own values are kept)
+    const u64 nact = (P == 0) ? (hull | (hull >> 1)) : (hull | (hull << 1));
+    hv.vx = w_sel(hull, A2_NEG, x);
+    h.act = nact;
+    h.in = in;
     h.fin = fin;
     h.ev = fin | (in & (P == 0 ? h.forbid_to1 : h.forbid_to0));
     h.it++;
@@ -417,6 +422,17 @@ W_FN int a2_place(A2Wave &w, A2Lanes &wl) {
         wl.vpark = wl.vx;
         w.st_park++;
     }
+    {   // outside the hulls of the rows just placed: A2_NEG (a track without rows: a single 0
+        // where its first cell looks for V[k+1] -- its own lane before an even row, the lane
+        // above before an odd one)
+        u64 keep = 0ull;
+        if (run0) keep |= w.T0.d > 0 ? w_lanes(w.T0.li - sh0, w.T0.hin - w.T0.li + 1) : (1ull << (nl0 + p));
+        if (run1) keep |= w.T1.d > 0 ? w_lanes(w.T1.li - sh1, w.T1.hin - w.T1.li + 1) : (1ull << (nl1 + p));
+        nx = w_sel(keep, A2_NEG, nx);
+#ifdef A2_HOOK_KEEP
+        A2_HOOK_KEEP(w, keep, run0, run1, sh0, sh1, nl0, nl1, p);
+#endif
+    }
     wl.vx = nx;
     if (run0) {
         if (w.T0.d == 0) {  // its first row: one cell, diagonal 0, on lane nl0
@@ -555,6 +571,77 @@ W_FN void a2_flush_partial(const A2Args &A, A2Wave &w, A2Lanes &wl) {
 // or `budget` iterations are done
 // ---------------------------------------------------------------------------------------
 
+// A band hull reached the edge of its track's lanes and no track finished: lay the running
+// tracks out again without leaving the row loop -- both side by side with the free lanes
+// shared out afresh (the boundary between them moves), or the single running track back to
+// the middle of the wave.  A few dozen instructions; what it cannot do (the two bands no
+// longer fit together: one has to be parked) is a2_place's business.  Returns true when the
+// rows can go on.
+struct A2TrackConst {  // what the lanes of a track hold of it
+    int q_len0, t_len0, q_len1, t_len1;
+    u32 qb0, tb0, qb1, tb1;
+};
+// the lanes no band hull may reach (PAIR: `split` = first lane of track 1's share; the two
+// lanes around the boundary stay free, so the two bands are never neighbours)
+template <bool PAIR>
+W_FN void a2_bounds(A2Hot &h) {
+    if (PAIR) {
+        h.zone1 = ~0ull << h.split;
+        const u64 fence = 3ull << (h.split - 1);
+        h.forbid_to1 = fence | 1ull;            // before an odd row a band grows one lane down
+        h.forbid_to0 = fence | (1ull << 63);    // before an even row one lane up
+    } else {
+        h.zone1 = 0ull;
+        h.forbid_to1 = h.forbid_to0 = 1ull | (1ull << 63);  // (the band then never spans all 64 lanes)
+    }
+}
+
+template <bool PAIR>
+W_FN bool a2_replace(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, const A2TrackConst &tc) {
+    if (h.fin) return false;
+    const vi lane = w_lane();
+    const u64 ahead = ~0ull << (h.it & 63u);  // the tape from this iteration on
+    const int down = (int)(h.it & 1u);        // the next row is an odd one: its band starts a lane below the hull
+    if (PAIR) {
+        const u64 in0 = h.in & ~h.zone1, in1 = h.in & h.zone1;
+        const int hull0 = w_span(in0), hull1 = w_span(in1), n0 = hull0 + 1, n1 = hull1 + 1;
+        const int free_lanes = 64 - n0 - n1;
+        if (free_lanes < A2_FREE_MIN) return false;
+        const int g0 = free_lanes / 4, mid = free_lanes / 2;
+        const int nl0 = g0, nl1 = g0 + n0 + mid;
+        const int sh0 = w_lowest(in0) - down - nl0, sh1 = w_lowest(in1) - down - nl1;
+        h.split = g0 + n0 + mid / 2;
+        a2_bounds<true>(h);
+        const vi vsh = w_sel(h.zone1, sh0, sh1);
+        h.in = w_lanes(nl0 + down, hull0) | w_lanes(nl1 + down, hull1);
+        hv.vx = w_sel(h.in, A2_NEG, w_gather_lanes(hv.vx, (lane + vsh) & 63));  // new lane l: what lane l + sh held
+        h.kb0 += (u32)(2 * sh0); h.kb1 += (u32)(2 * sh1);  // (the diagonals go with the rows)
+        hv.vnegk = w_sel(h.zone1, 1 - (int)h.kb0, 1 - (int)h.kb1) - 2 * lane;
+        hv.vqlen = w_sel(h.zone1, tc.q_len0, tc.q_len1);
+        hv.vtlen = w_sel(h.zone1, tc.t_len0, tc.t_len1);
+        hv.vqb = w_selu(h.zone1, tc.qb0, tc.qb1);
+        hv.vtb = w_selu(h.zone1, tc.tb0, tc.tb1);
+        hv.vtop = w_selu(h.zone1, 0u, 0x80000000u);
+        rc_k0 = w_selu(ahead, rc_k0, h.kb0);
+        rc_k1 = w_selu(ahead, rc_k1, h.kb1);
+        h.act = w_lanes(nl0, n0) | w_lanes(nl1, n1);
+    } else {
+        const int hull0 = w_span(h.in), n0 = hull0 + 1;
+        if (n0 > A2_MAX_N) return false;
+        const int nl0 = (64 - n0) / 2;
+        const int sh0 = w_lowest(h.in) - down - nl0;
+        h.in = w_lanes(nl0 + down, hull0);
+        hv.vx = w_sel(h.in, A2_NEG, w_gather_lanes(hv.vx, (lane + sh0) & 63));
+        hv.vnegk = hv.vnegk - 2 * sh0;
+        if (h.kb0 != A2_INVALID) { h.kb0 += (u32)(2 * sh0); rc_k0 = w_selu(ahead, rc_k0, h.kb0); }
+        else                     { h.kb1 += (u32)(2 * sh0); rc_k1 = w_selu(ahead, rc_k1, h.kb1); }
+        h.act = w_lanes(nl0, n0);
+    }
+    h.ev = 0ull;
+    h.n_replace++;
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------
 // The row loop proper, OUT OF LINE: inlined into the wavefront's event loop, hipcc folds it
 // into that loop's state machine and every row pays for the copies at its joins (k_align.hip
@@ -568,11 +655,13 @@ struct A2Regs {
     vu vqb, vtb, vtop, vacc, rc_mlo, rc_mhi, rc_k0, rc_k1;
     vu sc;  // lane i: the i-th wave-uniform value (A2_SC_*)
 };
-enum { A2_SC_ACT_LO = 0, A2_SC_ACT_HI, A2_SC_LO0, A2_SC_HI0, A2_SC_LO1, A2_SC_HI1, A2_SC_BEST0, A2_SC_BEST1,
+enum { A2_SC_ACT_LO = 0, A2_SC_ACT_HI, A2_SC_IN_LO, A2_SC_IN_HI, A2_SC_BEST0, A2_SC_BEST1,
        A2_SC_CELLS0, A2_SC_CELLS1, A2_SC_SPLIT, A2_SC_IT, A2_SC_NESC, A2_SC_KB0, A2_SC_KB1, A2_SC_IT_END,
        A2_SC_FIN_LO, A2_SC_FIN_HI, A2_SC_EV_LO, A2_SC_EV_HI, A2_SC_ROW_LO, A2_SC_ROW_HI,
        A2_SC_WORDS_LO, A2_SC_WORDS_HI, A2_SC_CELLS_LO, A2_SC_CELLS_HI, A2_SC_RECS_LO, A2_SC_RECS_HI,
-       A2_SC_ESC_LO, A2_SC_ESC_HI, A2_SC_RING, A2_SC_BAND };
+       A2_SC_ESC_LO, A2_SC_ESC_HI, A2_SC_RING, A2_SC_BAND,
+       A2_SC_QLEN0, A2_SC_TLEN0, A2_SC_QLEN1, A2_SC_TLEN1, A2_SC_QB0, A2_SC_TB0, A2_SC_QB1, A2_SC_TB1,
+       A2_SC_IT_LAST, A2_SC_JOIN_AT, A2_SC_NREPLACE };
 
 template <bool PAIR>
 W_NOINLINE A2Regs a2_fast(A2Regs r) {
@@ -583,40 +672,50 @@ W_NOINLINE A2Regs a2_fast(A2Regs r) {
     vu rc_k0 = r.rc_k0, rc_k1 = r.rc_k1;
     A2Hot h;
     h.act = ((u64)w_pack_get<A2_SC_ACT_HI>(r.sc) << 32) | w_pack_get<A2_SC_ACT_LO>(r.sc);
-    h.lo0 = (int)w_pack_get<A2_SC_LO0>(r.sc); h.hi0 = (int)w_pack_get<A2_SC_HI0>(r.sc);
-    h.lo1 = (int)w_pack_get<A2_SC_LO1>(r.sc); h.hi1 = (int)w_pack_get<A2_SC_HI1>(r.sc);
+    h.lo0 = h.hi0 = h.lo1 = h.hi1 = 0;
     h.best0 = (int)w_pack_get<A2_SC_BEST0>(r.sc); h.best1 = (int)w_pack_get<A2_SC_BEST1>(r.sc);
     h.cells0 = w_pack_get<A2_SC_CELLS0>(r.sc); h.cells1 = w_pack_get<A2_SC_CELLS1>(r.sc);
     h.split = (int)w_pack_get<A2_SC_SPLIT>(r.sc);
     h.it = w_pack_get<A2_SC_IT>(r.sc);
     h.n_esc = (int)w_pack_get<A2_SC_NESC>(r.sc);
     h.kb0 = w_pack_get<A2_SC_KB0>(r.sc); h.kb1 = w_pack_get<A2_SC_KB1>(r.sc);
-    const u32 it_end = w_pack_get<A2_SC_IT_END>(r.sc);
+    u32 it_end = w_pack_get<A2_SC_IT_END>(r.sc);
+    const u32 it_last = w_pack_get<A2_SC_IT_LAST>(r.sc);
+    const int join_at = (int)w_pack_get<A2_SC_JOIN_AT>(r.sc);
+    A2TrackConst tc;
+    tc.q_len0 = (int)w_pack_get<A2_SC_QLEN0>(r.sc); tc.t_len0 = (int)w_pack_get<A2_SC_TLEN0>(r.sc);
+    tc.q_len1 = (int)w_pack_get<A2_SC_QLEN1>(r.sc); tc.t_len1 = (int)w_pack_get<A2_SC_TLEN1>(r.sc);
+    tc.qb0 = w_pack_get<A2_SC_QB0>(r.sc); tc.tb0 = w_pack_get<A2_SC_TB0>(r.sc);
+    tc.qb1 = w_pack_get<A2_SC_QB1>(r.sc); tc.tb1 = w_pack_get<A2_SC_TB1>(r.sc);
+    h.n_replace = 0u;
     const u32 *words = (const u32 *)(((u64)w_pack_get<A2_SC_WORDS_HI>(r.sc) << 32) | w_pack_get<A2_SC_WORDS_LO>(r.sc));
     u32 *cells = (u32 *)(((u64)w_pack_get<A2_SC_CELLS_HI>(r.sc) << 32) | w_pack_get<A2_SC_CELLS_LO>(r.sc));
     u32 *recs = (u32 *)(((u64)w_pack_get<A2_SC_RECS_HI>(r.sc) << 32) | w_pack_get<A2_SC_RECS_LO>(r.sc));
     u64 *esc = (u64 *)(((u64)w_pack_get<A2_SC_ESC_HI>(r.sc) << 32) | w_pack_get<A2_SC_ESC_LO>(r.sc));
     const u32 ring = w_pack_get<A2_SC_RING>(r.sc);
     const int band = (int)w_pack_get<A2_SC_BAND>(r.sc);
-    if (PAIR) {
-        h.zone1 = ~0ull << h.split;
-        h.forbid_to1 = 1ull | (1ull << h.split);
-        h.forbid_to0 = (1ull << (h.split - 1)) | (1ull << 63);
-    } else {
-        h.zone1 = 0ull;
-        h.forbid_to1 = h.forbid_to0 = 1ull | (1ull << 63);
-    }
+    a2_bounds<PAIR>(h);
+    h.in = ((u64)w_pack_get<A2_SC_IN_HI>(r.sc) << 32) | w_pack_get<A2_SC_IN_LO>(r.sc);
     h.fin = 0ull; h.ev = 0ull; h.act_row = 0ull;
     const vi lane = w_lane();
     // the cell byte of an iteration is byte it & 3 of the lane's word: v_perm selectors that
     // put it there, alternating between (0, 1) and (2, 3) with every pair of rows
     u32 sel_even = (h.it & 2u) ? 0x03040100u : 0x03020104u;
     u32 sel_odd = (h.it & 2u) ? 0x04020100u : 0x03020400u;
+    // (`it_end`: where to look up from the rows -- the end of the tracks' rows `it_last`, or,
+    // with a neighbour parked, every A2_LOOK_EVERY iterations: when the running band has
+    // become narrow enough (<= join_at lanes) the loop leaves, for the neighbour to join)
     for (;;) {
         if ((h.it & 1u) == 0u) {  // (a call may begin at an odd iteration: then with the odd row)
             const u64 lanes_ = a2_row<0, -1, PAIR>(h, hv, words, esc, band, sel_even);
-            if (h.ev) { h.act_row = lanes_; break; }
-            if (h.it == it_end) break;
+            if (h.ev) {
+                h.act_row = lanes_;
+                if (!a2_replace<PAIR>(h, hv, rc_k0, rc_k1, tc)) break;
+            }
+            if (h.it == it_end) {
+                if (PAIR || it_end == it_last || w_span(h.in) + 1 <= join_at) break;
+                it_end = ((int)(it_last - it_end) > A2_LOOK_EVERY) ? it_end + A2_LOOK_EVERY : it_last;
+            }
         }
         const u64 lanes_ = a2_row<1, -1, PAIR>(h, hv, words, esc, band, sel_odd);
         if ((h.it & 3u) == 0u)
@@ -628,14 +727,24 @@ W_NOINLINE A2Regs a2_fast(A2Regs r) {
         }
         sel_even ^= 0x03040100u ^ 0x03020104u;
         sel_odd ^= 0x04020100u ^ 0x03020400u;
-        if (h.ev) { h.act_row = lanes_; break; }
-        if (h.it == it_end) break;
+        if (h.ev) {
+            h.act_row = lanes_;
+            if (!a2_replace<PAIR>(h, hv, rc_k0, rc_k1, tc)) break;
+        }
+        if (h.it == it_end) {
+            if (PAIR || it_end == it_last || w_span(h.in) + 1 <= join_at) break;
+            it_end = ((int)(it_last - it_end) > A2_LOOK_EVERY) ? it_end + A2_LOOK_EVERY : it_last;
+        }
     }
-    r.vx = hv.vx; r.vacc = hv.vacc; r.rc_mlo = hv.rc_mlo; r.rc_mhi = hv.rc_mhi;
+    r.vx = hv.vx; r.vnegk = hv.vnegk; r.vqlen = hv.vqlen; r.vtlen = hv.vtlen;
+    r.vqb = hv.vqb; r.vtb = hv.vtb; r.vtop = hv.vtop;
+    r.vacc = hv.vacc; r.rc_mlo = hv.rc_mlo; r.rc_mhi = hv.rc_mhi;
     r.rc_k0 = rc_k0; r.rc_k1 = rc_k1;
+    w_pack_put<A2_SC_SPLIT>(r.sc, (u32)h.split);
+    w_pack_put<A2_SC_KB0>(r.sc, h.kb0); w_pack_put<A2_SC_KB1>(r.sc, h.kb1);
+    w_pack_put<A2_SC_NREPLACE>(r.sc, h.n_replace);
     w_pack_put<A2_SC_ACT_LO>(r.sc, (u32)h.act); w_pack_put<A2_SC_ACT_HI>(r.sc, (u32)(h.act >> 32));
-    w_pack_put<A2_SC_LO0>(r.sc, (u32)h.lo0); w_pack_put<A2_SC_HI0>(r.sc, (u32)h.hi0);
-    w_pack_put<A2_SC_LO1>(r.sc, (u32)h.lo1); w_pack_put<A2_SC_HI1>(r.sc, (u32)h.hi1);
+    w_pack_put<A2_SC_IN_LO>(r.sc, (u32)h.in); w_pack_put<A2_SC_IN_HI>(r.sc, (u32)(h.in >> 32));
     w_pack_put<A2_SC_BEST0>(r.sc, (u32)h.best0); w_pack_put<A2_SC_BEST1>(r.sc, (u32)h.best1);
     w_pack_put<A2_SC_CELLS0>(r.sc, h.cells0); w_pack_put<A2_SC_CELLS1>(r.sc, h.cells1);
     w_pack_put<A2_SC_IT>(r.sc, h.it);
@@ -648,15 +757,15 @@ W_NOINLINE A2Regs a2_fast(A2Regs r) {
 
 // the call: marshal, run, take the state back
 template <bool PAIR>
-W_FN void a2_fast_call(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV &hv, u32 it_end) {
+W_FN void a2_fast_call(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV &hv, u32 it_end, u32 it_last,
+                       int join_at) {
     A2Regs r;
     r.vx = hv.vx; r.vnegk = hv.vnegk; r.vqlen = hv.vqlen; r.vtlen = hv.vtlen;
     r.vqb = hv.vqb; r.vtb = hv.vtb; r.vtop = hv.vtop; r.vacc = hv.vacc;
     r.rc_mlo = hv.rc_mlo; r.rc_mhi = hv.rc_mhi; r.rc_k0 = wl.rc_k0; r.rc_k1 = wl.rc_k1;
     r.sc = w_undef();
     w_pack_put<A2_SC_ACT_LO>(r.sc, (u32)h.act); w_pack_put<A2_SC_ACT_HI>(r.sc, (u32)(h.act >> 32));
-    w_pack_put<A2_SC_LO0>(r.sc, (u32)h.lo0); w_pack_put<A2_SC_HI0>(r.sc, (u32)h.hi0);
-    w_pack_put<A2_SC_LO1>(r.sc, (u32)h.lo1); w_pack_put<A2_SC_HI1>(r.sc, (u32)h.hi1);
+    w_pack_put<A2_SC_IN_LO>(r.sc, (u32)h.in); w_pack_put<A2_SC_IN_HI>(r.sc, (u32)(h.in >> 32));
     w_pack_put<A2_SC_BEST0>(r.sc, (u32)h.best0); w_pack_put<A2_SC_BEST1>(r.sc, (u32)h.best1);
     w_pack_put<A2_SC_CELLS0>(r.sc, h.cells0); w_pack_put<A2_SC_CELLS1>(r.sc, h.cells1);
     w_pack_put<A2_SC_SPLIT>(r.sc, (u32)h.split);
@@ -664,6 +773,12 @@ W_FN void a2_fast_call(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV
     w_pack_put<A2_SC_NESC>(r.sc, (u32)h.n_esc);
     w_pack_put<A2_SC_KB0>(r.sc, h.kb0); w_pack_put<A2_SC_KB1>(r.sc, h.kb1);
     w_pack_put<A2_SC_IT_END>(r.sc, it_end);
+    w_pack_put<A2_SC_IT_LAST>(r.sc, it_last);
+    w_pack_put<A2_SC_JOIN_AT>(r.sc, (u32)join_at);
+    w_pack_put<A2_SC_QLEN0>(r.sc, (u32)w.T0.q_len); w_pack_put<A2_SC_TLEN0>(r.sc, (u32)w.T0.t_len);
+    w_pack_put<A2_SC_QLEN1>(r.sc, (u32)w.T1.q_len); w_pack_put<A2_SC_TLEN1>(r.sc, (u32)w.T1.t_len);
+    w_pack_put<A2_SC_QB0>(r.sc, w.T0.qb); w_pack_put<A2_SC_TB0>(r.sc, w.T0.tb);
+    w_pack_put<A2_SC_QB1>(r.sc, w.T1.qb); w_pack_put<A2_SC_TB1>(r.sc, w.T1.tb);
     w_pack_put<A2_SC_WORDS_LO>(r.sc, (u32)(u64)A.words); w_pack_put<A2_SC_WORDS_HI>(r.sc, (u32)((u64)A.words >> 32));
     w_pack_put<A2_SC_CELLS_LO>(r.sc, (u32)(u64)w.cells); w_pack_put<A2_SC_CELLS_HI>(r.sc, (u32)((u64)w.cells >> 32));
     w_pack_put<A2_SC_RECS_LO>(r.sc, (u32)(u64)w.recs); w_pack_put<A2_SC_RECS_HI>(r.sc, (u32)((u64)w.recs >> 32));
@@ -671,11 +786,16 @@ W_FN void a2_fast_call(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV
     w_pack_put<A2_SC_RING>(r.sc, A.ring);
     w_pack_put<A2_SC_BAND>(r.sc, (u32)A.band);
     r = a2_fast<PAIR>(r);
-    hv.vx = r.vx; hv.vacc = r.vacc; hv.rc_mlo = r.rc_mlo; hv.rc_mhi = r.rc_mhi;
+    hv.vx = r.vx; hv.vnegk = r.vnegk; hv.vqlen = r.vqlen; hv.vtlen = r.vtlen;
+    hv.vqb = r.vqb; hv.vtb = r.vtb; hv.vtop = r.vtop;
+    hv.vacc = r.vacc; hv.rc_mlo = r.rc_mlo; hv.rc_mhi = r.rc_mhi;
     wl.rc_k0 = r.rc_k0; wl.rc_k1 = r.rc_k1;
+    h.split = (int)w_pack_get<A2_SC_SPLIT>(r.sc);
+    w.split = h.split;
+    h.kb0 = w_pack_get<A2_SC_KB0>(r.sc); h.kb1 = w_pack_get<A2_SC_KB1>(r.sc);
+    w.st_recenter += w_pack_get<A2_SC_NREPLACE>(r.sc);
     h.act = ((u64)w_pack_get<A2_SC_ACT_HI>(r.sc) << 32) | w_pack_get<A2_SC_ACT_LO>(r.sc);
-    h.lo0 = (int)w_pack_get<A2_SC_LO0>(r.sc); h.hi0 = (int)w_pack_get<A2_SC_HI0>(r.sc);
-    h.lo1 = (int)w_pack_get<A2_SC_LO1>(r.sc); h.hi1 = (int)w_pack_get<A2_SC_HI1>(r.sc);
+    h.in = ((u64)w_pack_get<A2_SC_IN_HI>(r.sc) << 32) | w_pack_get<A2_SC_IN_LO>(r.sc);
     h.best0 = (int)w_pack_get<A2_SC_BEST0>(r.sc); h.best1 = (int)w_pack_get<A2_SC_BEST1>(r.sc);
     h.cells0 = w_pack_get<A2_SC_CELLS0>(r.sc); h.cells1 = w_pack_get<A2_SC_CELLS1>(r.sc);
     h.it = w_pack_get<A2_SC_IT>(r.sc);
@@ -685,72 +805,13 @@ W_FN void a2_fast_call(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV
     h.act_row = ((u64)w_pack_get<A2_SC_ROW_HI>(r.sc) << 32) | w_pack_get<A2_SC_ROW_LO>(r.sc);
 }
 
-// A band hull reached the edge of its track's lanes and no track finished: lay the running
-// tracks out again without leaving the row loop -- both side by side with the free lanes
-// shared out afresh (the boundary between them moves), or the single running track back to
-// the middle of the wave.  A few dozen instructions; what it cannot do (the two bands no
-// longer fit together: one has to be parked) is a2_place's business.  Returns true when the
-// rows can go on.
-template <bool PAIR>
-W_FN bool a2_replace(A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV &hv) {
-    if (h.fin) return false;
-    const vi lane = w_lane();
-    const u64 ahead = ~0ull << (h.it & 63u);  // the tape from this iteration on
-    const int n0 = h.hi0 - h.lo0 + 1;
-    if (PAIR) {
-        const int n1 = h.hi1 - h.lo1 + 1, free_lanes = 64 - n0 - n1;
-        if (free_lanes < A2_FREE_MIN) return false;
-        const int g0 = free_lanes / 4, mid = free_lanes / 2;
-        const int sh0 = h.lo0 - g0, sh1 = h.lo1 - (g0 + n0 + mid);
-        h.split = g0 + n0 + mid / 2;
-        h.zone1 = ~0ull << h.split;
-        h.forbid_to1 = 1ull | (1ull << h.split);
-        h.forbid_to0 = (1ull << (h.split - 1)) | (1ull << 63);
-        w.split = h.split;
-        const vi vsh = w_sel(h.zone1, sh0, sh1);
-        hv.vx = w_gather_lanes(hv.vx, (lane + vsh) & 63);  // new lane l: what lane l + sh held
-        h.lo0 -= sh0; h.hi0 -= sh0; h.lo1 -= sh1; h.hi1 -= sh1;
-        h.kb0 += (u32)(2 * sh0); h.kb1 += (u32)(2 * sh1);  // (the diagonals go with the rows)
-        hv.vnegk = w_sel(h.zone1, 1 - (int)h.kb0, 1 - (int)h.kb1) - 2 * lane;
-        hv.vqlen = w_sel(h.zone1, w.T0.q_len, w.T1.q_len);
-        hv.vtlen = w_sel(h.zone1, w.T0.t_len, w.T1.t_len);
-        hv.vqb = w_selu(h.zone1, w.T0.qb, w.T1.qb);
-        hv.vtb = w_selu(h.zone1, w.T0.tb, w.T1.tb);
-        hv.vtop = w_selu(h.zone1, 0u, 0x80000000u);
-        wl.rc_k0 = w_selu(ahead, wl.rc_k0, h.kb0);
-        wl.rc_k1 = w_selu(ahead, wl.rc_k1, h.kb1);
-        h.act = w_lanes(h.lo0, n0) | w_lanes(h.lo1, n1);
-    } else {
-        if (n0 > A2_MAX_N) return false;
-        const int sh0 = h.lo0 - (64 - n0) / 2;
-        hv.vx = w_gather_lanes(hv.vx, (lane + sh0) & 63);
-        hv.vnegk = hv.vnegk - 2 * sh0;
-        h.lo0 -= sh0; h.hi0 -= sh0;
-        if (h.kb0 != A2_INVALID) { h.kb0 += (u32)(2 * sh0); wl.rc_k0 = w_selu(ahead, wl.rc_k0, h.kb0); }
-        else                     { h.kb1 += (u32)(2 * sh0); wl.rc_k1 = w_selu(ahead, wl.rc_k1, h.kb1); }
-        h.act = w_lanes(h.lo0, n0);
-    }
-    h.ev = 0ull;
-    w.st_recenter++;
-    return true;
-}
-
 // `budget`: iterations at most (the rows the tracks have left).  `join_at` (single mode with
-// a parked neighbour; else 0): every A2_LOOK_EVERY iterations the loop looks at the running
-// band, and leaves when it has become narrow enough (<= join_at lanes) for the neighbour to
-// join again.
+// a parked neighbour; else 0): the running band's width at which the neighbour fits again.
 template <bool PAIR>
 W_FN void a2_rows(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV &hv, int budget, int join_at) {
     const u32 it_last = h.it + (u32)budget;
-    u32 it_end = (!PAIR && join_at > 0 && budget > A2_LOOK_EVERY) ? h.it + A2_LOOK_EVERY : it_last;
-    for (;;) {
-        if (h.ev && !a2_replace<PAIR>(w, wl, h, hv)) break;
-        if ((int)(it_end - h.it) <= 0) {
-            if (PAIR || it_end == it_last || h.hi0 - h.lo0 + 1 <= join_at) break;
-            it_end = ((int)(it_last - it_end) > A2_LOOK_EVERY) ? it_end + A2_LOOK_EVERY : it_last;
-        }
-        a2_fast_call<PAIR>(A, w, wl, h, hv, it_end);
-    }
+    const u32 it_end = (!PAIR && join_at > 0 && budget > A2_LOOK_EVERY) ? h.it + A2_LOOK_EVERY : it_last;
+    a2_fast_call<PAIR>(A, w, wl, h, hv, it_end, it_last, join_at);
 }
 
 W_FN u64 a2_zone(const A2Wave &w, int ti) {
@@ -921,7 +982,8 @@ W_FN void a2_wide(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Track &t, vi from, 
         t.li = li;
         t.hin = li + hull_n - 1;
         const vi kp = t.kc + 2 * lane;
-        wl.vx = (vi)w_lds_load(ring + ((d - 1) & 1) * A2_WIDE_RING, (vu)(kp >> 1) & (A2_WIDE_RING - 1u));
+        wl.vx = w_sel(w_lanes(t.li, hull_n), A2_NEG,
+                      (vi)w_lds_load(ring + ((d - 1) & 1) * A2_WIDE_RING, (vu)(kp >> 1) & (A2_WIDE_RING - 1u)));
         t.state = A2_RUN;
     }
 }
@@ -1027,6 +1089,8 @@ W_FN void a2_wave(const A2Args &A, int slot) {
         hv.vtop = wl.vtop; hv.vacc = wl.vacc; hv.rc_mlo = wl.rc_mlo; hv.rc_mhi = wl.rc_mhi;
         h.split = w.split;
         h.zone1 = a2_zone(w, 1);
+        h.forbid_to0 = h.forbid_to1 = 0ull;  // (a2_fast works them out of `split`)
+        h.n_replace = 0u;
         h.it = w.it;
         h.n_esc = w.n_esc;
         h.fin = 0ull; h.ev = 0ull; h.act_row = 0ull;
@@ -1034,6 +1098,8 @@ W_FN void a2_wave(const A2Args &A, int slot) {
         h.kb1 = run1 ? (u32)(w.T1.kc + p) : A2_INVALID;
         int budget;
         const u32 it_in = w.it;
+        // (the rows count a band's cells when they lay it out: the first bands are counted here,
+        // and the bands laid out for the row after the last one are taken off again below)
         if (w.pair) {
             a2_next_band(w.T0, p, h.lo0, h.hi0);
             a2_next_band(w.T1, p, h.lo1, h.hi1);
@@ -1041,10 +1107,10 @@ W_FN void a2_wave(const A2Args &A, int slot) {
             if (w.T1.d == 0) h.lo1 = h.hi1 = -(w.T1.kc + (p ? 1 : -1)) / 2;
             h.best0 = w.T0.best;
             h.best1 = (int)((u32)w.T1.best + 0x80000000u);
-            h.cells0 = w.T0.cells; h.cells1 = w.T1.cells;
+            h.cells0 = w.T0.cells + (u32)(h.hi0 - h.lo0 + 1);
+            h.cells1 = w.T1.cells + (u32)(h.hi1 - h.lo1 + 1);
             h.act = w_lanes(h.lo0, h.hi0 - h.lo0 + 1) | w_lanes(h.lo1, h.hi1 - h.lo1 + 1);
-            h.forbid_to1 = 1ull | (1ull << w.split);
-            h.forbid_to0 = (1ull << (w.split - 1)) | (1ull << 63);
+            h.in = 0ull;
             budget = min(min(w.T0.max_d - w.T0.d, w.T1.max_d - w.T1.d), tape_left);
             a2_rows<true>(A, w, wl, h, hv, budget, 0);
         } else {
@@ -1063,10 +1129,9 @@ W_FN void a2_wave(const A2Args &A, int slot) {
             }
             h.lo1 = h.hi1 = 0;
             h.best0 = run0 ? w.T0.best : w.T1.best; h.best1 = 0;
-            h.cells0 = run0 ? w.T0.cells : w.T1.cells; h.cells1 = 0;
+            h.cells0 = (run0 ? w.T0.cells : w.T1.cells) + (u32)(h.hi0 - h.lo0 + 1); h.cells1 = 0;
             h.act = w_lanes(h.lo0, h.hi0 - h.lo0 + 1);
-            // (both edge lanes, whatever the phase: the band then never spans all 64 lanes)
-            h.forbid_to1 = h.forbid_to0 = 1ull | (1ull << 63);
+            h.in = 0ull;
             budget = min((run0 ? w.T0.max_d : w.T1.max_d) - t_d, tape_left);
             // (a parked neighbour joins again when the two bands fit with room to spare)
             int join_at = 0;
@@ -1077,30 +1142,33 @@ W_FN void a2_wave(const A2Args &A, int slot) {
             }
             a2_rows<false>(A, w, wl, h, hv, budget, join_at);
         }
-        // ---- back from the row loop
+        // ---- back from the row loop (at least one row was computed)
         const int done_it = (int)(h.it - it_in);
         if (w.pair) w.st_pair += (u32)done_it; else w.st_single += (u32)done_it;
         wl.vx = hv.vx; wl.vacc = hv.vacc; wl.rc_mlo = hv.rc_mlo; wl.rc_mhi = hv.rc_mhi;
         w.it = h.it;
         w.n_esc = h.n_esc;
-        const int p_next = (int)(w.it & 1u), p_last = p_next ^ 1;
-        // the hulls of the last row, from the bands computed for the next iteration's phase
+        const int p_last = (int)(w.it & 1u) ^ 1;
+        // the hulls of the last row: the lanes of it that passed the band filter
         if (w.pair) {
+            const u64 in0 = h.in & a2_zone(w, 0), in1 = h.in & a2_zone(w, 1);
             w.T0.d += done_it; w.T1.d += done_it;
             w.T0.kc = (int)h.kb0 - 1 + p_last; w.T1.kc = (int)h.kb1 - 1 + p_last;
-            if (p_next == 0) { w.T0.li = h.lo0; w.T0.hin = h.hi0 - 1; w.T1.li = h.lo1; w.T1.hin = h.hi1 - 1; }
-            else             { w.T0.li = h.lo0 + 1; w.T0.hin = h.hi0; w.T1.li = h.lo1 + 1; w.T1.hin = h.hi1; }
+            w.T0.li = w_lowest(in0); w.T0.hin = w_highest(in0);
+            w.T1.li = w_lowest(in1); w.T1.hin = w_highest(in1);
             w.T0.best = h.best0;
             w.T1.best = (int)((u32)h.best1 - 0x80000000u);
-            w.T0.cells = h.cells0; w.T1.cells = h.cells1;
+            w.T0.cells = h.cells0 - (u32)(w.T0.hin - w.T0.li + 2);
+            w.T1.cells = h.cells1 - (u32)(w.T1.hin - w.T1.li + 2);
         } else {
-            const int n_li = p_next == 0 ? h.lo0 : h.lo0 + 1, n_hin = p_next == 0 ? h.hi0 - 1 : h.hi0;
+            const int n_li = w_lowest(h.in), n_hin = w_highest(h.in);
+            const u32 n_cells = h.cells0 - (u32)(n_hin - n_li + 2);
             if (run0) {
                 w.T0.d += done_it; w.T0.kc = (int)h.kb0 - 1 + p_last; w.T0.li = n_li; w.T0.hin = n_hin;
-                w.T0.best = h.best0; w.T0.cells = h.cells0;
+                w.T0.best = h.best0; w.T0.cells = n_cells;
             } else {
                 w.T1.d += done_it; w.T1.kc = (int)h.kb1 - 1 + p_last; w.T1.li = n_li; w.T1.hin = n_hin;
-                w.T1.best = h.best0; w.T1.cells = h.cells0;
+                w.T1.best = h.best0; w.T1.cells = n_cells;
             }
         }
         if (w.n_esc > A2_ESC_CAP) {  // the escape list is full: everybody on the tape goes back

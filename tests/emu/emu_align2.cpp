@@ -39,6 +39,14 @@ static long hist_sum[130], hist_one[70];
 #define A2_HOOK_PLACE(h0, n0, h1, n1) do { if ((h0) && (h1)) hist_sum[std::min(129, (n0) + (n1))]++; if (h0) hist_one[std::min(69,(n0))]++; if (h1) hist_one[std::min(69,(n1))]++; } while (0)
 extern "C" void emu_hist(long *sum, long *one) { memcpy(sum, hist_sum, sizeof(hist_sum)); memcpy(one, hist_one, sizeof(hist_one)); }
 #endif
+#ifdef EMU_CHECK_ROW
+#define A2_HOOK_KEEP(w, keep, run0, run1, sh0, sh1, nl0, nl1, p) fprintf(stderr, "place it=%u p=%d keep=%016llx run %d %d | T0 st=%d d=%d li=%d hin=%d sh=%d nl=%d | T1 st=%d d=%d li=%d hin=%d sh=%d nl=%d\n", w.it, p, (unsigned long long)keep, (int)run0, (int)run1, w.T0.state, w.T0.d, w.T0.li, w.T0.hin, sh0, nl0, w.T1.state, w.T1.d, w.T1.li, w.T1.hin, sh1, nl1)
+#define A2_HOOK_ROW(P, PAIR, h, hv, a1, b, x, y, act, fa) do { \
+    for (int l_ = 0; l_ < 64; l_++) if (((act) >> l_) & 1) { \
+        if (x.v[l_] < 0 || x.v[l_] > hv.vqlen.v[l_] || y.v[l_] < 0 || y.v[l_] > hv.vtlen.v[l_]) { \
+            fprintf(stderr, "row P=%d PAIR=%d it=%u lane %d: x=%d y=%d a1=%d b=%d act=%016llx fa=%016llx split=%d in=%016llx\n", P, (int)PAIR, h.it, l_, x.v[l_], y.v[l_], a1.v[l_], b.v[l_], (unsigned long long)(act), (unsigned long long)(fa), h.split, (unsigned long long)h.in); \
+            for (int k_ = 0; k_ < 64; k_++) fprintf(stderr, "%d:%d ", k_, hv.vx.v[k_]); fprintf(stderr, "\n"); abort(); } } } while (0)
+#endif
 #include "k_align2_core.h"
 
 // words per arena slot for a tape of `ring` iterations (must match the engine's sizing)

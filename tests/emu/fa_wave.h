@@ -122,6 +122,7 @@ W_FN u64 w_bit_set(u64 m, int b) { return m | (1ull << (b & 63)); }
 W_FN int w_lowest(u64 m) { return m ? __builtin_ctzll(m) : -1; }
 W_FN int w_highest(u64 m) { return m ? 63 - __builtin_clzll(m) : -1; }
 W_FN int w_popc(u64 m) { return __builtin_popcountll(m); }
+W_FN int w_span(u64 m) { return m ? 64 - (__builtin_clzll(m) + __builtin_ctzll(m)) : 0; }
 W_FN vi w_rank_in(u64 m) { vi r; for (int l = 0; l < 64; l++) r.v[l] = __builtin_popcountll(m & ((1ull << l) - 1ull)); return r; }
 W_FN vu w_undef() { return vu(0xdeadbeefu); }
 template <int J>
