@@ -39,6 +39,13 @@ W_FN void w_writelane2(vu &a, vu &b, u32 sa, u32 sb, int l) {
                  : "+v"(a), "+v"(b)
                  : "s"(sa), "s"(sb), "s"(l));
 }
+// lane l of v := the wave-uniform s (l wave-uniform)
+W_FN void w_setlane(vi &v, int s, int l) {
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(fa_uni(s)), "s"(fa_uni(l)));
+}
+// lane dst (per lane, 0..63) receives this lane's v; lanes nobody sends to read 0, of two
+// senders to one lane the higher lane wins
+W_FN vi w_push_lanes(vi v, vi dst) { return __builtin_amdgcn_ds_permute(dst << 2, v); }
 // lane l takes v of lane src (per-lane src, 0..63)
 W_FN vi w_gather_lanes(vi v, vi src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
 W_FN int w_uni(int v) { return fa_uni(v); }
@@ -85,6 +92,8 @@ W_FN u64 w_bit_set(u64 m, int b) {
 W_FN int w_lowest(u64 m) { return __builtin_ctzll(m); }                 // m != 0
 W_FN int w_highest(u64 m) { return 63 - __builtin_clzll(m); }           // m != 0
 W_FN int w_popc(u64 m) { return __builtin_popcountll(m); }
+// sign-extended 16 bits of v from bit `off` (per lane)
+W_FN vi w_bfe_i16(vu v, vu off) { return __builtin_amdgcn_sbfe((int)v, off, 16u); }
 W_FN int w_span(u64 m) { return 64 - (__builtin_clzll(m) + __builtin_ctzll(m)); }  // highest - lowest + 1; m != 0
 // per lane: the number of set bits of m below the lane
 W_FN vi w_rank_in(u64 m) {

@@ -5,6 +5,7 @@
 // one atomic per alignment.
 //
 // Integer / latency / issue bound like the rest of the path; no MFMA.
+#include <cstdlib>
 #include "fa_wave.h"
 #include "k_align2_core.h"
 
@@ -52,6 +53,10 @@ void fa_launch_align2(const FaBatchDev &b, const FaAlign2Arena &a, double max_di
     A.script = b.script; A.script_off = b.script_off; A.aln = b.aln;
     A.band = band; A.max_diff = max_diff;
     A.stats = a.stats;
+    {   // (FALCON_AMD_A2_DEBUG: timing experiments, see A2Args::debug -- results are not valid then)
+        const char *e = getenv("FALCON_AMD_A2_DEBUG");
+        A.debug = e ? atoi(e) : 0;
+    }
     (void)hipMemsetAsync(a.counter, 0, sizeof(int), s);
     // two alignments per wavefront: half as many wavefronts have work
     int grid = a.n_slot;

@@ -43,7 +43,7 @@
 #define A2_INVALID 0x80000000u  // tape record: the track computed no row in this iteration
 #define A2_CONT 0x80000001u     // ... or: cells 64.. of the row the iteration before began (wide rows)
 #define A2_WIDE_RING 256        // LDS ring of a wide row's V values, per row parity (<= 191 live diagonals)
-#define A2_LDS_WORDS (256 + 2 * A2_WIDE_RING)  // trace-back staging + the two rings
+#define A2_LDS_WORDS (256 + 2 * A2_WIDE_RING)  // (256 spare words) + the two rings
 #ifndef A2_FREE_MIN
 #define A2_FREE_MIN 4           // free lanes two running tracks need to stay paired
 #endif
@@ -76,6 +76,7 @@ struct A2Args {
     int band;
     double max_diff;
     unsigned long long *stats;  // 8 counters (see A2_STAT_*)
+    int debug;                  // timing experiments only: 1 = no trace-back (the scripts stay unwritten)
 };
 // pair / single iterations, placements, parkings, hand-backs, wide rows, wide episodes, recenterings
 enum { A2_STAT_PAIR_IT = 0, A2_STAT_SINGLE_IT, A2_STAT_PLACE, A2_STAT_PARK, A2_STAT_BAIL,
@@ -485,68 +486,96 @@ W_FN int a2_place(A2Wave &w, A2Lanes &wl) {
 // ---------------------------------------------------------------------------------------
 template <int TI>
 W_FN int a2_trace(const A2Args &A, A2Wave &w, A2Lanes &wl, const A2Track &t, u32 it_f, int k_f, int fin_d) {
-    u32 *lds = w_lds();
+    if (A.debug & 1) return 0;
     const u32 ring_mask = A.ring - 1u, chunk_mask = (A.ring >> 2) - 1u;
     u32 *script = A.script + (((u64)t.script_hi << 32) | t.script_lo);
     const vi lane = w_lane();
-    vi kvv = k_f;       // the path's diagonal at the newest row not yet resolved (same in every lane)
+    int kv = k_f;       // the path's diagonal at the newest row not yet resolved
     int r_top = fin_d;  // its row
     int n_ins = 0;
     for (u32 ih = it_f;; ih -= 64u) {
-        const vu itj = ih - (vu)lane;  // lane j looks at iteration ih - j
+        vu itj = ih - (vu)lane;  // lane j looks at iteration ih - j
         const u64 have = w_ballot((vi)(itj - t.it0) >= 0);
         vu ra = 0u, rb = 0u, rc = 0u, rd = 0u;
-        W_WHERE(have) { w_load_x4(w.recs, itj & ring_mask, ra, rb, rc, rd); }
+        W_WHERE((A.debug & 8) ? 0ull : have) { w_load_x4(w.recs, itj & ring_mask, ra, rb, rc, rd); }
         const vu kb = TI ? rd : rc;
         const u64 valid = have & w_ballot((vi)kb > (vi)A2_CONT);  // (neither A2_INVALID nor A2_CONT)
-        const vi kc = (vi)kb - 1 + (vi)(itj & 1u);  // lane-0 diagonal of that iteration's row
-        w_lds_store(lds, (vu)lane * 4u + 0u, (vu)kc);
-        w_lds_store(lds, (vu)lane * 4u + 1u, ra);
-        w_lds_store(lds, (vu)lane * 4u + 2u, rb);
-        w_lds_store(lds, (vu)lane * 4u + 3u, w_selu(valid, 0u, 0xffffffffu));
-        w_fence_block();
-        // the chain of diagonals through the block, one iteration after the other
-        vi my_lane = 0, my_dir = 0;
-        const int n_it = w_popc(have);  // (`have` is a run of lanes from 0)
-        for (int l = 0; l < n_it; l++) {
-            const vi kc_l = (vi)w_lds_bcast(lds, 4 * l + 0);
-            const vu mlo = w_lds_bcast(lds, 4 * l + 1), mhi = w_lds_bcast(lds, 4 * l + 2);
-            const vu vm = w_lds_bcast(lds, 4 * l + 3);
-            const vi j = (kvv - kc_l) >> 1;
-            vu word = w_selu(w_ballot(j >= 32), mlo, mhi);
-            if (w_ballot(j >= 64) & w_ballot(vm != 0u)) {
-                // a wide row: cells 64.. and their bits are in the iterations behind it
-                const vu at = ((ih - (u32)l) + ((vu)j >> 6)) & ring_mask;
-                vu xa, xb, xc, xd;
-                w_load_x4(w.recs, at, xa, xb, xc, xd);
-                word = w_selu(w_ballot((j & 63) >= 32), xa, xb);
+        vi kc = (vi)kb - 1 + (vi)(itj & 1u);  // lane-0 diagonal of that iteration's row
+        const int n_rows = w_popc(valid);
+        if (n_rows > 0) {
+            if (valid != (n_rows >= 64 ? ~0ull : ((1ull << n_rows) - 1ull))) {
+                // iterations the track took no part in (parked; continuation records of wide
+                // rows): its rows move up to lanes 0 .. n_rows - 1
+                const vi to = w_sel(valid, 63, w_rank_in(valid));
+                kc = w_push_lanes(kc, to);
+                ra = (vu)w_push_lanes((vi)ra, to);
+                rb = (vu)w_push_lanes((vi)rb, to);
+                itj = (vu)w_push_lanes((vi)itj, to);
             }
-            const vi bit = (vi)((word >> ((vu)j & 31u)) & 1u);
-            const u64 me = 1ull << l;
-            my_lane = w_sel(me, my_lane, j);
-            my_dir = w_sel(me, my_dir, bit);
-            kvv = kvv + ((2 * bit - 1) & (vi)vm);  // from_above: pre_k = k + 1 (:190-196)
-        }
-        w_fence_block();
-        const vi r = r_top - w_rank_in(valid);
-        W_WHERE(valid) {
-            const vu itc = itj + ((vu)my_lane >> 6);  // (a wide row's cell 64 c + l: c iterations on)
-            const vu word = w_load32(w.cells, ((itc >> 2) & chunk_mask) * 64u + ((vu)my_lane & 63u));
-            vu m = (word >> ((itc & 3u) * 8u)) & 255u;
-            const u64 long_one = w_ballot(m == 255u);
-            if (long_one) {
-                const vu want = (itc << 6) | ((vu)my_lane & 63u);
-                for (int e = 0; e < w.n_esc; e++) {
-                    vu elo, ehi;
-                    w_load64(w.esc, (vu)e, elo, ehi);
-                    m = w_selu(w_ballot(ehi == want) & long_one, m, elo);
+            // From a row on diagonal k = kc + 2 j the path goes to k + 1 (from_above: pre_k =
+            // k + 1, DW_banded.c:190-196) or k - 1 of the row before -- lane l + 1, whose
+            // lane-0 diagonal differs by an odd number: in lanes, j moves by one of two
+            // per-row constants.  The chain itself is scalar work: one bit test and one add
+            // per row, the records read lane by lane.
+            const vi dk = kc - w_from_above(kc);
+            const vu step = ((vu)((dk + 1) >> 1) & 0xffffu) | ((vu)((dk - 1) >> 1) << 16);  // (if from_above | if not)
+            // (The chain runs on the VECTOR unit, every lane computing the same numbers: the
+            // kernel is bound by the scalar pipe, which a step then only needs for the loop
+            // itself.)
+            vi my_lane = 0;
+            vi vj = (kv - w_readlane(kc, 0)) >> 1;
+            for (int l = 0; l < ((A.debug & 2) ? 0 : n_rows); l++) {
+                my_lane = w_sel(w_ballot(lane == l), my_lane, vj);
+                vu lo = (vu)w_readlaneu(ra, l), hi = (vu)w_readlaneu(rb, l);
+                if (w_ballot(vj >= 64)) {
+                    // a wide row: cells 64.. and their bits are in the iterations behind it
+                    const vu at = ((vu)w_readlaneu(itj, l) + ((vu)vj >> 6)) & ring_mask;
+                    vu xc, xd;
+                    w_load_x4(w.recs, at, lo, hi, xc, xd);
+                }
+                const vu word = w_selu(w_ballot((vj & 32) != 0), lo, hi);
+                const vu bit = (word >> ((vu)vj & 31u)) & 1u;
+                if (l == n_rows - 1) {
+                    kv = w_uni(w_readlane(kc, l) + 2 * w_readlane(vj, 0) + 2 * (int)w_readlaneu(bit, 0) - 1);
+                } else {
+                    // the step of this row: its low half if the path came from above, else the high one
+                    const vu st = (vu)w_readlaneu(step, l);
+                    vj = vj + w_bfe_i16(st, (bit ^ 1u) << 4);
                 }
             }
-            const vi dir = w_sel(w_ballot(r == 0), my_dir, 0);  // row 0 starts at (0, 0): no edit
-            w_store32(script, (vu)r, (m << 1) | (vu)dir);
+            // every row's own bit, cell and script word, all rows at once
+            const u64 rows = n_rows >= 64 ? ~0ull : ((1ull << n_rows) - 1ull);
+            const vi r = r_top - lane;
+            vi my_dir = 0;
+            W_WHERE((A.debug & 4) ? 0ull : rows) {
+                vu word = w_selu(w_ballot((my_lane & 32) != 0), ra, rb);
+                const u64 far = w_ballot(my_lane >= 64);
+                if (far) {
+                    W_WHERE(far) {
+                        vu xa, xb, xc, xd;
+                        w_load_x4(w.recs, (itj + ((vu)my_lane >> 6)) & ring_mask, xa, xb, xc, xd);
+                        word = w_selu(w_ballot((my_lane & 32) != 0), xa, xb);
+                    }
+                }
+                my_dir = (vi)((word >> ((vu)my_lane & 31u)) & 1u);
+                const vu itc = itj + ((vu)my_lane >> 6);  // (a wide row's cell 64 c + l: c iterations on)
+                const vu cw = w_load32(w.cells, ((itc >> 2) & chunk_mask) * 64u + ((vu)my_lane & 63u));
+                vu m = (cw >> ((itc & 3u) * 8u)) & 255u;
+                const u64 long_one = w_ballot(m == 255u);
+                if (long_one) {
+                    const vu want = (itc << 6) | ((vu)my_lane & 63u);
+                    for (int e = 0; e < w.n_esc; e++) {
+                        vu elo, ehi;
+                        w_load64(w.esc, (vu)e, elo, ehi);
+                        m = w_selu(w_ballot(ehi == want) & long_one, m, elo);
+                    }
+                }
+                const vi dir = w_sel(w_ballot(r == 0), my_dir, 0);  // row 0 starts at (0, 0): no edit
+                w_store32(script, (vu)r, (m << 1) | (vu)dir);
+            }
+            n_ins += w_popc(rows & w_ballot(my_dir == 0) & w_ballot(r > 0));
+            r_top -= n_rows;
         }
-        n_ins += w_popc(valid & w_ballot(my_dir == 0) & w_ballot(r > 0));
-        r_top -= w_popc(valid);
         if (r_top < 0 || (int)(ih - t.it0) < 64) break;
     }
     return n_ins;

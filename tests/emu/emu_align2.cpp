@@ -75,6 +75,7 @@ extern "C" int emu_align2(const u32 *words, u64 n_words, const FaSeq *seq, int n
     A.script = script; A.script_off = script_off; A.aln = aln;
     A.band = band; A.max_diff = max_diff;
     A.stats = stats;
+    A.debug = 0;
     // the wavefronts of a launch run at the same time on the device and take work as they
     // go; here they run one after the other, wave w taking every n_wave-th chunk of the
     // queue is not needed for correctness -- any split of the queue is a legal schedule

@@ -95,6 +95,8 @@ W_FN vi w_from_above(const vi &v) { vi r; for (int l = 0; l < 64; l++) r.v[l] = 
 W_FN int w_readlane(const vi &v, int l) { return v.v[l & 63]; }
 W_FN u32 w_readlaneu(const vu &v, int l) { return v.v[l & 63]; }
 W_FN void w_writelane2(vu &a, vu &b, u32 sa, u32 sb, int l) { a.v[l & 63] = sa; b.v[l & 63] = sb; }
+W_FN void w_setlane(vi &v, int s, int l) { v.v[l & 63] = s; }
+W_FN vi w_push_lanes(const vi &v, const vi &dst) { vi r(0); for (int l = 0; l < 64; l++) r.v[dst.v[l] & 63] = v.v[l]; return r; }
 W_FN vi w_gather_lanes(const vi &v, const vi &src) { vi r; for (int l = 0; l < 64; l++) r.v[l] = v.v[src.v[l] & 63]; return r; }
 W_FN int w_uni(int v) { return v; }
 W_FN u32 w_uniu(u32 v) { return v; }
@@ -122,6 +124,7 @@ W_FN u64 w_bit_set(u64 m, int b) { return m | (1ull << (b & 63)); }
 W_FN int w_lowest(u64 m) { return m ? __builtin_ctzll(m) : -1; }
 W_FN int w_highest(u64 m) { return m ? 63 - __builtin_clzll(m) : -1; }
 W_FN int w_popc(u64 m) { return __builtin_popcountll(m); }
+W_FN vi w_bfe_i16(const vu &v, const vu &off) { vi r; for (int l = 0; l < 64; l++) r.v[l] = (int)(short)((v.v[l] >> (off.v[l] & 31u)) & 0xffffu); return r; }
 W_FN int w_span(u64 m) { return m ? 64 - (__builtin_clzll(m) + __builtin_ctzll(m)) : 0; }
 W_FN vi w_rank_in(u64 m) { vi r; for (int l = 0; l < 64; l++) r.v[l] = __builtin_popcountll(m & ((1ull << l) - 1ull)); return r; }
 W_FN vu w_undef() { return vu(0xdeadbeefu); }
