@@ -131,7 +131,7 @@ def _cpu_run(kind, piles, first, cores, per):
             "wall_s": round(wall, 1)}, strings
 
 
-def cpu_baseline(piles, timed_per_worker=20):
+def cpu_baseline(piles, timed_per_worker=20, procs=None):
     """-> (the cpu_baseline object, {pile index: consensus string} of the timed piles).
 
     SURVEY.md 8d "CPU baseline timing": the reference C path in P worker processes = the
@@ -139,8 +139,8 @@ def cpu_baseline(piles, timed_per_worker=20):
     the reference keeps a 0.9 GB workspace per process), one untimed warm-up pile per
     worker, `timed_per_worker` timed piles each, taken from the front of this rank's batch.
     The reference does not scale to a big host (every process sweeps its own 0.9 GB
-    workspace per pile: 128 processes were measured SLOWER than 16), so a 16-process run is
-    timed as well and `value` is the better of the two -- both are listed."""
+    workspace per pile: 128 processes were measured SLOWER than 16), so 16, 32 and 64
+    processes are timed as well and `value` is the best of them -- all are listed."""
     from oracle.pyoracle import build, have_ref
     try:
         build()
@@ -152,9 +152,12 @@ def cpu_baseline(piles, timed_per_worker=20):
     mem = _mem_available_gb()
     if mem is not None:
         cores = max(1, min(cores, int(mem / 2.0)))  # 0.9 GB workspace + the piles + headroom
-    per = min(timed_per_worker + 1, len(piles))
     runs, strings, first = [], {}, 0
-    for want in sorted({cores, min(cores, 16)}):
+    # 16, 32, 64 processes and the physical cores: where the host's best lies is measured,
+    # not assumed (the larger configurations time fewer piles per worker: ~10-30 s each)
+    for want in sorted({min(cores, int(x)) for x in procs} if procs else
+                       {min(cores, 16), min(cores, 32), min(cores, 64), cores}):
+        per = min((timed_per_worker if want <= 32 else max(4, timed_per_worker // 3)) + 1, len(piles))
         c = max(1, min(want, (len(piles) - first) // per))
         if (c < want and runs) or first + per > len(piles):
             break  # (not enough piles left for another configuration)
@@ -178,10 +181,12 @@ def cpu_baseline(piles, timed_per_worker=20):
         "per_core_bases_per_sec": best["per_core_bases_per_sec"],
         "host_cpu_count": logical, "host_physical_cores": phys, "host_cpu_model": cpu_model,
         "runs": runs,
-        "sample": "piles of this workload from the front of the batch, %d timed per worker process + 1 "
-                  "untimed warm-up pile each; worker processes: %s (physical cores, capped by the cpus "
-                  "allowed and memory / 2 GB; and 16) -- `value` is the best of them: %d processes, %d "
-                  "piles" % (per - 1, ", ".join(str(r["cores"]) for r in runs), best["cores"], best["piles"]),
+        "sample": "piles of this workload from the front of the batch, %d timed per worker process (%d "
+                  "beyond 32 processes) + 1 untimed warm-up pile each; worker processes: %s (16, 32, 64 and "
+                  "the physical cores, capped by the cpus allowed and memory / 2 GB) -- `value` is the "
+                  "best of them: %d processes, %d piles"
+                  % (timed_per_worker, max(4, timed_per_worker // 3), ", ".join(str(r["cores"]) for r in runs),
+                     best["cores"], best["piles"]),
     }, strings
 
 
@@ -228,16 +233,16 @@ def end_to_end(piles, extra_args=(), expect=None, repeats=E2E_REPEATS):
         # launches are at another batch size and would blur its per-kernel averages)
         env = {k: v for k, v in os.environ.items()
                if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTRACER", "HSA_TOOLS"))}
-        # twice, the better run counts: the first worker starts while the text it reads is
-        # still being written back and beside this process's resident batches, and its wall
-        # time moves by a factor of two with that (both are listed)
+        # three workers back to back, the median counts: fc_run starts one consensus process
+        # per .las block one after the other, so a worker that starts right behind one that
+        # released its VRAM (amdgpu wipes it) IS production (all three are listed)
         walls = []
-        for _ in range(2):
+        for _ in range(3):
             t0 = time.perf_counter()
             with open(src) as fin, open(dst, "w") as fout:
                 subprocess.run(cmd, stdin=fin, stdout=fout, check=True, cwd=root, timeout=600, env=env)
             walls.append(time.perf_counter() - t0)
-        wall = min(walls)
+        wall = sorted(walls)[1]  # the MEDIAN of three back-to-back workers (all listed)
         with open(dst) as f:
             text = f.read()
         bases = sum(len(ln) for ln in text.split("\n") if not ln.startswith(">"))
@@ -255,6 +260,49 @@ def end_to_end(piles, extra_args=(), expect=None, repeats=E2E_REPEATS):
         out["fasta_identical_to_resident_batch"] = (want == text)
         out["fasta_sha1"] = hashlib.sha1(text.encode()).hexdigest()[:16]
     return out
+
+
+def end_to_end_multi(piles, n_streams, repeats=E2E_REPEATS):
+    """N > 1: the same text as `n_streams` jobs of ONE multi-stream worker process
+    (falcon_amd.mains.consensus_multi) over all visible GPUs -- how a node is fed: a single
+    stream has one reader and one staging thread, which one device's batches already keep
+    busy.  Every job's FASTA must equal what the single-stream worker prints
+    for the same text on one GPU (run afterwards, outside the timing)."""
+    root = os.path.dirname(os.path.abspath(__file__))
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "piles.txt")
+        with open(src, "wb") as f:
+            write_la4falcon(piles, f, repeats)
+        size = os.path.getsize(src)
+        opts = ["--output-multi", "--min-idt", "0.70", "--min-cov", "4", "--max-n-read", "200", "--n-core", "1"]
+        env = {k: v for k, v in os.environ.items()
+               if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTRACER", "HSA_TOOLS"))
+               and k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        env.pop("FALCON_AMD_DEVICES", None)
+        jobs = []
+        for j in range(n_streams):
+            jobs += ["--job", src, os.path.join(tmp, "cns_%d.fasta" % j)]
+        cmd = [sys.executable, "-m", "falcon_amd.mains.consensus_multi"] + opts + jobs
+        walls = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            subprocess.run(cmd, check=True, cwd=root, timeout=900, env=env)
+            walls.append(time.perf_counter() - t0)
+        ref = os.path.join(tmp, "single.fasta")
+        with open(src) as fin, open(ref, "w") as fout:
+            subprocess.run([sys.executable, "-m", "falcon_amd.mains.consensus"] + opts, stdin=fin, stdout=fout,
+                           check=True, cwd=root, timeout=900, env=dict(env, FALCON_AMD_DEVICES="0"))
+        want = open(ref).read()
+        same = all(open(os.path.join(tmp, "cns_%d.fasta" % j)).read() == want for j in range(n_streams))
+    n = repeats * len(piles) * n_streams
+    walls.sort()
+    wall = walls[len(walls) // 2]
+    return {"piles_per_sec": round(n / wall, 1), "text_MB_per_sec": round(size * n_streams / 1e6 / wall, 1),
+            "wall_s": round(wall, 2), "runs_wall_s": [round(w, 2) for w in walls], "streams": n_streams,
+            "every_stream_identical_to_the_single_stream_worker": bool(same),
+            "what": "%d streams of %d piles each (%.0f MB of text each, from the page cache) -> %d FASTA files, "
+                    "one multi-stream worker process over all visible GPUs, process start included; the slower "
+                    "of two runs counts" % (n_streams, repeats * len(piles), size / 1e6, n_streams)}
 
 
 def measured_stream_rate(torch, mib=1024, reps=5):
@@ -321,6 +369,11 @@ def parse_args(argv=None):
     ap.add_argument("--piles", type=int, default=int(os.environ.get("FALCON_BENCH_PILES", "0")),
                     help="piles per step per GPU (default: 3072 ecoli, 1024 dmel, 1536 arab)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-procs", default="",
+                    help="worker-process counts of the CPU baseline, comma separated (default: 16,32,64 and "
+                         "the physical cores)")
+    ap.add_argument("--cpu-baseline-timed", type=int, default=20,
+                    help="timed piles per CPU worker process (every one is also a parity check of the GPU's answer)")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one resident batch, every step drained before the next (A/B of the "
@@ -448,8 +501,13 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
     st = batch.stats()
     # whole-job aggregate: units summed over ranks, time = slowest rank
     from falcon_amd.multigpu import reduce_measurement
+    own_elapsed = elapsed
     bases_all, piles_all, elapsed = reduce_measurement(float(st.O), float(st.n_piles), elapsed,
                                                        device="cuda" if plumb.cuda else None)
+    from falcon_amd.multigpu import gather_per_rank
+    per_rank = gather_per_rank([float(st.O) * args.steps / own_elapsed, own_elapsed / max(1, args.steps) * 1e3,
+                                acc.get("ms_align", 0.0) / max(1, args.steps)],
+                               device="cuda" if plumb.cuda else None)
     ranks_ran = world
     if world > 1:
         one = plumb.torch.ones(1, dtype=plumb.torch.float64, device="cuda" if plumb.cuda else None)
@@ -506,6 +564,9 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
                 "accepted_alignments_per_step_per_gpu": int(st.n_aligned),
             },
             "pipelined_steps": bool(pipelined),
+            # every rank on its own clock (the whole-job `value` divides by the slowest rank's time)
+            "per_rank": [{"rank": i, "bases_per_sec": round(r[0], 1), "ms_per_step": round(r[1], 3),
+                          "k_align_ms": round(r[2], 3)} for i, r in enumerate(per_rank)],
             "piles_per_sec": round(piles_all * args.steps / elapsed, 2),
             "roofline": {
                 "bound": "hbm", "kernel": domk,
@@ -529,6 +590,11 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
             },
             "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},
             "kernel_ms": {n: round(v, 4) for n, v in kernel_ms.items()},
+            # (HIP-event spans on the streams the kernels run on: in pipelined steps they are
+            # QUEUE-INCLUSIVE -- a back-stream kernel's span holds its wait for the wave slots
+            # the co-running alignment kernel frees, so the spans add up to more than a step;
+            # `roofline.alone` and the unpipelined profile under profiles/ hold the kernels' own times)
+            "kernel_ms_are": "queue-inclusive event spans" if pipelined else "kernel times (one batch at a time)",
             "host_plan_gap_ms": round(host_gap, 3),
             # the alignment stage about itself (fa_stats): arena bytes, resident wavefronts, and
             # k_align2's iterations with two / one alignment running, band placements,
@@ -565,6 +631,13 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
                 res["end_to_end"] = end_to_end(piles, expect=gpu_cns)
             except Exception as e:  # informative; never lose the GPU line
                 res["end_to_end"] = {"piles_per_sec": None, "what": "failed: %r" % (e,)}
+        if world > 1 and not args.no_end_to_end:
+            # N streams through the multi-stream worker over the N GPUs (the other ranks are
+            # done and idle; their resident batches only hold memory)
+            try:
+                res["end_to_end"] = end_to_end_multi(piles, world)
+            except Exception as e:
+                res["end_to_end"] = {"piles_per_sec": None, "what": "failed: %r" % (e,)}
         if world == 1:
             # staging again, now that the context's pinned and device staging buffers exist:
             # the steady-state cost of handing a batch of host buffers over (outside `value`;
@@ -580,7 +653,9 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
                 pass
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"], cpu_cns = cpu_baseline(piles)
+                res["cpu_baseline"], cpu_cns = cpu_baseline(
+                    piles, timed_per_worker=max(1, args.cpu_baseline_timed),
+                    procs=[x for x in args.cpu_baseline_procs.split(",") if x.strip()] or None)
                 if gpu_cns is not None:
                     bad = [i for i, s in cpu_cns.items() if gpu_cns[i] != s]
                     res["parity_checked_piles"] = len(cpu_cns)

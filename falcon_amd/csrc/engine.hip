@@ -313,6 +313,8 @@ struct fa_batch {
     HostBuf<FaPileOut> h_pile_out;
     HostBuf<FaTagAln> h_ta;
     std::vector<int> pile_err, pile_err_arg;  // per pile: 0 fine, else why it has no consensus
+    std::vector<int> pile_fixed_err;          // ... decided when the batch was built (3: a byte other than ACGT)
+    std::map<int, std::string> pile_err_msg;
     bool msa_static = false;  // seg lists and t_off (functions of the seed lengths) uploaded
     std::vector<int> h_out_eqv;
     std::vector<std::string> h_result;
@@ -560,6 +562,7 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
     }
     b->pile_err.assign(n_pile, 0);
     b->pile_err_arg.assign(n_pile, 0);
+    b->pile_fixed_err.assign(n_pile, 0);
     b->n_seq = g;
     b->n_words = woff;
     b->ascii_bytes = aoff + 16;
@@ -686,9 +689,14 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
             ok &= hipMemcpyAsync(b->d_probe_off.p, b->probe_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
         trace_stage(s, "upload");
         int first_bad = 0x7fffffff;
+        DevBuf<int> d_bad_pile;
+        if (ok && !pair_mode) {
+            ok &= d_bad_pile.alloc((size_t)n_pile) == 0;
+            if (ok) ok &= hipMemsetAsync(d_bad_pile.p, 0, (size_t)n_pile * sizeof(int), s) == hipSuccess;
+        }
         if (ok) {
             ok &= hipMemcpyAsync(ctx->d_first_bad, &first_bad, sizeof(int), hipMemcpyHostToDevice, s) == hipSuccess;
-            fa_launch_pack(b->dev(), ctx->d_first_bad, s);
+            fa_launch_pack(b->dev(), ctx->d_first_bad, pair_mode ? nullptr : d_bad_pile.p, s);
             ok &= hipGetLastError() == hipSuccess;
             ok &= hipMemcpyAsync(&first_bad, ctx->d_first_bad, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess;
         }
@@ -697,17 +705,46 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
         trace_stage(s, "pack");
         pt.mark("h2d+pack");
         b->ascii_dev = nullptr;
-        if (ok && first_bad != 0x7fffffff) {
+        auto describe = [&](int g) {
             // the reference aligns raw characters and codes other bytes specially
-            // (kmer_lookup.c:159-171, :236-249): outside the parity domain, refused
-            const FaSeq &sq = b->seq[first_bad];
+            // (kmer_lookup.c:159-171, :236-249): outside the parity domain
+            const FaSeq &sq = b->seq[g];
             int at = 0;
-            while (at < sq.len && strchr("ACGT", seqs[first_bad][at]) && seqs[first_bad][at]) at++;
-            set_err("falcon_amd: sequence %d of pile %d holds byte 0x%02x at position %d; only "
-                    "upper-case A, C, G, T are supported (what LA4Falcon emits)", sq.idx, sq.pile,
-                    at < sq.len ? (unsigned)(unsigned char)seqs[first_bad][at] : 0u, at);
+            while (at < sq.len && seqs[g][at] && strchr("ACGT", seqs[g][at])) at++;
+            char msg[256];
+            snprintf(msg, sizeof(msg), "sequence %d of pile %d holds byte 0x%02x at position %d; only "
+                     "upper-case A, C, G, T are supported (what LA4Falcon emits)", sq.idx, sq.pile,
+                     at < sq.len ? (unsigned)(unsigned char)seqs[g][at] : 0u, at);
+            return std::string(msg);
+        };
+        if (ok && first_bad != 0x7fffffff && pair_mode) {
+            // (the legacy align() has no way to report one pair: the call fails)
+            set_err("falcon_amd: %s", describe(first_bad).c_str());
             delete b;
             return nullptr;
+        }
+        if (ok && first_bad != 0x7fffffff) {
+            // Piles fail alone: a pile with such a sequence gets no consensus and an entry in
+            // fa_batch_pile_error; its reads are taken out of the stages (as index 0 they
+            // count as seeds: no chain, no alignment); the batch -- and the stream -- go on.
+            std::vector<int> bad((size_t)n_pile);
+            ok &= hipMemcpy(bad.data(), d_bad_pile.p, (size_t)n_pile * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+            for (int p = 0; ok && p < n_pile; p++) {
+                if (!bad[p]) continue;
+                const FaPile &pm = b->pile[p];
+                int g_bad = pm.first;
+                for (int j = 0; j < pm.n_seq; j++) {
+                    const int g = pm.first + j;
+                    int at = 0;
+                    while (at < b->seq[g].len && seqs[g][at] && strchr("ACGT", seqs[g][at])) at++;
+                    if (at < b->seq[g].len) { g_bad = g; break; }
+                }
+                b->pile_fixed_err[p] = 3;
+                b->pile_err_msg[p] = describe(g_bad);
+                for (int j = 0; j < pm.n_seq; j++) b->seq[pm.first + j].idx = 0;
+            }
+            if (ok)
+                ok &= hipMemcpy(b->d_seq.p, b->seq.data(), (size_t)g * sizeof(FaSeq), hipMemcpyHostToDevice) == hipSuccess;
         }
     }
     if (!ok) {
@@ -1163,7 +1200,7 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
         u64 levels = (u64)pm.seed_len + 2, cols = 8;
         acc_first[p] = (u32)n_ta;
         int n_acc = 0;
-        b->pile_err[p] = 0;
+        b->pile_err[p] = b->pile_fixed_err[p];
         // what the pile adds to the pools, committed below unless the pile is too deep
         const size_t n_ta0 = n_ta;
         const u64 desc0 = desc_tot, ins0 = ins_tot;
@@ -1597,7 +1634,9 @@ extern "C" int fa_batch_pile_error(fa_batch *b, int p, char *msg, int msg_cap) {
     if (!b || p < 0 || p >= b->n_pile) return -1;
     const int code = b->pile_err[p];
     if (code && msg && msg_cap > 0) {
-        if (code == 2)
+        if (code == 3)
+            snprintf(msg, (size_t)msg_cap, "%s", b->pile_err_msg.count(p) ? b->pile_err_msg[p].c_str() : "a byte other than ACGT");
+        else if (code == 2)
             snprintf(msg, (size_t)msg_cap, "%d usable reads; the GPU consensus stage handles at most %d per "
                      "pile (the reference has no such limit: lower --max-n-read)", b->pile_err_arg[p],
                      FA_CNS_MAX_ALN);

@@ -131,8 +131,9 @@ void fa_launch_align2(const FaBatchDev &b, const FaAlign2Arena &a, double max_di
                       const int *order, int n_work, hipStream_t s);
 
 // first_bad: device int, preset to INT_MAX; receives the lowest sequence index holding a byte
-// other than upper-case A, C, G, T
-void fa_launch_pack(const FaBatchDev &b, int *first_bad, hipStream_t s);
+// other than upper-case A, C, G, T.  bad_pile (optional, n_pile ints, zeroed): 1 for every
+// pile with such a sequence
+void fa_launch_pack(const FaBatchDev &b, int *first_bad, int *bad_pile, hipStream_t s);
 void fa_launch_index(const FaBatchDev &b, hipStream_t s);
 void fa_launch_chain(const FaBatchDev &b, int max_bins, hipStream_t s);
 // general banded alignment for band tolerances beyond FA_ALIGN_MAXCH chunks (k_align_wide.hip)

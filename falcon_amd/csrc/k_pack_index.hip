@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t *__restrict__ ascii,
                                               const u64 *__restrict__ ascii_off,
                                               const FaSeq *__restrict__ seq, int n_seq,
                                               u32 *__restrict__ words, u64 n_words,
-                                              int *__restrict__ first_bad) {
+                                              int *__restrict__ first_bad, int *__restrict__ bad_pile) {
     u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_words) return;
     // which sequence owns word w: last g with seq[g].woff <= w
@@ -53,14 +53,17 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t *__restrict__ ascii,
         }
     }
     words[w] = out;
-    if (bad) atomicMin(first_bad, lo);
+    if (bad) {
+        atomicMin(first_bad, lo);
+        if (bad_pile) bad_pile[s.pile] = 1;  // (piles fail alone: the engine takes this one out)
+    }
 }
 
-void fa_launch_pack(const FaBatchDev &b, int *first_bad, hipStream_t s) {
+void fa_launch_pack(const FaBatchDev &b, int *first_bad, int *bad_pile, hipStream_t s) {
     if (b.n_words == 0) return;
     unsigned grid = (unsigned)((b.n_words + 255) / 256);
     hipLaunchKernelGGL(k_pack, dim3(grid), dim3(256), 0, s, b.ascii, b.ascii_off, b.seq, b.n_seq,
-                       b.words, b.n_words, first_bad);
+                       b.words, b.n_words, first_bad, bad_pile);
 }
 
 // --------------------------------------------------------------------------

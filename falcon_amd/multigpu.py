@@ -43,3 +43,17 @@ def gather_in_order(local_results: List, rank: int, world: int) -> List:
     parts = [None] * world
     dist.all_gather_object(parts, list(local_results))
     return [x for p in parts for x in p]
+
+
+def gather_per_rank(values: Sequence[float], device=None) -> List[List[float]]:
+    """Every rank's list of numbers, in rank order (a row per rank); [values] when
+    torch.distributed is not initialised.  What rank 0 prints beside the whole-job figure, so
+    that a straggling rank shows."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [list(values)]
+    mine = torch.tensor(list(values), dtype=torch.float64, device=device)
+    rows = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(rows, mine)
+    return [[float(x) for x in r.tolist()] for r in rows]

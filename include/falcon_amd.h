@@ -178,8 +178,9 @@ int fa_batch_stats(fa_batch *b, fa_stats *out);
  * reference, falcon.c:597-647, any number; its driver's default --max-n-read is 500); a
  * deeper pile -- or one whose consensus stage reports a device error -- does not fail its
  * batch: fa_batch_run succeeds, fa_batch_result gives that pile an empty consensus, and this
- * returns why (0: the pile is fine; 2: too many usable reads; 1: device error), with a
- * description in msg if msg != NULL. */
+ * returns why (0: the pile is fine; 2: too many usable reads; 1: device error; 3: one of its
+ * sequences holds a byte other than upper-case A, C, G, T -- the reference aligns raw
+ * characters there, outside the parity domain), with a description in msg if msg != NULL. */
 int fa_batch_pile_error(fa_batch *b, int pile, char *msg, int msg_cap);
 /* The worker's output rules (falcon_kit/mains/consensus.py:275-299): the FASTA text the
  * reference prints for a consensus string -- nothing if it is shorter than 500; default:

@@ -372,11 +372,49 @@ def gen_f8(R):
     dump("f8_configs", dict(cases=cases))
 
 
+def _f10_one(seed):
+    """(worker process: the reference C is not re-entrant, one Ref per process)"""
+    s, rd = make_pile(seed, S=20000, coverage=40.0)
+    seqs = [codes_to_str(x) for x in pile_to_seqs(s, rd, 200)]
+    seq, eqv = Ref().generate_consensus(seqs, 4, 8, 0.70)
+    return dict(seed=seed, n_seq=len(seqs), input_sha=hashlib.sha1("\n".join(seqs).encode()).hexdigest()[:16],
+                cns_len=len(seq), cns_sha=hashlib.sha1(seq.encode()).hexdigest(), eqv_sha=sha_ints(eqv))
+
+
+def gen_f10(R):
+    """The 72 bench-scale piles of tests/test_gpu_parity.py::test_bench_scale_batch_properties
+    (BASELINE config 2: 20 kb seeds x 40x, e = 0.13; seeds 7000..7071) through the compiled
+    reference: per pile a digest of the input, of the consensus string and of eqv."""
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(16) as pool:
+        cases = pool.map(_f10_one, range(7000, 7072))
+    dump("f10_bench72", dict(S=20000, coverage=40.0, min_cov=4, K=8, min_idt=0.70, cases=cases))
+
+
+def gen_f11(R):
+    """BASELINE config 1 at the CLI level: the test_data/t1.fa-derived pile of f4's
+    `t1_config1` as LA4Falcon text through the reference's OWN driver (its main() under
+    python3, as for f5), in the three output modes."""
+    mod = import_reference_driver()
+    t1_id, t1 = read_t1()
+    r1 = np.random.default_rng(1)
+    t1c = to_codes(t1)
+    derived = [noisy(t1c, r1, 0.12) for _ in range(20)]
+    stdin_text = pile_to_la4falcon(t1_id, t1c, derived, 1) + "- -\n"
+    runs = []
+    for argv in ([], ["--output-multi"], ["--output-full"], ["--output-multi", "--min-cov", "6", "--min-idt", "0.75"]):
+        out = run_reference_cli(mod, argv, stdin_text)
+        runs.append(dict(argv=argv, stdout=out))
+        print("   cli %-60s -> %d bytes, %d records" % (" ".join(argv), len(out), out.count(">")))
+    dump("f11_cli_config1", dict(stdin_sha=hashlib.sha1(stdin_text.encode()).hexdigest(), seed_id=t1_id,
+                                 n_reads=len(derived), runs=runs))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     R = Ref()
-    if len(sys.argv) > 1 and sys.argv[1] in ("f7", "f8"):  # (the other fixtures are already committed)
-        {"f7": gen_f7, "f8": gen_f8}[sys.argv[1]](R)
+    if len(sys.argv) > 1 and sys.argv[1] in ("f7", "f8", "f10", "f11"):  # (the other fixtures are already committed)
+        {"f7": gen_f7, "f8": gen_f8, "f10": gen_f10, "f11": gen_f11}[sys.argv[1]](R)
         return
     gen_f1_f2(R)
     gen_f3(R)

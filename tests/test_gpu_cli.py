@@ -33,6 +33,38 @@ def test_module_cli(case):
     assert out == case["stdout"]
 
 
+F11 = load_golden("f11_cli_config1")
+
+
+def _config1_stream():
+    """The LA4Falcon text of BASELINE config 1, rebuilt the way oracle/gen_golden.py f11 built
+    it: the t1.fa read (frozen as the seed of f4's `t1_config1` pile) and 20 noisy copies of
+    it from the same seeded generator; the fixture's digest pins the bytes."""
+    import hashlib
+    import numpy as np
+    from falcon_amd.synth import noisy, pile_to_la4falcon
+    seed = {c["name"]: c for c in load_golden("f4_piles")["cases"]}["t1_config1"]["seqs"][0]
+    codes = np.frombuffer(seed.encode(), dtype=np.uint8)
+    t1c = np.zeros(len(codes), dtype=np.uint8)
+    for i, ch in enumerate(b"ACGT"):
+        t1c[codes == ch] = i
+    r1 = np.random.default_rng(1)
+    derived = [noisy(t1c, r1, 0.12) for _ in range(20)]
+    text = pile_to_la4falcon(F11["seed_id"], t1c, derived, 1) + "- -\n"
+    assert hashlib.sha1(text.encode()).hexdigest() == F11["stdin_sha"]
+    return text
+
+
+@pytest.mark.parametrize("case", F11["runs"], ids=[" ".join(r["argv"]) or "defaults" for r in F11["runs"]])
+def test_config1_t1_pile_cli(case):
+    """BASELINE config 1 at the CLI level: the test_data/t1.fa-derived pile as LA4Falcon text
+    through the worker, byte for byte what the reference's own driver prints for it
+    (tests/golden/f11_cli_config1, oracle/gen_golden.py f11)."""
+    out = run_cmd([sys.executable, "-m", "falcon_amd.mains.consensus"] + case["argv"] + ["--n-core", "1"],
+                  _config1_stream())
+    assert out == case["stdout"]
+
+
 def test_dropin_overlay_and_console_script():
     case = F5["runs"][1]  # the fc_run_ecoli.cfg flags
     out = run_cmd([sys.executable, "-m", "falcon_kit.mains.consensus"] + case["argv"] +
@@ -73,6 +105,31 @@ def test_a_pile_too_deep_for_the_gpu_fails_alone():
     p = subprocess.run(cmd, input=text, capture_output=True, text=True, cwd=ROOT, timeout=600,
                        env=dict(env, FALCON_AMD_SKIP_FAILED_PILES="1"))
     assert p.returncode == 0 and p.stdout == clean
+
+
+def test_a_dirty_pile_in_the_stream_fails_alone():
+    """A read with an N (or any byte that is not upper-case ACGT) in the middle of a stream:
+    its pile is named on stderr and left out, every other pile is printed exactly as without
+    it, exit status 3 -- the stream does not die (the reference aligns raw characters there;
+    LA4Falcon never emits them)."""
+    from falcon_amd.synth import make_pile, pile_to_la4falcon
+    chunks = []
+    for i in range(4):
+        seed, rd = make_pile(1700 + i, S=2500, coverage=14, min_read=500, mean_read=1500, sd_read=400)
+        chunks.append(pile_to_la4falcon("%09d" % i, seed, rd, 100000 * i + 1))
+    lines = chunks[2].split("\n")
+    name, bases = lines[3].split(" ")
+    lines[3] = name + " " + bases[:100] + "N" + bases[101:]
+    dirty = "\n".join(lines)
+    opts = ["--output-multi", "--min-idt", "0.70", "--min-cov", "4", "--n-core", "1"]
+    cmd = [sys.executable, "-m", "falcon_amd.mains.consensus"] + opts
+    clean = run_cmd(cmd, chunks[0] + chunks[1] + chunks[3] + "- -\n")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for extra in ({}, {"FALCON_AMD_BATCH_BASES": "60000"}, {"FALCON_AMD_PY_READER": "1"}):
+        p = subprocess.run(cmd, input=chunks[0] + chunks[1] + dirty + chunks[3] + "- -\n", capture_output=True,
+                           text=True, env=dict(env, **extra), cwd=ROOT, timeout=600)
+        assert p.returncode == 3 and p.stdout == clean, extra
+        assert "seed 000000002 is not corrected" in p.stderr and "holds byte 0x4e at position 100" in p.stderr
 
 
 def test_native_and_python_printers_agree():

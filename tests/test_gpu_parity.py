@@ -76,13 +76,35 @@ def test_limits_are_errors_not_silent_degradation(engine):
         engine.batch([[big, big[:5000]]])
     for bad, at in (("N", 700), ("a", 0), ("\r", 1199)):
         dirty = seq[:at] + bad + seq[at + 1:]
-        with pytest.raises(FalconAmdError, match="sequence 2 of pile 1 holds byte 0x%02x at position %d" % (ord(bad), at)):
-            engine.batch([[seq, seq, seq], [seq, seq, dirty, seq]])
-        with pytest.raises(FalconAmdError, match="holds byte"):
+        # the legacy align() has no way to report one pair: the call fails, naming the byte
+        with pytest.raises(FalconAmdError, match="holds byte 0x%02x at position %d" % (ord(bad), at)):
             engine.align_pairs([(seq, seq), (dirty, seq)], band=150)
     b = engine.batch([[seq, seq, seq]])  # the context is fine afterwards
     b.run(4, 8, 0.70)
     b.free()
+
+
+def test_a_dirty_pile_fails_alone(engine, port):
+    """A byte other than upper-case ACGT (the reference aligns raw characters there: outside
+    the parity domain) does not take its batch down: that pile alone gets no consensus and a
+    reason naming sequence, byte and position (fa_batch_pile_error code 3); the piles around
+    it are corrected as if it were not there -- whether the byte sits in a read or in the seed."""
+    clean = [_synthetic(61, S=5000, coverage=14), _synthetic(62, S=4000, coverage=12)]
+    want = [port.generate_consensus(p, 4, 8, 0.70) for p in clean]
+    for where, bad, at in ((3, "N", 700), (0, "a", 0), (2, "\r", 1500)):
+        dirty = list(_synthetic(63, S=4500, coverage=12))
+        dirty[where] = dirty[where][:at] + bad + dirty[where][at + 1:]
+        b = engine.batch([clean[0], dirty, clean[1]])
+        try:
+            b.run(4, 8, 0.70).fetch(True)
+            fails = b.failures()
+            assert len(fails) == 1 and fails[0][0] == 1
+            assert "sequence %d of pile 1 holds byte 0x%02x at position %d" % (where, ord(bad), at) in fails[0][1]
+            assert b.stats().n_piles_failed == 1
+            assert b.result(1)[0] == ""
+            assert tuple(b.result(0)) == tuple(want[0]) and tuple(b.result(2)) == tuple(want[1])
+        finally:
+            b.free()
 
 
 def test_wide_band_vs_oracle(engine):
@@ -465,8 +487,15 @@ def test_bench_scale_batch_properties(engine):
     assert rev == list(reversed(r1))                    # order of piles is irrelevant
     for i in (0, 31, 71):                               # and so is their company
         assert engine.consensus([piles[i]], 4, 8, 0.70, want_eqv=True) == [r1[i]]
-    digest = hashlib.sha1("".join(c for c, _ in r1).encode()).hexdigest()
-    assert len(digest) == 40
+    # ... and every one of the 72 is the COMPILED REFERENCE's answer (tests/golden/f10_bench72,
+    # oracle/gen_golden.py f10): input, consensus string and eqv digests per pile
+    from helpers import sha_ints
+    f10 = load_golden("f10_bench72")["cases"]
+    assert [c["seed"] for c in f10] == list(range(7000, 7072))
+    for i, (c, (cns, eqv)) in enumerate(zip(f10, r1)):
+        assert hashlib.sha1("\n".join(piles[i]).encode()).hexdigest()[:16] == c["input_sha"], i
+        assert (len(cns), hashlib.sha1(cns.encode()).hexdigest(), sha_ints(eqv)) == \
+               (c["cns_len"], c["cns_sha"], c["eqv_sha"]), i
 
 
 @pytest.mark.parametrize("kernel", ["two_per_wave", "one_per_wave"])

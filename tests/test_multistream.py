@@ -316,3 +316,65 @@ def test_a_job_with_an_uncorrected_pile_fails_alone(tmp_path, monkeypatch):
     res = go()
     assert [r[2] for r in res] == [None] * 3
     assert marker not in (tmp_path / "out_1.fasta").read_text()
+
+
+class TimedBackend(FakeBackend):
+    """A device modelled in time: staging a batch 8 ms of host work (copy into pinned memory,
+    upload), its throughput stages 20 ms under the engine's lock, the sequential stages and
+    the download 8 ms beside the next batch's."""
+
+    def stage(self, engine, ps):
+        time.sleep(0.008)
+        return super().stage(engine, ps)
+
+    def submit(self, batch):
+        engine, piles = batch
+        with self.lock:
+            self.running[engine] = self.running.get(engine, 0) + 1
+            self.overlap |= self.running[engine] > 1
+        time.sleep(0.020)
+        with self.lock:
+            self.running[engine] -= 1
+
+    def collect(self, batch):
+        engine, piles = batch
+        time.sleep(0.008)
+        with self.lock:
+            self.finished += 1
+        return [(p[0] * 20)[:600] for p in piles]
+
+
+def test_four_devices_are_fed_by_four_streams(tmp_path, monkeypatch):
+    """piles shard over the GPUs of a node with no collective -- but somebody has
+    to FEED them.  One stream has one reader and one staging thread, which a single device's
+    20 ms batches already keep busy; N devices are fed by N streams through the
+    multi-stream worker, each with its own reader and stager (one consensus job per .las
+    block is what fc_run starts anyway).  With a device modelled in time, four streams on four
+    engines must take at most a third of what they take on one -- a single staging thread, or
+    a lock shared by the devices, would show here -- and no engine ever runs two batches'
+    throughput stages at once."""
+    monkeypatch.setenv("FALCON_AMD_BATCH_BASES", "900")
+    rng = random.Random(12)
+    texts = [_rand_stream(rng, 60, with_noise=False) for _ in range(4)]
+
+    def run_on(n_engines, tag):
+        argv = ["prog"] + OPTS
+        for i, text in enumerate(texts):
+            path = tmp_path / ("s_%s_%d.txt" % (tag, i))
+            path.write_text(text)
+            argv += ["--job", str(path), str(tmp_path / ("o_%s_%d.fasta" % (tag, i)))]
+        args = multi.parse_args(argv)
+        backend = TimedBackend()
+        pool = multi.DevicePool([FakeEngine() for _ in range(n_engines)])
+        t0 = time.perf_counter()
+        results = multi.run(args, pool=pool, backend=backend)
+        wall = time.perf_counter() - t0
+        assert [r[2] for r in results] == [None] * len(texts)
+        assert not backend.overlap
+        return wall, backend.finished, [(tmp_path / ("o_%s_%d.fasta" % (tag, i))).read_text() for i in range(4)]
+
+    wall1, n1, out1 = run_on(1, "one")
+    wall4, n4, out4 = run_on(4, "four")
+    assert out1 == out4 and n1 == n4 and n1 >= 40
+    assert wall1 >= n1 * 0.020            # one engine: its throughput stages in a row
+    assert wall4 <= wall1 / 3.0, (wall1, wall4, n1)

@@ -47,3 +47,41 @@ def test_golden_quirks_are_present():
     assert len(c["sequence"]) == 1987 and c["sequence"][-1] == "A"
     low = {x["name"]: x for x in F4}["identical_copies_3_lowcov"]
     assert low["sequence"].islower()
+
+
+def test_bench_scale_fixture_matches_the_restatement(port):
+    """tests/golden/f10_bench72 (the compiled reference on 72 bench-scale piles): the
+    generator still produces the same inputs and the restatement the same answers, on a
+    sample (a pile takes the CPU a second)."""
+    import hashlib
+    from falcon_amd.synth import codes_to_str, make_pile, pile_to_seqs
+    from helpers import sha_ints
+    f10 = load_golden("f10_bench72")
+    assert len(f10["cases"]) == 72
+    for c in (f10["cases"][0], f10["cases"][41]):
+        s, rd = make_pile(c["seed"], S=f10["S"], coverage=f10["coverage"])
+        seqs = [codes_to_str(x) for x in pile_to_seqs(s, rd, 200)]
+        assert hashlib.sha1("\n".join(seqs).encode()).hexdigest()[:16] == c["input_sha"]
+        seq, eqv = port.generate_consensus(seqs, f10["min_cov"], f10["K"], f10["min_idt"])
+        assert (len(seq), hashlib.sha1(seq.encode()).hexdigest(), sha_ints(eqv)) == \
+               (c["cns_len"], c["cns_sha"], c["eqv_sha"])
+
+
+def test_config1_cli_fixture_matches_the_host_logic(port):
+    """tests/golden/f11_cli_config1 (the reference's own driver on the t1.fa-derived pile):
+    the restated driver logic (parser, read selection, output rules) around the oracle's
+    consensus prints the same bytes -- the CLI contract of config 1 without a GPU."""
+    import io
+    import sys
+    sys.path.insert(0, __import__("os").path.dirname(__file__))
+    from test_gpu_cli import _config1_stream
+    from falcon_amd.mains import consensus as cli
+    f11 = load_golden("f11_cli_config1")
+    text = _config1_stream()
+    for run in f11["runs"]:
+        args = cli.parse_args(["fc_consensus"] + run["argv"] + ["--n-core", "0"])
+        out = io.StringIO()
+        cli.run(args, stdin=io.StringIO(text), stdout=out,
+                consensus_map=lambda piles, a=args: (port.generate_consensus(p, a.min_cov, 8, a.min_idt)[0]
+                                                     for p in piles))
+        assert out.getvalue() == run["stdout"], run["argv"]
