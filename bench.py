@@ -207,8 +207,8 @@ def write_la4falcon(piles, f, repeats=1):
     f.write(b"- -\n")
 
 
-E2E_REPEATS = 3  # the end-to-end stream = the step's piles this many times (start-up amortised
-                 # the way a .las block of tens of thousands of piles amortises it)
+E2E_REPEATS = 10  # the end-to-end stream = the step's piles this many times: 30 720 piles, so
+                  # that start-up is amortised the way a .las block's tens of thousands amortise it
 
 
 def end_to_end(piles, extra_args=(), expect=None, repeats=E2E_REPEATS):
@@ -223,6 +223,10 @@ def end_to_end(piles, extra_args=(), expect=None, repeats=E2E_REPEATS):
     root = os.path.dirname(os.path.abspath(__file__))
     with tempfile.TemporaryDirectory() as tmp:
         src, dst = os.path.join(tmp, "piles.txt"), os.path.join(tmp, "cns.fasta")
+        # (as many repeats as the scratch directory holds with room to spare: ~0.83 MB of text per pile)
+        import shutil
+        per_repeat = sum(sum(len(x) + 10 for x in p) for p in piles) + 1
+        repeats = max(1, min(repeats, int(shutil.disk_usage(tmp).free * 0.6 // per_repeat)))
         with open(src, "wb") as f:
             write_la4falcon(piles, f, repeats)
         size = os.path.getsize(src)
@@ -236,12 +240,16 @@ def end_to_end(piles, extra_args=(), expect=None, repeats=E2E_REPEATS):
         # three workers back to back, the median counts: fc_run starts one consensus process
         # per .las block one after the other, so a worker that starts right behind one that
         # released its VRAM (amdgpu wipes it) IS production (all three are listed)
-        walls = []
+        walls, steady = [], []
         for _ in range(3):
             t0 = time.perf_counter()
             with open(src) as fin, open(dst, "w") as fout:
-                subprocess.run(cmd, stdin=fin, stdout=fout, check=True, cwd=root, timeout=600, env=env)
+                p = subprocess.run(cmd, stdin=fin, stdout=fout, stderr=subprocess.PIPE, check=True, cwd=root,
+                                   timeout=600, env=env, text=True)
             walls.append(time.perf_counter() - t0)
+            for ln in p.stderr.split("\n"):  # the worker's own report (consensus._run_native)
+                if "steady state" in ln:
+                    steady.append(float(ln.split("steady state")[1].split()[0]))
         wall = sorted(walls)[1]  # the MEDIAN of three back-to-back workers (all listed)
         with open(dst) as f:
             text = f.read()
@@ -250,8 +258,11 @@ def end_to_end(piles, extra_args=(), expect=None, repeats=E2E_REPEATS):
     out = {"piles_per_sec": round(n / wall, 1), "text_MB_per_sec": round(size / 1e6 / wall, 1),
            "fasta_bases_per_sec": round(bases / wall, 1), "wall_s": round(wall, 2),
            "runs_wall_s": [round(w, 2) for w in walls],
+           "worker_steady_state_piles_per_sec": steady,
            "what": "%d piles (the step's %d, %d times; %.0f MB of text from the page cache) -> FASTA, one "
-                   "worker process on one GPU, process start and HIP initialisation included"
+                   "worker process on one GPU, process start and HIP initialisation included; three workers "
+                   "back to back, the median wall time counts (`worker_steady_state_piles_per_sec`: what each "
+                   "worker reports between its first and its last batch printed)"
                    % (n, len(piles), repeats, size / 1e6)}
     if expect is not None:
         from falcon_amd.mains.consensus import fasta_records
@@ -325,7 +336,8 @@ def measured_stream_rate(torch, mib=1024, reps=5):
         return None
 
 
-KERNEL_SOURCE = {"k_align": "k_align.hip", "k_score": "k_msa.hip", "k_links": "k_msa.hip",
+KERNEL_SOURCE = {"k_align": ("k_align2.hip", "k_align2_core.h", "fa_wave.h", "k_align.hip"),
+                 "k_score": "k_msa.hip", "k_links": "k_msa.hip",
                  "k_tags": "k_msa.hip", "k_backtrace": "k_msa.hip", "k_chain": "k_chain.hip",
                  "k_seed_index": "k_pack_index.hip"}
 
@@ -334,8 +346,12 @@ def kernel_source_sha(kernel):
     """Digest of the source file a kernel lives in: a PMC measurement is only presented as
     this build's when it was taken on this source."""
     try:
-        with open(os.path.join(ROOT, "falcon_amd", "csrc", KERNEL_SOURCE[kernel]), "rb") as f:
-            return hashlib.sha1(f.read()).hexdigest()[:16]
+        names = KERNEL_SOURCE[kernel]
+        h = hashlib.sha1()
+        for name in ((names,) if isinstance(names, str) else names):
+            with open(os.path.join(ROOT, "falcon_amd", "csrc", name), "rb") as f:
+                h.update(f.read())
+        return h.hexdigest()[:16]
     except (KeyError, OSError):
         return None
 

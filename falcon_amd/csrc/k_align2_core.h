@@ -55,7 +55,8 @@
 #define A2_LOOK_EVERY 16        // iterations a track runs alone before the wave checks whether its parked neighbour fits again
 #endif
 #define A2_ESC_CAP 1024         // escape entries per slot (snakes of >= 255 bases)
-#define A2_WIDE_PATIENCE 128    // wide rows a track may take while its neighbour waits
+#define A2_WIDE_PATIENCE 512    // wide rows a track may take while its neighbour waits (reads that align badly open the
+                                // band by a diagonal per row: from 61 to the 151 that end them takes ~200 rows)
 
 struct A2Args {
     const u32 *words;

@@ -499,6 +499,8 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None)
                     return
                 getattr(item[2], "free", lambda: None)()
 
+    printed = []  # (time, piles) of every batch as it leaves, in order
+
     def printer():
         waiting, want = {}, 0
         try:
@@ -519,6 +521,7 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None)
                             (FAILED_PILES if failed_piles is None else failed_piles).append(ids[p])
                             LOG.error("seed %s is not corrected: %s", ids[p], reason)
                         write_bytes(text)
+                        printed.append((time.perf_counter(), len(ids)))
                         LOG.debug("t=%.3f printer: %d piles in %.3f s", _clock(), len(ids),
                                   time.perf_counter() - t0)
                         continue
@@ -526,6 +529,7 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None)
                     note_failed_piles(ids, cns_all, failed_piles)
                     stdout.write("".join(fasta_records(sid, cns, args.output_full, args.output_multi)
                                          for sid, cns in zip(ids, cns_all)))
+                    printed.append((time.perf_counter(), len(ids)))
                     LOG.debug("t=%.3f printer: %d piles in %.3f s", _clock(), len(ids),
                               time.perf_counter() - t0)
         except Exception as exc:  # (a closed stdout, say): stop the pipeline, report below
@@ -588,6 +592,15 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None)
                 getattr(item[2], "free", lambda: None)()
         reader.close()
     LOG.debug("t=%.3f stream finished", _clock())
+    if len(printed) >= 3:
+        # the worker's own steady state: from the first batch leaving to the last one (what
+        # start-up -- process, HIP, first buffers -- and exit add is the rest of the wall time)
+        span = printed[-1][0] - printed[0][0]
+        n_after = sum(n for _, n in printed[1:])
+        if span > 0:
+            LOG.info("falcon_amd consensus: %d piles in %d batches; steady state %.0f piles/s (%d piles in %.3f s "
+                     "between the first and the last batch printed)", sum(n for _, n in printed), len(printed),
+                     n_after / span, n_after, span)
     if failed:
         raise failed[0]
 
