@@ -92,6 +92,8 @@ W_FN u64 w_bit_set(u64 m, int b) {
 W_FN int w_lowest(u64 m) { return __builtin_ctzll(m); }                 // m != 0
 W_FN int w_highest(u64 m) { return 63 - __builtin_clzll(m); }           // m != 0
 W_FN int w_popc(u64 m) { return __builtin_popcountll(m); }
+// bit j (per lane, 0..63) of the wave-uniform mask: one 64-bit shift and an and
+W_FN vi w_bit_at(u64 mask, vi j) { return (vi)((mask >> (j & 63)) & 1ull); }
 // sign-extended 16 bits of v from bit `off` (per lane)
 W_FN vi w_bfe_i16(vu v, vu off) { return __builtin_amdgcn_sbfe((int)v, off, 16u); }
 W_FN int w_span(u64 m) { return 64 - (__builtin_clzll(m) + __builtin_ctzll(m)); }  // highest - lowest + 1; m != 0

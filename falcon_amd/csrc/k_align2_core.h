@@ -518,30 +518,43 @@ W_FN int a2_trace(const A2Args &A, A2Wave &w, A2Lanes &wl, const A2Track &t, u32
             // lane-0 diagonal differs by an odd number: in lanes, j moves by one of two
             // per-row constants.  The chain itself is scalar work: one bit test and one add
             // per row, the records read lane by lane.
+            // (dK + 1) / 2 if the path came from above, (dK - 1) / 2 if not: the second plus the bit.
             const vi dk = kc - w_from_above(kc);
-            const vu step = ((vu)((dk + 1) >> 1) & 0xffffu) | ((vu)((dk - 1) >> 1) << 16);  // (if from_above | if not)
+            const vi step_dn = (dk - 1) >> 1;
             // (The chain runs on the VECTOR unit, every lane computing the same numbers: the
-            // kernel is bound by the scalar pipe, which a step then only needs for the loop
-            // itself.)
+            // kernel as a whole is bound by instruction issue, and a step is eight vector
+            // instructions this way -- three records read by v_readlane, a 64-bit shift, an and,
+            // one three-operand add, and the lane that keeps the position.)
             vi my_lane = 0;
             vi vj = (kv - w_readlane(kc, 0)) >> 1;
-            for (int l = 0; l < ((A.debug & 2) ? 0 : n_rows); l++) {
-                my_lane = w_sel(w_ballot(lane == l), my_lane, vj);
-                vu lo = (vu)w_readlaneu(ra, l), hi = (vu)w_readlaneu(rb, l);
-                if (w_ballot(vj >= 64)) {
-                    // a wide row: cells 64.. and their bits are in the iterations behind it
-                    const vu at = ((vu)w_readlaneu(itj, l) + ((vu)vj >> 6)) & ring_mask;
-                    vu xc, xd;
-                    w_load_x4(w.recs, at, lo, hi, xc, xd);
+            const bool plain = (valid == have);  // no wide row (continuation record) in the block
+            if (plain && !(A.debug & 2)) {
+                const int last = n_rows - 1;
+                for (int l = 0; l < last; l++) {
+                    w_setlane(my_lane, w_readlane(vj, 0), l);
+                    const u64 mask = ((u64)w_readlaneu(rb, l) << 32) | w_readlaneu(ra, l);
+                    vj = vj + (w_readlane(step_dn, l) + w_bit_at(mask, vj));
                 }
-                const vu word = w_selu(w_ballot((vj & 32) != 0), lo, hi);
-                const vu bit = (word >> ((vu)vj & 31u)) & 1u;
-                if (l == n_rows - 1) {
-                    kv = w_uni(w_readlane(kc, l) + 2 * w_readlane(vj, 0) + 2 * (int)w_readlaneu(bit, 0) - 1);
-                } else {
-                    // the step of this row: its low half if the path came from above, else the high one
-                    const vu st = (vu)w_readlaneu(step, l);
-                    vj = vj + w_bfe_i16(st, (bit ^ 1u) << 4);
+                w_setlane(my_lane, w_readlane(vj, 0), last);
+                const u64 mask = ((u64)w_readlaneu(rb, last) << 32) | w_readlaneu(ra, last);
+                kv = w_uni(w_readlane(kc, last) + 2 * w_readlane(vj, 0) + 2 * w_readlane(w_bit_at(mask, vj), 0) - 1);
+            } else {
+                for (int l = 0; l < ((A.debug & 2) ? 0 : n_rows); l++) {
+                    my_lane = w_sel(1ull << l, my_lane, vj);
+                    vu lo = (vu)w_readlaneu(ra, l), hi = (vu)w_readlaneu(rb, l);
+                    if (w_ballot(vj >= 64)) {
+                        // a wide row: cells 64.. and their bits are in the iterations behind it
+                        const vu at = ((vu)w_readlaneu(itj, l) + ((vu)vj >> 6)) & ring_mask;
+                        vu xc, xd;
+                        w_load_x4(w.recs, at, lo, hi, xc, xd);
+                    }
+                    const vu word = w_selu(w_ballot((vj & 32) != 0), lo, hi);
+                    const vi bit = (vi)((word >> ((vu)vj & 31u)) & 1u);
+                    if (l == n_rows - 1) {
+                        kv = w_uni(w_readlane(kc, l) + 2 * w_readlane(vj, 0) + 2 * w_readlane(bit, 0) - 1);
+                    } else {
+                        vj = vj + (w_readlane(step_dn, l) + bit);
+                    }
                 }
             }
             // every row's own bit, cell and script word, all rows at once

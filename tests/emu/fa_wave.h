@@ -124,6 +124,7 @@ W_FN u64 w_bit_set(u64 m, int b) { return m | (1ull << (b & 63)); }
 W_FN int w_lowest(u64 m) { return m ? __builtin_ctzll(m) : -1; }
 W_FN int w_highest(u64 m) { return m ? 63 - __builtin_clzll(m) : -1; }
 W_FN int w_popc(u64 m) { return __builtin_popcountll(m); }
+W_FN vi w_bit_at(u64 mask, const vi &j) { vi r; for (int l = 0; l < 64; l++) r.v[l] = (int)((mask >> (j.v[l] & 63)) & 1ull); return r; }
 W_FN vi w_bfe_i16(const vu &v, const vu &off) { vi r; for (int l = 0; l < 64; l++) r.v[l] = (int)(short)((v.v[l] >> (off.v[l] & 31u)) & 0xffffu); return r; }
 W_FN int w_span(u64 m) { return m ? 64 - (__builtin_clzll(m) + __builtin_ctzll(m)) : 0; }
 W_FN vi w_rank_in(u64 m) { vi r; for (int l = 0; l < 64; l++) r.v[l] = __builtin_popcountll(m & ((1ull << l) - 1ull)); return r; }
