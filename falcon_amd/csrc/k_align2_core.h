@@ -163,6 +163,7 @@ struct A2HotV {   // per lane
     vu vtop;          // 0x80000000 in track 1's lanes (PAIR), else 0
     vu vacc;          // the cell bytes of up to 4 iterations
     vu rc_mlo, rc_mhi;  // ring of the last <= 64 iterations' from_above masks (lane = it & 63)
+    vu vm;            // the snake lengths of the last row
 };
 struct A2Hot {    // wave-uniform
     u64 act;          // lanes holding a cell in the next row
@@ -176,6 +177,7 @@ struct A2Hot {    // wave-uniform
     u64 fin;          // lanes whose cell reached an end of a sequence (this row)
     u64 ev;           // fin | hull on a forbidden lane
     u64 act_row;      // the lanes of the row that raised `ev`
+    u64 big;          // lanes of the last row whose snake is >= 255 bases long
     u32 it;
     int n_esc;
     u32 kb0, kb1;     // what the tape records say about the two tracks (lane-0 diagonal | A2_INVALID)
@@ -221,13 +223,10 @@ W_FN u64 a2_row(A2Hot &h, A2HotV &hv, const u32 *words, u64 *esc, int band, u32 
             x = r.x; y = r.y; m = r.m;
         }
     }
-    {
-        const u64 big = w_ballot(m >= 255u) & act;
-        if (big) {  // (a call's result arrives in a VGPR: w_uni)
-            h.n_esc = w_uni(a2_escape<void>(esc, h.n_esc, h.it, m, (u32)big, (u32)(big >> 32)));
-            m = w_minu(m, 255u);
-        }
-    }
+    // (snakes of >= 255 bases do not fit the cell byte: such a row raises an event, and where
+    // the row loop ends the lengths go to the escape list and the bytes become 255 -- a2_long_snakes)
+    const u64 big = w_ballot(m >= 255u) & act;
+    hv.vm = m;
     // the cell byte: the snake length
     if (J >= 0) hv.vacc = w_put_byte<(J >= 0 ? J : 0)>(hv.vacc, m);
     else hv.vacc = w_put_byte_sel(hv.vacc, m, byte_sel);  // (J < 0: the position comes as a v_perm selector)
@@ -270,7 +269,8 @@ W_FN u64 a2_row(A2Hot &h, A2HotV &hv, const u32 *words, u64 *esc, int band, u32 
     h.act = nact;
     h.in = in;
     h.fin = fin;
-    h.ev = fin | (in & (P == 0 ? h.forbid_to1 : h.forbid_to0));
+    h.big = big;
+    h.ev = fin | big | (in & (P == 0 ? h.forbid_to1 : h.forbid_to0));
     h.it++;
     return act;
 }
@@ -641,7 +641,7 @@ W_FN void a2_bounds(A2Hot &h) {
 
 template <bool PAIR>
 W_FN bool a2_replace(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, const A2TrackConst &tc) {
-    if (h.fin) return false;
+    if (h.fin | h.big) return false;
     const vi lane = w_lane();
     const u64 ahead = ~0ull << (h.it & 63u);  // the tape from this iteration on
     const int down = (int)(h.it & 1u);        // the next row is an odd one: its band starts a lane below the hull
@@ -739,7 +739,8 @@ W_NOINLINE A2Regs a2_fast(A2Regs r) {
     const int band = (int)w_pack_get<A2_SC_BAND>(r.sc);
     a2_bounds<PAIR>(h);
     h.in = ((u64)w_pack_get<A2_SC_IN_HI>(r.sc) << 32) | w_pack_get<A2_SC_IN_LO>(r.sc);
-    h.fin = 0ull; h.ev = 0ull; h.act_row = 0ull;
+    h.fin = 0ull; h.ev = 0ull; h.act_row = 0ull; h.big = 0ull;
+    hv.vm = 0u;
     const vi lane = w_lane();
     // the cell byte of an iteration is byte it & 3 of the lane's word: v_perm selectors that
     // put it there, alternating between (0, 1) and (2, 3) with every pair of rows
@@ -778,6 +779,19 @@ W_NOINLINE A2Regs a2_fast(A2Regs r) {
             if (PAIR || it_end == it_last || w_span(h.in) + 1 <= join_at) break;
             it_end = ((int)(it_last - it_end) > A2_LOOK_EVERY) ? it_end + A2_LOOK_EVERY : it_last;
         }
+    }
+    if (h.big) {
+        // the last row had snakes of >= 255 bases: their lengths to the escape list, 255 into
+        // their cell bytes (the row put the low byte of the length there) -- and into the
+        // tape, if the row completed its group of four
+        const u32 it_row = h.it - 1u;
+        h.n_esc = w_uni(a2_escape<void>(esc, h.n_esc, it_row, hv.vm, (u32)h.big, (u32)(h.big >> 32)));
+        const u32 where = (it_row & 2u) ? ((it_row & 1u) ? 0x04020100u : 0x03040100u)
+                                        : ((it_row & 1u) ? 0x03020400u : 0x03020104u);
+        hv.vacc = w_selu(h.big, hv.vacc, w_put_byte_sel(hv.vacc, (vu)255u, where));
+        if ((h.it & 3u) == 0u)
+            w_store32(cells, (((h.it >> 2) - 1u) & ((ring >> 2) - 1u)) * 64u + (vu)lane, hv.vacc);
+        h.ev &= ~h.big;
     }
     r.vx = hv.vx; r.vnegk = hv.vnegk; r.vqlen = hv.vqlen; r.vtlen = hv.vtlen;
     r.vqb = hv.vqb; r.vtb = hv.vtb; r.vtop = hv.vtop;
