@@ -391,6 +391,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-baseline-timed", type=int, default=20,
                     help="timed piles per CPU worker process (every one is also a parity check of the GPU's answer)")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="resident batches taking turns in the pipelined steps (>= 2): with 3, a "
+                         "batch's front stages are queued while the one before it is aligned and "
+                         "the one before that goes through its MSA stage")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one resident batch, every step drained before the next (A/B of the "
                          "two-batch pipelining)")
@@ -464,7 +468,8 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
     # recurrence, back-trace) -- fa_batch_submit / fa_batch_wait.  Every step is still one
     # full pass of the whole path over one batch.
     pipelined = hasattr(batch, "submit") and not args.no_pipeline
-    pair = [batch, eng.batch(piles)] if pipelined else [batch]
+    depth = max(2, args.in_flight)
+    pair = [batch] + [eng.batch(piles) for _ in range(depth - 1)] if pipelined else [batch]
     for b in pair:  # (first run of a batch sizes its MSA buffers: setup, not a step)
         b.run(MIN_COV, K, MIN_IDT)
 
@@ -479,15 +484,16 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
                 if record:
                     tally(batch.stats())
             return
-        cur, nxt = pair
-        cur.submit(MIN_COV, K, MIN_IDT)
+        # step i runs on batch i mod depth; depth - 1 submits stay ahead of every wait
+        for j in range(min(depth - 1, n)):
+            pair[j % depth].submit(MIN_COV, K, MIN_IDT)
         for i in range(n):
-            if i + 1 < n:
-                nxt.submit(MIN_COV, K, MIN_IDT)
+            if i + depth - 1 < n:
+                pair[(i + depth - 1) % depth].submit(MIN_COV, K, MIN_IDT)
+            cur = pair[i % depth]
             cur.wait()
             if record:
                 tally(cur.stats())
-            cur, nxt = nxt, cur
 
     def tally(st):
         for n in ("ms_align", "ms_consensus", "ms_chain", "ms_index", "ms_total", "ms_tags",
@@ -580,6 +586,7 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
                 "accepted_alignments_per_step_per_gpu": int(st.n_aligned),
             },
             "pipelined_steps": bool(pipelined),
+            "batches_in_flight": (depth if pipelined else 1),
             # every rank on its own clock (the whole-job `value` divides by the slowest rank's time)
             "per_rank": [{"rank": i, "bases_per_sec": round(r[0], 1), "ms_per_step": round(r[1], 3),
                           "k_align_ms": round(r[2], 3)} for i, r in enumerate(per_rank)],

@@ -10,6 +10,7 @@
 #include "fa_host.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -95,29 +96,33 @@ struct fa_ctx {
     int device = 0;
     int n_cu = 0;
     size_t total_mem = 0;
-    // Three streams.  `stream` (front): seed index, k-mer chaining, alignment, tags, links --
-    // the throughput kernels, one batch at a time (they share the alignment arena; front_mu).
-    // `back_stream`: k_score + k_backtrace, one wavefront per pile walking its levels in
-    // sequence, latency-bound at a few wavefronts per SIMD: they run next to the NEXT
-    // batch's front stages (fa_batch_submit / fa_batch_wait).  `dl_stream`: result
-    // download, so that a fetch never queues behind another batch's kernels.
-    // Two back streams take turns: a back stage lasts as long for 500 piles as for 3000 (one
+    // Streams.  `stream` (front): seed index, k-mer chaining, alignment -- one batch at a
+    // time (they share the alignment arena; front_mu).  `back_stream`: the MSA stage of a
+    // batch (k_tags, k_links, k_score, k_backtrace: atomics at the memory side, then one
+    // wavefront per pile walking its levels in sequence), which runs next to the NEXT
+    // batch's front stages: its kernels are bound by other things than k_align's instruction
+    // issue, and share the device with it better than with one another.
+    // `dl_stream`: result download, so that a fetch never queues behind another batch's kernels.
+    // Two back streams take turns: k_score lasts as long for 500 piles as for 3000 (one
     // wavefront per pile, each walking its own levels), so a worker's small batches would
     // otherwise queue up behind one another there while most wave slots are free.
-    static constexpr int N_BACK = 2;
+    static constexpr int N_BACK_MAX = 4;
+    int n_back = 2;  // (FALCON_AMD_NBACK: experiments)
     hipStream_t stream = nullptr;
-    hipStream_t back_stream[N_BACK] = {};
+    hipStream_t back_stream[N_BACK_MAX] = {};
     unsigned back_turn = 0;  // (back_mu)
     hipStream_t dl_stream = nullptr;
     std::mutex front_mu, fetch_mu;
-    // The back stage of the batch submitted last is not queued at once: it is queued by the
-    // NEXT submit, between that batch's k_chain and k_align (or by its own fa_batch_wait /
-    // fa_batch_free, whichever comes first).  Its wavefronts then start beside k_align --
-    // which is bound by the scalar pipe and gives up three of eight wave slots for ~30 ms at
-    // little cost -- instead of beside k_seed_index / k_chain, which need the wave slots and
-    // the LDS those wavefronts hold (measured: k_chain 9.5 -> 19 ms next to k_score).
-    std::mutex back_mu;
+    // The second half of a run -- the MSA plan (host; it needs the alignment summaries, i.e.
+    // waits for k_align) and the MSA kernels -- is not begun by the submit that launched the
+    // first half: the NEXT submit on the context begins it, after queueing its own front
+    // stages (or the batch's own fa_batch_wait, whichever comes first).  The front stream
+    // thus never waits for the host, and a submit never waits for its own k_align.
+    std::mutex back_mu;   // pending_back, back_turn
     fa_batch *pending_back = nullptr;
+    // repeat launches of alignments k_align2 handed back share arena2, from whichever stream
+    std::mutex redo_mu;
+    hipEvent_t ev_redo = nullptr;  // the last repeat launch (redo_mu)
     char *h_dl = nullptr;    // pinned landing buffer of the downloads (grow only; fetch_mu)
     size_t h_dl_cap = 0;
     // alignment work-slot arena (grow only)
@@ -137,6 +142,7 @@ struct fa_ctx {
     uint8_t *h_stage = nullptr, *d_stage = nullptr;
     size_t h_stage_cap = 0, d_stage_cap = 0;
     int *d_first_bad = nullptr;  // k_pack: lowest sequence index holding a byte other than ACGT
+    int *d_counter2 = nullptr;   // work counter of the repeat launches (arena2)
 };
 
 // Device and pinned-host blocks are recycled per device for the life of the process: a
@@ -322,16 +328,33 @@ struct fa_batch {
     bool have_range = false, have_aln = false, fetched = false, fetched_eqv = false;
     u64 out_slots = 0;
     fa_stats stats = {};
-    // timing events of the last run (0..7 on the front stream, 8..11 on the back stream)
-    hipEvent_t ev[12] = {};
+    // events of the last run: 0..3 on the front stream (index, chain, align), 4..11 on the
+    // back stream (MSA stage), 12: alignment summaries on the host, 13: a repeat launch done
+    hipEvent_t ev[14] = {};
     bool in_flight = false;  // fa_batch_submit done, fa_batch_wait pending
     // kernels of this batch were launched on the context's front stream (submit, pair and
     // unitig runs, also ones that failed half-way): fa_batch_free waits for that stream
     // before the batch's blocks go back to the cache, where another thread may take them
     bool front_launched = false;
-    bool back_queued = false;  // its k_score / k_backtrace are on the back stream
-    FaMsaDev md_saved = {};
-    unsigned min_cov_saved = 0;
+    // The MSA stage (plan on the host, then k_tags .. k_backtrace on a back stream) is the
+    // second half of a run, done by whichever thread gets to it first -- the next submit on
+    // the context, or this batch's own wait: 0 not begun, 1 some thread is at it, 2 queued
+    // on the back stream, -1 failed (back_err says why).
+    std::atomic<int> back_state{0};
+    std::string back_err;
+    int back_rc = 0;
+    struct {  // what the second half needs from the call that started the run
+        unsigned min_cov = 0;
+        double max_diff = 0;
+        int band = 0, force_accept_g = -1;
+        bool two_per_wave = false;
+        size_t n_seg = 0;
+        u64 t_tot = 0;
+    } run;
+    HostBuf<unsigned long long> h_a2_stats;
+    HostBuf<u32> h_acc_first;
+    HostBuf<u64> h_link_off, h_link_cap;
+    HostBuf<FaPile> h_pile_up;
     ~fa_batch() {
         for (auto &e : ev)
             if (e) (void)hipEventDestroy(e);
@@ -389,13 +412,19 @@ extern "C" fa_ctx *fa_create(int device) {
     {   // the back stream's few wavefronts go first when wave slots free up
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        for (hipStream_t &sb : c->back_stream)
-            HIP_OK_P(hipStreamCreateWithPriority(&sb, hipStreamNonBlocking, greatest));
+        if (const char *e = getenv("FALCON_AMD_NBACK")) c->n_back = std::max(1, std::min((int)fa_ctx::N_BACK_MAX, atoi(e)));
+        const char *pr = getenv("FALCON_AMD_BACK_PRIO");  // (experiments: "low" / "same"; default: the highest)
+        const int prio = pr && !strcmp(pr, "low") ? least : pr && !strcmp(pr, "same") ? 0 : greatest;
+        for (int i = 0; i < c->n_back; i++)
+            HIP_OK_P(hipStreamCreateWithPriority(&c->back_stream[i], hipStreamNonBlocking, prio));
     }
     HIP_OK_P(hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
     HIP_OK_P(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
     HIP_OK_P(hipMalloc((void **)&c->arena.counter, sizeof(int)));
     HIP_OK_P(hipMalloc((void **)&c->d_first_bad, sizeof(int)));
+    HIP_OK_P(hipMalloc((void **)&c->d_counter2, sizeof(int)));
+    HIP_OK_P(hipEventCreateWithFlags(&c->ev_redo, hipEventDisableTiming));
+    HIP_OK_P(hipEventRecord(c->ev_redo, c->stream));
     HIP_OK_P(hipMalloc((void **)&c->arena.prof, 8 * sizeof(u64)));
     HIP_OK_P(hipMemset(c->arena.prof, 0, 8 * sizeof(u64)));
     HIP_OK_P(hipMalloc((void **)&c->a2.stats, 8 * sizeof(unsigned long long)));
@@ -417,6 +446,8 @@ extern "C" void fa_destroy(fa_ctx *c) {
     if (c->a2.mem) (void)hipFree(c->a2.mem);
     if (c->a2.stats) (void)hipFree(c->a2.stats);
     if (c->d_first_bad) (void)hipFree(c->d_first_bad);
+    if (c->d_counter2) (void)hipFree(c->d_counter2);
+    if (c->ev_redo) (void)hipEventDestroy(c->ev_redo);
     if (c->h_dl) (void)hipHostFree(c->h_dl);
     for (hipStream_t sb : c->back_stream)
         if (sb) (void)hipStreamDestroy(sb);
@@ -769,8 +800,11 @@ extern "C" void fa_batch_free(fa_batch *b) {
     (void)hipSetDevice(b->ctx->device);
     {
         std::lock_guard<std::mutex> hold(b->ctx->back_mu);
-        if (b->ctx->pending_back == b) b->ctx->pending_back = nullptr;  // its back stage is never queued
+        if (b->ctx->pending_back == b) b->ctx->pending_back = nullptr;  // its MSA stage is never begun
     }
+    // (another thread's submit may be half-way through this batch's MSA stage)
+    while (b->back_state.load(std::memory_order_acquire) == 1)
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
     // Its buffers go to the per-device block cache, from where another thread's batch_build
     // may take them at once (hipFree used to wait for the device; the cache does not):
     // nothing of this batch may still be running.  Front stages (also of a submit that
@@ -779,7 +813,10 @@ extern "C" void fa_batch_free(fa_batch *b) {
     // (no front_mu here: callers may hold it, and waiting for a little more than this
     // batch's own work -- whatever another thread queued since -- is harmless)
     if (b->front_launched) (void)hipStreamSynchronize(b->ctx->stream);
-    if (b->back_queued && b->ev[6]) (void)hipEventSynchronize(b->ev[6]);
+    if (b->back_state.load() == 2 && b->ev[6]) (void)hipEventSynchronize(b->ev[6]);
+    if (b->back_state.load() == -1)  // (a stage that failed half-way may have queued part of its work)
+        for (hipStream_t sb : b->ctx->back_stream)
+            if (sb) (void)hipStreamSynchronize(sb);
     // (its device and pinned buffers release themselves)
     delete b;
 }
@@ -907,7 +944,7 @@ static int ensure_arena2(fa_ctx *c, const fa_batch *b, int n) {
     c->arena2.cells_per_slot = cells;
     c->arena2.rows_per_slot = rows;
     c->arena2.n_slot = n_slot;
-    c->arena2.counter = c->arena.counter;  // (same stream, one launch after the other)
+    c->arena2.counter = c->d_counter2;  // (its own: a repeat launch may run beside the next batch's k_align2)
     c->arena2.prof = c->arena.prof;
     return 0;
 }
@@ -963,14 +1000,10 @@ static int ensure_arena_a2(fa_ctx *c, const fa_batch *b) {
     return 0;
 }
 
-// Alignment summaries to the host.  0: fine; 1: some alignment outgrew its work slot (the
-// caller repeats those with worst-case slots); < 0: error.
-static int fetch_aln(fa_batch *b) {
-    if (b->h_aln.resize(b->n_seq)) return -1;
-    HIP_OK(hipMemcpyAsync(b->h_aln.data(), b->d_aln.p, (size_t)b->n_seq * sizeof(FaAln),
-                          hipMemcpyDeviceToHost, b->ctx->stream));
-    HIP_OK(hipStreamSynchronize(b->ctx->stream));
-    b->have_aln = true;
+// The alignment summaries are on the host (h_aln).  0: fine; 1: some alignment outgrew its
+// work slot or was handed back by k_align2 (the caller repeats those with worst-case
+// slots); < 0: error.
+static int check_aln(fa_batch *b) {
     bool outgrown = false;
     for (int g = 0; g < b->n_seq; g++) {
         if (b->h_aln[g].err == 2) {
@@ -980,20 +1013,27 @@ static int fetch_aln(fa_batch *b) {
             return -2;
         }
     }
-    if (outgrown) {
-        b->have_aln = false;
-        return 1;
-    }
-    return 0;
+    b->have_aln = !outgrown;
+    return outgrown ? 1 : 0;
+}
+
+// Alignment summaries to the host, through stream `s` (which is waited for).
+static int fetch_aln(fa_batch *b, hipStream_t s) {
+    if (b->h_aln.resize(b->n_seq)) return -1;
+    HIP_OK(hipMemcpyAsync(b->h_aln.data(), b->d_aln.p, (size_t)b->n_seq * sizeof(FaAln),
+                          hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    return check_aln(b);
 }
 
 // Alignments that came back with FaAln.err == 2 -- they outgrew their work slot, or k_align2
 // handed them back (a band that stayed wide, an alignment too long for the tape ring) -- are
 // done again, alone, by the general one-alignment-per-wavefront kernel in worst-case slots
-// (nothing was written past a slot).  Returns fetch_aln's verdict after the second launch.
-static int redo_handed_back(fa_batch *b, double max_diff, int band) {
+// (nothing was written past a slot), on stream `s`, which must be behind the first launch.
+// The worst-case slots belong to the context: repeat launches of different batches (each on
+// its own back stream) follow one another.  Returns check_aln's verdict after the launch.
+static int redo_handed_back(fa_batch *b, double max_diff, int band, hipStream_t s) {
     fa_ctx *c = b->ctx;
-    hipStream_t s = c->stream;
     std::vector<int> redo;
     for (int g = 0; g < b->n_seq; g++)
         if (b->h_aln[g].err == 2) redo.push_back(g);
@@ -1002,14 +1042,17 @@ static int redo_handed_back(fa_batch *b, double max_diff, int band) {
         set_err("falcon_amd: %zu alignments overflowed their work slots at band %d", redo.size(), band);
         return -1;
     }
+    std::lock_guard<std::mutex> one(c->redo_mu);
     if (ensure_arena2(c, b, (int)redo.size()) || b->d_redo.alloc(redo.size())) return -1;
+    HIP_OK(hipStreamWaitEvent(s, c->ev_redo, 0));
     HIP_OK(hipMemcpyAsync(b->d_redo.p, redo.data(), redo.size() * sizeof(int), hipMemcpyHostToDevice, s));
     fa_launch_align_list(b->dev(), c->arena2, b->max_read_len, b->max_seed_len, max_diff, band, b->d_redo.p,
                          (int)redo.size(), s);
     HIP_OK(hipGetLastError());
+    HIP_OK(hipEventRecord(c->ev_redo, s));
     b->stats.align_relaunched = (int)redo.size();
     // (the list must outlive the copy: fetch_aln synchronises the stream)
-    int rc = fetch_aln(b);
+    int rc = fetch_aln(b, s);
     if (rc == 1) {
         set_err("falcon_amd: an alignment overflowed a worst-case work slot");
         return -2;
@@ -1017,21 +1060,24 @@ static int redo_handed_back(fa_batch *b, double max_diff, int band) {
     return rc;
 }
 
-// Stages after the windows are known (d_range on the device, h_range on the host or on
-// its way there): banded alignment, then the MSA stage.  `band` <= 190 runs the tuned
-// kernel, wider bands the general one; `force_accept_g` >= 0 names a sequence whose
-// alignment is used whatever its length (the unitig's copy of itself,
-// falcon.c:699-704).
-static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int band,
-                           int force_accept_g);
+// A run has two halves.  start_align: the stages after the windows are known (d_range on
+// the device, h_range on the host or on its way there) up to the banded alignment, queued on
+// the front stream; nothing in it waits for the device.  `band` <= 190 runs the tuned
+// kernels, wider bands the general one; `force_accept_g` >= 0 names a sequence whose
+// alignment is used whatever its length (the unitig's copy of itself, falcon.c:699-704).
+// msa_stage: the MSA plan from the alignment summaries (waits for k_align) and the MSA
+// kernels on a back stream.  begin_back / finish_run decide which thread runs the latter.
+static int start_align(fa_batch *b, unsigned min_cov, double max_diff, int band, int force_accept_g);
+static int msa_stage(fa_batch *b);
 static int finish_run(fa_batch *b, bool grace);
-static int flush_pending_back(fa_ctx *c, fa_batch *only = nullptr, hipEvent_t after = nullptr);
+static void begin_back(fa_batch *p);
+static fa_batch *take_pending_back(fa_ctx *c, fa_batch *only = nullptr);
 
-// Front stages of a run (seed index, chaining, alignment, MSA plan, tags, links) on the
-// context's front stream.  The call waits for k_align (the MSA plan is sized from the
-// alignment summaries) and returns with k_tags / k_tscan / k_links only QUEUED; k_score and
-// k_backtrace are queued on a back stream by the next submit (or by this batch's own wait):
-// the next batch's fa_batch_submit overlaps their latency-bound walk.
+// First half of a run (seed index, chaining, alignment) on the context's front stream;
+// returns with everything only QUEUED.  The MSA stage of the batch submitted BEFORE this one
+// is begun here, once this batch's kernels are in the queue: its plan waits for its k_align,
+// while this batch's kernels keep the front stream busy, and its kernels (k_tags, k_links,
+// k_score, k_backtrace on a back stream) then run beside this batch's k_chain and k_align.
 extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double min_idt) {
     if (!b || b->pair_mode) {
         set_err("falcon_amd: fa_batch_submit on an invalid batch");
@@ -1053,47 +1099,47 @@ extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double
         return -1;
     }
     PhaseTimer pt("fa_batch_submit");
-    std::lock_guard<std::mutex> front(c->front_mu);  // one batch at a time on the front stream
-    pt.mark("front-lock");
-    hipStream_t s = c->stream;
-    b->front_launched = true;
-    b->fetched = b->fetched_eqv = false;
-    b->have_range = b->have_aln = false;
-    const double max_diff = 1.0 - min_idt;  // falcon.c:580
-    if (use_align2(b, FA_BAND)) {
-        if (ensure_arena_a2(c, b)) return -1;
-    } else {
-        size_t lds = fa_align_lds_bytes(b->max_read_len, b->max_seed_len);
-        if (ensure_arena(c, b, lds, false)) return -1;
-    }
-    pt.mark("arena");
-    FaBatchDev d = b->dev();
+    fa_batch *before = nullptr;
+    {
+        std::lock_guard<std::mutex> front(c->front_mu);  // one batch at a time on the front stream
+        pt.mark("front-lock");
+        hipStream_t s = c->stream;
+        b->front_launched = true;
+        b->fetched = b->fetched_eqv = false;
+        b->have_range = b->have_aln = false;
+        const double max_diff = 1.0 - min_idt;  // falcon.c:580
+        if (use_align2(b, FA_BAND)) {
+            if (ensure_arena_a2(c, b)) return -1;
+        } else {
+            size_t lds = fa_align_lds_bytes(b->max_read_len, b->max_seed_len);
+            if (ensure_arena(c, b, lds, false)) return -1;
+        }
+        pt.mark("arena");
+        FaBatchDev d = b->dev();
 
-    HIP_OK(hipEventRecord(b->ev[0], s));
-    fa_launch_index(d, s);
-    HIP_OK(hipEventRecord(b->ev[1], s));
-    trace_stage(s, "index");
-    fa_launch_chain(d, b->max_bins, s);
-    HIP_OK(hipEventRecord(b->ev[2], s));
-    trace_stage(s, "chain");
-    // s2 of every alignment (needed by the MSA plan) travels while k_align runs
-    if (b->h_range.resize(b->n_seq)) return -1;
-    HIP_OK(hipMemcpyAsync(b->h_range.data(), b->d_range.p, (size_t)b->n_seq * sizeof(FaRange),
-                          hipMemcpyDeviceToHost, s));
-    // The batch before this one: its k_score / k_backtrace are queued here.  They start as
-    // soon as their own links are done -- the host runs ahead of the device -- i.e. beside
-    // this batch's k_seed_index and k_chain; FALCON_AMD_BACK_AFTER_CHAIN=1 holds them until
-    // this batch's k_chain is done, beside k_align instead.  Measured per 3072 piles
-    // [MI355X]: beside index + chain 140 ms per step (k_chain 9.5 -> 19 ms: it loses LDS and
-    // wave slots), beside k_align 144 ms (k_align 72 -> 90 ms: its throughput follows its
-    // resident wavefronts), one batch at a time 158 ms.
-    static const bool after_chain = getenv("FALCON_AMD_BACK_AFTER_CHAIN") != nullptr;
-    static const bool after_align = getenv("FALCON_AMD_BACK_AFTER_ALIGN") != nullptr;
-    if (!after_align && flush_pending_back(c, nullptr, after_chain ? b->ev[2] : nullptr)) return -1;
-    pt.mark("launch-front");
-    const int rc = run_from_ranges(b, min_cov, max_diff, FA_BAND, -1);
-    pt.mark("align-wait+plan+msa-launch");
-    return rc;
+        HIP_OK(hipEventRecord(b->ev[0], s));
+        fa_launch_index(d, s);
+        HIP_OK(hipEventRecord(b->ev[1], s));
+        trace_stage(s, "index");
+        fa_launch_chain(d, b->max_bins, s);
+        HIP_OK(hipEventRecord(b->ev[2], s));
+        trace_stage(s, "chain");
+        // s2 of every alignment (needed by the MSA plan) travels while k_align runs
+        if (b->h_range.resize(b->n_seq)) return -1;
+        HIP_OK(hipMemcpyAsync(b->h_range.data(), b->d_range.p, (size_t)b->n_seq * sizeof(FaRange),
+                              hipMemcpyDeviceToHost, s));
+        if (start_align(b, min_cov, max_diff, FA_BAND, -1)) return -1;
+        pt.mark("launch-front");
+        // this batch's second half is the next submit's (or its own wait's); the one before it
+        // is this call's
+        std::lock_guard<std::mutex> hold(c->back_mu);
+        before = c->pending_back;
+        c->pending_back = b;
+        if (before) before->back_state = 1;
+    }
+    if (before) begin_back(before);  // (its failure is reported by its own fa_batch_wait)
+    pt.mark("msa stage of the batch before");
+    return 0;
 }
 
 // The rest of a submitted run: waits for the back stream's kernels, checks every pile's
@@ -1113,13 +1159,15 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     return finish_run(b, false);
 }
 
-static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int band,
-                           int force_accept_g) {
+static int start_align(fa_batch *b, unsigned min_cov, double max_diff, int band, int force_accept_g) {
     fa_ctx *c = b->ctx;
     hipStream_t s = c->stream;
     FaBatchDev d = b->dev();
-    PhaseTimer pt("align + msa plan");
+    PhaseTimer pt("align launch");
     const bool two_per_wave = use_align2(b, band);
+    b->run.min_cov = min_cov; b->run.max_diff = max_diff; b->run.band = band;
+    b->run.force_accept_g = force_accept_g; b->run.two_per_wave = two_per_wave;
+    if (b->h_aln.resize(b->n_seq) || b->h_a2_stats.resize(8)) return -1;
     if (two_per_wave) {
         (void)hipMemsetAsync(c->a2.stats, 0, 8 * sizeof(unsigned long long), s);
         fa_launch_align2(d, c->a2, max_diff, band, b->order_dev(), b->n_seq, s);
@@ -1140,6 +1188,17 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
         fprintf(stderr, "\n");
     }
     HIP_OK(hipGetLastError());
+    // the alignment summaries (they bound the MSA node pools) and the kernel's own counters
+    // leave for the host as soon as the kernel is done (pinned buffers: true asynchronous copies)
+    HIP_OK(hipMemcpyAsync(b->h_aln.data(), b->d_aln.p, (size_t)b->n_seq * sizeof(FaAln),
+                          hipMemcpyDeviceToHost, s));
+    if (two_per_wave)
+        HIP_OK(hipMemcpyAsync(b->h_a2_stats.data(), c->a2.stats, 8 * sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost, s));
+    HIP_OK(hipEventRecord(b->ev[12], s));
+    b->stats.align_relaunched = 0;
+    b->stats.align_slots = two_per_wave ? c->a2.n_slot : c->arena.n_slot;
+    b->stats.align_slot_cells = two_per_wave ? (long long)c->a2.ring * 64 : (long long)c->arena.cells_per_slot;
     // ---- while k_align runs: the part of the MSA plan that only depends on the seed
     // lengths (segment work list of k_links, per-pile offsets of the per-position arrays)
     const int TSEG = 128;  // must match k_msa.hip
@@ -1149,6 +1208,8 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
         t_tot += (u64)b->pile[p].seed_len;
         n_seg += (size_t)((b->pile[p].seed_len + TSEG - 1) / TSEG);
     }
+    b->run.t_tot = t_tot;
+    b->run.n_seg = n_seg;
     if (!b->msa_static) {
         std::vector<int> seg_pile, seg_t0;
         std::vector<u64> t_off(b->n_pile);
@@ -1165,36 +1226,53 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
         if (b->d_seg_pile.alloc(n_seg + 1) || b->d_seg_t0.alloc(n_seg + 1) ||
             b->d_wide.alloc(4 * (n_seg + 1) + 1) || b->d_t_off.alloc((size_t)b->n_pile + 1))
             return -1;
-        // (synchronous copies on the null stream; the context's stream is non-blocking,
+        // (synchronous copies on the null stream; the context's streams are non-blocking,
         // so they do not wait for k_align)
         HIP_OK(hipMemcpy(b->d_seg_pile.p, seg_pile.data(), n_seg * sizeof(int), hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(b->d_seg_t0.p, seg_t0.data(), n_seg * sizeof(int), hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(b->d_t_off.p, t_off.data(), t_off.size() * sizeof(u64), hipMemcpyHostToDevice));
         b->msa_static = true;
     }
-    if (b->h_ta.resize((size_t)b->n_seq + 1)) return -1;
+    if (b->h_ta.resize((size_t)b->n_seq + 1) || b->h_acc_first.resize((size_t)b->n_pile + 1) ||
+        b->h_link_off.resize((size_t)b->n_pile) || b->h_link_cap.resize((size_t)b->n_pile) ||
+        b->h_pile_up.resize((size_t)b->n_pile) || b->h_pile_out.resize(b->n_pile))
+        return -1;
     pt.mark("launch+static-plan");
-    // alignment summaries bound the MSA node pools (levels <= seed + insertions)
-    b->stats.align_relaunched = 0;
-    int rc_aln = fetch_aln(b);
-    pt.mark("align-wait+summaries");
-    if (rc_aln == 1) {
-        rc_aln = redo_handed_back(b, max_diff, band);
-        HIP_OK(hipEventRecord(b->ev[3], s));
+    b->back_state = 0;
+    b->back_err.clear();
+    b->in_flight = true;
+    return 0;
+}
+
+// Second half of a run, by the one thread that set back_state to 1: the MSA plan from the
+// alignment summaries (host, O(#reads)), then k_tags | k_tscan | k_links | k_score |
+// k_backtrace and the per-pile results' copy on a back stream.  Nothing here touches the
+// front stream, which meanwhile runs the next batch.
+static int msa_stage(fa_batch *b) {
+    fa_ctx *c = b->ctx;
+    PhaseTimer pt("msa stage");
+    const unsigned min_cov = b->run.min_cov;
+    const int force_accept_g = b->run.force_accept_g;
+    hipStream_t sb;
+    {
+        std::lock_guard<std::mutex> hold(c->back_mu);
+        sb = c->back_stream[c->back_turn++ % (unsigned)c->n_back];
     }
+    HIP_OK(hipEventSynchronize(b->ev[12]));
+    pt.mark("align-wait+summaries");
+    int rc_aln = check_aln(b);
+    HIP_OK(hipStreamWaitEvent(sb, b->ev[3], 0));
+    if (rc_aln == 1) rc_aln = redo_handed_back(b, b->run.max_diff, b->run.band, sb);
     if (rc_aln) return rc_aln;
-    // (FALCON_AMD_BACK_AFTER_ALIGN: the previous batch's back stage starts here, beside this
-    // batch's tags and links and the next one's index and chain)
-    if (getenv("FALCON_AMD_BACK_AFTER_ALIGN") && flush_pending_back(c)) return -1;
     b->have_range = true;  // its copy was queued ahead of k_align
     if (force_accept_g >= 0 && b->h_aln[force_accept_g].aligned) b->h_aln[force_accept_g].accept = 1;
-    // ---- plan the MSA stage from the alignment summaries (host, O(#reads))
+    // ---- plan the MSA stage from the alignment summaries
     u64 node_off = 0, desc_tot = 4, ins_tot = 0, link_tot = 0;  // (desc: front padding, k_links loads groups of 4)
     long long sC = 0, sD = 0, sA = 0, nal = 0;
     FaTagAln *ta = b->h_ta.data();
     size_t n_ta = 0;
-    std::vector<u32> acc_first(b->n_pile + 1, 0);
-    std::vector<u64> link_off(b->n_pile), link_cap(b->n_pile);
+    u32 *acc_first = b->h_acc_first.data();
+    u64 *link_off = b->h_link_off.data(), *link_cap = b->h_link_cap.data();
     for (int p = 0; p < b->n_pile; p++) {
         FaPile &pm = b->pile[p];
         u64 levels = (u64)pm.seed_len + 2, cols = 8;
@@ -1242,6 +1320,7 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
         link_off[p] = link_tot;
         link_cap[p] = cols;
         link_tot += cols;
+        b->h_pile_up[p] = pm;
     }
     acc_first[b->n_pile] = (u32)n_ta;
     pt.mark("plan");
@@ -1249,6 +1328,8 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
         set_err("falcon_amd: batch too large for the MSA stage");
         return -1;
     }
+    const u64 t_tot = b->run.t_tot;
+    const size_t n_seg = b->run.n_seg;
     const size_t tarr_ints = 3 * (size_t)(t_tot + (u64)b->n_pile);
     auto need = [&](auto &buf, size_t n) { return (buf.n < n) ? buf.alloc(n) : 0; };
     int rc2 = 0;
@@ -1268,15 +1349,17 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
     rc2 |= need(b->d_nodes, (size_t)node_off + 8);
     if (rc2) return -1;
     pt.mark("buffers");
+    // (pinned sources: the copies are queued, not staged -- a staged copy would wait for
+    // whatever the back stream still runs of the batch two before this one)
     auto up = [&](void *dst, const void *src, size_t bytes) {
-        return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s) == hipSuccess;
+        return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, sb) == hipSuccess;
     };
     bool okc = true;
     okc &= up(b->d_ta.p, ta, n_ta * sizeof(FaTagAln));
-    okc &= up(b->d_acc_first.p, acc_first.data(), acc_first.size() * sizeof(u32));
-    okc &= up(b->d_link_off.p, link_off.data(), link_off.size() * sizeof(u64));
-    okc &= up(b->d_link_cap.p, link_cap.data(), link_cap.size() * sizeof(u64));
-    okc &= up(b->d_pile.p, b->pile.data(), (size_t)b->n_pile * sizeof(FaPile));
+    okc &= up(b->d_acc_first.p, acc_first, ((size_t)b->n_pile + 1) * sizeof(u32));
+    okc &= up(b->d_link_off.p, link_off, (size_t)b->n_pile * sizeof(u64));
+    okc &= up(b->d_link_cap.p, link_cap, (size_t)b->n_pile * sizeof(u64));
+    okc &= up(b->d_pile.p, b->h_pile_up.data(), (size_t)b->n_pile * sizeof(FaPile));
     if (!okc) {
         set_err("falcon_amd: uploading the MSA plan failed");
         return -1;
@@ -1292,31 +1375,24 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
     md.wide_count = b->d_wide.p; md.wide_list = b->d_wide.p + 1;
     md.first_links_back = force_accept_g >= 0 ? 1 : 0;
     md.force_generic = getenv("FALCON_AMD_SCORE_GENERIC") ? 1 : 0;  // (tests: pins the generic path of k_score)
-    d = b->dev();
+    const FaBatchDev d = b->dev();
     pt.mark("upload");
-    HIP_OK(hipEventRecord(b->ev[4], s));
-    fa_launch_msa_front(d, md, min_cov, s, b->ev[8], b->ev[9]);  // k_tags + k_tscan | k_links
-    HIP_OK(hipEventRecord(b->ev[5], s));
-    pt.mark("msa-launch");
-    trace_stage(s, "links");
+    HIP_OK(hipEventRecord(b->ev[4], sb));
+    fa_launch_msa_front(d, md, min_cov, sb, b->ev[8], b->ev[9]);  // k_tags + k_tscan | k_links
+    HIP_OK(hipEventRecord(b->ev[5], sb));
+    trace_stage(sb, "links");
+    HIP_OK(hipEventRecord(b->ev[7], sb));
+    fa_launch_msa_back(d, md, min_cov, sb, b->ev[10], b->ev[11]);  // k_score | k_backtrace
+    trace_stage(sb, "consensus");
     HIP_OK(hipGetLastError());
-    // k_score + k_backtrace: queued later, see fa_ctx::pending_back
-    b->md_saved = md;
-    b->min_cov_saved = min_cov;
-    b->back_queued = false;
-    if (b->h_pile_out.resize(b->n_pile)) return -1;
-    {
-        std::lock_guard<std::mutex> hold(c->back_mu);
-        c->pending_back = b;
-    }
+    HIP_OK(hipMemcpyAsync(b->h_pile_out.data(), b->d_pile_out.p,
+                          (size_t)b->n_pile * sizeof(FaPileOut), hipMemcpyDeviceToHost, sb));
+    HIP_OK(hipEventRecord(b->ev[6], sb));
+    pt.mark("msa-launch");
     // what the statistics need of this plan
     b->stats.C = sC; b->stats.D = sD; b->stats.A = sA; b->stats.n_aligned = nal;
-    if (two_per_wave) {
-        unsigned long long st[8];
-        HIP_OK(hipMemcpyAsync(st, c->a2.stats, sizeof(st), hipMemcpyDeviceToHost, s));
-        HIP_OK(hipStreamSynchronize(s));  // (k_align is long done: fetch_aln waited for it)
-        b->stats.align_slots = c->a2.n_slot;
-        b->stats.align_slot_cells = (long long)c->a2.ring * 64;
+    if (b->run.two_per_wave) {
+        const unsigned long long *st = b->h_a2_stats.data();  // (landed with the summaries)
         b->stats.align_arena_bytes = (long long)c->a2_bytes + (long long)c->arena2_cells_bytes +
                                      2 * (long long)c->arena2_rows_bytes;
         b->stats.align_pair_iterations = (long long)st[0];
@@ -1327,69 +1403,69 @@ static int run_from_ranges(fa_batch *b, unsigned min_cov, double max_diff, int b
         b->stats.align_wide_rows = (long long)st[5];
         b->stats.align_replacements = (long long)st[7];
     } else {
-        b->stats.align_slots = c->arena.n_slot;
-        b->stats.align_slot_cells = (long long)c->arena.cells_per_slot;
         b->stats.align_arena_bytes = (long long)c->arena_cells_bytes + 2 * (long long)c->arena_rows_bytes +
                                      (long long)c->arena2_cells_bytes + 2 * (long long)c->arena2_rows_bytes;
         b->stats.align_pair_iterations = b->stats.align_single_iterations = b->stats.align_placements = 0;
         b->stats.align_parkings = b->stats.align_handed_back = b->stats.align_wide_rows = 0;
         b->stats.align_replacements = 0;
     }
-    b->in_flight = true;
     return 0;
 }
 
-// k_score + k_backtrace of `b` on the back stream, behind its links.  Caller holds back_mu.
-static int queue_back(fa_batch *b, hipEvent_t after) {
-    fa_ctx *c = b->ctx;
-    hipStream_t sb = c->back_stream[c->back_turn++ % fa_ctx::N_BACK];
-    HIP_OK(hipStreamWaitEvent(sb, b->ev[5], 0));
-    // (the host runs ahead of the device: without this the stage would start as soon as
-    // its own links are done, i.e. beside the next batch's k_seed_index and k_chain)
-    if (after) HIP_OK(hipStreamWaitEvent(sb, after, 0));
-    HIP_OK(hipEventRecord(b->ev[7], sb));
-    fa_launch_msa_back(b->dev(), b->md_saved, b->min_cov_saved, sb, b->ev[10], b->ev[11]);  // k_score | k_backtrace
-    trace_stage(sb, "consensus");
-    HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpyAsync(b->h_pile_out.data(), b->d_pile_out.p,
-                          (size_t)b->n_pile * sizeof(FaPileOut), hipMemcpyDeviceToHost, sb));
-    HIP_OK(hipEventRecord(b->ev[6], sb));
-    b->back_queued = true;
-    return 0;
-}
-// Queue the context's pending back stage, if any (or only if it is `only`).
-static int flush_pending_back(fa_ctx *c, fa_batch *only, hipEvent_t after) {
+// The context's pending batch (or only if it is `only`), marked as being taken care of by
+// the calling thread.
+static fa_batch *take_pending_back(fa_ctx *c, fa_batch *only) {
     std::lock_guard<std::mutex> hold(c->back_mu);
     fa_batch *p = c->pending_back;
-    if (!p || (only && p != only)) return 0;
+    if (!p || (only && p != only)) return nullptr;
     c->pending_back = nullptr;
-    return queue_back(p, after);
+    p->back_state = 1;
+    return p;
+}
+
+// Run the second half of `p` (back_state 1, set by this thread) and publish the outcome; a
+// failure is kept with the batch, for the thread that waits for it.
+static void begin_back(fa_batch *p) {
+    const std::string mine = g_err;  // (another batch's failure is not this call's)
+    const int rc = msa_stage(p);
+    if (rc) {
+        p->back_err = g_err;
+        p->back_rc = rc;
+        g_err = mine;
+    }
+    p->back_state.store(rc ? -1 : 2, std::memory_order_release);
 }
 
 static int finish_run(fa_batch *b, bool grace) {
-    // Still pending: a submit of the next batch that is under way (it holds front_mu) queues
-    // this batch's back stage at the right moment, right after its own k_chain; with
-    // `grace`, one that is about to start (another thread of a worker, between two calls)
-    // gets a millisecond to do so; otherwise this call queues it itself.
+    // Second half not begun: a submit of the next batch that is under way (it holds front_mu)
+    // will begin it once its own kernels are queued; with `grace`, one that is about to start
+    // (another thread of a worker, between two calls) gets a millisecond to do so; otherwise
+    // this call runs it.  Begun by another thread: wait until that thread has queued it.
     fa_ctx *c = b->ctx;
     for (int idle = 0;; ) {
-        {
-            std::lock_guard<std::mutex> hold(c->back_mu);
-            if (b->back_queued || c->pending_back != b) break;
-        }
-        if (c->front_mu.try_lock()) {
+        const int st = b->back_state.load(std::memory_order_acquire);
+        if (st == 2 || st == -1) break;
+        if (st == 0 && c->front_mu.try_lock()) {
             c->front_mu.unlock();
             if (!grace || ++idle > 20) {
-                if (flush_pending_back(c, b)) return -1;
-                break;
+                fa_batch *p = take_pending_back(c, b);
+                if (p) {
+                    begin_back(p);
+                    continue;
+                }
+                if (b->back_state.load(std::memory_order_acquire) == 0) {
+                    b->in_flight = false;
+                    set_err("falcon_amd: the batch's consensus stage was never queued");
+                    return -1;
+                }
             }
         }
         std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
     b->in_flight = false;
-    if (!b->back_queued) {
-        set_err("falcon_amd: the batch's consensus stage was never queued");
-        return -1;
+    if (b->back_state.load() == -1) {
+        g_err = b->back_err;
+        return b->back_rc ? b->back_rc : -1;
     }
     HIP_OK(hipEventSynchronize(b->ev[6]));
     long long sO = 0;
@@ -1416,8 +1492,8 @@ static int finish_run(fa_batch *b, bool grace) {
     (void)hipEventElapsedTime(&st.ms_links, b->ev[8], b->ev[9]);
     (void)hipEventElapsedTime(&st.ms_score, b->ev[7], b->ev[10]);
     (void)hipEventElapsedTime(&st.ms_backtrace, b->ev[10], b->ev[11]);
-    // the consensus stage = its four kernels (the last two may have run beside another
-    // batch's front stages); total = first launch to last result, whatever ran in between
+    // the consensus stage = its four kernels (they may have run beside another batch's front
+    // stages); total = first launch to last result, whatever ran in between
     st.ms_consensus = st.ms_tags + st.ms_links + st.ms_score + st.ms_backtrace;
     (void)hipEventElapsedTime(&st.ms_total, b->ev[0], b->ev[6]);
     return 0;
@@ -1491,12 +1567,14 @@ extern "C" fa_batch *fa_utg_consensus(fa_ctx *ctx, int n_seq, const char *const 
     {
         std::lock_guard<std::mutex> front(c->front_mu);
         b->front_launched = true;
-        // (a batch submitted on this context and not yet waited for keeps its back stage)
-        if (flush_pending_back(c)) return fail(nullptr);
+        // (a batch submitted on this context and not yet waited for stays pending: its own
+        // fa_batch_wait runs its MSA stage)
         if (ensure_arena(c, b, fa_align_lds_bytes(b->max_read_len, b->max_seed_len), true)) return fail(nullptr);
         for (int i = 0; i < 3; i++) (void)hipEventRecord(b->ev[i], s);
-        if (run_from_ranges(b, 0, 1.0 - min_idt, band, 1)) return fail(nullptr);
+        if (start_align(b, 0, 1.0 - min_idt, band, 1)) return fail(nullptr);
+        b->back_state = 1;
     }
+    begin_back(b);
     if (finish_run(b, false)) return fail(nullptr);
     return b;
 }
@@ -1763,8 +1841,8 @@ extern "C" int fa_align_pairs(fa_ctx *ctx, int n, const char *const *q, const in
         set_err("falcon_amd: k_align launch failed");
         return fail(-1);
     }
-    rc = fetch_aln(b);
-    if (rc == 1) rc = redo_handed_back(b, 2.0, band_tolerance);
+    rc = fetch_aln(b, s);
+    if (rc == 1) rc = redo_handed_back(b, 2.0, band_tolerance, s);
     if (rc) return fail(rc);
     std::vector<u32> script;
     if (get_aln_str > 0) {

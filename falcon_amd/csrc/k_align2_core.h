@@ -200,7 +200,10 @@ W_FN u64 a2_row(A2Hot &h, A2HotV &hv, const u32 *words, u64 *esc, int band, u32 
     // from_above: k == min_k, or k != max_k and V[k-1] < V[k+1] -- the lanes outside the
     // hull of the previous row hold A2_NEG, so the two edges of a band decide themselves:
     // at min_k V[k-1] is A2_NEG (from above), at max_k V[k+1] is (from below)
-    const u64 fa = w_ballot(a1 <= b) & act;
+    // (Lane 0 has no lane below it -- an even row reads 0 there, not A2_NEG: a cell on lane 0
+    // is its band's min_k by position, and with V[k+1] = 0, the low edge of an alignment's
+    // first rows, the comparison alone would get it wrong.)
+    const u64 fa = (P == 0 ? (w_ballot(a1 <= b) | 1ull) : w_ballot(a1 <= b)) & act;
     vi x = w_sel(fa, a1, b);
     vi y = (P == 0) ? x + hv.vnegk : x + hv.vnegk - 1;
     vu m = w_undef();  // (idle lanes: whatever -- their cell bytes are never read)
@@ -503,6 +506,9 @@ W_FN int a2_trace(const A2Args &A, A2Wave &w, A2Lanes &wl, const A2Track &t, u32
         const u64 valid = have & w_ballot((vi)kb > (vi)A2_CONT);  // (neither A2_INVALID nor A2_CONT)
         vi kc = (vi)kb - 1 + (vi)(itj & 1u);  // lane-0 diagonal of that iteration's row
         const int n_rows = w_popc(valid);
+#ifdef A2_HOOK_TRACE
+        A2_HOOK_TRACE(t, ih, have, valid, n_rows, r_top, kv, kb);
+#endif
         if (n_rows > 0) {
             if (valid != (n_rows >= 64 ? ~0ull : ((1ull << n_rows) - 1ull))) {
                 // iterations the track took no part in (parked; continuation records of wide
@@ -526,8 +532,11 @@ W_FN int a2_trace(const A2Args &A, A2Wave &w, A2Lanes &wl, const A2Track &t, u32
             // instructions this way -- three records read by v_readlane, a 64-bit shift, an and,
             // one three-operand add, and the lane that keeps the position.)
             vi my_lane = 0;
-            vi vj = (kv - w_readlane(kc, 0)) >> 1;
-            const bool plain = (valid == have);  // no wide row (continuation record) in the block
+            const int j_top = (kv - w_readlane(kc, 0)) >> 1;
+            vi vj = j_top;
+            // no wide row in the block: no continuation record in it, and the newest row (whose
+            // continuation records would lie in the block done before this one) is not one
+            const bool plain = (valid == have) && j_top < 64;
             if (plain && !(A.debug & 2)) {
                 const int last = n_rows - 1;
                 for (int l = 0; l < last; l++) {
@@ -1228,6 +1237,9 @@ W_FN void a2_wave(const A2Args &A, int slot) {
                 w.T1.best = h.best0; w.T1.cells = n_cells;
             }
         }
+#ifdef A2_HOOK_EXIT
+        A2_HOOK_EXIT(w, h);
+#endif
         if (w.n_esc > A2_ESC_CAP) {  // the escape list is full: everybody on the tape goes back
             if (w.T0.state != A2_IDLE) a2_hand_back(A, w, w.T0);
             if (w.T1.state != A2_IDLE) a2_hand_back(A, w, w.T1);

@@ -47,6 +47,22 @@ extern "C" void emu_hist(long *sum, long *one) { memcpy(sum, hist_sum, sizeof(hi
             fprintf(stderr, "row P=%d PAIR=%d it=%u lane %d: x=%d y=%d a1=%d b=%d act=%016llx fa=%016llx split=%d in=%016llx\n", P, (int)PAIR, h.it, l_, x.v[l_], y.v[l_], a1.v[l_], b.v[l_], (unsigned long long)(act), (unsigned long long)(fa), h.split, (unsigned long long)h.in); \
             for (int k_ = 0; k_ < 64; k_++) fprintf(stderr, "%d:%d ", k_, hv.vx.v[k_]); fprintf(stderr, "\n"); abort(); } } } while (0)
 #endif
+#ifdef EMU_ROWS
+#define A2_HOOK_ROW(P, PAIR, h, hv, a1, b, x, y, act, fa) do { if (h.it >= EMU_ROWS_FROM && h.it < EMU_ROWS_TO) \
+    fprintf(stderr, "row it=%u P=%d pair=%d act0=%d act1=%d cells0=%u cells1=%u split=%d act=%016llx\n", h.it, P, (int)PAIR, \
+            __builtin_popcountll((act) & ~h.zone1), __builtin_popcountll((act) & h.zone1), h.cells0, h.cells1, h.split, (unsigned long long)(act)); \
+    if (h.it >= EMU_ROWS_FROM && h.it < EMU_ROWS_FROM + 12) { fprintf(stderr, "   best0=%d kb0=%d vx:", h.best0, (int)h.kb0); for (int l_ = 0; l_ < 24; l_++) fprintf(stderr, " %d", hv.vx.v[l_]); \
+      fprintf(stderr, "\n   x/y pre-snake:"); for (int l_ = 0; l_ < 24; l_++) fprintf(stderr, " %d/%d", x.v[l_], y.v[l_]); fprintf(stderr, "\n"); } } while (0)
+#endif
+#ifdef EMU_TRACE_G
+#define A2_HOOK_EXIT(w, h) do { \
+    if ((w).T0.state != A2_IDLE && (w).T0.g == EMU_TRACE_G) fprintf(stderr, "exit T0 it=%u pair=%d d=%d cells=%u li=%d hin=%d ev=%016llx fin=%016llx\n", (w).it, (w).pair, (w).T0.d, (w).T0.cells, (w).T0.li, (w).T0.hin, (unsigned long long)(h).ev, (unsigned long long)(h).fin); \
+    if ((w).T1.state != A2_IDLE && (w).T1.g == EMU_TRACE_G) fprintf(stderr, "exit T1 it=%u pair=%d d=%d cells=%u li=%d hin=%d ev=%016llx fin=%016llx\n", (w).it, (w).pair, (w).T1.d, (w).T1.cells, (w).T1.li, (w).T1.hin, (unsigned long long)(h).ev, (unsigned long long)(h).fin); } while (0)
+#define A2_HOOK_TRACE(t, ih, have, valid, n_rows, r_top, kv, kb) do { if ((t).g == EMU_TRACE_G) { \
+    fprintf(stderr, "trace g=%d it0=%u ih=%u have=%016llx valid=%016llx n_rows=%d r_top=%d kv=%d kb:", (t).g, (t).it0, ih, \
+            (unsigned long long)(have), (unsigned long long)(valid), n_rows, r_top, kv); \
+    for (int l_ = 0; l_ < 64; l_++) fprintf(stderr, " %x", (unsigned)kb.v[l_]); fprintf(stderr, "\n"); } } while (0)
+#endif
 #include "k_align2_core.h"
 
 // words per arena slot for a tape of `ring` iterations (must match the engine's sizing)
@@ -59,6 +75,14 @@ extern "C" int emu_align2(const u32 *words, u64 n_words, const FaSeq *seq, int n
     if (ring < 256 || (ring & (ring - 1))) return -1;
     if (n_wave < 1) n_wave = 1;
     std::vector<u32> arena((size_t)slot_words_for(ring) * (size_t)n_wave, 0xA5A5A5A5u);
+    if (const char *fill = getenv("EMU_FILL")) {  // what earlier launches may have left there
+        u64 x = strtoull(fill, nullptr, 0) * 0x9E3779B97F4A7C15ull + 1;
+        for (u32 &w : arena) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            // (mostly plausible cell bytes and record words, now and then anything)
+            w = (x >> 60) ? (u32)(x >> 8) & 0x0f1f3f7fu : (u32)(x >> 16);
+        }
+    }
     int counter = 0;
     emu::n_regions = 0;
     emu::reg(words, n_words * 4, false);

@@ -129,7 +129,10 @@ def align_pairs(pairs, band=150, ring=8192, order=None, max_diff=2.0, windows=No
                  t_aln_str="")
         if r["aligned"]:
             sc = script[int(script_off[2 * i + 1]):]
-            qs, ts, x, y = expand(sc, r["dist"], q[s1:e1], t[s2:e2])
+            try:
+                qs, ts, x, y = expand(sc, r["dist"], q[s1:e1], t[s2:e2])
+            except IndexError:
+                raise AssertionError("pair %d: the edit script runs past the sequences: %r" % (i, r))
             assert (x, y) == (r["aln_q_e"], r["aln_t_e"]), (i, x, y, r)
             r["q_aln_str"], r["t_aln_str"] = qs, ts
             r["aln_str_size"] = len(qs)
