@@ -44,15 +44,22 @@
 #define A2_CONT 0x80000001u     // ... or: cells 64.. of the row the iteration before began (wide rows)
 #define A2_WIDE_RING 256        // LDS ring of a wide row's V values, per row parity (<= 191 live diagonals)
 #define A2_LDS_WORDS (256 + 2 * A2_WIDE_RING)  // (256 spare words) + the two rings
+// Placement policy, measured on the bench workload [MI355X] (scripts/r03_variants.sh +
+// r03_sweep.sh, profiles/r03_policy_sweep.txt): leaving the pair costs a trip through the
+// wavefront's event loop (~800 instructions) and halves the rows per iteration, laying the
+// two bands out again inside the row loop a few dozen instructions -- so two running tracks
+// stay paired as long as their bands fit the 64 lanes AT ALL (0 free lanes: 54.2 ms; 2: 56.6;
+// 4: 58.8; 6: 60.6), and a parked neighbour is looked at every 8 iterations (16: +0.5 ms,
+// 32: +1.9) and joins with 6 lanes to spare (2..8: within 0.5 ms).
 #ifndef A2_FREE_MIN
-#define A2_FREE_MIN 4           // free lanes two running tracks need to stay paired
+#define A2_FREE_MIN 0           // free lanes two running tracks need to stay paired
 #endif
 #ifndef A2_FREE_JOIN
 #define A2_FREE_JOIN 6          // ... and to (re)join a parked or a new track
 #endif
 #define A2_MAX_N 60             // widest band a track may have (alone in the wave)
 #ifndef A2_LOOK_EVERY
-#define A2_LOOK_EVERY 16        // iterations a track runs alone before the wave checks whether its parked neighbour fits again
+#define A2_LOOK_EVERY 8         // iterations a track runs alone before the wave checks whether its parked neighbour fits again
 #endif
 #define A2_ESC_CAP 1024         // escape entries per slot (snakes of >= 255 bases)
 #define A2_WIDE_PATIENCE 512    // wide rows a track may take while its neighbour waits (reads that align badly open the

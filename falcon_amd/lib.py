@@ -11,7 +11,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libfalcon_amd.so")
+# (FALCON_AMD_LIB: another build of the same library -- kernel experiments, scripts/r03_variants.sh)
+SO_PATH = os.environ.get("FALCON_AMD_LIB") or os.path.join(HERE, "libfalcon_amd.so")
 
 
 class FalconAmdError(RuntimeError):
