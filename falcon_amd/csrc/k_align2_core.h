@@ -57,6 +57,7 @@
 #ifndef A2_FREE_JOIN
 #define A2_FREE_JOIN 6          // ... and to (re)join a parked or a new track
 #endif
+static_assert(A2_FREE_JOIN >= 4, "a new track's first cell needs its V[k+1] lane on its side of the boundary");
 #define A2_MAX_N 60             // widest band a track may have (alone in the wave)
 #ifndef A2_LOOK_EVERY
 #define A2_LOOK_EVERY 8         // iterations a track runs alone before the wave checks whether its parked neighbour fits again
@@ -393,7 +394,11 @@ W_FN int a2_place(A2Wave &w, A2Lanes &wl) {
     bool run0 = have0, run1 = have1;
     if (have0 && have1) {
         const int free_lanes = 64 - n0 - n1;
-        const bool paired_now = w.pair && w.T0.state == A2_RUN && w.T1.state == A2_RUN;
+        // (a track without rows joins like a parked one: the lane its first cell reads
+        // V[k+1] = 0 from lies a lane above its band before an odd row, and must be on its
+        // side of the boundary -- A2_FREE_JOIN >= 4 puts two lanes between band and boundary)
+        const bool paired_now = w.pair && w.T0.state == A2_RUN && w.T1.state == A2_RUN &&
+                                w.T0.d > 0 && w.T1.d > 0;
         if (free_lanes < (paired_now ? A2_FREE_MIN : A2_FREE_JOIN)) {
             if (n1 > n0) run0 = false; else run1 = false;   // the wider one goes on alone
         }
@@ -594,6 +599,9 @@ W_FN int a2_trace(const A2Args &A, A2Wave &w, A2Lanes &wl, const A2Track &t, u32
                 const u64 long_one = w_ballot(m == 255u);
                 if (long_one) {
                     const vu want = (itc << 6) | ((vu)my_lane & 63u);
+#ifdef A2_HOOK_ESC
+                    A2_HOOK_ESC(t, w, long_one, want, itc, my_lane);
+#endif
                     for (int e = 0; e < w.n_esc; e++) {
                         vu elo, ehi;
                         w_load64(w.esc, (vu)e, elo, ehi);
@@ -1144,6 +1152,9 @@ W_FN void a2_wave(const A2Args &A, int slot) {
                 if (w.T0.state == A2_RUN) { wl.vpark = wl.vx; w.T0.state = A2_PARKED; w.st_park++; }
                 a2_wide<1>(A, w, wl, w.T1, from, w.T0.state == A2_IDLE ? 0x7fffffff : A2_WIDE_PATIENCE);
             }
+#ifdef A2_HOOK_WIDE
+            A2_HOOK_WIDE(w, wl, rc);
+#endif
             w.st_wide++;
             w.pair = 0;
             if (w.n_esc > A2_ESC_CAP) {

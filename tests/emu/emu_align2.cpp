@@ -51,10 +51,17 @@ extern "C" void emu_hist(long *sum, long *one) { memcpy(sum, hist_sum, sizeof(hi
 #define A2_HOOK_ROW(P, PAIR, h, hv, a1, b, x, y, act, fa) do { if (h.it >= EMU_ROWS_FROM && h.it < EMU_ROWS_TO) \
     fprintf(stderr, "row it=%u P=%d pair=%d act0=%d act1=%d cells0=%u cells1=%u split=%d act=%016llx\n", h.it, P, (int)PAIR, \
             __builtin_popcountll((act) & ~h.zone1), __builtin_popcountll((act) & h.zone1), h.cells0, h.cells1, h.split, (unsigned long long)(act)); \
-    if (h.it >= EMU_ROWS_FROM && h.it < EMU_ROWS_FROM + 12) { fprintf(stderr, "   best0=%d kb0=%d vx:", h.best0, (int)h.kb0); for (int l_ = 0; l_ < 24; l_++) fprintf(stderr, " %d", hv.vx.v[l_]); \
-      fprintf(stderr, "\n   x/y pre-snake:"); for (int l_ = 0; l_ < 24; l_++) fprintf(stderr, " %d/%d", x.v[l_], y.v[l_]); fprintf(stderr, "\n"); } } while (0)
+    if (h.it >= EMU_ROWS_FROM && h.it < EMU_ROWS_FROM + 40) { fprintf(stderr, "   best0=%d kb0=%d vx:", h.best0, (int)h.kb0); for (int l_ = 0; l_ < 40; l_++) fprintf(stderr, " %d", hv.vx.v[l_]); \
+      fprintf(stderr, "\n   x/y pre-snake:"); for (int l_ = 0; l_ < 40; l_++) fprintf(stderr, " %d/%d", x.v[l_], y.v[l_]); fprintf(stderr, "\n"); } } while (0)
 #endif
 #ifdef EMU_TRACE_G
+#define A2_HOOK_WIDE(w, wl, rc) do { fprintf(stderr, "wide episode over: rc=%d it=%u T0 st=%d g=%d d=%d li=%d hin=%d | T1 st=%d g=%d d=%d li=%d hin=%d\n   vx:", rc, (w).it, (w).T0.state, (w).T0.g, (w).T0.d, (w).T0.li, (w).T0.hin, (w).T1.state, (w).T1.g, (w).T1.d, (w).T1.li, (w).T1.hin); \
+    for (int l_ = 0; l_ < 64; l_++) fprintf(stderr, " %d", (wl).vx.v[l_] < -1000 ? -1 : (wl).vx.v[l_]); fprintf(stderr, "\n   vpark:"); \
+    for (int l_ = 0; l_ < 64; l_++) fprintf(stderr, " %d", (wl).vpark.v[l_] < -1000 ? -1 : (wl).vpark.v[l_]); fprintf(stderr, "\n"); } while (0)
+#define A2_HOOK_ESC(t, w, long_one, want, itc, my_lane) do { if ((t).g == EMU_TRACE_G) { \
+    fprintf(stderr, "esc lookup: n_esc=%d long_one=%016llx", (w).n_esc, (unsigned long long)(long_one)); \
+    for (int l_ = 0; l_ < 64; l_++) if (((long_one) >> l_) & 1) fprintf(stderr, " [lane %d: it %u lane %d]", l_, itc.v[l_], my_lane.v[l_]); \
+    fprintf(stderr, "\n  list:"); for (int e_ = 0; e_ < (w).n_esc; e_++) fprintf(stderr, " (%u,%u:%u)", (unsigned)((w).esc[e_] & 0xffffffffu), (unsigned)((w).esc[e_] >> 38), (unsigned)(((w).esc[e_] >> 32) & 63)); fprintf(stderr, "\n"); } } while (0)
 #define A2_HOOK_EXIT(w, h) do { \
     if ((w).T0.state != A2_IDLE && (w).T0.g == EMU_TRACE_G) fprintf(stderr, "exit T0 it=%u pair=%d d=%d cells=%u li=%d hin=%d ev=%016llx fin=%016llx\n", (w).it, (w).pair, (w).T0.d, (w).T0.cells, (w).T0.li, (w).T0.hin, (unsigned long long)(h).ev, (unsigned long long)(h).fin); \
     if ((w).T1.state != A2_IDLE && (w).T1.g == EMU_TRACE_G) fprintf(stderr, "exit T1 it=%u pair=%d d=%d cells=%u li=%d hin=%d ev=%016llx fin=%016llx\n", (w).it, (w).pair, (w).T1.d, (w).T1.cells, (w).T1.li, (w).T1.hin, (unsigned long long)(h).ev, (unsigned long long)(h).fin); } while (0)

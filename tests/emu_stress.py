@@ -60,9 +60,9 @@ def main():
         try:
             res, st = align_pairs(pairs, order=order, ring=ring)
         except Exception as exc:  # (a script that does not even expand)
-            np.save("/tmp/emu_stress_order.npy", order)
+            np.save("/tmp/emu_stress_order_%d_%d.npy" % (lo, trial), order)
             print("trial", trial, "broke:", repr(exc), "fill", os.environ["EMU_FILL"],
-                  "order saved to /tmp/emu_stress_order.npy", flush=True)
+                  "order saved to /tmp/emu_stress_order_%d_%d.npy" % (lo, trial), flush=True)
             n_bad += 1
             continue
         back = 0

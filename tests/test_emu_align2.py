@@ -183,3 +183,46 @@ def test_wide_rows_run_in_the_kernel(port):
     assert _check(port, pairs, res, allow_handback=True) == 1
     res, st = align_pairs(pairs[1:])  # ... and alone it is not
     assert _check(port, pairs[1:], res) == 0
+
+
+def _campaign_pairs(lo, hi):
+    from oracle.campaign_cases import function_cases
+    return [(q, t) for s in range(lo, hi + 1) for q, t, band in function_cases(s) if band == 150]
+
+
+def _check_sub_order(port, pairs, order):
+    """A queue that names only some of the pairs: those pairs, renumbered."""
+    ids = sorted(set(int(g) // 2 for g in order))
+    at = {p: k for k, p in enumerate(ids)}
+    sub = [pairs[p] for p in ids]
+    o = [2 * at[int(g) // 2] + (int(g) & 1) for g in order]
+    o += [2 * k + 1 for k in range(len(sub)) if 2 * k + 1 not in set(o)]
+    res, _ = align_pairs(sub, order=np.array(o, dtype=np.int32))
+    _check(port, sub, res, allow_handback=True)
+
+
+@pytest.mark.parametrize("case", ["wide_row_on_a_block_boundary", "cell_on_lane_0_of_an_even_row",
+                                  "new_track_joins_a_full_wave"])
+def test_queue_orders_that_went_wrong_once(port, case):
+    """Three wrong answers tests/emu_stress.py found in round 3, each with the queue order that
+    produced it (tests/golden/emu_orders.json.gz; pairs of the frozen campaign):
+    a trace-back block whose newest row was a wide row took the fast chain; a cell on lane 0
+    of an even row read V[k-1] = 0 instead of 'outside the band' (the DP-cell count, not the
+    path, differed); a track without rows joined a wave with fewer than four free lanes and
+    read its first V[k+1] from the other track's side."""
+    from conftest import load_golden
+    c = load_golden("emu_orders")[case]
+    pairs = _campaign_pairs(*c["seeds"])
+    _check_sub_order(port, pairs, c["order"])
+
+
+def test_random_queue_orders_over_random_tape_contents(port, monkeypatch):
+    """A slice of tests/emu_stress.py in the suite: campaign pairs in random orders, the arena
+    filled with random words first."""
+    pairs = _campaign_pairs(208, 223)
+    rng = np.random.default_rng(2083)
+    for trial in range(3):
+        monkeypatch.setenv("EMU_FILL", str(int(rng.integers(1, 1 << 30))))
+        order = rng.permutation(2 * len(pairs)).astype(np.int32)
+        res, _ = align_pairs(pairs, order=order)
+        _check(port, pairs, res, allow_handback=True)
