@@ -69,6 +69,43 @@ W_FN vu w_prefix_max(vu v) {
     return t;
 }
 
+// The tail of a band row as ONE instruction stream: the inclusive prefix maximum of `key`
+// (as w_prefix_max) with the row's other work in the wait states of its DPP steps, where
+// s_nop would sit otherwise -- a VGPR written by a VALU instruction may be read through DPP
+// two instructions later at the earliest.  Beside the maximum:
+//   fin  = (x >= qlen | y >= tlen) & act      big = (m > 254) & act      keyb = key + band
+//   lane `slot` of rc_lo / rc_hi := the two halves of `fa`
+// (11 instructions + 6 DPP steps + 1 s_nop, where the parts took 23.)
+W_FN vu w_row_tail(vu key, vi x, vi qlen, vi y, vi tlen, vu m, u64 act, u32 band, u64 fa, int slot,
+                   vu &rc_lo, vu &rc_hi, u64 &fin, u64 &big, vu &keyb) {
+    vu t;
+    u64 f, b;
+    vu kb;
+    asm volatile("v_cmp_ge_i32_e32 vcc, %7, %8\n\t"
+                 "v_cmp_ge_i32_e64 %1, %9, %10\n\t"
+                 "v_max_u32_dpp %0, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_or_b64 %1, %1, vcc\n\t"
+                 "v_cmp_lt_u32_e32 vcc, 0xfe, %11\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_and_b64 %2, vcc, %12\n\t"
+                 "s_and_b64 %1, %1, %12\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_u32_e32 %3, %13, %6\n\t"
+                 "s_mov_b32 m0, %16\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_writelane_b32 %4, %14, m0\n\t"
+                 "v_writelane_b32 %5, %15, m0\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                 : "=&v"(t), "=&s"(f), "=&s"(b), "=&v"(kb), "+v"(rc_lo), "+v"(rc_hi)
+                 : "v"(key), "v"(x), "v"(qlen), "v"(y), "v"(tlen), "v"(m), "s"(act), "s"(band),
+                   "s"((u32)fa), "s"((u32)(fa >> 32)), "s"(slot)
+                 : "vcc");
+    fin = f; big = b; keyb = kb;
+    return t;
+}
+
 W_FN vi w_min(vi a, vi b) { return min(a, b); }
 W_FN vi w_max(vi a, vi b) { return max(a, b); }
 W_FN vu w_minu(vu a, vu b) { return min(a, b); }

@@ -236,26 +236,28 @@ W_FN u64 a2_row(A2Hot &h, A2HotV &hv, const u32 *words, u64 *esc, int band, u32 
     }
     // (snakes of >= 255 bases do not fit the cell byte: such a row raises an event, and where
     // the row loop ends the lengths go to the escape list and the bytes become 255 -- a2_long_snakes)
-    const u64 big = w_ballot(m >= 255u) & act;
     hv.vm = m;
     // the cell byte: the snake length
     if (J >= 0) hv.vacc = w_put_byte<(J >= 0 ? J : 0)>(hv.vacc, m);
     else hv.vacc = w_put_byte_sel(hv.vacc, m, byte_sel);  // (J < 0: the position comes as a v_perm selector)
-    const u64 fin = (w_ballot(x >= hv.vqlen) | w_ballot(y >= hv.vtlen)) & act;  // :220
-    w_writelane2(hv.rc_mlo, hv.rc_mhi, (u32)fa, (u32)(fa >> 32), (int)(h.it & 63u));
     // band (:228-243): keep the hull of the cells with x + y >= best_m - band.  One prefix
-    // maximum serves both tracks: track 1's keys carry the top bit.
+    // maximum serves both tracks: track 1's keys carry the top bit.  In the wait states of
+    // its DPP steps (w_row_tail): the cells that reached an end of a sequence (:220), the
+    // snakes that do not fit a cell byte, the row's from_above bits into the tape record.
     const vu key = w_selu(act, 0u, (vu)(x + y) + hv.vtop);
-    const vu pm = w_prefix_max(key);
+    u64 fin, big;
+    vu keyb;
+    const vu pm = w_row_tail(key, x, hv.vqlen, y, hv.vtlen, m, act, (u32)band, fa, (int)(h.it & 63u),
+                             hv.rc_mlo, hv.rc_mhi, fin, big, keyb);
     u64 in;
     if (PAIR) {
         h.best0 = max(h.best0, (int)w_readlaneu(pm, h.split - 1));
         h.best1 = (int)max((u32)h.best1, w_readlaneu(pm, 63));
         const vu vbest = w_selu(h.zone1, (vu)h.best0, (vu)h.best1);
-        in = w_ballot(key + (vu)band >= vbest) & act;
+        in = w_ballot(keyb >= vbest) & act;
     } else {
         h.best0 = max(h.best0, (int)w_readlaneu(pm, 63));
-        in = w_ballot(key + (vu)band >= (vu)h.best0) & act;
+        in = w_ballot(keyb >= (vu)h.best0) & act;
     }
     // the next row's bands: the hulls, one diagonal wider on either side -- in lanes: one
     // lane down before an odd row, one lane up before an even one.  (Lane numbers never

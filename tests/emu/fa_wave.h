@@ -105,6 +105,19 @@ W_FN vu w_prefix_max(const vu &v) {
     for (int l = 0; l < 64; l++) { m = std::max(m, v.v[l]); r.v[l] = m; }
     return r;
 }
+W_FN vu w_row_tail(const vu &key, const vi &x, const vi &qlen, const vi &y, const vi &tlen, const vu &m, u64 act,
+                   u32 band, u64 fa, int slot, vu &rc_lo, vu &rc_hi, u64 &fin, u64 &big, vu &keyb) {
+    fin = 0; big = 0;
+    for (int l = 0; l < 64; l++) {
+        if (!((act >> l) & 1)) continue;
+        if (x.v[l] >= qlen.v[l] || y.v[l] >= tlen.v[l]) fin |= 1ull << l;
+        if (m.v[l] > 254u) big |= 1ull << l;
+    }
+    for (int l = 0; l < 64; l++) keyb.v[l] = key.v[l] + band;
+    rc_lo.v[slot & 63] = (u32)fa;
+    rc_hi.v[slot & 63] = (u32)(fa >> 32);
+    return w_prefix_max(key);
+}
 W_FN vi w_min(const vi &a, const vi &b) { vi r; for (int l = 0; l < 64; l++) r.v[l] = std::min(a.v[l], b.v[l]); return r; }
 W_FN vi w_max(const vi &a, const vi &b) { vi r; for (int l = 0; l < 64; l++) r.v[l] = std::max(a.v[l], b.v[l]); return r; }
 W_FN vu w_minu(const vu &a, const vu &b) { vu r; for (int l = 0; l < 64; l++) r.v[l] = std::min(a.v[l], b.v[l]); return r; }
