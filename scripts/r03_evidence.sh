@@ -4,6 +4,7 @@ TAG=${1:-r03e}; QUICK=$2
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG; mkdir -p $O/pmc
 cd $R
+( timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 ) > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
 timeout 700 python bench.py > $O/bench_ecoli.json.txt 2> $O/bench_ecoli.err; cut -c1-200 $O/bench_ecoli.json.txt
 timeout 300 python bench.py --no-pipeline --no-cpu-baseline --no-end-to-end > $O/bench_ecoli_serial.json.txt 2> /dev/null; cut -c1-160 $O/bench_ecoli_serial.json.txt
 FALCON_AMD_ALIGN1=1 timeout 300 python bench.py --no-cpu-baseline --no-end-to-end > $O/bench_ecoli_k_align1.json.txt 2> /dev/null; cut -c1-160 $O/bench_ecoli_k_align1.json.txt
@@ -31,3 +32,7 @@ done
 python $R/scripts/pmc_table.py $O/pmc > $O/pmc_table.txt 2>&1
 find $O -name "*.db" -size +5M -delete
 find $O -name "*.csv" -size +2M -delete
+cd $R
+FALCON_AMD_TIMING=1 timeout 600 python scripts/exp_e2e.py 3072 3 FALCON_AMD_NOTHING=1 FALCON_AMD_NOTHING=2 > $O/e2e.txt 2>&1
+grep -i "steady" /tmp/e2e_stream.txt.err | tail -1 >> $O/e2e.txt
+tail -4 $O/e2e.txt | cut -c1-220
