@@ -9,10 +9,7 @@
 #include "fa_wave.h"
 #include "k_align2_core.h"
 
-#ifndef A2_WAVES_PER_SIMD
-#define A2_WAVES_PER_SIMD 8
-#endif
-__global__ __launch_bounds__(64, A2_WAVES_PER_SIMD) void k_align2(A2Args A) {
+__global__ __launch_bounds__(64, 8) void k_align2(A2Args A) {
     a2_wave(A, (int)blockIdx.x);
 }
 
