@@ -342,15 +342,25 @@ KERNEL_SOURCE = {"k_align": ("k_align2.hip", "k_align2_core.h", "fa_wave.h", "k_
                  "k_seed_index": "k_pack_index.hip"}
 
 
+def _code_only(text):
+    """C++ source without comments and blank space: what the digest below is taken of (a
+    reworded comment does not make a measurement stale; string literals -- the inline asm --
+    are kept as they are)."""
+    import re
+    pat = re.compile(r'"(?:\\.|[^"\\])*"|\'(?:\\.|[^\'\\])*\'|//[^\n]*|/\*.*?\*/', re.S)
+    text = pat.sub(lambda m: m.group(0) if m.group(0)[0] in "\"'" else " ", text)
+    return "\n".join(" ".join(ln.split()) for ln in text.splitlines() if ln.strip())
+
+
 def kernel_source_sha(kernel):
-    """Digest of the source file a kernel lives in: a PMC measurement is only presented as
-    this build's when it was taken on this source."""
+    """Digest of the code (comments and layout aside) of the source files a kernel lives in:
+    a PMC measurement is only presented as this build's when it was taken on this code."""
     try:
         names = KERNEL_SOURCE[kernel]
         h = hashlib.sha1()
         for name in ((names,) if isinstance(names, str) else names):
-            with open(os.path.join(ROOT, "falcon_amd", "csrc", name), "rb") as f:
-                h.update(f.read())
+            with open(os.path.join(ROOT, "falcon_amd", "csrc", name), "r", errors="replace") as f:
+                h.update(_code_only(f.read()).encode())
         return h.hexdigest()[:16]
     except (KeyError, OSError):
         return None

@@ -1,34 +1,41 @@
-// k_align.hip -- banded O(ND) alignment with trace-back, one wavefront per read.
+// k_align.hip -- banded O(ND) alignment with trace-back, one wavefront per alignment: the
+// GENERAL kernel of the alignment stage.  The falcon_sense path runs k_align2 (two alignments
+// per wavefront, k_align2.hip); this kernel takes what k_align2 hands back (FaAln.err == 2:
+// repeated alone in worst-case slots), band tolerances below 64, and everything when
+// FALCON_AMD_ALIGN1 is set (A/B runs, tests).
 //
 // Restates align() of the reference (src/c/DW_banded.c:115-330) for every
-// (read window, seed window) pair of the batch:
+// (read window, seed window) pair of the work list:
 //
-//   forward  row d of the furthest-reaching table lives on diagonals
-//            min_k, min_k+2, .. max_k; lane j of the wave owns diagonal
-//            min_k + 2j (rows wider than 64 diagonals take up to 3 passes).
-//            All cells of a row depend only on the previous row,
-//            so a row is one data-parallel step:
-//              - V of the previous row comes from an LDS ring indexed by k>>1,
-//                split by parity so consecutive lanes hit consecutive banks;
-//              - the snake compares 2-bit packed bases, up to 32 per step, from
-//                the read/seed windows staged in LDS (coalesced HBM loads);
-//              - best_m is a DPP wave max, the next band comes from one
-//                __ballot + ffs/clz per pass, the finishing diagonal ("first k
-//                in ascending order", DW_banded.c:220-224) from a ballot;
-//            each cell's reached x (+ from_above bit) is streamed to a per-slot
-//            HBM arena, one 32-byte record per row keeps min_k, the row offset
-//            and the from_above bits.
-//   trace    (DW_banded.c:264-319) the diagonal chain k_d is resolved 64 rows
-//            at a time from the per-row from_above bits held in registers
-//            (v_readlane), then all 64 rows gather their x2 in parallel and emit
-//            one u32 per row: (snake_length << 1) | from_above.  The gapped
-//            strings of the reference are never materialised; they are a pure
+//   forward  lane l owns diagonal kd + 2 l of the row, kd falling by one per row; the previous
+//            row of the furthest-reaching table lives in ONE VGPR, so V[k+1] and V[k-1] are the
+//            lane's own value and one DPP wave_shr:1 -- no parity case; the band climbs a lane
+//            every two rows and is re-seated with a shuffle every few dozen rows.  Rows wider
+//            than 60 diagonals (rare) fall back to a ring in LDS, up to 3 passes of 64 cells.
+//            All cells of a row depend only on the previous row, so a row is
+//            one data-parallel step:
+//              - the snake compares 2-bit packed bases, 16 per step (v_alignbit of two packed
+//                words, xor, v_ffbl), read through the vector L1 (FALCON_AMD_ALIGN_LDS=1: from
+//                windows staged in LDS -- slower, it costs occupancy);
+//              - lane sets (band, from_above, finished, next band) are scalar 64-bit masks:
+//                every ballot is one v_cmp, the masks are combined by the scalar unit;
+//              - best_m is a DPP wave maximum, the next band comes from s_ff1 / s_flbit, the
+//                finishing diagonal ("first k in ascending order", DW_banded.c:220-224) from
+//                a ballot;
+//            each cell's reached x goes to the slot's arena (4 bytes, coalesced), one 16-byte
+//            record per row (first diagonal, cell offset, from_above bits) is kept in a
+//            register ring (v_writelane) and flushed 64 rows at a time.
+//   trace    (DW_banded.c:264-319) the diagonal chain k_d is resolved 64 rows at a time from the
+//            per-row from_above bits held in registers (v_readlane), then all 64 rows gather
+//            their x in parallel and emit one u32 per row: (snake_length << 1) | from_above.
+//            The gapped strings of the reference are never materialised; they are a pure
 //            function of this edit script and the two sequences.
 //
 // The reference's qsort + bsearch over (d,k) records (:260,:267-277) and its
 // O(max_d * band) calloc (:164) have no counterpart here.
 //
-// Integer / LDS / HBM-write bound (4 B per DP cell); no MFMA.
+// Bound by the CU's scalar and vector instruction streams; 4 B per DP
+// cell to HBM; no MFMA.
 #include "fa_device.h"
 #include <cstdlib>
 #include <type_traits>
