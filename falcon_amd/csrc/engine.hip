@@ -351,6 +351,7 @@ struct fa_batch {
         size_t n_seg = 0;
         u64 t_tot = 0;
     } run;
+    size_t n_ta = 0;  // accepted alignments of the last run's plan (h_ta)
     HostBuf<unsigned long long> h_a2_stats;
     HostBuf<u32> h_acc_first;
     HostBuf<u64> h_link_off, h_link_cap;
@@ -1323,6 +1324,7 @@ static int msa_stage(fa_batch *b) {
         b->h_pile_up[p] = pm;
     }
     acc_first[b->n_pile] = (u32)n_ta;
+    b->n_ta = n_ta;
     pt.mark("plan");
     if (ins_tot >= 0xffffffffull || link_tot >= 0xffffffffull * 4) {
         set_err("falcon_amd: batch too large for the MSA stage");
@@ -1763,6 +1765,84 @@ extern "C" int fa_batch_alignment(fa_batch *b, int g, int *dist, int *q_e, int *
     if (accept) *accept = a.accept;
     if (cells) *cells = a.cells;
     return 0;
+}
+
+// Diagnostics: the k-mer hits of sequence g against its pile's seed, as the chain stage
+// enumerates them (find_kmer_pos_for_seq, kmer_lookup.c:207-286: query offsets 0, 4, 8, ..
+// ascending, seed positions of a k-mer ascending) -- rebuilt on the host from exactly what
+// k_chain's later passes walk: the per-probe bucket bounds its first pass left in the probe
+// buffer, and the seed index's position lists.  Returns the number of hits (which may be
+// more than `cap`, the number stored), or -1.
+extern "C" int fa_batch_debug_hits(fa_batch *b, int g, int *q_pos, int *t_pos, int cap) {
+    if (!b || b->pair_mode || g < 0 || g >= b->n_seq || b->in_flight || !b->have_range) {
+        set_err("falcon_amd: fa_batch_debug_hits needs a completed run and a valid sequence index");
+        return -1;
+    }
+    HIP_OK(hipSetDevice(b->ctx->device));
+    const FaSeq &sq = b->seq[g];
+    if (sq.idx == 0) return 0;  // the seed itself
+    const FaPile &pm = b->pile[sq.pile];
+    const int n_probe = (sq.len > FA_K) ? (sq.len - FA_K + 3) / 4 : 0;
+    if (n_probe == 0) return 0;
+    std::vector<u64> pr((size_t)n_probe);
+    std::vector<u32> pos((size_t)pm.seed_len + 4);
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(pr.data(), b->d_probe.p + b->probe_off[g], pr.size() * sizeof(u64), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(pos.data(), b->d_kpos.p + pm.kpos_off, pos.size() * sizeof(u32), hipMemcpyDeviceToHost));
+    long long n = 0;
+    for (int p = 0; p < n_probe; p++) {
+        const u32 first = (u32)pr[p], cnt = (u32)(pr[p] >> 32);
+        for (u32 e = 0; e < cnt; e++, n++) {
+            if (n < cap) {
+                if (first + e >= pos.size()) {
+                    set_err("falcon_amd: probe %d of sequence %d points outside its pile's index", p, g);
+                    return -1;
+                }
+                q_pos[n] = 4 * p;
+                t_pos[n] = (int)pos[first + e];
+            }
+        }
+    }
+    return (int)std::min<long long>(n, 0x7fffffff);
+}
+
+// Diagnostics: the tag words k_tags made of the accepted alignment of sequence g (one per
+// covered seed position, k_msa.hip: bit 31 the read deletes the seed base, bits 30..23 the
+// length of the insertion run behind it, bits 22..0 the run -- up to 11 bases inline, 2 bits
+// each, first base lowest; a longer run: the index of its first base in `ins`), the word of
+// the slot before the alignment's first position (a leading insertion run; 0: none) and the
+// alignment's inserted bases (codes 0..3).  Returns the number of covered positions (words
+// stored: min(that, cap_words)), 0 for an alignment that was not accepted, -1 on error.
+extern "C" int fa_batch_debug_tags(fa_batch *b, int g, unsigned *words, int cap_words, unsigned *lead_word,
+                                   unsigned char *ins, int cap_ins, int *n_ins) {
+    if (!b || b->pair_mode || g < 0 || g >= b->n_seq || b->in_flight || !b->have_aln ||
+        b->back_state.load() != 2) {
+        set_err("falcon_amd: fa_batch_debug_tags needs a completed run and a valid sequence index");
+        return -1;
+    }
+    HIP_OK(hipSetDevice(b->ctx->device));
+    const FaTagAln *ta = b->h_ta.data();
+    const FaTagAln *mine = nullptr;
+    int k = 0;
+    for (size_t i = 0; i < b->n_ta; i++)
+        if (ta[i].g == g) { mine = &ta[i]; k = (int)i; }
+    if (!mine) return 0;
+    const FaAln &al = b->h_aln[g];
+    HIP_OK(hipDeviceSynchronize());
+    int tcov = 0;
+    HIP_OK(hipMemcpy(&tcov, b->d_tcov.p + k, sizeof(int), hipMemcpyDeviceToHost));
+    const int n_cov = tcov & 0x3fffffff;  // (bit 30: the alignment opens with an insertion run)
+    if (n_cov > al.t_e + 2) {
+        set_err("falcon_amd: alignment %d covers %d positions but ends at %d", g, n_cov, al.t_e);
+        return -1;
+    }
+    if (lead_word) HIP_OK(hipMemcpy(lead_word, b->d_desc.p + mine->desc_off - 1, sizeof(u32), hipMemcpyDeviceToHost));
+    const int nw = std::min(n_cov, cap_words);
+    if (nw > 0) HIP_OK(hipMemcpy(words, b->d_desc.p + mine->desc_off, (size_t)nw * sizeof(u32), hipMemcpyDeviceToHost));
+    if (n_ins) *n_ins = al.n_ins;
+    const int ni = std::min(al.n_ins, cap_ins);
+    if (ni > 0) HIP_OK(hipMemcpy(ins, b->d_insb.p + mine->ins_off, (size_t)ni, hipMemcpyDeviceToHost));
+    return n_cov;
 }
 
 // ---------------------------------------------------------------------------

@@ -230,6 +230,46 @@ class Batch:
         return dict(dist=v[0].value, q_e=v[1].value, t_e=v[2].value, size=v[3].value,
                     accept=v[4].value, cells=cells.value)
 
+    def debug_hits(self, g: int):
+        """(query_pos[], target_pos[]) of sequence g's k-mer hits on its seed, in the order the
+        chain stage enumerates them (tests)."""
+        n = self.lib.fa_batch_debug_hits(self.h, g, None, None, 0)
+        if n < 0:
+            raise FalconAmdError(last_error())
+        q, t = (C.c_int * max(n, 1))(), (C.c_int * max(n, 1))()
+        if self.lib.fa_batch_debug_hits(self.h, g, q, t, n) != n:
+            raise FalconAmdError(last_error())
+        return list(q[:n]), list(t[:n])
+
+    def debug_tags(self, g: int):
+        """The tag words of sequence g's accepted alignment decoded into the reference's tag
+        list [(t_pos relative to the alignment's first seed position, delta, base or '-' or
+        None)] -- base None: the read has the seed's base there (tests); [] when the alignment
+        was not accepted."""
+        lead, n_ins = C.c_uint(), C.c_int()
+        n = self.lib.fa_batch_debug_tags(self.h, g, None, 0, C.byref(lead), None, 0, C.byref(n_ins))
+        if n < 0:
+            raise FalconAmdError(last_error())
+        if n == 0:
+            return []
+        words = (C.c_uint * n)()
+        ins = (C.c_ubyte * max(n_ins.value, 1))()
+        if self.lib.fa_batch_debug_tags(self.h, g, words, n, C.byref(lead), ins, n_ins.value, C.byref(n_ins)) != n:
+            raise FalconAmdError(last_error())
+
+        def run(word, t):
+            k = (word >> 23) & 0xff
+            pay = word & 0x7fffff
+            for d in range(k):
+                code = (pay >> (2 * d)) & 3 if k <= 11 else ins[pay + d]
+                yield (t, d + 1, "ACGT"[code])
+
+        out = list(run(lead.value, -1))
+        for t in range(n):
+            out.append((t, 0, "-" if words[t] >> 31 else None))
+            out.extend(run(words[t], t))
+        return out
+
     def free(self):
         if self.h:
             self.lib.fa_batch_free(self.h)

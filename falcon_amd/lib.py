@@ -89,6 +89,11 @@ def load() -> C.CDLL:
         [C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.fa_batch_alignment.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_int)] * 5 + \
         [C.POINTER(C.c_longlong)]
+    lib.fa_batch_debug_hits.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    lib.fa_batch_debug_hits.restype = C.c_int
+    lib.fa_batch_debug_tags.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint), C.c_int, C.POINTER(C.c_uint),
+                                        C.POINTER(C.c_ubyte), C.c_int, C.POINTER(C.c_int)]
+    lib.fa_batch_debug_tags.restype = C.c_int
     lib.fa_align_pairs.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p),
                                    C.POINTER(C.c_int), C.POINTER(C.c_char_p),
                                    C.POINTER(C.c_int), C.c_int, C.c_int,

@@ -204,6 +204,23 @@ int fa_batch_range(fa_batch *b, int g, int *s1, int *e1, int *s2, int *e2, long 
                    int *ok, int *n_hit);
 int fa_batch_alignment(fa_batch *b, int g, int *dist, int *q_e, int *t_e, int *size, int *accept,
                        long long *cells);
+/* ... and two intermediate lists of the last completed run, for a direct comparison with the
+ * reference's (tests/test_gpu_parity.py); no caller of the path needs them.
+ * fa_batch_debug_hits: the k-mer hits of sequence g against its pile's seed in the order
+ * find_kmer_pos_for_seq reports them (src/c/kmer_lookup.c:207-286: query_pos[], target_pos[]),
+ * as the chain stage enumerates them on the device.  Returns the number of hits (min(that,
+ * cap) are stored), -1 on error.
+ * fa_batch_debug_tags: what get_align_tags (src/c/falcon.c:106-162) yields for the accepted
+ * alignment of sequence g, in the device's position-major form: words[t] for the t-th covered
+ * seed position -- bit 31: the read deletes the seed base; bits 30..23: length n of the
+ * insertion run behind it; bits 22..0: the run, n <= 11: 2 bits per base (0..3 = ACGT), first
+ * base lowest, else the index of its first base in ins[] -- plus *lead_word, the word of the
+ * position before the alignment's first (an alignment opening with an insertion run; 0: none),
+ * and ins[], the alignment's inserted bases in read order.  Returns the number of covered
+ * positions (0: the alignment was not accepted), -1 on error. */
+int fa_batch_debug_hits(fa_batch *b, int g, int *q_pos, int *t_pos, int cap);
+int fa_batch_debug_tags(fa_batch *b, int g, unsigned *words, int cap_words, unsigned *lead_word,
+                        unsigned char *ins, int cap_ins, int *n_ins);
 
 /* --trim (falcon_kit/mains/consensus.py:48-99 get_alignment): for every read of the
  * batch the window find_best_aln_range2 reports on its pile's seed, k-mers occurring

@@ -319,6 +319,67 @@ def test_stage_outputs_vs_oracle(engine, port):
     b.free()
 
 
+def _reference_tags(q_aln, t_aln):
+    """The tag list of one alignment as get_align_tags builds it (src/c/falcon.c:106-162), seed
+    positions counted from the alignment's first one: every column yields (t, delta, base) --
+    t the last seed position consumed (-1 before the first), delta the number of read bases
+    inserted behind it so far, base the read's character ('-' where it skips the seed base);
+    tagging stops where an insertion run reaches 255."""
+    out, t, delta, prev_delta = [], -1, 0, 0
+    for qc, tc in zip(q_aln, t_aln):
+        if qc != "-":
+            delta += 1
+        if tc != "-":
+            t += 1
+            delta = 0
+        if delta >= 255 or prev_delta >= 255:
+            break
+        out.append((t, delta, qc))
+        prev_delta = delta
+    return out
+
+
+def test_hit_lists_and_tag_words_vs_reference(engine, port):
+    """Two intermediate lists compared directly (fa_batch_debug_hits / _tags), not through what
+    later stages make of them: every read's k-mer hit list in the reference's order
+    (kmer_lookup.c:207-286) as k_chain enumerates it, and every accepted alignment's tags
+    (falcon.c:106-162) as k_tags packs them into its per-position words."""
+    piles = [_synthetic(43, S=5000, coverage=15, min_read=800, mean_read=3000, sd_read=1000),
+             _synthetic(44, S=9000, coverage=25),
+             _synthetic(45, S=4000, coverage=12, min_read=2500, mean_read=3500, sd_read=300)]
+    # (insertion runs of more than 11 bases leave the tag word for the alignment's byte list)
+    rng = np.random.default_rng(45)
+    for j, n in ((1, 20), (2, 40), (3, 13)):
+        r = piles[2][j]
+        piles[2][j] = r[:len(r) // 2] + "".join("ACGT"[c] for c in rng.integers(0, 4, n)) + r[len(r) // 2:]
+    b = engine.batch(piles)
+    b.run(4, 8, 0.70)
+    g0, n_hits, n_tags, n_long = 0, 0, 0, 0
+    for pile in piles:
+        seed = pile[0]
+        assert b.debug_hits(g0) == ([], [])  # (the seed is the target, not a query)
+        for j in range(1, len(pile)):
+            g = g0 + j
+            hq, ht = port.find_hits(seed, pile[j])
+            gq, gt = b.debug_hits(g)
+            assert (gq, gt) == (hq, ht), (g, len(gq), len(hq))
+            n_hits += len(hq)
+            r, ga = b.range(g), b.alignment(g)
+            tags = b.debug_tags(g)
+            if not (r["ok"] and ga["accept"]):
+                assert tags == []
+                continue
+            a = port.align(pile[j][r["s1"]:r["e1"]], seed[r["s2"]:r["e2"]], 150, 1)
+            want = _reference_tags(a["q_aln_str"], a["t_aln_str"])
+            got = [(t, d, seed[r["s2"] + t] if c is None else c) for t, d, c in tags]
+            assert got == want, (g, len(got), len(want))
+            n_tags += len(want)
+            n_long += sum(1 for t, d, c in want if d > 11)
+        g0 += len(pile)
+    b.free()
+    assert n_hits > 20000 and n_tags > 250000 and n_long > 0
+
+
 def test_ecoli_scale_pile_vs_oracle(engine, port):
     """BASELINE config 2 shape: ~20 kb seed x 40x."""
     pile = _synthetic(7, S=20000, coverage=40)
