@@ -484,6 +484,7 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
         b.run(MIN_COV, K, MIN_IDT)
 
     acc = {}
+    submit_ms = []  # host time of every fa_batch_submit of the timed region
 
     def steps(n, record):
         if n <= 0:
@@ -495,11 +496,17 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
                     tally(batch.stats())
             return
         # step i runs on batch i mod depth; depth - 1 submits stay ahead of every wait
+        def submit(bt):
+            t_s = time.perf_counter()
+            bt.submit(MIN_COV, K, MIN_IDT)
+            if record:
+                submit_ms.append((time.perf_counter() - t_s) * 1e3)
+
         for j in range(min(depth - 1, n)):
-            pair[j % depth].submit(MIN_COV, K, MIN_IDT)
+            submit(pair[j % depth])
         for i in range(n):
             if i + depth - 1 < n:
-                pair[(i + depth - 1) % depth].submit(MIN_COV, K, MIN_IDT)
+                submit(pair[(i + depth - 1) % depth])
             cur = pair[i % depth]
             cur.wait()
             if record:
@@ -629,6 +636,10 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
             # `roofline.alone` and the unpipelined profile under profiles/ hold the kernels' own times)
             "kernel_ms_are": "queue-inclusive event spans" if pipelined else "kernel times (one batch at a time)",
             "host_plan_gap_ms": round(host_gap, 3),
+            # what a call of fa_batch_submit costs the calling thread (it queues the front
+            # kernels and hands the batch to the context's planner thread): mean and worst
+            "host_submit_ms": ({"mean": round(sum(submit_ms) / len(submit_ms), 3), "max": round(max(submit_ms), 3)}
+                               if submit_ms else None),
             # the alignment stage about itself (fa_stats): arena bytes, resident wavefronts, and
             # k_align2's iterations with two / one alignment running, band placements,
             # parkings, alignments handed to the general kernel, wide rows

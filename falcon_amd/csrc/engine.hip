@@ -11,6 +11,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -114,12 +116,17 @@ struct fa_ctx {
     hipStream_t dl_stream = nullptr;
     std::mutex front_mu, fetch_mu;
     // The second half of a run -- the MSA plan (host; it needs the alignment summaries, i.e.
-    // waits for k_align) and the MSA kernels -- is not begun by the submit that launched the
-    // first half: the NEXT submit on the context begins it, after queueing its own front
-    // stages (or the batch's own fa_batch_wait, whichever comes first).  The front stream
-    // thus never waits for the host, and a submit never waits for its own k_align.
-    std::mutex back_mu;   // pending_back, back_turn
-    fa_batch *pending_back = nullptr;
+    // waits for k_align) and the MSA kernels -- is not the submitting thread's business: the
+    // context's PLANNER thread takes the batches in submit order, waits for each one's
+    // summaries and queues its MSA stage on a back stream.  fa_batch_submit therefore never
+    // waits for the device, and the front stream never waits for the host.
+    std::mutex back_mu;   // back_turn
+    std::thread planner;
+    std::mutex plan_mu;                  // plan_q, plan_stop
+    std::condition_variable plan_cv;     // the planner's: work or stop
+    std::condition_variable done_cv;     // the waiters': some batch's back_state settled
+    std::deque<fa_batch *> plan_q;
+    bool plan_stop = false;
     // repeat launches of alignments k_align2 handed back share arena2, from whichever stream
     std::mutex redo_mu;
     hipEvent_t ev_redo = nullptr;  // the last repeat launch (redo_mu)
@@ -388,6 +395,8 @@ extern "C" int fa_device_count(void) {
     return n;
 }
 
+static void planner_main(fa_ctx *c);
+
 extern "C" fa_ctx *fa_create(int device) {
     int n = fa_device_count();
     if (n <= 0) {
@@ -431,12 +440,21 @@ extern "C" fa_ctx *fa_create(int device) {
     HIP_OK_P(hipMalloc((void **)&c->a2.stats, 8 * sizeof(unsigned long long)));
     HIP_OK_P(hipMemset(c->a2.stats, 0, 8 * sizeof(unsigned long long)));
     c->a2.counter = c->arena.counter;  // (the front stream runs one alignment launch at a time)
+    c->planner = std::thread(planner_main, c);
     return c;
 }
 
 extern "C" void fa_destroy(fa_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->planner.joinable()) {  // (it finishes what was submitted first)
+        {
+            std::lock_guard<std::mutex> hold(c->plan_mu);
+            c->plan_stop = true;
+        }
+        c->plan_cv.notify_all();
+        c->planner.join();
+    }
     if (c->arena.cells) (void)hipFree(c->arena.cells);
     if (c->arena.rows) (void)hipFree(c->arena.rows);
     if (c->arena.rowx) (void)hipFree(c->arena.rowx);
@@ -799,13 +817,16 @@ extern "C" fa_batch *fa_batch_create(fa_ctx *ctx, int n_pile, const int *pile_n_
 extern "C" void fa_batch_free(fa_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
-    {
-        std::lock_guard<std::mutex> hold(b->ctx->back_mu);
-        if (b->ctx->pending_back == b) b->ctx->pending_back = nullptr;  // its MSA stage is never begun
+    {   // still waiting for the planner: its MSA stage is never begun; the planner at it: wait
+        std::unique_lock<std::mutex> hold(b->ctx->plan_mu);
+        auto &q = b->ctx->plan_q;
+        auto it = std::find(q.begin(), q.end(), b);
+        if (it != q.end()) {
+            q.erase(it);
+            b->back_state = 0;
+        }
+        b->ctx->done_cv.wait(hold, [&] { return b->back_state.load(std::memory_order_acquire) != 1; });
     }
-    // (another thread's submit may be half-way through this batch's MSA stage)
-    while (b->back_state.load(std::memory_order_acquire) == 1)
-        std::this_thread::sleep_for(std::chrono::microseconds(50));
     // Its buffers go to the per-device block cache, from where another thread's batch_build
     // may take them at once (hipFree used to wait for the device; the cache does not):
     // nothing of this batch may still be running.  Front stages (also of a submit that
@@ -1067,18 +1088,18 @@ static int redo_handed_back(fa_batch *b, double max_diff, int band, hipStream_t 
 // kernels, wider bands the general one; `force_accept_g` >= 0 names a sequence whose
 // alignment is used whatever its length (the unitig's copy of itself, falcon.c:699-704).
 // msa_stage: the MSA plan from the alignment summaries (waits for k_align) and the MSA
-// kernels on a back stream.  begin_back / finish_run decide which thread runs the latter.
+// kernels on a back stream -- run by the context's planner thread (planner_main), batch after
+// batch in submit order; finish_run waits for its outcome.
 static int start_align(fa_batch *b, unsigned min_cov, double max_diff, int band, int force_accept_g);
 static int msa_stage(fa_batch *b);
 static int finish_run(fa_batch *b, bool grace);
 static void begin_back(fa_batch *p);
-static fa_batch *take_pending_back(fa_ctx *c, fa_batch *only = nullptr);
 
 // First half of a run (seed index, chaining, alignment) on the context's front stream;
-// returns with everything only QUEUED.  The MSA stage of the batch submitted BEFORE this one
-// is begun here, once this batch's kernels are in the queue: its plan waits for its k_align,
-// while this batch's kernels keep the front stream busy, and its kernels (k_tags, k_links,
-// k_score, k_backtrace on a back stream) then run beside this batch's k_chain and k_align.
+// returns with everything only QUEUED -- it never waits for the device.  The batch then
+// belongs to the context's planner thread, which waits for its alignment summaries, sizes the
+// MSA pools and queues k_tags, k_links, k_score, k_backtrace on a back stream: they run beside
+// the kernels of whatever was submitted next.
 extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double min_idt) {
     if (!b || b->pair_mode) {
         set_err("falcon_amd: fa_batch_submit on an invalid batch");
@@ -1100,7 +1121,6 @@ extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double
         return -1;
     }
     PhaseTimer pt("fa_batch_submit");
-    fa_batch *before = nullptr;
     {
         std::lock_guard<std::mutex> front(c->front_mu);  // one batch at a time on the front stream
         pt.mark("front-lock");
@@ -1131,15 +1151,12 @@ extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double
                               hipMemcpyDeviceToHost, s));
         if (start_align(b, min_cov, max_diff, FA_BAND, -1)) return -1;
         pt.mark("launch-front");
-        // this batch's second half is the next submit's (or its own wait's); the one before it
-        // is this call's
-        std::lock_guard<std::mutex> hold(c->back_mu);
-        before = c->pending_back;
-        c->pending_back = b;
-        if (before) before->back_state = 1;
+        // its second half is the planner's (a failure there is reported by fa_batch_wait)
+        std::lock_guard<std::mutex> hold(c->plan_mu);
+        b->back_state = 1;
+        c->plan_q.push_back(b);
     }
-    if (before) begin_back(before);  // (its failure is reported by its own fa_batch_wait)
-    pt.mark("msa stage of the batch before");
+    c->plan_cv.notify_one();
     return 0;
 }
 
@@ -1245,7 +1262,7 @@ static int start_align(fa_batch *b, unsigned min_cov, double max_diff, int band,
     return 0;
 }
 
-// Second half of a run, by the one thread that set back_state to 1: the MSA plan from the
+// Second half of a run, by the one thread the batch was handed to (back_state 1): the MSA plan from the
 // alignment summaries (host, O(#reads)), then k_tags | k_tscan | k_links | k_score |
 // k_backtrace and the per-pile results' copy on a back stream.  Nothing here touches the
 // front stream, which meanwhile runs the next batch.
@@ -1414,19 +1431,8 @@ static int msa_stage(fa_batch *b) {
     return 0;
 }
 
-// The context's pending batch (or only if it is `only`), marked as being taken care of by
-// the calling thread.
-static fa_batch *take_pending_back(fa_ctx *c, fa_batch *only) {
-    std::lock_guard<std::mutex> hold(c->back_mu);
-    fa_batch *p = c->pending_back;
-    if (!p || (only && p != only)) return nullptr;
-    c->pending_back = nullptr;
-    p->back_state = 1;
-    return p;
-}
-
-// Run the second half of `p` (back_state 1, set by this thread) and publish the outcome; a
-// failure is kept with the batch, for the thread that waits for it.
+// Run the second half of `p` (back_state 1) and publish the outcome; a failure is kept with
+// the batch, for the thread that waits for it.
 static void begin_back(fa_batch *p) {
     const std::string mine = g_err;  // (another batch's failure is not this call's)
     const int rc = msa_stage(p);
@@ -1435,34 +1441,44 @@ static void begin_back(fa_batch *p) {
         p->back_rc = rc;
         g_err = mine;
     }
-    p->back_state.store(rc ? -1 : 2, std::memory_order_release);
+    {
+        std::lock_guard<std::mutex> hold(p->ctx->plan_mu);
+        p->back_state.store(rc ? -1 : 2, std::memory_order_release);
+    }
+    p->ctx->done_cv.notify_all();
+}
+
+// The planner thread of a context: the second halves of the submitted runs, in submit order.
+static void planner_main(fa_ctx *c) {
+    (void)hipSetDevice(c->device);
+    for (;;) {
+        fa_batch *p = nullptr;
+        {
+            std::unique_lock<std::mutex> hold(c->plan_mu);
+            c->plan_cv.wait(hold, [&] { return c->plan_stop || !c->plan_q.empty(); });
+            if (c->plan_q.empty()) return;  // (stop, and nothing left to do)
+            p = c->plan_q.front();
+            c->plan_q.pop_front();
+        }
+        begin_back(p);
+    }
 }
 
 static int finish_run(fa_batch *b, bool grace) {
-    // Second half not begun: a submit of the next batch that is under way (it holds front_mu)
-    // will begin it once its own kernels are queued; with `grace`, one that is about to start
-    // (another thread of a worker, between two calls) gets a millisecond to do so; otherwise
-    // this call runs it.  Begun by another thread: wait until that thread has queued it.
+    // (the second half is the planner's, or -- unitig runs -- was the caller's own)
+    (void)grace;
     fa_ctx *c = b->ctx;
-    for (int idle = 0;; ) {
-        const int st = b->back_state.load(std::memory_order_acquire);
-        if (st == 2 || st == -1) break;
-        if (st == 0 && c->front_mu.try_lock()) {
-            c->front_mu.unlock();
-            if (!grace || ++idle > 20) {
-                fa_batch *p = take_pending_back(c, b);
-                if (p) {
-                    begin_back(p);
-                    continue;
-                }
-                if (b->back_state.load(std::memory_order_acquire) == 0) {
-                    b->in_flight = false;
-                    set_err("falcon_amd: the batch's consensus stage was never queued");
-                    return -1;
-                }
-            }
+    {
+        std::unique_lock<std::mutex> hold(c->plan_mu);
+        if (b->back_state.load(std::memory_order_acquire) == 0) {
+            b->in_flight = false;
+            set_err("falcon_amd: the batch's consensus stage was never queued");
+            return -1;
         }
-        std::this_thread::sleep_for(std::chrono::microseconds(50));
+        c->done_cv.wait(hold, [&] {
+            const int st = b->back_state.load(std::memory_order_acquire);
+            return st == 2 || st == -1;
+        });
     }
     b->in_flight = false;
     if (b->back_state.load() == -1) {
@@ -1569,8 +1585,8 @@ extern "C" fa_batch *fa_utg_consensus(fa_ctx *ctx, int n_seq, const char *const 
     {
         std::lock_guard<std::mutex> front(c->front_mu);
         b->front_launched = true;
-        // (a batch submitted on this context and not yet waited for stays pending: its own
-        // fa_batch_wait runs its MSA stage)
+        // (batches submitted on this context and not yet waited for are the planner's; this
+        // run's second half is done by the calling thread, below)
         if (ensure_arena(c, b, fa_align_lds_bytes(b->max_read_len, b->max_seed_len), true)) return fail(nullptr);
         for (int i = 0; i < 3; i++) (void)hipEventRecord(b->ev[i], s);
         if (start_align(b, 0, 1.0 - min_idt, band, 1)) return fail(nullptr);
