@@ -500,7 +500,7 @@ static int rows_bound(int len, int T, bool filtered) {
 
 // Grow the context's staging pair (pinned host buffer, device twin) to `bytes`.
 // Caller holds stage_mu.
-static int stage_reserve(fa_ctx *c, size_t bytes) {
+static int stage_reserve(fa_ctx *c, size_t bytes, bool device_twin) {
     if (bytes > c->h_stage_cap) {
         if (c->h_stage) (void)hipHostFree(c->h_stage);
         c->h_stage = nullptr;
@@ -513,7 +513,7 @@ static int stage_reserve(fa_ctx *c, size_t bytes) {
         }
         c->h_stage_cap = cap;
     }
-    if (bytes > c->d_stage_cap) {
+    if (device_twin && bytes > c->d_stage_cap) {
         if (c->d_stage) (void)hipFree(c->d_stage);
         c->d_stage = nullptr;
         c->d_stage_cap = 0;
@@ -663,12 +663,15 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
             for (size_t j = 0; j < stream[x].size(); j++) b->chain_order[j * 8 + x] = stream[x][j];
     }
 
-    // Stage the ASCII through the context's pinned buffer: sequences are copied in by a
-    // few threads (one memcpy stream does not come near the PCIe rate), uploaded, packed
-    // to 2 bits on the device; only the packed form stays resident.
+    // The sequences are packed to 2 bits per base on the way into the context's pinned
+    // buffer, by a few threads (pack_host.cpp), and uploaded as they will lie in HBM: a
+    // quarter of the host writes and of the PCIe bytes of the text, which the device never
+    // sees.  (FALCON_AMD_DEVICE_PACK=1: the text is copied, uploaded and packed by k_pack --
+    // round 2's route, kept for the counter calibration of scripts/pmc_traffic_record.py.)
     pt.mark("layout");
+    static const bool device_pack = getenv("FALCON_AMD_DEVICE_PACK") != nullptr;
     int rc = 0;
-    rc |= b->d_ascii_off.alloc(g);
+    if (device_pack) rc |= b->d_ascii_off.alloc(g);
     rc |= b->d_words.alloc(b->n_words + 8);
     rc |= b->d_seq.alloc(g);
     rc |= b->d_pile.alloc(n_pile);
@@ -696,16 +699,28 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
     {
         std::lock_guard<std::mutex> hold(ctx->stage_mu);
         pt.mark("stage-lock");
-        if (stage_reserve(ctx, b->ascii_bytes)) {
+        const size_t stage_bytes = device_pack ? (size_t)b->ascii_bytes : (size_t)b->n_words * sizeof(u32);
+        if (stage_reserve(ctx, stage_bytes, device_pack)) {
             delete b;
             return nullptr;
         }
         pt.mark("stage-reserve");
         uint8_t *h_ascii = ctx->h_stage;
+        u32 *h_words = reinterpret_cast<u32 *>(ctx->h_stage);
         const u64 *aoffs = b->ascii_off.data();
         const FaSeq *sq = b->seq.data();
+        const u64 n_words = b->n_words;
+        std::vector<int> bad_at((size_t)g, -1);  // per sequence: its first byte outside ACGT
+        int *bad_at_p = bad_at.data();
         auto copy_part = [=](int i0, int i1) {
-            for (int i = i0; i < i1; i++) memcpy(h_ascii + aoffs[i], seqs[i], (size_t)sq[i].len);
+            for (int i = i0; i < i1; i++) {
+                if (device_pack) {
+                    memcpy(h_ascii + aoffs[i], seqs[i], (size_t)sq[i].len);
+                } else {
+                    const u64 end = i + 1 < g ? (u64)sq[i + 1].woff : n_words;
+                    bad_at_p[i] = fa_pack_host(seqs[i], sq[i].len, h_words + sq[i].woff, (long long)(end - sq[i].woff));
+                }
+            }
         };
         const int n_thr = stage_threads(b->ascii_bytes);
         if (n_thr <= 1) {
@@ -723,11 +738,16 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
             }
             for (auto &t : pool) t.join();
         }
-        pt.mark("host-copy");
-        b->ascii_dev = ctx->d_stage;
+        pt.mark(device_pack ? "host-copy" : "host-pack");
         hipStream_t s = ctx->up_stream;
-        ok &= hipMemcpyAsync(ctx->d_stage, h_ascii, b->ascii_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
-        ok &= hipMemcpyAsync(b->d_ascii_off.p, b->ascii_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
+        if (device_pack) {
+            b->ascii_dev = ctx->d_stage;
+            ok &= hipMemcpyAsync(ctx->d_stage, h_ascii, b->ascii_bytes, hipMemcpyHostToDevice, s) == hipSuccess;
+            ok &= hipMemcpyAsync(b->d_ascii_off.p, b->ascii_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
+        } else {
+            ok &= n_words == 0 ||
+                  hipMemcpyAsync(b->d_words.p, h_words, (size_t)n_words * sizeof(u32), hipMemcpyHostToDevice, s) == hipSuccess;
+        }
         ok &= hipMemcpyAsync(b->d_seq.p, b->seq.data(), g * sizeof(FaSeq), hipMemcpyHostToDevice, s) == hipSuccess;
         ok &= hipMemcpyAsync(b->d_pile.p, b->pile.data(), n_pile * sizeof(FaPile), hipMemcpyHostToDevice, s) == hipSuccess;
         ok &= hipMemcpyAsync(b->d_order.p, b->order.data(), g * sizeof(int), hipMemcpyHostToDevice, s) == hipSuccess;
@@ -739,22 +759,33 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
             ok &= hipMemcpyAsync(b->d_probe_off.p, b->probe_off.data(), g * sizeof(u64), hipMemcpyHostToDevice, s) == hipSuccess;
         trace_stage(s, "upload");
         int first_bad = 0x7fffffff;
+        std::vector<int> bad((size_t)n_pile, 0);  // piles holding a byte outside ACGT
         DevBuf<int> d_bad_pile;
-        if (ok && !pair_mode) {
-            ok &= d_bad_pile.alloc((size_t)n_pile) == 0;
-            if (ok) ok &= hipMemsetAsync(d_bad_pile.p, 0, (size_t)n_pile * sizeof(int), s) == hipSuccess;
-        }
-        if (ok) {
-            ok &= hipMemcpyAsync(ctx->d_first_bad, &first_bad, sizeof(int), hipMemcpyHostToDevice, s) == hipSuccess;
-            fa_launch_pack(b->dev(), ctx->d_first_bad, pair_mode ? nullptr : d_bad_pile.p, s);
-            ok &= hipGetLastError() == hipSuccess;
-            ok &= hipMemcpyAsync(&first_bad, ctx->d_first_bad, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess;
+        if (device_pack) {
+            if (ok && !pair_mode) {
+                ok &= d_bad_pile.alloc((size_t)n_pile) == 0;
+                if (ok) ok &= hipMemsetAsync(d_bad_pile.p, 0, (size_t)n_pile * sizeof(int), s) == hipSuccess;
+            }
+            if (ok) {
+                ok &= hipMemcpyAsync(ctx->d_first_bad, &first_bad, sizeof(int), hipMemcpyHostToDevice, s) == hipSuccess;
+                fa_launch_pack(b->dev(), ctx->d_first_bad, pair_mode ? nullptr : d_bad_pile.p, s);
+                ok &= hipGetLastError() == hipSuccess;
+                ok &= hipMemcpyAsync(&first_bad, ctx->d_first_bad, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess;
+            }
+        } else {
+            for (int i = 0; i < g; i++) {
+                if (bad_at[i] < 0) continue;
+                first_bad = std::min(first_bad, i);
+                bad[b->seq[i].pile] = 1;
+            }
         }
         // (also on the error path: nothing may still read the staging buffers)
         ok &= hipStreamSynchronize(s) == hipSuccess;
         trace_stage(s, "pack");
-        pt.mark("h2d+pack");
+        pt.mark(device_pack ? "h2d+pack" : "h2d");
         b->ascii_dev = nullptr;
+        if (device_pack && ok && first_bad != 0x7fffffff && !pair_mode)
+            ok &= hipMemcpy(bad.data(), d_bad_pile.p, (size_t)n_pile * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
         auto describe = [&](int g) {
             // the reference aligns raw characters and codes other bytes specially
             // (kmer_lookup.c:159-171, :236-249): outside the parity domain
@@ -777,8 +808,6 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
             // Piles fail alone: a pile with such a sequence gets no consensus and an entry in
             // fa_batch_pile_error; its reads are taken out of the stages (as index 0 they
             // count as seeds: no chain, no alignment); the batch -- and the stream -- go on.
-            std::vector<int> bad((size_t)n_pile);
-            ok &= hipMemcpy(bad.data(), d_bad_pile.p, (size_t)n_pile * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
             for (int p = 0; ok && p < n_pile; p++) {
                 if (!bad[p]) continue;
                 const FaPile &pm = b->pile[p];
@@ -1781,6 +1810,12 @@ extern "C" int fa_batch_alignment(fa_batch *b, int g, int *dist, int *q_e, int *
     if (accept) *accept = a.accept;
     if (cells) *cells = a.cells;
     return 0;
+}
+
+// Diagnostics: the host packer on one sequence (tests, no device needed).
+extern "C" int fa_debug_pack(const char *s, int len, unsigned *out, long long n_out) {
+    if (!s || len < 0 || !out || n_out < (long long)((len + 15) / 16)) return -2;
+    return fa_pack_host(s, len, out, n_out);
 }
 
 // Diagnostics: the k-mer hits of sequence g against its pile's seed, as the chain stage

@@ -89,6 +89,8 @@ def load() -> C.CDLL:
         [C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.fa_batch_alignment.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_int)] * 5 + \
         [C.POINTER(C.c_longlong)]
+    lib.fa_debug_pack.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_uint), C.c_longlong]
+    lib.fa_debug_pack.restype = C.c_int
     lib.fa_batch_debug_hits.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
     lib.fa_batch_debug_hits.restype = C.c_int
     lib.fa_batch_debug_tags.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint), C.c_int, C.POINTER(C.c_uint),

@@ -218,6 +218,12 @@ int fa_batch_alignment(fa_batch *b, int g, int *dist, int *q_e, int *t_e, int *s
  * position before the alignment's first (an alignment opening with an insertion run; 0: none),
  * and ins[], the alignment's inserted bases in read order.  Returns the number of covered
  * positions (0: the alignment was not accepted), -1 on error. */
+/* fa_debug_pack: the host-side 2-bit packer batches are staged with (replaces the ASCII -> code
+ * loops of src/c/kmer_lookup.c:159-171, :236-249) on one sequence, no device involved:
+ * out[0 .. n_out) = 16 bases per word, base i at bits 2 (i mod 16), A C G T = 0 1 2 3, zero words
+ * behind the sequence; returns the position of the first byte other than upper-case A, C, G,
+ * T, or -1 (-2: bad arguments). */
+int fa_debug_pack(const char *s, int len, unsigned *out, long long n_out);
 int fa_batch_debug_hits(fa_batch *b, int g, int *q_pos, int *t_pos, int cap);
 int fa_batch_debug_tags(fa_batch *b, int g, unsigned *words, int cap_words, unsigned *lead_word,
                         unsigned char *ins, int cap_ins, int *n_ins);

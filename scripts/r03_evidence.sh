@@ -18,6 +18,8 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python $R/bench.p
 python $R/scripts/rocpd_summary.py $(ls $O/kt/*/*.db $O/kt/*.db 2>/dev/null | head -1) > $O/kernel_stats_pipelined.txt 2>&1; head -14 $O/kernel_stats_pipelined.txt | cut -c1-140
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/kts -o kts -- python $R/bench.py --no-pipeline --no-cpu-baseline --no-end-to-end > $O/kts.log 2>&1
 python $R/scripts/rocpd_summary.py $(ls $O/kts/*/*.db $O/kts/*.db 2>/dev/null | head -1) > $O/kernel_stats.txt 2>&1; head -14 $O/kernel_stats.txt | cut -c1-140
+# (the counter passes stage the batch through k_pack, whose traffic is known exactly: the calibration)
+export FALCON_AMD_DEVICE_PACK=1
 B="python $R/bench.py --steps 1 --warmup 0 --no-pipeline --no-cpu-baseline --no-end-to-end"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "k_align|k_pack" --output-format csv -d $O/pmc/$c -o $c -- $B > $O/pmc/$c.log 2>&1; echo "pmc $c rc=$?"
@@ -33,6 +35,7 @@ python $R/scripts/pmc_table.py $O/pmc > $O/pmc_table.txt 2>&1
 find $O -name "*.db" -size +5M -delete
 find $O -name "*.csv" -size +2M -delete
 cd $R
+unset FALCON_AMD_DEVICE_PACK
 FALCON_AMD_TIMING=1 timeout 600 python scripts/exp_e2e.py 3072 3 FALCON_AMD_NOTHING=1 FALCON_AMD_NOTHING=2 > $O/e2e.txt 2>&1
 grep -i "steady" /tmp/e2e_stream.txt.err | tail -1 >> $O/e2e.txt
 tail -4 $O/e2e.txt | cut -c1-220

@@ -380,6 +380,30 @@ def test_hit_lists_and_tag_words_vs_reference(engine, port):
     assert n_hits > 20000 and n_tags > 250000 and n_long > 0
 
 
+def test_device_side_packing_route_gives_the_same_answers(engine):
+    """Batches are packed to 2 bits per base on the host (pack_host.cpp); round 2's route --
+    the text uploaded and packed by k_pack -- is still there behind FALCON_AMD_DEVICE_PACK (the
+    counter calibration of the traffic measurement runs on k_pack): same consensus either way,
+    a dirty pile failing alone either way."""
+    import json
+    import subprocess
+    import sys
+    piles = [_synthetic(46, S=4000, coverage=12, min_read=800, mean_read=2500, sd_read=800),
+             _synthetic(47, S=6000, coverage=20)]
+    dirty = list(piles[0])
+    dirty[3] = dirty[3][:100] + "N" + dirty[3][101:]
+    here = engine.consensus(piles + [dirty], 4, 8, 0.70)
+    code = ("import json,sys; from falcon_amd.engine import Engine; piles=json.load(sys.stdin); e=Engine(0);"
+            "print(json.dumps([str(x) for x in e.consensus(piles,4,8,0.70)])); e.close()")
+    out = subprocess.run([sys.executable, "-c", code], input=json.dumps(piles + [dirty]), capture_output=True,
+                         text=True, cwd=os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."),
+                         env=dict(os.environ, FALCON_AMD_DEVICE_PACK="1"), check=True)
+    there = json.loads(out.stdout.strip().splitlines()[-1])
+    assert [str(x) for x in here] == there
+    from falcon_amd.engine import FailedPile
+    assert len(here[0]) > 3000 and len(here[1]) > 5000 and isinstance(here[2], FailedPile) and "0x4e" in here[2].reason
+
+
 def test_ecoli_scale_pile_vs_oracle(engine, port):
     """BASELINE config 2 shape: ~20 kb seed x 40x."""
     pile = _synthetic(7, S=20000, coverage=40)
