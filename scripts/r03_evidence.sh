@@ -4,7 +4,7 @@ TAG=${1:-r03e}; QUICK=$2
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG; mkdir -p $O/pmc
 cd $R
-( timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 ) > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
+if [ -z "$QUICK" ]; then ( timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 ) > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt; fi
 timeout 700 python bench.py > $O/bench_ecoli.json.txt 2> $O/bench_ecoli.err; cut -c1-200 $O/bench_ecoli.json.txt
 timeout 300 python bench.py --no-pipeline --no-cpu-baseline --no-end-to-end > $O/bench_ecoli_serial.json.txt 2> /dev/null; cut -c1-160 $O/bench_ecoli_serial.json.txt
 FALCON_AMD_ALIGN1=1 timeout 300 python bench.py --no-cpu-baseline --no-end-to-end > $O/bench_ecoli_k_align1.json.txt 2> /dev/null; cut -c1-160 $O/bench_ecoli_k_align1.json.txt
