@@ -722,6 +722,7 @@ W_FN bool a2_replace(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, const A2TrackCo
 struct A2Regs {
     vi vx, vnegk, vqlen, vtlen;
     vu vqb, vtb, vtop, vacc, rc_mlo, rc_mhi, rc_k0, rc_k1;
+    vi vpark;  // the last row of a parked track, in the lanes it had
     vu sc;  // lane i: the i-th wave-uniform value (A2_SC_*)
 };
 enum { A2_SC_ACT_LO = 0, A2_SC_ACT_HI, A2_SC_IN_LO, A2_SC_IN_HI, A2_SC_BEST0, A2_SC_BEST1,
@@ -730,7 +731,155 @@ enum { A2_SC_ACT_LO = 0, A2_SC_ACT_HI, A2_SC_IN_LO, A2_SC_IN_HI, A2_SC_BEST0, A2
        A2_SC_WORDS_LO, A2_SC_WORDS_HI, A2_SC_CELLS_LO, A2_SC_CELLS_HI, A2_SC_RECS_LO, A2_SC_RECS_HI,
        A2_SC_ESC_LO, A2_SC_ESC_HI, A2_SC_RING, A2_SC_BAND,
        A2_SC_QLEN0, A2_SC_TLEN0, A2_SC_QLEN1, A2_SC_TLEN1, A2_SC_QB0, A2_SC_TB0, A2_SC_QB1, A2_SC_TB1,
-       A2_SC_IT_LAST, A2_SC_JOIN_AT, A2_SC_NREPLACE };
+       A2_SC_IT_LAST, A2_SC_JOIN_AT, A2_SC_NREPLACE,
+       // parking and joining inside the row loop's function (a2_park / a2_join):
+       A2_SC_PARKED,      // 0: nobody; 1 / 2: track 0 / 1 waits in vpark with the state below
+       A2_SC_P_KC, A2_SC_P_LI, A2_SC_P_HIN, A2_SC_P_BEST, A2_SC_P_CELLS,
+       A2_SC_D0, A2_SC_D1,          // rows the tracks computed since the caller handed them over
+       A2_SC_REM0, A2_SC_REM1,      // rows they had left then (max_d - d)
+       A2_SC_TAPE_LAST,             // the iteration the tape allows the wave to reach
+       A2_SC_ITS,                   // the iteration the current stretch began at
+       A2_SC_AGAIN,                 // 1: the tracks were laid out anew -- call the function of MODE again
+       A2_SC_MODE,                  // 1: both tracks run, 0: one
+       A2_SC_IT_PAIR, A2_SC_IT_SINGLE, A2_SC_NPARK, A2_SC_NJOIN };
+static_assert(A2_SC_NJOIN < 64, "the wave-uniform state must fit the lanes of one register");
+
+// ---------------------------------------------------------------------------------------
+// Leaving and re-forming the pair WITHOUT going back to the wavefront's event loop (a trip
+// through it is ~800 instructions; two thirds of all trips were these two transitions).  Both
+// work on the row loop's own state, the way a2_replace does, and leave the result packed for
+// the other instance of a2_fast: the caller (a2_drive_call) only looks at AGAIN / MODE.
+//   a2_park: the two bands no longer fit the wave.  The narrower track's last row, hull,
+//            lane-0 diagonal, best_m and cell count go into vpark / the P_* fields, the wider
+//            one is centred and goes on alone (what a2_place decides and does).
+//   a2_join: the running band has become narrow enough for the waiting track to fit beside
+//            it with A2_FREE_JOIN lanes to spare: both are laid out side by side.
+// Neither touches anything before it knows it will go through with it; whatever they decline
+// (a band too wide to run alone, no rows or tape left, a waiting track without rows) is the
+// event loop's business as before.
+// ---------------------------------------------------------------------------------------
+W_FN int a2_rows_left(const A2Regs &r, bool t0, bool t1, u32 it, u32 &it_last) {
+    int rem = 0x7fffffff;
+    if (t0) rem = min(rem, (int)w_pack_get<A2_SC_REM0>(r.sc) - (int)w_pack_get<A2_SC_D0>(r.sc));
+    if (t1) rem = min(rem, (int)w_pack_get<A2_SC_REM1>(r.sc) - (int)w_pack_get<A2_SC_D1>(r.sc));
+    const int tape = (int)(w_pack_get<A2_SC_TAPE_LAST>(r.sc) - it);
+    rem = min(rem, tape);
+    it_last = it + (u32)max(rem, 0);
+    return rem;
+}
+
+W_FN bool a2_park(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, const A2TrackConst &tc, A2Regs &r) {
+    const u64 in0 = h.in & ~h.zone1, in1 = h.in & h.zone1;
+    if (in0 == 0ull || in1 == 0ull) return false;
+    const int n0 = w_span(in0) + 1, n1 = w_span(in1) + 1;
+    const bool park0 = n1 > n0;  // the wider one goes on alone (a2_place)
+    if ((park0 ? n1 : n0) > A2_MAX_N) return false;
+    u32 it_last;
+    // (a track that has used up its rows is the event loop's to retire, not to be parked)
+    if (a2_rows_left(r, true, true, h.it, it_last) <= 0) return false;
+    (void)a2_rows_left(r, !park0, park0, h.it, it_last);
+    const vi lane = w_lane();
+    const int p_last = (int)(h.it & 1u) ^ 1;
+    const u64 inp = park0 ? in0 : in1;
+    const int p_li = w_lowest(inp), p_hin = w_highest(inp);
+    w_pack_put<A2_SC_P_KC>(r.sc, (u32)((int)(park0 ? h.kb0 : h.kb1) - 1 + p_last));
+    w_pack_put<A2_SC_P_LI>(r.sc, (u32)p_li);
+    w_pack_put<A2_SC_P_HIN>(r.sc, (u32)p_hin);
+    w_pack_put<A2_SC_P_BEST>(r.sc, park0 ? (u32)h.best0 : (u32)h.best1 - 0x80000000u);
+    w_pack_put<A2_SC_P_CELLS>(r.sc, (park0 ? h.cells0 : h.cells1) - (u32)(p_hin - p_li + 2));
+    w_pack_put<A2_SC_PARKED>(r.sc, park0 ? 1u : 2u);
+    r.vpark = hv.vx;
+    const u64 ahead = ~0ull << (h.it & 63u);
+    // the runner plays "track 0" of the single loop, whichever it is
+    if (park0) {
+        h.best0 = (int)((u32)h.best1 - 0x80000000u);
+        h.cells0 = h.cells1;
+        h.kb0 = A2_INVALID;
+        rc_k0 = w_selu(ahead, rc_k0, A2_INVALID);
+        hv.vqlen = tc.q_len1; hv.vtlen = tc.t_len1; hv.vqb = tc.qb1; hv.vtb = tc.tb1;
+        hv.vnegk = (1 - (int)h.kb1) - 2 * lane;
+    } else {
+        h.kb1 = A2_INVALID;
+        rc_k1 = w_selu(ahead, rc_k1, A2_INVALID);
+        hv.vqlen = tc.q_len0; hv.vtlen = tc.t_len0; hv.vqb = tc.qb0; hv.vtb = tc.tb0;
+        hv.vnegk = (1 - (int)h.kb0) - 2 * lane;
+    }
+    h.best1 = 0; h.cells1 = 0u;
+    hv.vtop = 0u;
+    h.in = park0 ? in1 : in0;
+    h.split = park0 ? 0 : 64;
+    h.zone1 = 0ull;
+    h.ev = 0ull;
+    (void)a2_replace<false>(h, hv, rc_k0, rc_k1, tc);  // centres the runner (its width was looked at above)
+    const int join_at = max(1, 64 - A2_FREE_JOIN - (p_hin - p_li + 2));
+    w_pack_put<A2_SC_IT_LAST>(r.sc, it_last);
+    w_pack_put<A2_SC_IT_END>(r.sc, ((int)(it_last - h.it) > A2_LOOK_EVERY) ? h.it + A2_LOOK_EVERY : it_last);
+    w_pack_put<A2_SC_JOIN_AT>(r.sc, (u32)join_at);
+    w_pack_put<A2_SC_MODE>(r.sc, 0u);
+    w_pack_put<A2_SC_AGAIN>(r.sc, 1u);
+    w_pack_put<A2_SC_NPARK>(r.sc, w_pack_get<A2_SC_NPARK>(r.sc) + 1u);
+#ifdef A2_HOOK_DRIVE
+    A2_HOOK_DRIVE(0);
+#endif
+    return true;
+}
+
+W_FN bool a2_join(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, const A2TrackConst &tc, A2Regs &r) {
+    const u32 parked = w_pack_get<A2_SC_PARKED>(r.sc);
+    if (parked == 0u || h.in == 0ull) return false;
+    const bool run_is0 = parked == 2u;  // track 1 waits: the runner is track 0
+    const int p_li = (int)w_pack_get<A2_SC_P_LI>(r.sc), p_hin = (int)w_pack_get<A2_SC_P_HIN>(r.sc);
+    const int nr = w_span(h.in) + 1, np = p_hin - p_li + 2;
+    const int free_lanes = 64 - nr - np;
+    if (free_lanes < A2_FREE_JOIN) return false;
+    u32 it_last;
+    if (a2_rows_left(r, true, true, h.it, it_last) <= 0) return false;
+    const vi lane = w_lane();
+    const int down = (int)(h.it & 1u);  // the next row is an odd one: its band starts a lane below the hull
+    const int n0 = run_is0 ? nr : np, n1 = run_is0 ? np : nr;
+    const int g0 = free_lanes / 4, mid = free_lanes / 2;
+    const int nl0 = g0, nl1 = g0 + n0 + mid;
+    h.split = g0 + n0 + mid / 2;
+    a2_bounds<true>(h);
+    const int sh_r = w_lowest(h.in) - down - (run_is0 ? nl0 : nl1);
+    const int sh_p = p_li - down - (run_is0 ? nl1 : nl0);
+    const vi vr = w_gather_lanes(hv.vx, (lane + sh_r) & 63);
+    const vi vp = w_gather_lanes(r.vpark, (lane + sh_p) & 63);
+    h.in = w_lanes(nl0 + down, n0 - 1) | w_lanes(nl1 + down, n1 - 1);
+    hv.vx = w_sel(h.in, A2_NEG, w_sel(h.zone1, run_is0 ? vr : vp, run_is0 ? vp : vr));
+    const u32 kb_r = (run_is0 ? h.kb0 : h.kb1) + (u32)(2 * sh_r);
+    const u32 kb_p = (u32)((int)w_pack_get<A2_SC_P_KC>(r.sc) + 2 * sh_p + down);
+    h.kb0 = run_is0 ? kb_r : kb_p;
+    h.kb1 = run_is0 ? kb_p : kb_r;
+    const u32 best_r = (u32)h.best0, best_p = w_pack_get<A2_SC_P_BEST>(r.sc);  // (the runner played track 0)
+    const u32 cells_r = h.cells0, cells_p = w_pack_get<A2_SC_P_CELLS>(r.sc) + (u32)np;
+    h.best0 = (int)(run_is0 ? best_r : best_p);
+    h.best1 = (int)((run_is0 ? best_p : best_r) + 0x80000000u);
+    h.cells0 = run_is0 ? cells_r : cells_p;
+    h.cells1 = run_is0 ? cells_p : cells_r;
+    hv.vnegk = w_sel(h.zone1, 1 - (int)h.kb0, 1 - (int)h.kb1) - 2 * lane;
+    hv.vqlen = w_sel(h.zone1, tc.q_len0, tc.q_len1);
+    hv.vtlen = w_sel(h.zone1, tc.t_len0, tc.t_len1);
+    hv.vqb = w_selu(h.zone1, tc.qb0, tc.qb1);
+    hv.vtb = w_selu(h.zone1, tc.tb0, tc.tb1);
+    hv.vtop = w_selu(h.zone1, 0u, 0x80000000u);
+    const u64 ahead = ~0ull << (h.it & 63u);
+    rc_k0 = w_selu(ahead, rc_k0, h.kb0);
+    rc_k1 = w_selu(ahead, rc_k1, h.kb1);
+    h.act = w_lanes(nl0, n0) | w_lanes(nl1, n1);
+    h.ev = 0ull;
+    w_pack_put<A2_SC_PARKED>(r.sc, 0u);
+    w_pack_put<A2_SC_IT_LAST>(r.sc, it_last);
+    w_pack_put<A2_SC_IT_END>(r.sc, it_last);
+    w_pack_put<A2_SC_JOIN_AT>(r.sc, 0u);
+    w_pack_put<A2_SC_MODE>(r.sc, 1u);
+    w_pack_put<A2_SC_AGAIN>(r.sc, 1u);
+    w_pack_put<A2_SC_NJOIN>(r.sc, w_pack_get<A2_SC_NJOIN>(r.sc) + 1u);
+#ifdef A2_HOOK_DRIVE
+    A2_HOOK_DRIVE(1);
+#endif
+    return true;
+}
 
 template <bool PAIR>
 W_NOINLINE A2Regs a2_fast(A2Regs r) {
@@ -756,7 +905,7 @@ W_NOINLINE A2Regs a2_fast(A2Regs r) {
     tc.q_len1 = (int)w_pack_get<A2_SC_QLEN1>(r.sc); tc.t_len1 = (int)w_pack_get<A2_SC_TLEN1>(r.sc);
     tc.qb0 = w_pack_get<A2_SC_QB0>(r.sc); tc.tb0 = w_pack_get<A2_SC_TB0>(r.sc);
     tc.qb1 = w_pack_get<A2_SC_QB1>(r.sc); tc.tb1 = w_pack_get<A2_SC_TB1>(r.sc);
-    h.n_replace = 0u;
+    h.n_replace = w_pack_get<A2_SC_NREPLACE>(r.sc);
     const u32 *words = (const u32 *)(((u64)w_pack_get<A2_SC_WORDS_HI>(r.sc) << 32) | w_pack_get<A2_SC_WORDS_LO>(r.sc));
     u32 *cells = (u32 *)(((u64)w_pack_get<A2_SC_CELLS_HI>(r.sc) << 32) | w_pack_get<A2_SC_CELLS_LO>(r.sc));
     u32 *recs = (u32 *)(((u64)w_pack_get<A2_SC_RECS_HI>(r.sc) << 32) | w_pack_get<A2_SC_RECS_LO>(r.sc));
@@ -819,6 +968,25 @@ W_NOINLINE A2Regs a2_fast(A2Regs r) {
             w_store32(cells, (((h.it >> 2) - 1u) & ((ring >> 2) - 1u)) * 64u + (vu)lane, hv.vacc);
         h.ev &= ~h.big;
     }
+    {   // the rows of this stretch, per track
+        const u32 dn = h.it - w_pack_get<A2_SC_ITS>(r.sc);
+        if (PAIR || h.kb0 != A2_INVALID) w_pack_put<A2_SC_D0>(r.sc, w_pack_get<A2_SC_D0>(r.sc) + dn);
+        if (PAIR || h.kb0 == A2_INVALID) w_pack_put<A2_SC_D1>(r.sc, w_pack_get<A2_SC_D1>(r.sc) + dn);
+        if (PAIR) w_pack_put<A2_SC_IT_PAIR>(r.sc, w_pack_get<A2_SC_IT_PAIR>(r.sc) + dn);
+        else      w_pack_put<A2_SC_IT_SINGLE>(r.sc, w_pack_get<A2_SC_IT_SINGLE>(r.sc) + dn);
+        w_pack_put<A2_SC_ITS>(r.sc, h.it);
+        w_pack_put<A2_SC_AGAIN>(r.sc, 0u);
+        w_pack_put<A2_SC_MODE>(r.sc, PAIR ? 1u : 0u);
+    }
+    if (PAIR) {
+        // the two bands no longer fit the wave (a2_replace declined): the narrower track waits
+        if (h.ev != 0ull && h.fin == 0ull && h.big == 0ull && w_pack_get<A2_SC_PARKED>(r.sc) == 0u)
+            (void)a2_park(h, hv, rc_k0, rc_k1, tc, r);
+    } else {
+        // the look-ahead found the running band narrow enough for the waiting track
+        if (h.ev == 0ull && h.fin == 0ull && h.it != it_last && join_at > 0 && w_span(h.in) + 1 <= join_at)
+            (void)a2_join(h, hv, rc_k0, rc_k1, tc, r);
+    }
     r.vx = hv.vx; r.vnegk = hv.vnegk; r.vqlen = hv.vqlen; r.vtlen = hv.vtlen;
     r.vqb = hv.vqb; r.vtb = hv.vtb; r.vtop = hv.vtop;
     r.vacc = hv.vacc; r.rc_mlo = hv.rc_mlo; r.rc_mhi = hv.rc_mhi;
@@ -838,14 +1006,28 @@ W_NOINLINE A2Regs a2_fast(A2Regs r) {
     return r;
 }
 
-// the call: marshal, run, take the state back
-template <bool PAIR>
-W_FN void a2_fast_call(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV &hv, u32 it_end, u32 it_last,
-                       int join_at) {
+// What the event loop hands over besides the row loop's own state, and takes back
+struct A2Drive {
+    int pair;                  // in: the placement runs both tracks; out: the last stretch did
+    int parked;                // 0, or 1 + the track that waits in vpark with rows of its own
+    int p_kc, p_li, p_hin, p_best;
+    u32 p_cells;
+    int rem0, rem1;            // in: rows the tracks have left
+    int tape_left;             // in: iterations the tape has left
+    int d0, d1;                // out: rows the tracks computed
+    u32 it_pair, it_single, n_park, n_join;  // out: statistics
+};
+
+// the call: marshal, run stretch after stretch until an event needs the event loop, take the
+// state back.  (it_end / it_last / join_at of the first stretch come from the caller; the
+// later ones are worked out by a2_park / a2_join.)
+W_FN void a2_drive_call(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV &hv, u32 it_end, u32 it_last,
+                        int join_at, A2Drive &dr) {
     A2Regs r;
     r.vx = hv.vx; r.vnegk = hv.vnegk; r.vqlen = hv.vqlen; r.vtlen = hv.vtlen;
     r.vqb = hv.vqb; r.vtb = hv.vtb; r.vtop = hv.vtop; r.vacc = hv.vacc;
     r.rc_mlo = hv.rc_mlo; r.rc_mhi = hv.rc_mhi; r.rc_k0 = wl.rc_k0; r.rc_k1 = wl.rc_k1;
+    r.vpark = wl.vpark;
     r.sc = w_undef();
     w_pack_put<A2_SC_ACT_LO>(r.sc, (u32)h.act); w_pack_put<A2_SC_ACT_HI>(r.sc, (u32)(h.act >> 32));
     w_pack_put<A2_SC_IN_LO>(r.sc, (u32)h.in); w_pack_put<A2_SC_IN_HI>(r.sc, (u32)(h.in >> 32));
@@ -868,11 +1050,30 @@ W_FN void a2_fast_call(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV
     w_pack_put<A2_SC_ESC_LO>(r.sc, (u32)(u64)w.esc); w_pack_put<A2_SC_ESC_HI>(r.sc, (u32)((u64)w.esc >> 32));
     w_pack_put<A2_SC_RING>(r.sc, A.ring);
     w_pack_put<A2_SC_BAND>(r.sc, (u32)A.band);
-    r = a2_fast<PAIR>(r);
+    w_pack_put<A2_SC_PARKED>(r.sc, (u32)dr.parked);
+    w_pack_put<A2_SC_P_KC>(r.sc, (u32)dr.p_kc); w_pack_put<A2_SC_P_LI>(r.sc, (u32)dr.p_li);
+    w_pack_put<A2_SC_P_HIN>(r.sc, (u32)dr.p_hin); w_pack_put<A2_SC_P_BEST>(r.sc, (u32)dr.p_best);
+    w_pack_put<A2_SC_P_CELLS>(r.sc, dr.p_cells);
+    w_pack_put<A2_SC_D0>(r.sc, 0u); w_pack_put<A2_SC_D1>(r.sc, 0u);
+    w_pack_put<A2_SC_REM0>(r.sc, (u32)dr.rem0); w_pack_put<A2_SC_REM1>(r.sc, (u32)dr.rem1);
+    w_pack_put<A2_SC_TAPE_LAST>(r.sc, h.it + (u32)dr.tape_left);
+    w_pack_put<A2_SC_ITS>(r.sc, h.it);
+    w_pack_put<A2_SC_AGAIN>(r.sc, 0u);
+    w_pack_put<A2_SC_MODE>(r.sc, dr.pair ? 1u : 0u);
+    w_pack_put<A2_SC_IT_PAIR>(r.sc, 0u); w_pack_put<A2_SC_IT_SINGLE>(r.sc, 0u);
+    w_pack_put<A2_SC_NPARK>(r.sc, 0u); w_pack_put<A2_SC_NJOIN>(r.sc, 0u);
+    w_pack_put<A2_SC_NREPLACE>(r.sc, 0u);
+    bool pair = dr.pair != 0;
+    for (;;) {
+        if (pair) r = a2_fast<true>(r); else r = a2_fast<false>(r);
+        if (w_pack_get<A2_SC_AGAIN>(r.sc) == 0u) break;
+        pair = w_pack_get<A2_SC_MODE>(r.sc) != 0u;
+    }
     hv.vx = r.vx; hv.vnegk = r.vnegk; hv.vqlen = r.vqlen; hv.vtlen = r.vtlen;
     hv.vqb = r.vqb; hv.vtb = r.vtb; hv.vtop = r.vtop;
     hv.vacc = r.vacc; hv.rc_mlo = r.rc_mlo; hv.rc_mhi = r.rc_mhi;
     wl.rc_k0 = r.rc_k0; wl.rc_k1 = r.rc_k1;
+    wl.vpark = r.vpark;
     h.split = (int)w_pack_get<A2_SC_SPLIT>(r.sc);
     w.split = h.split;
     h.kb0 = w_pack_get<A2_SC_KB0>(r.sc); h.kb1 = w_pack_get<A2_SC_KB1>(r.sc);
@@ -886,15 +1087,14 @@ W_FN void a2_fast_call(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV
     h.fin = ((u64)w_pack_get<A2_SC_FIN_HI>(r.sc) << 32) | w_pack_get<A2_SC_FIN_LO>(r.sc);
     h.ev = ((u64)w_pack_get<A2_SC_EV_HI>(r.sc) << 32) | w_pack_get<A2_SC_EV_LO>(r.sc);
     h.act_row = ((u64)w_pack_get<A2_SC_ROW_HI>(r.sc) << 32) | w_pack_get<A2_SC_ROW_LO>(r.sc);
-}
-
-// `budget`: iterations at most (the rows the tracks have left).  `join_at` (single mode with
-// a parked neighbour; else 0): the running band's width at which the neighbour fits again.
-template <bool PAIR>
-W_FN void a2_rows(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Hot &h, A2HotV &hv, int budget, int join_at) {
-    const u32 it_last = h.it + (u32)budget;
-    const u32 it_end = (!PAIR && join_at > 0 && budget > A2_LOOK_EVERY) ? h.it + A2_LOOK_EVERY : it_last;
-    a2_fast_call<PAIR>(A, w, wl, h, hv, it_end, it_last, join_at);
+    dr.pair = w_pack_get<A2_SC_MODE>(r.sc) != 0u ? 1 : 0;
+    dr.parked = (int)w_pack_get<A2_SC_PARKED>(r.sc);
+    dr.p_kc = (int)w_pack_get<A2_SC_P_KC>(r.sc); dr.p_li = (int)w_pack_get<A2_SC_P_LI>(r.sc);
+    dr.p_hin = (int)w_pack_get<A2_SC_P_HIN>(r.sc); dr.p_best = (int)w_pack_get<A2_SC_P_BEST>(r.sc);
+    dr.p_cells = w_pack_get<A2_SC_P_CELLS>(r.sc);
+    dr.d0 = (int)w_pack_get<A2_SC_D0>(r.sc); dr.d1 = (int)w_pack_get<A2_SC_D1>(r.sc);
+    dr.it_pair = w_pack_get<A2_SC_IT_PAIR>(r.sc); dr.it_single = w_pack_get<A2_SC_IT_SINGLE>(r.sc);
+    dr.n_park = w_pack_get<A2_SC_NPARK>(r.sc); dr.n_join = w_pack_get<A2_SC_NJOIN>(r.sc);
 }
 
 W_FN u64 a2_zone(const A2Wave &w, int ti) {
@@ -1141,6 +1341,9 @@ W_FN void a2_wave(const A2Args &A, int slot) {
             if (span0 >= span1) a2_hand_back(A, w, w.T0); else a2_hand_back(A, w, w.T1);
             continue;
         }
+#ifdef A2_HOOK_TRIP
+        A2_HOOK_TRIP();
+#endif
         const int rc = a2_place(w, wl);
         if (rc) {
             // a band too wide for the lanes: that track goes through its wide rows alone (its
@@ -1182,8 +1385,7 @@ W_FN void a2_wave(const A2Args &A, int slot) {
         h.fin = 0ull; h.ev = 0ull; h.act_row = 0ull;
         h.kb0 = run0 ? (u32)(w.T0.kc + p) : A2_INVALID;
         h.kb1 = run1 ? (u32)(w.T1.kc + p) : A2_INVALID;
-        int budget;
-        const u32 it_in = w.it;
+        int budget, join_at = 0;
         // (the rows count a band's cells when they lay it out: the first bands are counted here,
         // and the bands laid out for the row after the last one are taken off again below)
         if (w.pair) {
@@ -1198,7 +1400,6 @@ W_FN void a2_wave(const A2Args &A, int slot) {
             h.act = w_lanes(h.lo0, h.hi0 - h.lo0 + 1) | w_lanes(h.lo1, h.hi1 - h.lo1 + 1);
             h.in = 0ull;
             budget = min(min(w.T0.max_d - w.T0.d, w.T1.max_d - w.T1.d), tape_left);
-            a2_rows<true>(A, w, wl, h, hv, budget, 0);
         } else {
             // the running track plays "track 0" of the row loop, whichever it is.  (Its fields
             // are picked value by value: a reference chosen at run time would force both
@@ -1220,25 +1421,47 @@ W_FN void a2_wave(const A2Args &A, int slot) {
             h.in = 0ull;
             budget = min((run0 ? w.T0.max_d : w.T1.max_d) - t_d, tape_left);
             // (a parked neighbour joins again when the two bands fit with room to spare)
-            int join_at = 0;
             if (w.T0.state == A2_PARKED || w.T1.state == A2_PARKED) {
                 int plo, phi;
                 if (w.T0.state == A2_PARKED) a2_next_band(w.T0, 0, plo, phi); else a2_next_band(w.T1, 0, plo, phi);
                 join_at = max(1, 64 - A2_FREE_JOIN - (phi - plo + 1));
             }
-            a2_rows<false>(A, w, wl, h, hv, budget, join_at);
         }
-        // ---- back from the row loop (at least one row was computed)
-        const int done_it = (int)(h.it - it_in);
-        if (w.pair) w.st_pair += (u32)done_it; else w.st_single += (u32)done_it;
+        // what the row loop's function needs to park and to join on its own (a waiting track
+        // without rows of its own is placed by a2_place, not by a2_join: not announced)
+        A2Drive dr;
+        dr.pair = w.pair;
+        dr.parked = (w.T0.state == A2_PARKED && w.T0.d > 0) ? 1 : (w.T1.state == A2_PARKED && w.T1.d > 0) ? 2 : 0;
+        dr.p_kc = dr.parked == 1 ? w.T0.kc : w.T1.kc;
+        dr.p_li = dr.parked == 1 ? w.T0.li : w.T1.li;
+        dr.p_hin = dr.parked == 1 ? w.T0.hin : w.T1.hin;
+        dr.p_best = dr.parked == 1 ? w.T0.best : w.T1.best;
+        dr.p_cells = dr.parked == 1 ? w.T0.cells : w.T1.cells;
+        dr.rem0 = w.T0.state != A2_IDLE ? w.T0.max_d - w.T0.d : 0;
+        dr.rem1 = w.T1.state != A2_IDLE ? w.T1.max_d - w.T1.d : 0;
+        dr.tape_left = tape_left;
+        dr.d0 = dr.d1 = 0;
+        dr.it_pair = dr.it_single = dr.n_park = dr.n_join = 0u;
+        {
+            const u32 it_last = h.it + (u32)budget;
+            const u32 it_end = (!w.pair && join_at > 0 && budget > A2_LOOK_EVERY) ? h.it + A2_LOOK_EVERY : it_last;
+            a2_drive_call(A, w, wl, h, hv, it_end, it_last, join_at, dr);
+        }
+        // ---- back from the row loop: at least one row was computed; the pair may have been
+        // left and formed again any number of times, the state is the last stretch's
+        w.st_pair += dr.it_pair; w.st_single += dr.it_single;
+        w.st_park += dr.n_park; w.st_place += dr.n_join;
+        const int done_it = dr.d0 + dr.d1;
+        w.pair = dr.pair;
         wl.vx = hv.vx; wl.vacc = hv.vacc; wl.rc_mlo = hv.rc_mlo; wl.rc_mhi = hv.rc_mhi;
         w.it = h.it;
         w.n_esc = h.n_esc;
         const int p_last = (int)(w.it & 1u) ^ 1;
+        const bool ran0 = h.kb0 != A2_INVALID, ran1 = h.kb1 != A2_INVALID;  // who ran the last stretch
         // the hulls of the last row: the lanes of it that passed the band filter
         if (w.pair) {
             const u64 in0 = h.in & a2_zone(w, 0), in1 = h.in & a2_zone(w, 1);
-            w.T0.d += done_it; w.T1.d += done_it;
+            w.T0.d += dr.d0; w.T1.d += dr.d1;
             w.T0.kc = (int)h.kb0 - 1 + p_last; w.T1.kc = (int)h.kb1 - 1 + p_last;
             w.T0.li = w_lowest(in0); w.T0.hin = w_highest(in0);
             w.T1.li = w_lowest(in1); w.T1.hin = w_highest(in1);
@@ -1246,15 +1469,28 @@ W_FN void a2_wave(const A2Args &A, int slot) {
             w.T1.best = (int)((u32)h.best1 - 0x80000000u);
             w.T0.cells = h.cells0 - (u32)(w.T0.hin - w.T0.li + 2);
             w.T1.cells = h.cells1 - (u32)(w.T1.hin - w.T1.li + 2);
+            w.T0.state = A2_RUN; w.T1.state = A2_RUN;
         } else {
             const int n_li = w_lowest(h.in), n_hin = w_highest(h.in);
             const u32 n_cells = h.cells0 - (u32)(n_hin - n_li + 2);
-            if (run0) {
-                w.T0.d += done_it; w.T0.kc = (int)h.kb0 - 1 + p_last; w.T0.li = n_li; w.T0.hin = n_hin;
+            if (ran0) {
+                w.T0.d += dr.d0; w.T0.kc = (int)h.kb0 - 1 + p_last; w.T0.li = n_li; w.T0.hin = n_hin;
                 w.T0.best = h.best0; w.T0.cells = n_cells;
+                w.T0.state = A2_RUN;
             } else {
-                w.T1.d += done_it; w.T1.kc = (int)h.kb1 - 1 + p_last; w.T1.li = n_li; w.T1.hin = n_hin;
+                w.T1.d += dr.d1; w.T1.kc = (int)h.kb1 - 1 + p_last; w.T1.li = n_li; w.T1.hin = n_hin;
                 w.T1.best = h.best0; w.T1.cells = n_cells;
+                w.T1.state = A2_RUN;
+            }
+            // a track that was parked in there waits with what a2_park kept of it
+            if (dr.parked == 1 && (dr.d0 > 0 || w.T0.state == A2_RUN)) {
+                w.T0.d += dr.d0; w.T0.kc = dr.p_kc; w.T0.li = dr.p_li; w.T0.hin = dr.p_hin;
+                w.T0.best = dr.p_best; w.T0.cells = dr.p_cells;
+                w.T0.state = A2_PARKED;
+            } else if (dr.parked == 2 && (dr.d1 > 0 || w.T1.state == A2_RUN)) {
+                w.T1.d += dr.d1; w.T1.kc = dr.p_kc; w.T1.li = dr.p_li; w.T1.hin = dr.p_hin;
+                w.T1.best = dr.p_best; w.T1.cells = dr.p_cells;
+                w.T1.state = A2_PARKED;
             }
         }
 #ifdef A2_HOOK_EXIT
@@ -1268,8 +1504,8 @@ W_FN void a2_wave(const A2Args &A, int slot) {
         }
         if (done_it > 0) {
             const u64 fin0 = h.fin & a2_zone(w, 0), fin1 = h.fin & a2_zone(w, 1);
-            if (run0 && fin0) a2_finish<0>(A, w, wl, w.T0, fin0, h.act_row);
-            if (run1 && fin1) a2_finish<1>(A, w, wl, w.T1, fin1, h.act_row);
+            if (ran0 && fin0) a2_finish<0>(A, w, wl, w.T0, fin0, h.act_row);
+            if (ran1 && fin1) a2_finish<1>(A, w, wl, w.T1, fin1, h.act_row);
         }
         // rows exhausted without reaching an end: unaligned (DW_banded.c:183, :171)
         if (w.T0.state == A2_RUN && w.T0.d >= w.T0.max_d) {

@@ -70,6 +70,15 @@ extern "C" void emu_hist(long *sum, long *one) { memcpy(sum, hist_sum, sizeof(hi
             (unsigned long long)(have), (unsigned long long)(valid), n_rows, r_top, kv); \
     for (int l_ = 0; l_ < 64; l_++) fprintf(stderr, " %x", (unsigned)kb.v[l_]); fprintf(stderr, "\n"); } } while (0)
 #endif
+#ifdef EMU_DRIVE_LOG
+#define A2_HOOK_DRIVE(i) do { if ((i) < 2 && h.it >= EMU_DRIVE_LOG_FROM && h.it < EMU_DRIVE_LOG_TO) fprintf(stderr, "%s it=%u kb0=%d kb1=%d split=%d in=%016llx act=%016llx parked=%u p_li=%d p_hin=%d p_kc=%d d0=%u d1=%u it_last=%u\n", (i) ? "JOIN" : "PARK", h.it, (int)h.kb0, (int)h.kb1, h.split, (unsigned long long)h.in, (unsigned long long)h.act, w_pack_get<A2_SC_PARKED>(r.sc), (int)w_pack_get<A2_SC_P_LI>(r.sc), (int)w_pack_get<A2_SC_P_HIN>(r.sc), (int)w_pack_get<A2_SC_P_KC>(r.sc), w_pack_get<A2_SC_D0>(r.sc), w_pack_get<A2_SC_D1>(r.sc), w_pack_get<A2_SC_IT_LAST>(r.sc)); } while (0)
+#endif
+#ifdef EMU_DRIVE
+static long drive_n[3];
+#define A2_HOOK_DRIVE(i) drive_n[i]++
+#define A2_HOOK_TRIP() drive_n[2]++
+extern "C" void emu_drive_counts(long *out) { out[0] = drive_n[0]; out[1] = drive_n[1]; out[2] = drive_n[2]; }
+#endif
 #include "k_align2_core.h"
 
 // words per arena slot for a tape of `ring` iterations (must match the engine's sizing)

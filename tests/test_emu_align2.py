@@ -202,14 +202,16 @@ def _check_sub_order(port, pairs, order):
 
 
 @pytest.mark.parametrize("case", ["wide_row_on_a_block_boundary", "cell_on_lane_0_of_an_even_row",
-                                  "new_track_joins_a_full_wave"])
+                                  "new_track_joins_a_full_wave", "track_out_of_rows_is_not_parked"])
 def test_queue_orders_that_went_wrong_once(port, case):
     """Three wrong answers tests/emu_stress.py found in round 3, each with the queue order that
     produced it (tests/golden/emu_orders.json.gz; pairs of the frozen campaign):
     a trace-back block whose newest row was a wide row took the fast chain; a cell on lane 0
     of an even row read V[k-1] = 0 instead of 'outside the band' (the DP-cell count, not the
     path, differed); a track without rows joined a wave with fewer than four free lanes and
-    read its first V[k+1] from the other track's side."""
+    read its first V[k+1] from the other track's side; (while parking moved into the row loop's
+    function) a track whose rows were used up in the very iteration the pair broke up was parked
+    instead of retired, and aligned on past the reference's row limit."""
     from conftest import load_golden
     c = load_golden("emu_orders")[case]
     pairs = _campaign_pairs(*c["seeds"])
