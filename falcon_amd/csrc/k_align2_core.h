@@ -13,10 +13,12 @@
 //              even iteration computes diagonals Kc - 1 + 2 l (V[k-1] comes from lane l - 1,
 //              V[k+1] is the lane's own value), an odd one Kc + 1 + 2 l (V[k-1] own,
 //              V[k+1] from lane l + 1).  A band only moves when the alignment's diagonal
-//              drifts; when a band reaches the edge of its share of the wave, or the two
-//              bands no longer fit together, the wave re-places them (`a2_place`) -- or
-//              parks the narrower track (its last row waits in a spare register) and runs
-//              the wider one alone until they fit again.
+//              drifts; when a band reaches the edge of its share of the wave the row loop
+//              lays both out again (`a2_replace`); when the two bands no longer fit together
+//              it parks the narrower track (`a2_park`: its last row waits in a spare
+//              register) and runs the wider one alone until they fit again (`a2_join`).
+//              All three work on the row loop's own state; the wavefront's event loop
+//              (`a2_wave`) fetches, finishes, and handles what they decline.
 //   tape       the wavefront writes ONE record per iteration, shared by both tracks, into a
 //              ring in its arena slot: 64 one-byte cells (the snake length of each lane's
 //              cell, 255 = "look it up in the escape list"), the 64 from_above bits, and per
@@ -27,8 +29,9 @@
 //              the diagonal chain is resolved from the from_above bits, then all 64 rows
 //              fetch their cell byte in parallel and emit `(snake << 1) | from_above`.
 //
-// Anything outside the common case -- a band wider than 60 diagonals, an alignment too
-// long for the tape ring, too many snakes of >= 255 bases -- is handed back (FaAln.err = 2)
+// Rows wider than 60 diagonals are computed alone through an LDS ring (`a2_wide`).  What is
+// left outside -- a band that stays wide while a neighbour waits, an alignment too long for
+// the tape ring, too many snakes of >= 255 bases -- is handed back (FaAln.err = 2)
 // and repeated by the general one-alignment-per-wavefront kernel (k_align.hip) in a
 // worst-case slot, the same way alignments that outgrew their slot always were.
 //
@@ -45,9 +48,10 @@
 #define A2_WIDE_RING 256        // LDS ring of a wide row's V values, per row parity (<= 191 live diagonals)
 #define A2_LDS_WORDS (256 + 2 * A2_WIDE_RING)  // (256 spare words) + the two rings
 // Placement policy, measured on the bench workload [MI355X] (scripts/r03_variants.sh +
-// r03_sweep.sh, profiles/r03_policy_sweep.txt): leaving the pair costs a trip through the
-// wavefront's event loop (~800 instructions) and halves the rows per iteration, laying the
-// two bands out again inside the row loop a few dozen instructions -- so two running tracks
+// r03_sweep.sh, profiles/r03_policy_sweep.txt; taken while parking and joining still went
+// through the event loop, ~800 instructions a trip -- now ~100 and a call): leaving the pair
+// halves the rows per iteration, laying the two bands out again inside the row loop costs a
+// few dozen instructions -- so two running tracks
 // stay paired as long as their bands fit the 64 lanes AT ALL (0 free lanes: 54.2 ms; 2: 56.6;
 // 4: 58.8; 6: 60.6), and a parked neighbour is looked at every 8 iterations (16: +0.5 ms,
 // 32: +1.9) and joins with 6 lanes to spare (2..8: within 0.5 ms).
