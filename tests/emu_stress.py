@@ -26,7 +26,7 @@ def main():
     port = Port()
     trials = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     ring = int(sys.argv[4]) if len(sys.argv) > 4 else 8192
-    pairs, ids = [], []
+    pairs, ids, windows = [], [], []
     if sys.argv[1] == "synth":
         from falcon_amd.synth import codes_to_str, noisy
         lo = hi = int(sys.argv[2])
@@ -43,6 +43,12 @@ def main():
                 t = codes_to_str(g.integers(0, 4, int(g.integers(1, 200)), dtype=np.uint8)) + t
             pairs.append((q, t))
             ids.append(("synth", n))
+            # (windows that begin and end anywhere: base offsets that are no multiples of 16)
+            if g.random() < 0.5 and len(q) > 200 and len(t) > 200:
+                a, b = int(g.integers(0, 40)), int(g.integers(0, 40))
+                windows.append((a, len(q) - int(g.integers(0, 40)), b, len(t) - int(g.integers(0, 40))))
+            else:
+                windows.append((0, len(q), 0, len(t)))
     else:
         lo, hi = int(sys.argv[1]), int(sys.argv[2])
         for s in range(lo, hi + 1):
@@ -50,7 +56,9 @@ def main():
                 if band == 150:
                     pairs.append((q, tt))
                     ids.append((s, t))
-    want = [port.align(q, t, 150, 1) for q, t in pairs]
+    if not windows:
+        windows = [(0, len(q), 0, len(t)) for q, t in pairs]
+    want = [port.align(q[w[0]:w[1]], t[w[2]:w[3]], 150, 1) for (q, t), w in zip(pairs, windows)]
     print("%d pairs" % len(pairs), flush=True)
     rng = np.random.default_rng(lo * 1000 + hi)
     n_bad = 0
@@ -58,7 +66,7 @@ def main():
         order = rng.permutation(2 * len(pairs)).astype(np.int32)
         os.environ["EMU_FILL"] = str(int(rng.integers(1, 1 << 30)))
         try:
-            res, st = align_pairs(pairs, order=order, ring=ring)
+            res, st = align_pairs(pairs, order=order, ring=ring, windows=windows)
         except Exception as exc:  # (a script that does not even expand)
             np.save("/tmp/emu_stress_order_%d_%d.npy" % (lo, trial), order)
             print("trial", trial, "broke:", repr(exc), "fill", os.environ["EMU_FILL"],
