@@ -129,3 +129,17 @@ def test_launcher_world_size_must_match_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"],
                        capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode != 0 and "launcher started 2 rank(s)" in r.stderr
+
+
+def test_traffic_record_digest_ignores_comments_not_code():
+    """`roofline.traffic` is only shown for the code it was measured on: the digest is taken of
+    the kernel's sources without comments and layout -- a reworded comment keeps it, a changed
+    token, or a changed string (the inline asm), does not."""
+    import bench
+    a = 'int f(int x) { // add one\n    return x + 1; /* really */ }\nconst char *s = "v_add // not a comment";\n'
+    b = 'int f(int x) {\n\n  return x + 1; }   // reworded\nconst char *s = "v_add // not a comment";\n'
+    c = a.replace("x + 1", "x + 2")
+    d = a.replace("not a comment", "still not a comment")
+    assert bench._code_only(a) == bench._code_only(b)
+    assert bench._code_only(a) != bench._code_only(c)
+    assert bench._code_only(a) != bench._code_only(d)
