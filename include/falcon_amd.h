@@ -154,18 +154,19 @@ void fa_destroy(fa_ctx *ctx);
 
 /* Stage a batch: n_pile piles, pile p owns pile_n_seq[p] consecutive entries of
  * seqs[]/seq_len[] (first entry = seed).  seq_len may be NULL (strlen is used).
- * Copies the ASCII bases to HBM and packs them to 2 bits per base.  The host
- * strings are not referenced after the call returns. */
+ * Packs the bases to 2 bits each on the host, straight into pinned memory, and uploads them
+ * (L/4 bytes over PCIe).  The host strings are not referenced after the call returns. */
 fa_batch *fa_batch_create(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
                           const char *const *seqs, const int *seq_len);
 /* Run the whole path on the resident batch (may be called repeatedly). */
 int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double min_idt);
-/* The same in two halves, for callers that keep two batches of one context in flight:
- * fa_batch_submit returns when the throughput stages (seed index, chaining, alignment,
- * tags, links) are done and the per-pile sequential stages (score recurrence, back-trace)
- * are queued on a stream of their own; fa_batch_wait collects them.  Submitting batch i+1
- * between the two calls for batch i runs its throughput stages beside batch i's sequential
- * ones (they need few wavefronts and mostly wait).  Same results as fa_batch_run, which is
+/* The same in two calls, for callers that keep several (three is enough) batches of one
+ * context in flight: fa_batch_submit queues the batch's seed index, chaining and alignment
+ * kernels and returns at once -- it never waits for the device (0.06 ms); the rest of the run
+ * (the host-side sizing of the consensus stage from the alignment summaries, then its kernels
+ * on a stream of their own, beside the kernels of the batches submitted later) is taken care of
+ * by a thread the context owns.  fa_batch_wait returns when the batch's results are ready, or
+ * reports what went wrong in its consensus stage.  Same results as fa_batch_run, which is
  * submit + wait.  Calls on different batches of a context may come from different threads. */
 int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double min_idt);
 int fa_batch_wait(fa_batch *b);
