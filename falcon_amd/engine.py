@@ -148,9 +148,10 @@ class Batch:
         return self
 
     def submit(self, min_cov: int = 6, K: int = 8, min_idt: float = 0.70) -> "Batch":
-        """First half of ``run``: returns once the throughput stages are done and the
-        per-pile sequential ones (score recurrence, back-trace) are queued on their own
-        stream.  Submit the next batch of the same engine before ``wait`` to overlap them."""
+        """First half of ``run``: queues the batch's seed index, chaining and alignment kernels
+        and returns at once (it never waits for the device); the consensus stage follows on a
+        stream of its own, driven by a thread of the engine's context.  Keep two or three
+        batches of an engine submitted ahead of every ``wait`` to overlap them."""
         if self.lib.fa_batch_submit(self.h, min_cov, K, min_idt):
             raise FalconAmdError(last_error())
         return self
