@@ -470,13 +470,13 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
 
     eng = make_engine(plumb.local_rank)
     t_up = time.perf_counter()
-    batch = eng.batch(piles)  # ASCII -> HBM, packed to 2 bits/base on the GPU
+    batch = eng.batch(piles)  # ASCII -> 2 bits/base on the host -> HBM
     t_up = time.perf_counter() - t_up
-    # Steps are pipelined the way a streaming job runs them: two resident batches (the same
-    # piles staged twice) alternate, step i+1's throughput stages (index, chaining,
-    # alignment, tags, links) running beside step i's per-pile sequential stages (score
-    # recurrence, back-trace) -- fa_batch_submit / fa_batch_wait.  Every step is still one
-    # full pass of the whole path over one batch.
+    # Steps are pipelined the way a streaming job runs them: `--in-flight` resident batches
+    # (the same piles staged that many times) take turns, two submits ahead of every wait, so
+    # that a step's index, chaining and alignment run beside the consensus stage (tags, links,
+    # score recurrence, back-trace) of the step before -- fa_batch_submit / fa_batch_wait.
+    # Every step is still one full pass of the whole path over one batch.
     pipelined = hasattr(batch, "submit") and not args.no_pipeline
     depth = max(2, args.in_flight)
     pair = [batch] + [eng.batch(piles) for _ in range(depth - 1)] if pipelined else [batch]
@@ -527,7 +527,7 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
     stream_gbs = measured_stream_rate(plumb.torch) if plumb.cuda else None
 
     # the dominant kernel with the device to itself (outside the timed region): in the
-    # pipelined steps its launches share the CUs with the previous step's sequential stages
+    # pipelined steps its launches share the CUs with the previous step's consensus stage
     alone_ms = {}
     if pipelined and rank == 0:
         for _ in range(2):
@@ -559,10 +559,10 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
         k = max(1, args.steps)
         stage_ms = {"index": acc["ms_index"] / k, "chain": acc["ms_chain"] / k,
                     "align": acc["ms_align"] / k, "consensus": acc["ms_consensus"] / k}
-        # between k_align and the MSA kernels the host sizes the MSA pools from the
-        # alignment summaries (D2H, O(#reads) loop, H2D): device-idle time of the step
-        # (pipelined steps: the sequential stages of a step wait for the wave slots the next
-        # step's alignment leaves them, so this also holds that queueing)
+        # between the alignment and the MSA kernels the host (the context's planner thread)
+        # sizes the MSA pools from the alignment summaries (D2H, O(#reads) loop, H2D): a gap in
+        # THIS batch's kernels, during which the device runs the next batch's (pipelined
+        # steps: the figure also holds the MSA kernels' wait for wave slots)
         host_gap = acc["ms_total"] / k - sum(stage_ms.values())
         # algorithmic bytes per launch
         alg = {

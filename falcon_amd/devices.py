@@ -7,10 +7,10 @@ varies 3x, so shards are never cut ahead of time), at most ``MAX_QUEUED`` batche
 per engine.  Piles never interact, so there is no collective anywhere; results are put
 back in input order by whoever prints them.
 
-A batch runs in two halves (falcon_amd.h: fa_batch_submit / fa_batch_wait): the throughput
-stages hold the engine's front lock, the per-pile sequential stages (score recurrence,
-back-trace) run on a stream of their own while the NEXT batch's throughput stages hold the
-lock -- two batches in flight per engine."""
+A batch runs in two halves (falcon_amd.h: fa_batch_submit / fa_batch_wait): submit queues
+its index, chaining and alignment kernels under the engine's front lock and returns; its
+consensus stage runs on a stream of its own, beside the kernels of the batches submitted
+behind it -- three batches in flight per engine."""
 from __future__ import annotations
 
 import os

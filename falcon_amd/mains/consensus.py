@@ -243,7 +243,7 @@ class GpuConsensus:
     Piles are cut into batches of ``batch_bases``; every batch goes to the engine with the
     least work queued (falcon_amd/devices.py: independent work queues -- piles never
     interact, so there is no collective) and three batches per engine are in flight, the
-    sequential stages of two beside the throughput stages of the next."""
+    consensus stage of one beside the index, chaining and alignment of the next."""
 
     def __init__(self, min_cov, min_idt, engines=None, batch_bases=400_000_000, backend=None):
         from falcon_amd.devices import DevicePool, EngineBackend, SharedGpu, open_engines
@@ -399,8 +399,9 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None)
       staging thread   that batch onto the device with the least work queued (``gpu.stage``),
                        while the ingest thread reads the one behind it
       runner threads   ``gpu.parallel`` of them (three per engine): a batch's GPU stages
-                       (``gpu.finish``: throughput stages under the engine's lock, then the
-                       per-pile sequential stages beside the next batch's) and the download
+                       (``gpu.finish``: submit -- index, chaining and alignment queued under the
+                       engine's lock -- then wait, while the consensus stage runs beside the
+                       next batch's kernels) and the download
       printer thread   batches back in input order -> FASTA text
 
     ``gpu``: ``stage(pileset) -> handle`` (``handle.free()`` drops it), ``finish(handle) ->
