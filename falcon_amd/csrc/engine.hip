@@ -355,6 +355,7 @@ struct fa_batch {
         double max_diff = 0;
         int band = 0, force_accept_g = -1;
         bool two_per_wave = false;
+        int score_mode = 0, force_generic = 0;  // FALCON_AMD_SCORE1 / _SCORE_GENERIC, read by the calling thread
         size_t n_seg = 0;
         u64 t_tot = 0;
     } run;
@@ -1119,7 +1120,7 @@ static int redo_handed_back(fa_batch *b, double max_diff, int band, hipStream_t 
 // msa_stage: the MSA plan from the alignment summaries (waits for k_align) and the MSA
 // kernels on a back stream -- run by the context's planner thread (planner_main), batch after
 // batch in submit order; finish_run waits for its outcome.
-static int start_align(fa_batch *b, unsigned min_cov, double max_diff, int band, int force_accept_g);
+static int start_align(fa_batch *b, unsigned min_cov, double max_diff, int band, int force_accept_g, bool two_per_wave);
 static int msa_stage(fa_batch *b);
 static int finish_run(fa_batch *b, bool grace);
 static void begin_back(fa_batch *p);
@@ -1158,7 +1159,9 @@ extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double
         b->fetched = b->fetched_eqv = false;
         b->have_range = b->have_aln = false;
         const double max_diff = 1.0 - min_idt;  // falcon.c:580
-        if (use_align2(b, FA_BAND)) {
+        // (decided once per run: the arena sized here is the one start_align launches on)
+        const bool two_per_wave = use_align2(b, FA_BAND);
+        if (two_per_wave) {
             if (ensure_arena_a2(c, b)) return -1;
         } else {
             size_t lds = fa_align_lds_bytes(b->max_read_len, b->max_seed_len);
@@ -1178,7 +1181,7 @@ extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double
         if (b->h_range.resize(b->n_seq)) return -1;
         HIP_OK(hipMemcpyAsync(b->h_range.data(), b->d_range.p, (size_t)b->n_seq * sizeof(FaRange),
                               hipMemcpyDeviceToHost, s));
-        if (start_align(b, min_cov, max_diff, FA_BAND, -1)) return -1;
+        if (start_align(b, min_cov, max_diff, FA_BAND, -1, two_per_wave)) return -1;
         pt.mark("launch-front");
         // its second half is the planner's (a failure there is reported by fa_batch_wait)
         std::lock_guard<std::mutex> hold(c->plan_mu);
@@ -1206,12 +1209,16 @@ extern "C" int fa_batch_run(fa_batch *b, unsigned min_cov, unsigned K, double mi
     return finish_run(b, false);
 }
 
-static int start_align(fa_batch *b, unsigned min_cov, double max_diff, int band, int force_accept_g) {
+static int start_align(fa_batch *b, unsigned min_cov, double max_diff, int band, int force_accept_g,
+                       bool two_per_wave) {
     fa_ctx *c = b->ctx;
     hipStream_t s = c->stream;
     FaBatchDev d = b->dev();
     PhaseTimer pt("align launch");
-    const bool two_per_wave = use_align2(b, band);
+    // (the experiment switches of the second half are read here, by the thread that called
+    // submit: the planner thread must not race a test's setenv)
+    b->run.score_mode = getenv("FALCON_AMD_SCORE1") ? 1 : 0;
+    b->run.force_generic = getenv("FALCON_AMD_SCORE_GENERIC") ? 1 : 0;
     b->run.min_cov = min_cov; b->run.max_diff = max_diff; b->run.band = band;
     b->run.force_accept_g = force_accept_g; b->run.two_per_wave = two_per_wave;
     if (b->h_aln.resize(b->n_seq) || b->h_a2_stats.resize(8)) return -1;
@@ -1422,7 +1429,8 @@ static int msa_stage(fa_batch *b) {
     md.n_seg = (int)n_seg;
     md.wide_count = b->d_wide.p; md.wide_list = b->d_wide.p + 1;
     md.first_links_back = force_accept_g >= 0 ? 1 : 0;
-    md.force_generic = getenv("FALCON_AMD_SCORE_GENERIC") ? 1 : 0;  // (tests: pins the generic path of k_score)
+    md.force_generic = b->run.force_generic;  // (tests: pins the generic path of k_score1)
+    md.score_mode = b->run.score_mode;        // (FALCON_AMD_SCORE1: k_score1 for every pile)
     const FaBatchDev d = b->dev();
     pt.mark("upload");
     HIP_OK(hipEventRecord(b->ev[4], sb));
@@ -1618,7 +1626,7 @@ extern "C" fa_batch *fa_utg_consensus(fa_ctx *ctx, int n_seq, const char *const 
         // run's second half is done by the calling thread, below)
         if (ensure_arena(c, b, fa_align_lds_bytes(b->max_read_len, b->max_seed_len), true)) return fail(nullptr);
         for (int i = 0; i < 3; i++) (void)hipEventRecord(b->ev[i], s);
-        if (start_align(b, 0, 1.0 - min_idt, band, 1)) return fail(nullptr);
+        if (start_align(b, 0, 1.0 - min_idt, band, 1, false)) return fail(nullptr);
         b->back_state = 1;
     }
     begin_back(b);

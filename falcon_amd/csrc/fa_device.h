@@ -1,5 +1,7 @@
 // fa_device.h -- wave64 device helpers for gfx950 (CDNA4).
-#pragma once
+// (a classic include guard: tests/emu/simt pre-includes its host twin under the same name)
+#ifndef FA_DEVICE_H
+#define FA_DEVICE_H
 #include "fa_internal.h"
 
 #define FA_WAVE 64
@@ -115,6 +117,57 @@ __device__ __forceinline__ double fa_uni(double v) {
 template <class T>
 __device__ __forceinline__ T *fa_uni(T *p) { return (T *)fa_uni((u64)p); }
 
+// Copy through an opaque VALU move: the wait for the load that produced v is paid
+// here, once, and the copy carries no pending-load state into the loops that read
+// it (otherwise the compiler's conservative s_waitcnt vmcnt(0) at every such read
+// also drains the stores in flight).
+__device__ __forceinline__ u32 fa_settled(u32 v) {
+    u32 r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+// prefix maximum of unsigned keys inside each row of 16 lanes, in place: 4 VALU
+// (lanes without a source lane keep their value; s_nop 1: a VGPR written by VALU needs 2
+// wait states before a DPP read)
+__device__ __forceinline__ u32 fa_row_prefix_max_u32(u32 v) {
+    asm volatile("s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
+                 : "+v"(v));
+    return v;
+}
+// the same over all 64 lanes: the two row broadcasts behind the in-row steps
+__device__ __forceinline__ u32 fa_wave_prefix_max_u32(u32 v) {
+    asm volatile("s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                 : "+v"(v));
+    return v;
+}
+
+// lane `l` (wave-uniform) of a and of b := the wave-uniform sa, sb; the other lanes keep theirs
+// (M0 written once; v_writelane needs its lane select there when the data is an SGPR)
+__device__ __forceinline__ void fa_writelane2(int &a, int &b, int sa, int sb, int l) {
+    asm volatile("s_mov_b32 m0, %2\n\t"
+                 "v_writelane_b32 %0, %3, m0\n\t"
+                 "v_writelane_b32 %1, %4, m0"
+                 : "+v"(a), "+v"(b)
+                 : "s"(l), "s"(sa), "s"(sb));
+}
+
+// The lanes of a wavefront run in lockstep: where one lane reads what another lane wrote to
+// LDS or HBM an instruction earlier, the hardware needs nothing.  This marks such places -- it
+// keeps the compiler from moving memory operations across it and costs no instruction (the
+// host-side SIMT emulator of tests/emu/simt turns it into a rendezvous of its 64 fibers).
+__device__ __forceinline__ void fa_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
 // ---------------------------------------------------------------------------
 // shared by the alignment kernels (k_align.hip, k_align_wide.hip)
 // ---------------------------------------------------------------------------
@@ -194,4 +247,4 @@ __device__ __forceinline__ void snake16(QP qL, TP tL, int qb, int tb, int q_len,
         gm = fa_ballot(mlast == 16u);
     }
 }
-
+#endif  // FA_DEVICE_H

@@ -68,8 +68,8 @@ struct FaScoreOut { // per pile
     int n_levels;
     int n_links;
     int err;
-    int wide;       // 1: scores may outgrow the fast path's key (k_score takes the generic path)
-    int pad;
+    int wide;       // 1: scores may outgrow the fast paths' keys (k_score1's generic path takes the pile)
+    int redo;       // 1: k_score2 handed the pile on to k_score1
 };
 
 // ---- launcher prototypes (each .hip file owns its kernels) ----
@@ -172,7 +172,8 @@ struct FaMsaDev {
     const int *seg_t0;
     int n_seg;
     int first_links_back;  // unitig mode: a read's first column links back to (s2 - 1, 0, '-')
-    int force_generic;     // k_score: every level through the generic path (tests)
+    int force_generic;     // k_score1: every level through the generic path (tests)
+    int score_mode;        // 0: k_score2, k_score1 for what it hands on; 1: k_score1 for every pile
     int *wide_count;
     int *wide_list;
 };

@@ -1,0 +1,266 @@
+// k_score2.hip -- the score recurrence of the MSA graph (src/c/falcon.c:405-475), one wavefront
+// per pile, written so that the DEPENDENT chain of a level is as short as the hardware allows.
+//
+// A pile has ~2 levels (t, delta) per seed position and every level's scores depend on the
+// level before it: 40 000 steps in sequence.  k_score1 (round 1-3) walked them with the whole
+// work of a level on that chain -- link-word decoding, the node bookkeeping, the back pointers,
+// the position loop's scalar control flow: ~180 instructions per level, and since a wavefront
+// issues in order, ~1300 clocks per level whatever the occupancy.  Here a pile is walked in
+// blocks of up to S2_NL levels, each block in three phases:
+//
+//   A  decode (data-parallel, lane = level, a loop over the level's links): every link word of
+//      k_links becomes an 8-byte record in LDS -- the LDS address of its predecessor's score,
+//      the LDS address its node's score goes to if the link is the node's last one (a dump word
+//      otherwise), and the key addend `node base << 29 | (2 count - coverage)`.  Nothing here
+//      depends on the scores.
+//   B  the chain (lane = link of the CURRENT level): read the record, read the predecessor's
+//      score, add, prefix maximum over the lanes (the node base on top of the key: a node's
+//      winner is on its last link, falcon.c:440-447), floor at the reference's -1, store the
+//      node's score.  A dozen instructions and ONE LDS round trip per level; scores live in an
+//      LDS ring addressed by node id, so every insertion depth takes the same path (no
+//      register-resident levels, no deep-level scratch).  Lanes beyond the level's links hold
+//      the records of the following levels: what they compute lands on nodes that are scored
+//      -- and overwritten -- later, before anybody reads them (LDS operations of a wavefront
+//      execute in order), so the chain carries no lane masks at all.
+//   C  resolve (data-parallel, lane = level again): with all scores of the block final, every
+//      node finds its winning link -- the FIRST link in stored (= insertion, Q5) order that
+//      reaches the node's score, and only if that score beat the -1 floor (strict '>',
+//      falcon.c:420,447; Q4) -- and writes its 8-byte node record {score, (best predecessor
+//      + 1) << 1 | upper}; the lane keeps its best node for the global maximum (first strict
+//      maximum in (t, delta, base) order, falcon.c:464-469).
+//
+// What it does not hold goes to k_score1 through FaScoreOut.redo: the unitig mode (its links
+// may name absent nodes, which k_score1's registers read as the floor), piles whose scores
+// could outgrow 29 bits less the bias (never: `wide`), a position with more than S2_NL levels
+// or S2_NK links, a level with more than 64 links.
+#include "k_msa.h"
+
+#define S2_NL 48              // levels per block
+#define S2_NK 320             // link records per block
+#define S2_RING 512           // node score slots (u32), slot = node id & 511
+#define S2_BIAS 2048u         // score + bias > 0: a link scores >= -2 - coverage (coverage <= 1023)
+#define S2_FLOOR (S2_BIAS - 2u)   // the reference's -1, in half units
+#define S2_SMASK 0x1fffffffu  // score bits of a key (the node base sits on top)
+// LDS layout, byte offsets
+#define S2_DUMP_B (S2_RING * 4)           // 64 words: where a link that is not its node's last one stores
+#define S2_ZERO_B (S2_DUMP_B + 64 * 4)    // one word holding score 0 (start links, falcon.c:434)
+#define S2_REC_B (S2_ZERO_B + 64)         // records, 8 bytes per link: S2_NK + 64 of them
+#define S2_MARK_B (S2_REC_B + (S2_NK + 64) * 8)   // 64 words: level slot -> position of the block
+#define S2_LDS_WORDS ((S2_MARK_B + 64 * 4) / 4)
+
+__device__ __forceinline__ u32 &s2_at(u32 *L, u32 byte) {
+    return *reinterpret_cast<u32 *>(reinterpret_cast<char *>(L) + byte);
+}
+
+typedef u32 s2_u32x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(64) void k_score2(MsaArgs A) {
+    __shared__ __attribute__((aligned(8))) u32 L[S2_LDS_WORDS];
+    const int lane = fa_lane();
+    const int p = blockIdx.x;
+    if (p >= A.n_pile) return;
+    const FaPile pm = A.pile[p];
+    FaScoreOut so = A.score_out[p];
+    so.err = fa_uni(so.err); so.wide = fa_uni(so.wide);
+    so.n_levels = fa_uni(so.n_levels); so.n_links = fa_uni(so.n_links);
+    if (so.err) return;
+    so.redo = 1;
+    if (so.wide || A.first_links_back) {
+        A.score_out[p] = so;  // every lane stores the same record
+        return;
+    }
+    const int T = pm.seed_len;
+    const u32 *tiw = reinterpret_cast<const u32 *>(A.tinfo + A.t_off[p]);  // 3 words per position
+    const u32 *links = A.links + A.link_off[p];
+    const u16 *nlk = A.lvl_nlink16 + pm.node_off / 5;
+    s2_u32x2 *nodes = reinterpret_cast<s2_u32x2 *>(A.nodes + pm.node_off);
+    const u32 min_cov = A.min_cov;
+
+    s2_at(L, S2_ZERO_B) = S2_BIAS;  // (every lane, the same word)
+    if (lane < 5) {
+        // slot 0 = (t 0, delta 0): the target of the zero back pointer (Q4), whichever of its
+        // nodes exist
+        s2_u32x2 r;
+        r.x = (u32)-2; r.y = (u32)(((0 + 1) << 1) | (((tiw[2] & 0xffffu) > min_cov) ? 1 : 0));
+        nodes[lane] = r;
+    }
+    u32 best_s = S2_FLOOR;         // this lane's best node: biased score, node id, winning link
+    int best_node = -1, best_ck = 0;
+    u32 carry_plvl = 0;            // first level slot of the position before the block
+    u32 lk_run = 0;                // the block's first link word: k_links writes the links of a segment of TSEG
+                                   // positions back to back from the segment's first link slot
+    const bool slot0_empty = (tiw[2] & 0xffffu) == 0u;  // position 0 uncovered: its level slot has no links, and no count
+    int t0 = 0;
+    while (t0 < T) {
+        // ---- a block: as many positions (<= 63) of one k_links segment as fit S2_NL levels and
+        // S2_NK links.  Lane j holds position t0 + j (a block of j positions ends where position
+        // t0 + j starts) and, as a level lane, the link count of level slot lvl0 + j.
+        const int tl = t0 + lane;
+        u32 x_lvl = 0, x_link = 0, x_cn = 0;
+        if (tl < T) { x_lvl = tiw[3 * tl]; x_link = tiw[3 * tl + 1]; x_cn = tiw[3 * tl + 2]; }
+        const u32 lvl0 = fa_uni(x_lvl);
+        if ((t0 & (TSEG - 1)) == 0) lk_run = fa_uni(x_link);
+        const int seg_end = (t0 / TSEG + 1) * TSEG;
+        int nl = 0;  // links of level slot lvl0 + lane
+        if (lvl0 + (u32)lane < (u32)so.n_levels && !(slot0_empty && lvl0 + (u32)lane == 0u)) nl = (int)nlk[lvl0 + (u32)lane];
+        const int nl_sum = wave_incl_sum(nl, lane);
+        const int lv_j = (int)(((tl < T) ? x_lvl : (u32)so.n_levels) - lvl0);  // levels of the first `lane` positions
+        const int lk_j = __shfl(nl_sum, max(0, min(lv_j, 64) - 1));               // and their links
+        const bool fits = lane >= 1 && tl <= T && tl <= seg_end && lv_j <= S2_NL && (lv_j == 0 || lk_j <= S2_NK);
+        const int nb = __popcll(__ballot(fits));  // prefix sums are monotone, so is `fits`
+        if (nb == 0) {  // one position too large for a block
+            A.score_out[p] = so;
+            return;
+        }
+        const int n_l = __builtin_amdgcn_readlane(lv_j, nb);
+        const int n_k = n_l > 0 ? __builtin_amdgcn_readlane(nl_sum, max(0, n_l - 1)) : 0;
+        if (lane >= n_l) nl = 0;
+        // ---- stage the link words (the high word of each record), null records behind them
+        fa_wave_sync();  // (the block before is done with the records)
+        for (int i = lane; i < n_k; i += 64) s2_at(L, S2_REC_B + 8u * (u32)i + 4u) = links[lk_run + (u32)i];
+        s2_at(L, S2_REC_B + 8u * (u32)(n_k + lane)) = (u32)S2_ZERO_B | ((u32)(S2_DUMP_B + 4 * lane) << 16);
+        s2_at(L, S2_REC_B + 8u * (u32)(n_k + lane) + 4u) = 0u;
+        s2_at(L, S2_MARK_B + 4u * (u32)lane) = (u32)-1;
+        fa_wave_sync();
+        // ---- which position does level slot lvl0 + lane belong to: every position with levels
+        // marks its first slot, the slots take the last mark at or below them
+        const int cov_j = (int)(x_cn & 0xffffu), nlev_j = (int)(x_cn >> 16);
+        if (lane < nb && nlev_j > 0) s2_at(L, S2_MARK_B + 4u * (x_lvl - lvl0)) = (u32)lane;
+        fa_wave_sync();
+        const int js = max(0, wave_incl_max((int)s2_at(L, S2_MARK_B + 4u * (u32)lane), lane));
+        const u32 plvl_j = (u32)__builtin_amdgcn_update_dpp((int)carry_plvl, (int)x_lvl, 0x138, 0xf, 0xf, false);  // wave_shr:1
+        const u32 lvl_s = (u32)__shfl((int)x_lvl, js);
+        const u32 cn_s = (u32)__shfl((int)x_cn, js);
+        const u32 plvl_s = (u32)__shfl((int)plvl_j, js);
+        (void)cov_j;
+        const int cov_s = (int)(cn_s & 0xffffu);
+        const int dl_s = (int)(lvl0 + (u32)lane - lvl_s);
+        const u32 base5_s = (dl_s == 0 ? plvl_s : lvl_s) * 5u;  // node id of a link's predecessor = base5 + its index
+        const u32 upper_s = (u32)cov_s > min_cov ? 1u : 0u;     // falcon.c:498 (Q7)
+        const u32 node5 = (lvl0 + (u32)lane) * 5u;
+        const int off = nl_sum - nl;  // (lanes < n_l)
+        const int maxn = fa_wave_max(nl);
+        carry_plvl = (u32)__builtin_amdgcn_readlane((int)x_lvl, nb - 1);
+        if (maxn > 64) {
+            A.score_out[p] = so;
+            return;
+        }
+        // ---- A: decode.  Lane = level, k = its k-th link (node-major, insertion order inside
+        // a node: k_links).
+        for (int k = 0; k < maxn; k++) {
+            if (k < nl) {
+                const u32 ra = S2_REC_B + 8u * (u32)(off + k);
+                const u32 w = s2_at(L, ra + 4u);
+                const u32 wn = (k + 1 < nl) ? s2_at(L, ra + 12u) : 0u;
+                const int cnt = (int)(w & 0x3ffu);
+                const u32 nbase = (w >> 10) & 7u;
+                const u32 pidx = (w >> 13) & 0x7ffu;
+                const bool start = (w >> 24) & 1u;
+                const bool tail = (k + 1 == nl) || ((wn >> 10) & 7u) != nbase;
+                const u32 src = start ? (u32)S2_ZERO_B : (((base5_s + pidx) & (S2_RING - 1u)) << 2);
+                const u32 dst = tail ? (((node5 + nbase) & (S2_RING - 1u)) << 2) : (u32)(S2_DUMP_B + 4 * k);
+                s2_at(L, ra) = src | (dst << 16);
+                s2_at(L, ra + 4u) = (nbase << 29) + (u32)(2 * cnt - cov_s);
+            }
+        }
+        fa_wave_sync();
+        // ---- B: the chain.  Lane l holds link l of the level being scored.
+        {
+            u32 ra = S2_REC_B + 8u * (u32)lane;
+            if (maxn <= 16) {
+                // (the record of the next level is requested behind the gather: both are under way
+                // while the loop's bookkeeping issues, and the gather heads the LDS queue)
+                s2_u32x2 r = *reinterpret_cast<const s2_u32x2 *>(&s2_at(L, ra));
+                // (consumed here, so that the loop head need not wait for it -- a wait there is also
+                // a wait for the store of the level before, on every level)
+                r.x = fa_settled(r.x); r.y = fa_settled(r.y);
+                for (int i = 0; i < n_l; i++) {
+                    const int n_i = __builtin_amdgcn_readlane(nl, i);
+                    ra += 8u * (u32)n_i;
+                    const u32 ph = s2_at(L, r.x & 0xffffu);
+                    const s2_u32x2 rn = *reinterpret_cast<const s2_u32x2 *>(&s2_at(L, ra));
+                    const u32 key = fa_row_prefix_max_u32(ph + r.y);
+                    s2_at(L, r.x >> 16) = max(key & S2_SMASK, S2_FLOOR);
+                    fa_wave_sync();
+                    r = rn;
+                }
+            } else {
+                s2_u32x2 r = *reinterpret_cast<const s2_u32x2 *>(&s2_at(L, ra));
+                // (consumed here, so that the loop head need not wait for it -- a wait there is also
+                // a wait for the store of the level before, on every level)
+                r.x = fa_settled(r.x); r.y = fa_settled(r.y);
+                for (int i = 0; i < n_l; i++) {
+                    const int n_i = __builtin_amdgcn_readlane(nl, i);
+                    ra += 8u * (u32)n_i;
+                    const u32 ph = s2_at(L, r.x & 0xffffu);
+                    const s2_u32x2 rn = *reinterpret_cast<const s2_u32x2 *>(&s2_at(L, ra));
+                    const u32 key = fa_wave_prefix_max_u32(ph + r.y);
+                    s2_at(L, r.x >> 16) = max(key & S2_SMASK, S2_FLOOR);
+                    fa_wave_sync();
+                    r = rn;
+                }
+            }
+        }
+        // ---- C: resolve.  Lane = level; its links in stored order.
+        {
+            const int lo = (int)(lvl0 * 5u) - 256;  // every node a record of this block names lies in [lo, lo + 512)
+            u32 cur_nb = 8u;
+            bool found = false;
+            int cin = 0, ck = 0, pid = -1;
+            for (int k = 0; k < maxn; k++) {
+                if (k < nl) {
+                    const u32 ra = S2_REC_B + 8u * (u32)(off + k);
+                    const u32 w0 = s2_at(L, ra), w1 = s2_at(L, ra + 4u);
+                    // (the addend is node base << 29 PLUS a small signed number)
+                    const u32 nbase = (w1 + 0x10000000u) >> 29;
+                    const u32 cv = w1 - (nbase << 29);
+                    const u32 src = w0 & 0xffffu, dst = w0 >> 16;
+                    if (nbase != cur_nb) { cur_nb = nbase; found = false; cin = 0; }
+                    const u32 node = node5 + nbase;
+                    const u32 sn = s2_at(L, (node & (S2_RING - 1u)) << 2);
+                    const u32 h = s2_at(L, src) + cv;
+                    if (!found && sn > S2_FLOOR && h == sn) {
+                        found = true;
+                        ck = cin;
+                        pid = (src == (u32)S2_ZERO_B) ? -1 : lo + (int)(((src >> 2) - (u32)lo) & (S2_RING - 1u));
+                    }
+                    cin++;
+                    if (dst < (u32)S2_DUMP_B) {  // the node's last link: its record
+                        s2_u32x2 r;
+                        r.x = sn - S2_BIAS;
+                        r.y = (u32)((((found ? pid : 0) + 1) << 1)) | upper_s;
+                        nodes[node] = r;
+                        if (sn > best_s) {  // strict: the lane's first maximum (its nodes ascend)
+                            best_s = sn;
+                            best_node = (int)node;
+                            best_ck = found ? ck : 0;
+                        }
+                    }
+                }
+            }
+        }
+        t0 += nb;
+        lk_run += (u32)n_k;
+    }
+    // global best = first strict maximum in (t, delta, base) order (falcon.c:464-469): the
+    // highest score, among equals the lowest node id
+    const u32 top = (u32)fa_wave_max((int)best_s);
+    const int cand = (best_s == top && best_node >= 0) ? best_node : 0x7fffffff;
+    const int g_node = fa_wave_min(cand);
+    const u64 who = fa_ballot(cand == g_node);
+    so.redo = 0;
+    if (g_node == 0x7fffffff) {
+        so.g_h = -2; so.g_node = -1; so.g_ck = 0;
+    } else {
+        so.g_h = (int)(top - S2_BIAS);
+        so.g_node = g_node;
+        so.g_ck = __builtin_amdgcn_readlane(best_ck, (int)__builtin_ctzll(who));
+    }
+    A.score_out[p] = so;  // every lane stores the same record
+}
+
+#ifndef FA_EMU
+void fa_launch_score2(const MsaArgs &A, hipStream_t s) {
+    hipLaunchKernelGGL(k_score2, dim3(A.n_pile), dim3(64), 0, s, A);
+}
+#endif

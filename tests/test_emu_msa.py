@@ -1,0 +1,149 @@
+"""The consensus-stage kernels' SOURCE (k_msa.hip: k_tags, k_tscan, k_links, k_backtrace;
+k_score2.hip: k_score2) on the host-side SIMT emulator of tests/emu/simt, against the CPU oracle
+and, stage by stage, against the plain-python graph model of tests/msa_model.py.  No GPU: this is
+what pins the kernels' logic here, in the dev container; the GPU suite then only has to confirm
+that the hardware runs the same source the same way.  (src/c/falcon.c:106-162, :232-263,
+:308-558)"""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+import emu_msa_driver as D  # noqa: E402
+from emu_driver import expand  # noqa: E402
+from msa_model import Graph, tags_of  # noqa: E402
+from oracle.campaign_cases import pile_cases  # noqa: E402
+from oracle.pyoracle import Port  # noqa: E402
+from falcon_amd.synth import codes_to_str, make_pile, pile_to_seqs  # noqa: E402
+
+TSEG = 128  # k_msa.h
+
+
+@pytest.fixture(scope="module")
+def port():
+    return Port()
+
+
+def model_of(st, pile):
+    """The model's graph from the staged alignments (their edit scripts expanded again)."""
+    G = Graph(len(pile[0]))
+    for g in range(1, len(pile)):
+        a = st["aln"][g]
+        if not a["accept"]:
+            continue
+        r = st["rng"][g]
+        sc = st["script"][int(st["script_off"][g]):]
+        qs, ts, _x, _y = expand(sc, int(a["dist"]), pile[g][r["s1"]:r["e1"]], pile[0][r["s2"]:r["e2"]])
+        G.add(tags_of(qs, ts, int(r["s1"]), int(r["s2"])))
+    return G
+
+
+def check_stages(st, pile, min_cov):
+    """One pile through the emulated kernels; every intermediate product against the model."""
+    graph = {}
+    res, so, nodes, _pl = D.run(st, min_cov, want_nodes=True, graph=graph)
+    G = model_of(st, pile)
+    ls, ks, nlev, n_lvl, n_lnk = G.layout()
+    ti = graph["tinfo"]
+    for t in range(G.T):  # k_tags + k_tscan
+        assert (int(ti[t]["lvl_start"]), int(ti[t]["link_start"]), int(ti[t]["cov"]), int(ti[t]["nlev"])) == \
+            (ls[t], ks[t], min(G.cov[t], 65535), nlev[t]), t
+    assert (int(so[0]["n_levels"]), int(so[0]["n_links"])) == (n_lvl, n_lnk)
+    k = 0
+    for t in range(G.T):  # k_links: a segment's links back to back from its first link slot
+        if t % TSEG == 0:
+            k = ks[t]
+        if G.cov[t] == 0:
+            continue
+        for d in range(nlev[t]):
+            exp = G.link_words(t, d, ls)
+            assert [int(x) for x in graph["links"][k:k + len(exp)]] == exp, (t, d)
+            assert int(graph["nlk"][ls[t] + d]) == len(exp), (t, d)
+            k += len(exp)
+    assert so[0]["redo"] == 0 and so[0]["err"] == 0
+    sc, best = G.scores(ls)  # k_score2
+    t_of_slot = {ls[t] + d: t for t in range(G.T) for d in range(nlev[t])}
+    for nid, (h, bp, _bk) in sc.items():
+        got = nodes[nid]
+        assert int(got["score_h"]) == h, (nid, got, h)
+        assert int(got["link"]) >> 1 == (bp if bp is not None else 0) + 1, (nid, got, bp)
+        assert int(got["link"]) & 1 == (1 if G.cov[t_of_slot[nid // 5]] > min_cov else 0), nid  # falcon.c:498
+    if best[1] >= 0:
+        assert (int(so[0]["g_h"]), int(so[0]["g_node"]), int(so[0]["g_ck"])) == best
+    else:
+        assert int(so[0]["g_node"]) == -1
+    return res[0]
+
+
+def test_smoke_pile_every_stage(port):
+    s, rd = make_pile(5, S=4000, coverage=14, min_read=800, mean_read=2500, sd_read=800)
+    pile = [codes_to_str(x) for x in pile_to_seqs(s, rd)]
+    st = D.stage_piles([pile], port)
+    got = check_stages(st, pile, 4)
+    assert got == tuple(port.generate_consensus(pile, 4, 8, 0.70))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_campaign_piles_vs_oracle(port, seed):
+    """Twelve piles per seed of the differential campaign's generator: depth 4-60x, error 1-25 %,
+    unrelated reads, low-complexity seeds, min_cov 0-8, min_idt 0.60-0.95; consensus and eqv
+    against the oracle, four of them stage by stage against the model as well."""
+    cases = pile_cases(seed)
+    sts = [D.stage_piles([p], port, min_idt=idt) for (p, _mc, idt) in cases]
+    for i, ((pile, mc, idt), st) in enumerate(zip(cases, sts)):
+        exp = tuple(port.generate_consensus(pile, mc, 8, idt))
+        if i % 3 == 0:
+            got = check_stages(st, pile, mc)
+        else:
+            res, so, _n, _p = D.run(st, mc)
+            assert so[0]["redo"] == 0
+            got = res[0]
+        assert got == exp, (seed, i, len(got[0]), len(exp[0]))
+
+
+def test_a_batch_of_piles_in_one_launch(port):
+    """Several piles in one batch: per-pile offsets into every pool, one wavefront per pile."""
+    cases = pile_cases(7)[:5]
+    piles = [c[0] for c in cases]
+    st = D.stage_piles(piles, port, min_idt=0.70)
+    res, so, _n, _p = D.run(st, 2)
+    for pile, got in zip(piles, res):
+        assert got == tuple(port.generate_consensus(pile, 2, 8, 0.70))
+
+
+def test_deep_pile_many_links_per_level(port):
+    """A deep, noisy pile: levels with more than 16 links take the 64-lane prefix maximum of
+    k_score2's chain (365 accepted alignments on a 3 kb seed)."""
+    s, rd = make_pile(77, S=3000, coverage=250, e=0.13, min_read=1500, mean_read=2500, sd_read=500)
+    pile = [codes_to_str(x) for x in pile_to_seqs(s, rd, 600)]
+    st = D.stage_piles([pile], port)
+    graph = {}
+    res, so, _n, _p = D.run(st, 4, graph=graph)
+    assert so[0]["redo"] == 0
+    assert int(graph["nlk"][:int(so[0]["n_levels"])].max()) > 16
+    assert res[0] == tuple(port.generate_consensus(pile, 4, 8, 0.70))
+
+
+def test_long_insertion_runs(port):
+    """Reads carrying runs of 13-40 inserted bases: tag words with out-of-line runs, positions
+    with dozens of levels, blocks of k_score2 that hold a single position."""
+    rng = random.Random(11)
+    s, rd = make_pile(31, S=3000, coverage=12, e=0.08, min_read=1200, mean_read=2200, sd_read=400)
+    reads = []
+    for r in rd:
+        r = list(codes_to_str(r))
+        for _ in range(3):
+            at = rng.randrange(200, len(r) - 200)
+            r[at:at] = [rng.choice("ACGT") for _ in range(rng.choice([13, 20, 40]))]
+        reads.append("".join(r))
+    seed = codes_to_str(s)
+    pile = [seed, seed] + reads
+    st = D.stage_piles([pile], port)
+    got = check_stages(st, pile, 2)
+    assert got == tuple(port.generate_consensus(pile, 2, 8, 0.70))
