@@ -30,9 +30,10 @@
 //               scores of the previous and current target position live in two
 //               VGPRs (lane = delta * 5 + base); writes the 8-byte node records
 //               and the global best.
-//   k_backtrace one wavefront per pile: walks the node records through a
-//               64-level LDS window and writes the consensus right-aligned,
-//               64 characters per store (falcon.c:494-528, no reversal pass).
+//   k_backtrace one wavefront per pile: collects the best path 64 nodes at a time out of a
+//               64-level LDS window of node records, then turns the 64 nodes into characters
+//               and eqv values at once, written right-aligned (falcon.c:494-528, no reversal
+//               pass).
 //
 // Integer only; per-column reduction over aligned bases; no MFMA.
 #include "k_msa.h"
@@ -671,7 +672,16 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
     }
 }
 // ---------------------------------------------------------------------------
-// k_backtrace: one wavefront per pile (falcon.c:494-528)
+// k_backtrace: one wavefront per pile (falcon.c:494-528).
+//
+// The walk from the best node back along the best-predecessor pointers is a pointer chase --
+// one LDS read and a handful of scalar instructions per node when that is ALL a step does.
+// So the walk only collects: 64 nodes per round, lane s keeping the s-th node's record, out
+// of a 64-level window of node records in LDS (the window below it is requested from HBM
+// while this one is walked).  What the reference does per step -- the character by base and
+// case, the skipped '-', the eqv difference to the next node's score, the output index --
+// then happens for the round's 64 nodes at once, lanes = nodes (round 3 did it per step on
+// the scalar unit: 7.2 ms per 3072 piles, five times the chase).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_backtrace(MsaArgs A) {
     __shared__ __attribute__((aligned(8))) u32 win[2 * 5 * BT_WIN];
@@ -681,7 +691,7 @@ __global__ __launch_bounds__(64) void k_backtrace(MsaArgs A) {
     const FaPile pm = A.pile[p];
     const FaScoreOut so = A.score_out[p];
     const int T = pm.seed_len;
-    const FaNode *nodes = A.nodes + pm.node_off;
+    const uint2 *nodes = reinterpret_cast<const uint2 *>(A.nodes + pm.node_off);
     FaPileOut po;
     po.len = 0; po.start = 2 * T;
     po.n_aligned = (int)(A.acc_first[p + 1] - A.acc_first[p]);
@@ -691,25 +701,51 @@ __global__ __launch_bounds__(64) void k_backtrace(MsaArgs A) {
         char *oseq = A.out_seq + pm.out_off;
         int *oeqv = A.out_eqv + pm.out_off;
         const unsigned lim = (unsigned)T * 2u;
-        unsigned index = 0;
-        int ck = so.g_ck;
-        char bb = '$';
-        int win_lo = -1, win_hi = -2;  // node-id range [win_lo, win_hi] resident in LDS
+        unsigned index = 0;                // characters written so far
+        int win_lo = 0, n_win = 0;         // node ids [win_lo, win_lo + n_win) are in LDS
+        int pf_lo = 0, pf_n = 0;           // ... and these are on their way, five records per lane
+        uint2 pf[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) { pf[q].x = 0; pf[q].y = 0; }
+        auto request_below = [&](int first_node) {  // the 64 levels under the window
+            const int lvl_hi = first_node / 5 - 1;
+            const int lvl_lo = max(0, lvl_hi - (BT_WIN - 1));
+            pf_lo = lvl_lo * 5;
+            pf_n = lvl_hi < 0 ? 0 : (lvl_hi - lvl_lo + 1) * 5;
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const int i = lane + 64 * q;
+                if (i < pf_n) pf[q] = nodes[pf_lo + i];
+            }
+        };
         auto fetch = [&](int node) -> FaNode {
-            if (node < win_lo || node > win_hi) {
-                const int lvl_hi = node / 5;
-                const int lvl_lo = max(0, lvl_hi - (BT_WIN - 1));
-                win_lo = lvl_lo * 5;
-                win_hi = lvl_hi * 5 + 4;
-                const int n_rec = win_hi - win_lo + 1;
-                __syncthreads();
-                const uint2 *src = reinterpret_cast<const uint2 *>(nodes + win_lo);
-                for (int i = lane; i < n_rec; i += 64) {
-                    const uint2 v = src[i];
-                    win[2 * i] = v.x;
-                    win[2 * i + 1] = v.y;
+            if ((unsigned)(node - win_lo) >= (unsigned)n_win) {
+                fa_wave_sync();
+                if ((unsigned)(node - pf_lo) < (unsigned)pf_n) {  // the usual case: the window below
+                    win_lo = pf_lo;
+                    n_win = pf_n;
+#pragma unroll
+                    for (int q = 0; q < 5; q++) {
+                        const int i = lane + 64 * q;
+                        if (i < pf_n) { win[2 * i] = pf[q].x; win[2 * i + 1] = pf[q].y; }
+                    }
+                } else {  // the first window, and the jump of a zero back pointer (Q4)
+                    const int lvl_hi = node / 5;
+                    const int lvl_lo = max(0, lvl_hi - (BT_WIN - 1));
+                    win_lo = lvl_lo * 5;
+                    n_win = (lvl_hi - lvl_lo + 1) * 5;
+                    for (int i = lane; i < n_win; i += 64) {
+                        const uint2 v = nodes[win_lo + i];
+                        win[2 * i] = v.x;
+                        win[2 * i + 1] = v.y;
+                    }
                 }
-                __syncthreads();
+                fa_wave_sync();
+                win_lo = fa_uni(win_lo);  // (wave-uniform: the window test of every step stays on the scalar unit)
+                n_win = fa_uni(n_win);
+                request_below(win_lo);
+                pf_lo = fa_uni(pf_lo);
+                pf_n = fa_uni(pf_n);
             }
             // (one 8-byte LDS read at a wave-uniform address; the walk itself is scalar)
             const uint2 v = *reinterpret_cast<const uint2 *>(&win[2 * (node - win_lo)]);
@@ -718,37 +754,44 @@ __global__ __launch_bounds__(64) void k_backtrace(MsaArgs A) {
             r.link = __builtin_amdgcn_readfirstlane((int)v.y);
             return r;
         };
-        FaNode rec = fetch(so.g_node);
-        int out_c = 0, out_e = 0;  // lane (index & 63) holds character `index`
+        int node = so.g_node;
+        FaNode rec = fetch(node);
+        bool first = true;  // the round holds the path's first node, whose character comes from g_ck (Q2)
         for (;;) {
-            const int up = rec.link & 1;
-            // 0..3: the base, upper case where the coverage allowed; 4: '-'; a link index
-            // >= 5 keeps the previous character (Q2) -- as arithmetic, not a jump table
-            const u32 letters = up ? 0x54474341u /* "ACGT" */ : 0x74676361u /* "acgt" */;
-            const char base_c = (char)((letters >> (8 * (ck & 3))) & 0xffu);
-            bb = ck < 4 ? base_c : (ck == 4 ? '-' : bb);
-            const int score0 = rec.score_h;
-            const int prev = (rec.link >> 1) - 1;
-            if (prev == -1 || index >= lim) break;  // :517-519 (Q1)
-            ck = prev % 5;
-            rec = fetch(prev);
-            if (bb != '-') {
-                if (lane == (int)(index & 63u)) {
-                    out_c = bb;
-                    out_e = score0 / 2 - rec.score_h / 2;  // (int) truncations (Q6)
-                }
-                index++;
-                if ((index & 63u) == 0u) {  // 64 characters ready: one coalesced store
-                    const unsigned pos = lim - 1u - (index - 64u + (unsigned)lane);
-                    oseq[pos] = (char)out_c;
-                    oeqv[pos] = out_e;
-                }
+            // ---- collect up to 64 nodes: lane s keeps the s-th
+            int my_node = 0, my_score = 0, my_link = 0;
+            int n = 0;
+            bool last = false;  // the round's last node has no predecessor: the path ends
+            for (int s = 0; s < 64; s++) {
+                if (lane == s) { my_node = node; my_score = rec.score_h; my_link = rec.link; }
+                n = s + 1;
+                const int prev = (rec.link >> 1) - 1;
+                if (prev < 0) { last = true; break; }
+                node = prev;
+                rec = fetch(node);
             }
-        }
-        if ((index & 63u) != 0u && lane < (int)(index & 63u)) {
-            const unsigned pos = lim - 1u - ((index & ~63u) + (unsigned)lane);
-            oseq[pos] = (char)out_c;
-            oeqv[pos] = out_e;
+            // ---- what the reference does per node, for all of them (falcon.c:494-528): node i
+            // yields a character unless it is the path's last one (:517-519, Q1), the character
+            // is skipped when it is '-'; eqv = (int)score - (int)next node's score (Q6)
+            const int n_out = last ? n - 1 : n;
+            int next_score = __builtin_amdgcn_update_dpp(rec.score_h, my_score, 0x130, 0xf, 0xf, false);  // wave_shl:1
+            if (lane == n - 1) next_score = rec.score_h;  // (the node the next round starts with)
+            const int ck = (first && lane == 0) ? so.g_ck : my_node % 5;
+            const u32 letters = (my_link & 1) ? 0x54474341u /* "ACGT" */ : 0x74676361u /* "acgt" */;
+            // 0..3: the base, upper case where the coverage allowed; 4: '-'; a link index >= 5
+            // (the first node only) leaves the reference's initial '$' (Q2)
+            const int bb = ck < 4 ? (int)((letters >> (8 * (ck & 3))) & 0xffu) : (ck == 4 ? '-' : '$');
+            const bool is_char = lane < n_out && bb != '-';
+            const u64 m = fa_ballot(is_char);
+            const unsigned idx = index + (unsigned)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+            if (is_char && idx < lim) {  // (index >= lim ends the walk, :519)
+                const unsigned pos = lim - 1u - idx;
+                oseq[pos] = (char)bb;
+                oeqv[pos] = my_score / 2 - next_score / 2;
+            }
+            index = min(lim, index + (unsigned)__popcll(m));
+            first = false;
+            if (last || index >= lim) break;
         }
         po.len = (int)index;
         po.start = (int)(lim - index);

@@ -90,19 +90,38 @@ __global__ __launch_bounds__(64) void k_score2(MsaArgs A) {
     u32 lk_run = 0;                // the block's first link word: k_links writes the links of a segment of TSEG
                                    // positions back to back from the segment's first link slot
     const bool slot0_empty = (tiw[2] & 0xffffu) == 0u;  // position 0 uncovered: its level slot has no links, and no count
+    const u32 link_end = (u32)A.link_cap[p];             // the pile's link slots
+    // What a block reads from HBM -- the records of positions t0 + lane, the link counts of level
+    // slots lvl0 + lane, S2_NK link words from lk_run on -- is requested while the block BEFORE
+    // it is scored: where it starts is known as soon as that block's extent is, and three
+    // dependent round trips to HBM per 48 levels would otherwise cost as much as the chain.
+    struct Ahead { u32 x_lvl, x_link, x_cn, nl, lw[S2_NK / 64]; };
+    auto request = [&](int t_first, u32 lvl_first, u32 lk_first) {
+        Ahead a;
+        const int tl = t_first + lane;
+        a.x_lvl = 0; a.x_link = 0; a.x_cn = 0; a.nl = 0;
+        if (tl < T) { a.x_lvl = tiw[3 * tl]; a.x_link = tiw[3 * tl + 1]; a.x_cn = tiw[3 * tl + 2]; }
+        if (lvl_first + (u32)lane < (u32)so.n_levels && !(slot0_empty && lvl_first + (u32)lane == 0u))
+            a.nl = (u32)nlk[lvl_first + (u32)lane];
+#pragma unroll
+        for (int q = 0; q < S2_NK / 64; q++) {
+            const u32 i = lk_first + (u32)(64 * q + lane);
+            a.lw[q] = i < link_end ? links[i] : 0u;
+        }
+        return a;
+    };
     int t0 = 0;
+    Ahead cur = request(0, 0u, tiw[1]);
     while (t0 < T) {
         // ---- a block: as many positions (<= 63) of one k_links segment as fit S2_NL levels and
         // S2_NK links.  Lane j holds position t0 + j (a block of j positions ends where position
         // t0 + j starts) and, as a level lane, the link count of level slot lvl0 + j.
         const int tl = t0 + lane;
-        u32 x_lvl = 0, x_link = 0, x_cn = 0;
-        if (tl < T) { x_lvl = tiw[3 * tl]; x_link = tiw[3 * tl + 1]; x_cn = tiw[3 * tl + 2]; }
+        const u32 x_lvl = cur.x_lvl, x_link = cur.x_link, x_cn = cur.x_cn;
         const u32 lvl0 = fa_uni(x_lvl);
         if ((t0 & (TSEG - 1)) == 0) lk_run = fa_uni(x_link);
         const int seg_end = (t0 / TSEG + 1) * TSEG;
-        int nl = 0;  // links of level slot lvl0 + lane
-        if (lvl0 + (u32)lane < (u32)so.n_levels && !(slot0_empty && lvl0 + (u32)lane == 0u)) nl = (int)nlk[lvl0 + (u32)lane];
+        int nl = (int)cur.nl;  // links of level slot lvl0 + lane
         const int nl_sum = wave_incl_sum(nl, lane);
         const int lv_j = (int)(((tl < T) ? x_lvl : (u32)so.n_levels) - lvl0);  // levels of the first `lane` positions
         const int lk_j = __shfl(nl_sum, max(0, min(lv_j, 64) - 1));               // and their links
@@ -117,7 +136,16 @@ __global__ __launch_bounds__(64) void k_score2(MsaArgs A) {
         if (lane >= n_l) nl = 0;
         // ---- stage the link words (the high word of each record), null records behind them
         fa_wave_sync();  // (the block before is done with the records)
-        for (int i = lane; i < n_k; i += 64) s2_at(L, S2_REC_B + 8u * (u32)i + 4u) = links[lk_run + (u32)i];
+#pragma unroll
+        for (int q = 0; q < S2_NK / 64; q++)
+            if (64 * q + lane < n_k) s2_at(L, S2_REC_B + 8u * (u32)(64 * q + lane) + 4u) = cur.lw[q];
+        {   // the next block's extent is known: request its data
+            const int t_nx = t0 + nb;
+            const u32 lvl_nx = lvl0 + (u32)n_l;
+            u32 lk_nx = lk_run + (u32)n_k;
+            if ((t_nx & (TSEG - 1)) == 0) lk_nx = (u32)__builtin_amdgcn_readlane((int)x_link, nb & 63);  // (a new segment: its own link slot)
+            cur = request(t_nx, lvl_nx, lk_nx);
+        }
         s2_at(L, S2_REC_B + 8u * (u32)(n_k + lane)) = (u32)S2_ZERO_B | ((u32)(S2_DUMP_B + 4 * lane) << 16);
         s2_at(L, S2_REC_B + 8u * (u32)(n_k + lane) + 4u) = 0u;
         s2_at(L, S2_MARK_B + 4u * (u32)lane) = (u32)-1;
