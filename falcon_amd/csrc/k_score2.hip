@@ -10,18 +10,15 @@
 //
 //   A  decode (data-parallel, lane = level, a loop over the level's links): every link word of
 //      k_links becomes an 8-byte record in LDS -- the LDS address of its predecessor's score,
-//      the LDS address its node's score goes to if the link is the node's last one (a dump word
-//      otherwise), and the key addend `node base << 29 | (2 count - coverage)`.  Nothing here
-//      depends on the scores.
+//      the LDS address of its node's score, and the addend `2 count - coverage`.  Nothing
+//      here depends on the scores.
 //   B  the chain (lane = link of the CURRENT level): read the record, read the predecessor's
-//      score, add, prefix maximum over the lanes (the node base on top of the key: a node's
-//      winner is on its last link, falcon.c:440-447), floor at the reference's -1, store the
-//      node's score.  A dozen instructions and ONE LDS round trip per level; scores live in an
-//      LDS ring addressed by node id, so every insertion depth takes the same path (no
-//      register-resident levels, no deep-level scratch).  Lanes beyond the level's links hold
-//      the records of the following levels: what they compute lands on nodes that are scored
-//      -- and overwritten -- later, before anybody reads them (LDS operations of a wavefront
-//      execute in order), so the chain carries no lane masks at all.
+//      score, add, and an LDS atomic maximum on the node's score slot, floored at the
+//      reference's -1 beforehand.  Half a dozen instructions and ONE LDS round trip per level:
+//      LDS operations of a wavefront execute in order, so the next level's reads see the
+//      maxima without any wait.  Scores live in an LDS ring addressed by node id, so every
+//      insertion depth takes the same path (no register-resident levels, no deep-level
+//      scratch), and a node's links may come in any order.
 //   C  resolve (data-parallel, lane = level again): with all scores of the block final, every
 //      node finds its winning link -- the FIRST link in stored (= insertion, Q5) order that
 //      reaches the node's score, and only if that score beat the -1 floor (strict '>',
@@ -32,7 +29,7 @@
 // What it does not hold goes to k_score1 through FaScoreOut.redo: the unitig mode (its links
 // may name absent nodes, which k_score1's registers read as the floor), piles whose scores
 // could outgrow 29 bits less the bias (never: `wide`), a position with more than S2_NL levels
-// or S2_NK links, a level with more than 64 links.
+// or S2_NK links, a level with more than 63 links.
 #include "k_msa.h"
 
 #define S2_NL 48              // levels per block
@@ -40,9 +37,8 @@
 #define S2_RING 512           // node score slots (u32), slot = node id & 511
 #define S2_BIAS 2048u         // score + bias > 0: a link scores >= -2 - coverage (coverage <= 1023)
 #define S2_FLOOR (S2_BIAS - 2u)   // the reference's -1, in half units
-#define S2_SMASK 0x1fffffffu  // score bits of a key (the node base sits on top)
 // LDS layout, byte offsets
-#define S2_DUMP_B (S2_RING * 4)           // 64 words: where a link that is not its node's last one stores
+#define S2_DUMP_B (S2_RING * 4)           // 64 words: one per lane, for the lanes beyond a level's links
 #define S2_ZERO_B (S2_DUMP_B + 64 * 4)    // one word holding score 0 (start links, falcon.c:434)
 #define S2_REC_B (S2_ZERO_B + 64)         // records, 8 bytes per link: S2_NK + 64 of them
 #define S2_MARK_B (S2_REC_B + (S2_NK + 64) * 8)   // 64 words: level slot -> position of the block
@@ -169,99 +165,93 @@ __global__ __launch_bounds__(64) void k_score2(MsaArgs A) {
         const int off = nl_sum - nl;  // (lanes < n_l)
         const int maxn = fa_wave_max(nl);
         carry_plvl = (u32)__builtin_amdgcn_readlane((int)x_lvl, nb - 1);
-        if (maxn > 64) {
+        if (maxn > 63) {
             A.score_out[p] = so;
             return;
         }
-        // ---- A: decode.  Lane = level, k = its k-th link (node-major, insertion order inside
-        // a node: k_links).
+        // ---- A: decode.  Lane = level, k = its k-th link (any order of the nodes; insertion
+        // order inside a node: k_links).  Every node of the block starts at the floor.
+        if (lane < n_l) {
+#pragma unroll
+            for (u32 b = 0; b < 5u; b++) s2_at(L, ((node5 + b) & (S2_RING - 1u)) << 2) = S2_FLOOR;
+        }
         for (int k = 0; k < maxn; k++) {
             if (k < nl) {
                 const u32 ra = S2_REC_B + 8u * (u32)(off + k);
                 const u32 w = s2_at(L, ra + 4u);
-                const u32 wn = (k + 1 < nl) ? s2_at(L, ra + 12u) : 0u;
                 const int cnt = (int)(w & 0x3ffu);
                 const u32 nbase = (w >> 10) & 7u;
                 const u32 pidx = (w >> 13) & 0x7ffu;
                 const bool start = (w >> 24) & 1u;
-                const bool tail = (k + 1 == nl) || ((wn >> 10) & 7u) != nbase;
                 const u32 src = start ? (u32)S2_ZERO_B : (((base5_s + pidx) & (S2_RING - 1u)) << 2);
-                const u32 dst = tail ? (((node5 + nbase) & (S2_RING - 1u)) << 2) : (u32)(S2_DUMP_B + 4 * k);
+                const u32 dst = ((node5 + nbase) & (S2_RING - 1u)) << 2;
                 s2_at(L, ra) = src | (dst << 16);
-                s2_at(L, ra + 4u) = (nbase << 29) + (u32)(2 * cnt - cov_s);
+                s2_at(L, ra + 4u) = (u32)(2 * cnt - cov_s);  // falcon.c:440-445, half units
             }
         }
         fa_wave_sync();
-        // ---- B: the chain.  Lane l holds link l of the level being scored.
+        // ---- B: the chain.  Lanes 0 .. n_i - 1 hold the links of the level being scored: the
+        // predecessor's score, the link's own addend, and an LDS atomic maximum on the node's
+        // slot -- the links of a node meet there in any order, and the next level's reads are
+        // behind it in the LDS queue.  (The record of the next level is requested by every lane,
+        // behind the gather; lanes beyond a level's links read records of later levels or the
+        // null records at the end, and do nothing with them.)
         {
             u32 ra = S2_REC_B + 8u * (u32)lane;
-            if (maxn <= 16) {
-                // (the record of the next level is requested behind the gather: both are under way
-                // while the loop's bookkeeping issues, and the gather heads the LDS queue)
-                s2_u32x2 r = *reinterpret_cast<const s2_u32x2 *>(&s2_at(L, ra));
-                // (consumed here, so that the loop head need not wait for it -- a wait there is also
-                // a wait for the store of the level before, on every level)
-                r.x = fa_settled(r.x); r.y = fa_settled(r.y);
-                for (int i = 0; i < n_l; i++) {
-                    const int n_i = __builtin_amdgcn_readlane(nl, i);
-                    ra += 8u * (u32)n_i;
-                    const u32 ph = s2_at(L, r.x & 0xffffu);
-                    const s2_u32x2 rn = *reinterpret_cast<const s2_u32x2 *>(&s2_at(L, ra));
-                    const u32 key = fa_row_prefix_max_u32(ph + r.y);
-                    s2_at(L, r.x >> 16) = max(key & S2_SMASK, S2_FLOOR);
-                    fa_wave_sync();
-                    r = rn;
-                }
-            } else {
-                s2_u32x2 r = *reinterpret_cast<const s2_u32x2 *>(&s2_at(L, ra));
-                // (consumed here, so that the loop head need not wait for it -- a wait there is also
-                // a wait for the store of the level before, on every level)
-                r.x = fa_settled(r.x); r.y = fa_settled(r.y);
-                for (int i = 0; i < n_l; i++) {
-                    const int n_i = __builtin_amdgcn_readlane(nl, i);
-                    ra += 8u * (u32)n_i;
-                    const u32 ph = s2_at(L, r.x & 0xffffu);
-                    const s2_u32x2 rn = *reinterpret_cast<const s2_u32x2 *>(&s2_at(L, ra));
-                    const u32 key = fa_wave_prefix_max_u32(ph + r.y);
-                    s2_at(L, r.x >> 16) = max(key & S2_SMASK, S2_FLOOR);
-                    fa_wave_sync();
-                    r = rn;
-                }
+            const u32 dump = (u32)(S2_DUMP_B + 4 * lane);
+            s2_u32x2 r = *reinterpret_cast<const s2_u32x2 *>(&s2_at(L, ra));
+            // (consumed here, so that the loop head need not wait for it -- a wait there is also
+            // a wait for the atomic of the level before, on every level)
+            r.x = fa_settled(r.x); r.y = fa_settled(r.y);
+            for (int i = 0; i < n_l; i++) {
+                const int n_i = __builtin_amdgcn_readlane(nl, i);
+                ra += 8u * (u32)n_i;
+                const u64 here = fa_lane_range(0, n_i);  // (n_i <= 63)
+                const s2_u32x2 rn = *reinterpret_cast<const s2_u32x2 *>(&s2_at(L, ra));
+                // (no branch around the level's lanes: the others aim at their dump word -- a join
+                // here would make the compiler wait for the atomic before the next level starts)
+                const bool mine = __builtin_amdgcn_inverse_ballot_w64(here);
+                const u32 ph = s2_at(L, mine ? (r.x & 0xffffu) : (u32)S2_ZERO_B);
+                atomicMax(&s2_at(L, mine ? (r.x >> 16) : dump), ph + r.y);
+                fa_wave_sync();
+                r = rn;
             }
         }
-        // ---- C: resolve.  Lane = level; its links in stored order.
+        // ---- C: resolve.  Lane = level; its links in stored order.  A node's winner is the
+        // first of its links that reaches the node's score, if that score beat the floor.
         {
             const int lo = (int)(lvl0 * 5u) - 256;  // every node a record of this block names lies in [lo, lo + 512)
-            u32 cur_nb = 8u;
-            bool found = false;
-            int cin = 0, ck = 0, pid = -1;
+            u32 seen = 0;   // nodes (bit = base) met / resolved so far
+            u32 won = 0;
+            u32 cin = 0;    // links met per node, 6 bits each
             for (int k = 0; k < maxn; k++) {
                 if (k < nl) {
                     const u32 ra = S2_REC_B + 8u * (u32)(off + k);
-                    const u32 w0 = s2_at(L, ra), w1 = s2_at(L, ra + 4u);
-                    // (the addend is node base << 29 PLUS a small signed number)
-                    const u32 nbase = (w1 + 0x10000000u) >> 29;
-                    const u32 cv = w1 - (nbase << 29);
+                    const u32 w0 = s2_at(L, ra), cv = s2_at(L, ra + 4u);
                     const u32 src = w0 & 0xffffu, dst = w0 >> 16;
-                    if (nbase != cur_nb) { cur_nb = nbase; found = false; cin = 0; }
+                    const u32 nbase = ((dst >> 2) - node5) & (S2_RING - 1u);
                     const u32 node = node5 + nbase;
-                    const u32 sn = s2_at(L, (node & (S2_RING - 1u)) << 2);
+                    const u32 bit = 1u << nbase;
+                    const u32 sn = s2_at(L, dst);
                     const u32 h = s2_at(L, src) + cv;
-                    if (!found && sn > S2_FLOOR && h == sn) {
-                        found = true;
-                        ck = cin;
-                        pid = (src == (u32)S2_ZERO_B) ? -1 : lo + (int)(((src >> 2) - (u32)lo) & (S2_RING - 1u));
-                    }
-                    cin++;
-                    if (dst < (u32)S2_DUMP_B) {  // the node's last link: its record
+                    const u32 ck = (cin >> (6u * nbase)) & 63u;
+                    cin += 1u << (6u * nbase);
+                    const bool wins = !(won & bit) && sn > S2_FLOOR && h == sn;
+                    const bool stays = !(seen & bit) && sn <= S2_FLOOR;  // no link beats the floor: the zero back pointer (Q4)
+                    seen |= bit;
+                    if (wins || stays) {
+                        won |= bit;
+                        const int pid = (wins && src != (u32)S2_ZERO_B) ? lo + (int)(((src >> 2) - (u32)lo) & (S2_RING - 1u))
+                                                                        : (wins ? -1 : 0);
                         s2_u32x2 r;
                         r.x = sn - S2_BIAS;
-                        r.y = (u32)((((found ? pid : 0) + 1) << 1)) | upper_s;
+                        r.y = (u32)((pid + 1) << 1) | upper_s;
                         nodes[node] = r;
-                        if (sn > best_s) {  // strict: the lane's first maximum (its nodes ascend)
+                        // the first strict maximum in (t, delta, base) order: among equals the lowest node
+                        if (sn > best_s || (sn == best_s && sn > S2_FLOOR && (int)node < best_node)) {
                             best_s = sn;
                             best_node = (int)node;
-                            best_ck = found ? ck : 0;
+                            best_ck = wins ? (int)ck : 0;
                         }
                     }
                 }

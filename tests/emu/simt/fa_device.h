@@ -22,6 +22,7 @@ inline u64 simt_uni(u64 v, int site) {
 }
 template <class T> inline T *simt_uni(T *p, int site) { return (T *)simt_uni((u64)(uintptr_t)p, site); }
 
+inline u64 fa_lane_range(int lo, int n) { return (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) << lo; }
 inline int fa_sel(u64 mask, int a, int b) { return ((mask >> simt::lane()) & 1ull) ? b : a; }
 inline u32 fa_settled(u32 v) { return v; }
 #define fa_wave_sync() simt::sync(__LINE__)
