@@ -167,6 +167,10 @@ __device__ __forceinline__ void fa_writelane2(int &a, int &b, int sa, int sb, in
 // keeps the compiler from moving memory operations across it and costs no instruction (the
 // host-side SIMT emulator of tests/emu/simt turns it into a rendezvous of its 64 fibers).
 __device__ __forceinline__ void fa_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+// The same between LDS operations on one array: nothing at all on the device -- the LDS executes
+// a wavefront's operations in order, and the compiler keeps accesses that may alias in program
+// order -- so that adjacent regions under one lane mask compile to one (the emulator: a rendezvous).
+__device__ __forceinline__ void fa_lds_order() {}
 
 // ---------------------------------------------------------------------------
 // shared by the alignment kernels (k_align.hip, k_align_wide.hip)

@@ -181,12 +181,8 @@ __global__ __launch_bounds__(64) void k_score1(MsaArgs A) {
     // HBM -- LDS here would cost occupancy (one wave per pile must all be resident)
     int *s_deep = A.score_ovf + (u64)p * (2 * 256 * 5);
     const int ldl = lane / 5;
-    const u32 le_lane_mask = lane < 31 ? (2u << lane) - 1u : 0xffffffffu;  // bits 0 .. lane
     const int h_init = (lane == SC_ZERO) ? 0 : -2;
-    // (the fast path's key holds a score in 25 bits: piles whose scores could outgrow them,
-    // or every level when the tests ask for it, take the generic path)
-    const bool fast_pile = so.wide == 0 && A.force_generic == 0;
-    const int reg_max = fa_uni(fast_pile ? SC_REG : -1);  // most levels a position of the fast path may have
+    (void)A.force_generic;  // (every level takes the general path now)
 
     ScoreAcc cur;
     cur.h = h_init; cur.p = 0; cur.k = 0; cur.n = 0;
@@ -280,11 +276,6 @@ __global__ __launch_bounds__(64) void k_score1(MsaArgs A) {
             cur.h = h_init; cur.p = 0; cur.k = 0;
             curbuf ^= 1;
             u32 lk = lk_run;
-            // no level of this position and no predecessor of one lies beyond the
-            // register-resident levels: the per-level test of the fast path is one compare
-            int fast_lim;  // 16 if so, else -1 (scalar arithmetic instead of lane-mask algebra)
-            asm("s_max_i32 %0, %1, %2\n\ts_cmp_le_i32 %0, %3\n\ts_cselect_b32 %0, 16, -1"
-                : "=&s"(fast_lim) : "s"(nlev), "s"(prev_nlev), "s"(reg_max) : "scc");
             for (int dl = 0; dl < nlev; dl++) {
                 const u32 slot = y_lvl + (u32)dl;
                 int n_link;
@@ -305,63 +296,7 @@ __global__ __launch_bounds__(64) void k_score1(MsaArgs A) {
                     if (lane < n_link) w = links[lk + (u32)lane];
                     w = fa_settled(w);
                 }
-                const bool have = lane < n_link;
-                const int cnt = (int)(w & 0x3ffu), nbase = (int)((w >> 10) & 7u);
-                const int pidx = (int)((w >> 13) & 0x7ffu);
-                const bool start = (w >> 24) & 1u;
-                if (__builtin_expect(n_link <= fast_lim, 1)) {
-                    // ---- the usual level: <= 16 links in lanes 0..15, node-major (k_links).
-                    // ONE unsegmented prefix maximum resolves all five nodes -- the node's base
-                    // sits on top of the key, so a later node's links beat any link of an
-                    // earlier node and every node's winner ends up on its last link; no loop,
-                    // no branch, no masks.  Independent of the scores (issued while the gather
-                    // below is in flight):
-                    const u64 have_m = (1ull << n_link) - 1ull;
-                    const int nbp = have ? nbase + 1 : 0;  // 0: no link in this lane
-                    const int n1 = __builtin_amdgcn_mov_dpp(nbp, 0x111, 0xf, 0xf, true);  // row_shr:1
-                    const int nx = __builtin_amdgcn_mov_dpp(nbp, 0x101, 0xf, 0xf, true);  // row_shl:1
-                    // (first link of its node; also flags the lane behind the last link, which no
-                    // lane with a link looks at)
-                    const u64 first_raw = fa_ballot(n1 != nbp);
-                    const u64 tail_m = fa_ballot(nx != nbp) & have_m;   // last link of its node
-                    // first lane of my node: the highest first link at or below my lane
-                    // (lane 0 is one whenever the level has links; lanes without a link read 0
-                    // or garbage that nobody uses)
-                    int ss;  // (v_ffbh_u32 as the hardware defines it: -1 for 0, which only lanes without a link see)
-                    // (the AND stays with the compiler: the mask may sit in VCC, written by the
-                    // v_cmp just before, and reading VCC by its SGPR number right behind an
-                    // implicit write needs a wait state that nobody inserts inside an asm block)
-                    const u32 first_le = (u32)first_raw & le_lane_mask;
-                    asm("v_ffbh_u32 %0, %1\n\tv_sub_u32 %0, 31, %0" : "=v"(ss) : "v"(first_le));
-                    const int cv = 2 * cnt - cov;
-                    const int lidx = start ? SC_ZERO : pidx;
-                    const int pidv = start ? -1 : (int)(plvl5 + (u32)pidx);
-                    const int dst = fa_sel(tail_m, 62, dl * 5 + nbase);  // 62: a lane nobody reads
-                    const u32 kfix = have ? (((u32)nbase << 29) | (u32)(15 - lane)) : 0u;
-                    // The dependent chain: previous scores -> link scores -> per node the first
-                    // maximum (falcon.c:440-447: strict '>', links in insertion order) -> the
-                    // node's score lane.  key = (node, score, 15 - lane): inside a node the
-                    // larger score wins, among equals the lower lane.  (Scores fit the key's 25
-                    // bits: SC_FAST_SCORE_MAX, k_tscan.)
-                    const int ph = __builtin_amdgcn_ds_bpermute(lidx << 2, dl == 0 ? prev_h : cur.h);
-                    const int h = ph + cv;
-                    u32 key = have ? (((u32)(h + SC_BIAS) << 4) | kfix) : 0u;
-                    key = fa_row_prefix_max_u32(key);
-                    const int wl = 15 - (int)(key & 15u);  // lane of my node's winning link
-                    const int pidw = __builtin_amdgcn_ds_bpermute(wl << 2, pidv);
-                    const u32 pp = ((u32)pidw << 4) | (u32)ss;  // (-1, a start link, stays -1 under >> 4)
-                    const u32 r_key = (u32)__builtin_amdgcn_ds_permute(dst << 2, fa_sel(tail_m, 0, (int)key)) & 0x1fffffffu;
-                    const u32 r_pp = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)pp);
-                    // a node of this level landed on my lane, with a link above the floor: a
-                    // node keeps -1 (-2 half units) and the zero back pointer unless some link
-                    // scores strictly more (falcon.c:420,447; Q4)
-                    // (selects by the lane mask: as `got ? .. : ..` the compiler branches around
-                    // the three updates, three scalar instructions per level for nothing)
-                    const u64 got = fa_ballot(r_key > (((u32)(SC_BIAS - 2) << 4) | 15u));
-                    cur.h = fa_sel(got, cur.h, (int)(r_key >> 4) - SC_BIAS);
-                    cur.p = fa_sel(got, cur.p, (int)r_pp >> 4);
-                    cur.k = fa_sel(got, cur.k, 15 - (int)(r_key & 15u) - (int)(r_pp & 15u));
-                } else {
+                {
                     s_io[lane] = cur.h; s_io[64 + lane] = cur.p; s_io[128 + lane] = cur.k;
                     // (scalar -> vector here and nowhere else: the "s" operands keep the
                     // loop-carried scalars they derive from in scalar registers)

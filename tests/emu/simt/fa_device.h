@@ -26,6 +26,7 @@ inline u64 fa_lane_range(int lo, int n) { return (n >= 64 ? ~0ull : ((1ull << n)
 inline int fa_sel(u64 mask, int a, int b) { return ((mask >> simt::lane()) & 1ull) ? b : a; }
 inline u32 fa_settled(u32 v) { return v; }
 #define fa_wave_sync() simt::sync(__LINE__)
+#define fa_lds_order() simt::sync(__LINE__)
 
 inline int simt_wave_max(int v, int site) {
     const simt::X x = simt::xchg((uint32_t)v, site);

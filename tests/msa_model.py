@@ -34,6 +34,7 @@ class Graph:
         self.cov = [0] * T
         # (t, delta) -> base -> {(p_t, p_delta, p_base): count}, links in first-insertion order
         self.lv = collections.defaultdict(lambda: collections.defaultdict(collections.OrderedDict))
+        self.order = collections.defaultdict(list)  # (t, delta) -> [(base, link key)] in first-insertion order
         self.max_delta = [0] * T
 
     def add(self, tags):
@@ -43,6 +44,8 @@ class Graph:
             self.max_delta[t] = max(self.max_delta[t], d)
             node = self.lv[(t, d)][_B[b]]
             key = (pt, pd, _B[pb])
+            if key not in node:
+                self.order[(t, d)].append((_B[b], key))
             node[key] = node.get(key, 0) + 1
 
     def layout(self):
@@ -58,15 +61,16 @@ class Graph:
         return lvl_start, link_start, nlev, ls, ks
 
     def link_words(self, t, d, lvl_start):
-        """The level's link words in k_links' order: node base ascending, insertion order inside
-        a node: count | base << 10 | (p_delta * 5 + p_base) << 13 | start << 24."""
+        """The level's link words in k_links' order: first-insertion order over the whole level
+        (which is insertion order inside every node, falcon.c:245-262; the nodes interleave):
+        count | base << 10 | (p_delta * 5 + p_base) << 13 | start << 24."""
         out = []
-        for b in sorted(self.lv[(t, d)]):
-            for (pt, pd, pb), c in self.lv[(t, d)][b].items():
-                if pt == -1:
-                    out.append(c | (b << 10) | (1 << 24))
-                else:
-                    out.append(c | (b << 10) | ((pd * 5 + pb) << 13))
+        for b, (pt, pd, pb) in self.order[(t, d)]:
+            c = self.lv[(t, d)][b][(pt, pd, pb)]
+            if pt == -1:
+                out.append(c | (b << 10) | (1 << 24))
+            else:
+                out.append(c | (b << 10) | ((pd * 5 + pb) << 13))
         return out
 
     def scores(self, lvl_start):
