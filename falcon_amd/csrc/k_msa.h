@@ -19,7 +19,6 @@
 #define TAG_PAY_MASK 0x7fffffu
 #define TG_WIN 1024    // target positions per k_tags LDS window
 #define TG_BLK 16      // positions per k_links tag block
-#define LK_SLOTS 128u  // entries of k_links' grouping table
 #define TCOV_LEAD 0x40000000  // tcov flag: the alignment opens with an insertion run (see k_tags)
 // scores are bounded by the sum over levels of the coverage; beyond this bound the 25-bit
 // score field of k_score's fast-path keys could overflow and the pile takes the generic path

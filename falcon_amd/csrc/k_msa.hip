@@ -306,7 +306,6 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
     // (only what this instance can take is kept: a segment with more is handed on; LDS per
     // wavefront decides how many of these latency-bound wavefronts a CU holds)
     __shared__ int act[NCHT * 64];
-    __shared__ u32 gmin[LK_SLOTS], gcnt[LK_SLOTS];  // the grouping table (see the level loop)
     const int lane = fa_lane();
     constexpr int LVL = NCHT == 1 ? -1 : NCHT == 2 ? 0 : NCHT == 4 ? 1 : NCHT == 8 ? 2 : 3;
     const int lstride = A.n_seg + 1;
@@ -337,7 +336,6 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
         if (ov && n_act + rank < NCHT * 64) act[n_act + rank] = (int)i;
         n_act += __popcll(m);
     }
-    for (int i = fa_lane(); i < (int)LK_SLOTS; i += 64) { gmin[i] = 0xffffffffu; gcnt[i] = 0u; }
     __syncthreads();
     if (n_act > MAXACT) {  // cannot happen: <= FA_CNS_MAX_ALN accepted alignments per pile
         if (lane == 0) A.score_out[p].err = 2;
@@ -592,69 +590,71 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
                     if (dl == 0 && covd[c] && nins[c] == 0) { pbv[c] = base0[c]; pnv[c] = 0; }
                 }
             }
-            // Lanes with equal keys are one link (update_col, falcon.c:232-263); the lowest lane
-            // of a group -- its leader -- stores the word, and the leaders store in lane order,
-            // which inside every node is the reference's first-insertion order (Q5; the nodes of
-            // a level interleave: k_score2 takes them in any order).  Round 1-3 peeled the groups
-            // off one by one on the scalar unit (a find-first-bit, a readlane, a ballot, a
-            // popcount and two writelanes per group, five times a level's nodes) -- the kernel ran
-            // at 90 % of the CU's one scalar pipe.  Now the lanes find their group through a
-            // 128-entry table in LDS: an atomic minimum of (key << 10 | lane id) on the key's slot
-            // elects the leader of the smallest key there, the lanes holding that key count
-            // themselves with an atomic add, everybody reads both back.  Two different keys in
-            // one slot (bits 0..6 of the key: node base, previous base, parity of the previous
-            // depth) are rare; the lanes of the key that lost simply go round again.
-            u32 hv[NCHT], hslot[NCHT];
-            bool open[NCHT], lead[NCHT];
-            int mycnt[NCHT];
-#pragma unroll
-            for (int c = 0; c < NCHT; c++) {
-                open[c] = key[c] >= 0;
-                hv[c] = ((u32)key[c] << 10) | (u32)(c * 64 + lane);
-                hslot[c] = (u32)key[c] & (LK_SLOTS - 1u);
-                lead[c] = false;
-                mycnt[c] = 0;
-            }
-            // one round: what it settles leaves `open`; true if some lane has to go round again
-            auto round = [&]() -> bool {
-                u32 got[NCHT];
-                bool hit[NCHT];
-#pragma unroll
-                for (int c = 0; c < NCHT; c++)
-                    if (open[c]) atomicMin(&gmin[hslot[c]], hv[c]);
-                fa_lds_order();
-#pragma unroll
-                for (int c = 0; c < NCHT; c++) {
-                    got[c] = open[c] ? gmin[hslot[c]] : 0u;
-                    hit[c] = open[c] && (got[c] >> 10) == (u32)key[c];
-                    if (hit[c]) atomicAdd(&gcnt[hslot[c]], 1u);
-                }
-                fa_lds_order();
-#pragma unroll
-                for (int c = 0; c < NCHT; c++)
-                    if (hit[c]) mycnt[c] = (int)gcnt[hslot[c]];
-                fa_lds_order();
-                bool more = false;
-#pragma unroll
-                for (int c = 0; c < NCHT; c++) {
-                    if (hit[c]) { gmin[hslot[c]] = 0xffffffffu; gcnt[hslot[c]] = 0u; }  // (the table as it was)
-                    lead[c] = lead[c] || (hit[c] && got[c] == hv[c]);
-                    open[c] = open[c] && !hit[c];
-                    more = more || fa_ballot(open[c]) != 0ull;
-                }
-                fa_lds_order();
-                return more;
-            };
-            if (round()) {  // (rare)
-                while (round()) {}
-            }
+            // Lanes with equal keys are one link (update_col, falcon.c:232-263).  The groups are
+            // peeled off in the order of their lowest lanes -- the leaders: inside every node that
+            // is the reference's first-insertion order (Q5); the nodes of a level interleave, which
+            // k_score2 does not mind (rounds 1-3 emitted them node by node: five more ballots and
+            // loop tests per level on the scalar pipe that bounds this kernel).  The leader takes
+            // the group's rank and size by v_writelane and stores the word.  (Grouping through an
+            // LDS table -- atomic minimum for the leader, atomic add for the size -- was built and
+            // measured this round: fewer instructions, 17.6 ms instead of 13.8: thirty lanes of one
+            // group are thirty conflicting updates of one LDS word.)
             int n_link = 0;
+            if constexpr (NCHT == 1) {
+                int myrank = -1, mycnt = 0;
+                u64 rem = fa_ballot(key[0] >= 0);
+                while (rem) {
+                    const int ldr = __builtin_ctzll(rem);
+                    const int kk = __builtin_amdgcn_readlane(key[0], ldr);
+                    const u64 m = fa_ballot(key[0] == kk);
+                    const int cnt = __popcll(m);
+                    rem &= ~m;
+                    fa_writelane2(myrank, mycnt, n_link, cnt, ldr);
+                    n_link++;
+                }
+                if (myrank >= 0) links[out + (u32)myrank] = wv[0] | (u32)mycnt;
+            } else {
+                // several chunks: the same, the leader in the lowest chunk that still holds lanes
+                int myrank[NCHT], mycnt[NCHT];
+                u64 rem[NCHT];
+                bool any = false;
 #pragma unroll
-            for (int c = 0; c < NCHT; c++) {
-                const u64 m = fa_ballot(lead[c]);
-                const int rank = n_link + (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-                if (lead[c]) links[out + (u32)rank] = wv[c] | (u32)mycnt[c];
-                n_link += __popcll(m);
+                for (int c = 0; c < NCHT; c++) {
+                    myrank[c] = -1; mycnt[c] = 0;
+                    rem[c] = (c < nch) ? fa_ballot(key[c] >= 0) : 0ull;
+                    any = any || rem[c] != 0ull;
+                }
+                while (any) {
+                    int c0 = 0;
+#pragma unroll
+                    for (int c = NCHT - 1; c >= 0; c--)
+                        if (rem[c]) c0 = c;
+                    int kk = 0, ldr = 0;
+#pragma unroll
+                    for (int c = 0; c < NCHT; c++)
+                        if (c == c0) {
+                            ldr = __builtin_ctzll(rem[c]);
+                            kk = __builtin_amdgcn_readlane(key[c], ldr);
+                        }
+                    int cnt = 0;
+                    any = false;
+#pragma unroll
+                    for (int c = 0; c < NCHT; c++) {
+                        if (c < nch) {
+                            const u64 m = fa_ballot(key[c] == kk);
+                            cnt += __popcll(m);
+                            rem[c] &= ~m;
+                            any = any || rem[c] != 0ull;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < NCHT; c++)
+                        if (c == c0) fa_writelane2(myrank[c], mycnt[c], n_link, cnt, ldr);
+                    n_link++;
+                }
+#pragma unroll
+                for (int c = 0; c < NCHT; c++)
+                    if (myrank[c] >= 0) links[out + (u32)myrank[c]] = wv[c] | (u32)mycnt[c];
             }
             out += (u32)n_link;
             nlk[x.lvl_start + (u32)dl] = (u16)n_link;
