@@ -356,6 +356,7 @@ struct fa_batch {
         int band = 0, force_accept_g = -1;
         bool two_per_wave = false;
         int score_mode = 0, force_generic = 0;  // FALCON_AMD_SCORE1 / _SCORE_GENERIC, read by the calling thread
+        int links_mode = 0;                     // FALCON_AMD_LINKS1
         size_t n_seg = 0;
         u64 t_tot = 0;
     } run;
@@ -1219,6 +1220,7 @@ static int start_align(fa_batch *b, unsigned min_cov, double max_diff, int band,
     // submit: the planner thread must not race a test's setenv)
     b->run.score_mode = getenv("FALCON_AMD_SCORE1") ? 1 : 0;
     b->run.force_generic = getenv("FALCON_AMD_SCORE_GENERIC") ? 1 : 0;
+    b->run.links_mode = getenv("FALCON_AMD_LINKS1") ? 1 : 0;
     b->run.min_cov = min_cov; b->run.max_diff = max_diff; b->run.band = band;
     b->run.force_accept_g = force_accept_g; b->run.two_per_wave = two_per_wave;
     if (b->h_aln.resize(b->n_seq) || b->h_a2_stats.resize(8)) return -1;
@@ -1278,7 +1280,7 @@ static int start_align(fa_batch *b, unsigned min_cov, double max_diff, int band,
             }
         }
         if (b->d_seg_pile.alloc(n_seg + 1) || b->d_seg_t0.alloc(n_seg + 1) ||
-            b->d_wide.alloc(4 * (n_seg + 1) + 1) || b->d_t_off.alloc((size_t)b->n_pile + 1))
+            b->d_wide.alloc(5 * (n_seg + 1) + 1) || b->d_t_off.alloc((size_t)b->n_pile + 1))
             return -1;
         // (synchronous copies on the null stream; the context's streams are non-blocking,
         // so they do not wait for k_align)
@@ -1431,6 +1433,7 @@ static int msa_stage(fa_batch *b) {
     md.first_links_back = force_accept_g >= 0 ? 1 : 0;
     md.force_generic = b->run.force_generic;  // (tests: pins the generic path of k_score1)
     md.score_mode = b->run.score_mode;        // (FALCON_AMD_SCORE1: k_score1 for every pile)
+    md.links_mode = b->run.links_mode;        // (FALCON_AMD_LINKS1: k_links for every segment)
     const FaBatchDev d = b->dev();
     pt.mark("upload");
     HIP_OK(hipEventRecord(b->ev[4], sb));

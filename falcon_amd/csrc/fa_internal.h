@@ -174,6 +174,7 @@ struct FaMsaDev {
     int first_links_back;  // unitig mode: a read's first column links back to (s2 - 1, 0, '-')
     int force_generic;     // k_score1: every level through the generic path (tests)
     int score_mode;        // 0: k_score2, k_score1 for what it hands on; 1: k_score1 for every pile
+    int links_mode;        // 0: k_links2, k_links for what it hands on; 1: k_links for every segment
     int *wide_count;
     int *wide_list;
 };

@@ -1,0 +1,228 @@
+// k_links2.hip -- the MSA graph's links (update_col, src/c/falcon.c:232-263), lanes = target POSITIONS.
+//
+// k_links (k_msa.hip, rounds 1-3) gives a lane to every alignment overlapping a segment and
+// walks the positions one by one: per level a ballot-and-peel loop on the scalar unit finds the
+// lanes holding the same (base, previous node) -- ~250 instructions per position, most of them
+// scalar, with 45 of 64 lanes holding anything.  Here the segment's positions are the lanes
+// and the alignments are walked one by one (64 tag words per load, one per lane, coalesced):
+// what an alignment's column adds to a position is a handful of per-lane vector instructions,
+// every lane busy with its own position, nothing scalar, nothing cross-lane:
+//
+//   * the tag word of the alignment at the position and at the position before it give the
+//     column's key (node base, previous node's base and depth) for delta 0 and for every
+//     inserted base -- the same keys k_links builds (falcon.c:126-160);
+//   * the groups of a position live in lane-private LDS words.  The keys that make up nearly
+//     all links have a slot of their own -- delta 0 after a plain column (4 keys), delta 0 after
+//     a one-base insertion (8), delta 1 (8): a read-modify-write, no search; the others (deeper
+//     insertions, alignment starts, the unitig mode's first columns) go to a short list that
+//     is searched linearly;
+//   * a group's rank among the links of its LEVEL is taken when it is created -- alignments
+//     come in read order, so that is the reference's first-insertion order (Q5) -- and with the
+//     groups per level of every lane known, a prefix sum over the lanes places every link word:
+//     the segment's links leave back to back, level by level inside a position, exactly where
+//     k_links puts them.
+//
+// A position with more groups than the list holds (runs of a dozen inserted bases) sends its
+// SEGMENT to k_links through a to-do list; so the tables stay small whatever the input.
+#include "k_msa.h"
+
+#define L2_DIR 20   // groups with a slot of their own, per position
+#define L2_RARE 8   // listed groups per position
+
+// base `d` (1-based) of a tag's insertion run
+__device__ __forceinline__ u32 l2_ins_base(const MsaArgs &A, u32 ins_off, u32 w, int d) {
+    if (tag_nins(w) <= INL) return (w >> (2 * (d - 1))) & 3u;
+    return (u32)A.insb[ins_off + (w & TAG_PAY_MASK) + (u32)(d - 1)];
+}
+// link word (without the count) of a group key: node base | previous base << 3 | previous depth << 6
+// | start << 14 (| 1 << 15: the unitig mode's first column, whose previous node reads as '-')
+__device__ __forceinline__ u32 l2_word(u32 key) {
+    const u32 nb = key & 7u, pb = (key >> 3) & 7u, pd = (key >> 6) & 0xffu;
+    return (nb << LW_NB_SHIFT) | (((key >> 14) & 1u) ? (1u << LW_START_BIT) : ((pd * 5u + pb) << LW_PIDX_SHIFT));
+}
+
+__global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
+    __shared__ u32 dir[L2_DIR * 64];                    // count | rank in level << 16
+    __shared__ u32 rk[L2_RARE * 64], rc[L2_RARE * 64];  // level << 16 | key ; count | rank << 16
+    const int lane = fa_lane();
+    const int sidx = blockIdx.x;
+    if (sidx >= A.n_seg) return;
+    const int p = fa_uni(A.seg_pile[sidx]);
+    const int t_lo = fa_uni(A.seg_t0[sidx]);
+    const FaPile pm = A.pile[p];
+    const int T = pm.seed_len;
+    const int t_hi = min(T, t_lo + TSEG);
+    if (A.score_out[p].err) return;
+    const u32 *seedw = A.words + A.seq[pm.first].woff;
+    const FaTInfo *ti = A.tinfo + A.t_off[p];
+    u32 *links = A.links + A.link_off[p];
+    u16 *nlk = A.lvl_nlink16 + pm.node_off / 5;
+    const u32 a0 = A.acc_first[p], a1 = A.acc_first[p + 1];
+    u32 out = fa_uni(ti[t_lo].link_start);
+    const bool unitig = A.first_links_back != 0;
+    bool overflow = A.links_old != 0;
+
+    for (int h0 = t_lo; h0 < t_hi && !A.links_old; h0 += 64) {
+        const int t = h0 + lane;
+        const bool tin = t < t_hi;
+        FaTInfo x;
+        x.lvl_start = 0; x.link_start = 0; x.cov = 0; x.nlev = 0;
+        if (tin) x = ti[t];
+        const u32 sb = tin ? fa_base_at(seedw, t) : 0u;
+        const u32 sbp = (tin && t > 0) ? fa_base_at(seedw, t - 1) : 0u;
+#pragma unroll
+        for (int s = 0; s < L2_DIR; s++) dir[s * 64 + lane] = 0u;
+        int nrare = 0;
+        u32 lvln = 0;  // groups of levels 0..3, 8 bits each
+
+        // rank of a new group among its level's links (levels 0..3 count in lvln)
+        auto new_rank = [&](int dl) -> u32 {
+            if (dl < 4) {
+                const u32 r = (lvln >> (8 * dl)) & 255u;
+                if (r == 255u) overflow = true;
+                lvln += 1u << (8 * dl);
+                return r;
+            }
+            u32 r = 0;
+            for (int e = 0; e < nrare; e++) r += (rk[e * 64 + lane] >> 16) == (u32)dl ? 1u : 0u;
+            return r;
+        };
+        auto add_group = [&](int dl, u32 key, int slot) {
+            if (slot >= 0) {
+                const u32 d = dir[slot * 64 + lane];
+                dir[slot * 64 + lane] = (d & 0xffffu) ? d + 1u : (1u | (new_rank(dl) << 16));
+                return;
+            }
+            const u32 k = ((u32)dl << 16) | key;
+            for (int e = 0; e < nrare; e++)
+                if (rk[e * 64 + lane] == k) { rc[e * 64 + lane] += 1u; return; }
+            if (nrare == L2_RARE || dl > 255) { overflow = true; return; }
+            rk[nrare * 64 + lane] = k;
+            rc[nrare * 64 + lane] = 1u | (new_rank(dl) << 16);
+            nrare++;
+        };
+
+        // ---- the alignments, 64 at a time in the lanes, those overlapping the 64 positions one by one
+        for (u32 c0 = a0; c0 < a1; c0 += 64) {
+            const u32 ai = c0 + (u32)lane;
+            int v_s2 = 0, v_tc = 0, v_ld = 0;
+            u32 v_dlo = 0, v_dhi = 0, v_ins = 0;
+            bool ov = false;
+            if (ai < a1) {
+                const FaTagAln ta = A.ta[ai];
+                const int tcw = A.tcov[ai];
+                v_ld = (tcw & TCOV_LEAD) ? 1 : 0;  // (a leading insertion run sits at s2 - 1, k_tags)
+                v_s2 = ta.s2 - v_ld;
+                v_tc = (tcw & ~TCOV_LEAD) + v_ld;
+                const u64 doff = ta.desc_off - (u64)v_ld;
+                v_dlo = (u32)doff; v_dhi = (u32)(doff >> 32);
+                v_ins = ta.ins_off;
+                ov = v_tc > v_ld && v_s2 < min(h0 + 64, t_hi) && v_s2 + v_tc > h0;
+            }
+            for (u64 m = fa_ballot(ov); m; m &= m - 1) {
+                const int j = (int)__builtin_ctzll(m);
+                const int s2 = __builtin_amdgcn_readlane(v_s2, j);
+                const int tc = __builtin_amdgcn_readlane(v_tc, j);
+                const int ld = __builtin_amdgcn_readlane(v_ld, j);
+                const u32 insoff = (u32)__builtin_amdgcn_readlane((int)v_ins, j);
+                const u64 doff = ((u64)(u32)__builtin_amdgcn_readlane((int)v_dhi, j) << 32) |
+                                 (u64)(u32)__builtin_amdgcn_readlane((int)v_dlo, j);
+                const u32 *dptr = A.desc + doff;
+                const int u = t - s2;
+                if (tin && u >= 0 && u < tc) {  // the alignment has a column at my position
+                    const u32 w = dptr[u];
+                    const int nins = tag_nins(w);
+                    const u32 base0 = (w & TAG_DEL) ? 4u : sb;
+                    const bool nocol = ld != 0 && u == 0;  // only the leading insertion run, no delta-0 column
+                    if (!nocol) {
+                        if (u == 0) {
+                            // the alignment's first column: no previous node (p_t_pos == -1, falcon.c:434);
+                            // in the unitig mode a read placed at t > 0 links to (t - 1, delta 0) with the
+                            // '.' base, which the scorer reads as '-' (:140, :431)
+                            if (t == 0 || !unitig) add_group(0, base0 | (5u << 3) | (1u << 14), -1);
+                            else add_group(0, base0 | (4u << 3) | (1u << 15), -1);
+                        } else {
+                            // the column before it (falcon.c:129-160): its last inserted base, or its base / '-'
+                            const u32 wp = dptr[u - 1];
+                            const u32 pn = (u32)tag_nins(wp);
+                            const u32 pb = pn > 0 ? l2_ins_base(A, insoff, wp, (int)pn) : ((wp & TAG_DEL) ? 4u : sbp);
+                            const int del = base0 == 4u ? 1 : 0;
+                            int slot = -1;
+                            if (pn == 0) slot = del * 2 + (pb == 4u ? 1 : 0);
+                            else if (pn == 1) slot = 4 + del * 4 + (int)pb;
+                            add_group(0, base0 | (pb << 3) | (pn << 6), slot);
+                        }
+                    }
+                    for (int dl = 1; dl <= nins; dl++) {
+                        const u32 b = l2_ins_base(A, insoff, w, dl);
+                        if (nocol && dl == 1) {
+                            // the alignment's very first tag (see above)
+                            if (unitig) add_group(1, b | (4u << 3) | (1u << 15), -1);
+                            else add_group(1, b | (5u << 3) | (1u << 14), -1);
+                        } else {
+                            const u32 pbb = dl == 1 ? base0 : l2_ins_base(A, insoff, w, dl - 1);
+                            const int slot = dl == 1 ? 12 + (base0 == 4u ? 4 : 0) + (int)b : -1;
+                            add_group(dl, b | (pbb << 3) | ((u32)(dl - 1) << 6), slot);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- a position's links: level by level, inside a level by rank
+        if (fa_ballot(overflow)) break;
+        const u32 n0 = lvln & 255u, n1 = (lvln >> 8) & 255u, n2 = (lvln >> 16) & 255u, n3 = lvln >> 24;
+        const u32 sum4 = n0 + n1 + n2 + n3;
+        u32 deep = 0;  // groups of levels >= 4
+        for (int e = 0; e < nrare; e++) deep += (rk[e * 64 + lane] >> 16) >= 4u ? 1u : 0u;
+        const u32 gtot = sum4 + deep;
+        const u32 gsum = (u32)wave_incl_sum((int)gtot, lane);
+        const u32 base = out + gsum - gtot;
+        auto level_off = [&](u32 dl) -> u32 {
+            if (dl < 4u) return dl == 0u ? 0u : dl == 1u ? n0 : dl == 2u ? n0 + n1 : n0 + n1 + n2;
+            u32 o = sum4;
+            for (int e = 0; e < nrare; e++) {
+                const u32 de = rk[e * 64 + lane] >> 16;
+                o += (de >= 4u && de < dl) ? 1u : 0u;
+            }
+            return o;
+        };
+#pragma unroll
+        for (int s = 0; s < L2_DIR; s++) {
+            const u32 d = dir[s * 64 + lane];
+            if (d & 0xffffu) {
+                u32 key, dl;
+                if (s < 4) { key = ((s & 2) ? 4u : sb) | (((s & 1) ? 4u : sbp) << 3); dl = 0; }
+                else if (s < 12) { key = (((s - 4) & 4) ? 4u : sb) | ((u32)((s - 4) & 3) << 3) | (1u << 6); dl = 0; }
+                else { key = (u32)((s - 12) & 3) | ((((s - 12) & 4) ? 4u : sb) << 3); dl = 1; }
+                links[base + level_off(dl) + (d >> 16)] = l2_word(key) | (d & 0xffffu);
+            }
+        }
+        for (int e = 0; e < nrare; e++) {
+            const u32 k = rk[e * 64 + lane], c = rc[e * 64 + lane];
+            links[base + level_off(k >> 16) + (c >> 16)] = l2_word(k & 0xffffu) | (c & 0xffffu);
+        }
+        if (tin && x.cov != 0) {  // links per level slot
+            for (u32 dl = 0; dl < (u32)x.nlev; dl++) {
+                u32 n = dl == 0u ? n0 : dl == 1u ? n1 : dl == 2u ? n2 : dl == 3u ? n3 : 0u;
+                if (dl >= 4u)
+                    for (int e = 0; e < nrare; e++) n += (rk[e * 64 + lane] >> 16) == dl ? 1u : 0u;
+                nlk[x.lvl_start + dl] = (u16)n;
+            }
+        }
+        out += (u32)__builtin_amdgcn_readlane((int)gsum, 63);
+    }
+    if (fa_ballot(overflow)) {
+        // more groups at some position than the tables hold: k_links takes the segment
+        if (lane == 0) {
+            int *todo = A.wide_count;  // list 0
+            todo[1 + atomicAdd(todo, 1)] = sidx;
+        }
+    }
+}
+
+#ifndef FA_EMU
+void fa_launch_links2(const MsaArgs &A, hipStream_t s) {
+    hipLaunchKernelGGL(k_links2, dim3(A.n_seg), dim3(64), 0, s, A);
+}
+#endif

@@ -20,9 +20,17 @@
 #define TG_WIN 1024    // target positions per k_tags LDS window
 #define TG_BLK 16      // positions per k_links tag block
 #define TCOV_LEAD 0x40000000  // tcov flag: the alignment opens with an insertion run (see k_tags)
-// scores are bounded by the sum over levels of the coverage; beyond this bound the 25-bit
-// score field of k_score's fast-path keys could overflow and the pile takes the generic path
-#define SC_FAST_SCORE_MAX 33000000ll
+// link word of one (node, previous node) pair of a level (update_col, falcon.c:232-263):
+//   bits 15..0  alignments on the link      bits 18..16  the node's base (A0 C1 G2 T3 -4)
+//   bits 29..19 the previous node's index delta * 5 + base at the previous position (delta 0)
+//               or at this one (delta >= 1)   bit 30  no previous node (the alignment starts, :434)
+#define LW_CNT_MASK 0xffffu
+#define LW_NB_SHIFT 16
+#define LW_PIDX_SHIFT 19
+#define LW_START_BIT 30
+// scores are bounded by the sum over levels of the coverage; a pile whose bound would not fit
+// k_score2's 32-bit biased scores takes k_score1
+#define SC_FAST_SCORE_MAX 2000000000ll
 
 struct MsaArgs {
     const u32 *words;
@@ -55,13 +63,17 @@ struct MsaArgs {
     const int *seg_pile;       // k_links work list
     const int *seg_t0;
     int n_seg;
-    int *wide_count;           // to-do lists of the wider k_links instances (4 lists of 1 + n_seg
-    int *wide_list;            // ints: [count, segments...]; wide_count = first list's count)
+    int *wide_count;           // to-do lists of the k_links instances (5 lists of 1 + n_seg ints:
+    int *wide_list;            // [count, segments...]; the first is filled by k_links2)
     unsigned min_cov;
     int first_links_back;      // unitig mode (falcon.c:668-773): see k_links
     int force_generic;         // k_score1: every level through the generic path (tests)
     int only_redo;             // k_score1: only the piles k_score2 handed on (FaScoreOut.redo)
+    int links_old;             // k_links2 hands every segment to k_links (A/B runs, tests of the fallback)
 };
+
+// the links of every segment (k_links2.hip); what it cannot hold goes to k_links through A.wide_count
+void fa_launch_links2(const MsaArgs &A, hipStream_t s);
 
 // the score recurrence, one wavefront per pile: k_score2 (k_score2.hip) takes every pile and
 // hands what it does not hold -- FaScoreOut.redo -- to the general kernel (k_score1.hip)

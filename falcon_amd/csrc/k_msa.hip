@@ -282,17 +282,14 @@ __global__ __launch_bounds__(64) void k_tscan(MsaArgs A) {
 template <int NCHT>
 __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx);
 
-// Instance NCHT works off the list the narrower one before it filled and hands what is too
-// wide for itself to the next (1 -> 2 -> 4 -> 8 -> 16 chunks of 64 alignments).  The first
-// instance is one wavefront per segment; the wider ones a fixed grid looping over their
-// list (how long it is only the device knows; usually it is empty).
+// The segments k_links2 (k_links2.hip: lanes = positions) could not hold, through to-do lists:
+// instance NCHT works off the list the one before it filled -- k_links2 fills the first -- and
+// hands what is too wide for itself to the next (1 -> 2 -> 4 -> 8 -> 16 chunks of 64
+// alignments).  Fixed grids looping over their list (how long it is only the device knows;
+// usually it is empty).
 template <int NCHT>
 __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
-    constexpr int LVL = NCHT == 1 ? -1 : NCHT == 2 ? 0 : NCHT == 4 ? 1 : NCHT == 8 ? 2 : 3;
-    if (NCHT == 1) {
-        if ((int)blockIdx.x < A.n_seg) links_segment<NCHT>(A, (int)blockIdx.x);
-        return;
-    }
+    constexpr int LVL = NCHT == 1 ? 0 : NCHT == 2 ? 1 : NCHT == 4 ? 2 : NCHT == 8 ? 3 : 4;
     const int *in = A.wide_count + LVL * (A.n_seg + 1);
     const int n_in = __builtin_amdgcn_readfirstlane(in[0]);
     for (int i = (int)blockIdx.x; i < n_in; i += (int)gridDim.x) {
@@ -307,7 +304,7 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
     // wavefront decides how many of these latency-bound wavefronts a CU holds)
     __shared__ int act[NCHT * 64];
     const int lane = fa_lane();
-    constexpr int LVL = NCHT == 1 ? -1 : NCHT == 2 ? 0 : NCHT == 4 ? 1 : NCHT == 8 ? 2 : 3;
+    constexpr int LVL = NCHT == 1 ? 0 : NCHT == 2 ? 1 : NCHT == 4 ? 2 : NCHT == 8 ? 3 : 4;
     const int lstride = A.n_seg + 1;
     const int p = __builtin_amdgcn_readfirstlane(A.seg_pile[sidx]);
     const int t_lo = __builtin_amdgcn_readfirstlane(A.seg_t0[sidx]);
@@ -515,7 +512,7 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
             // key of every participating lane (-1 = none):
             //   node base | prev base << 3 | prev delta << 6 | start << 14
             // and its link word without the count (falcon.c:232-263 update_col):
-            //   count | node base << 10 | prev score index (delta * 5 + base) << 13 | start << 24
+            //   count | node base << LW_NB_SHIFT | prev score index (delta * 5 + base) << LW_PIDX_SHIFT | start << LW_START_BIT
             int key[NCHT];
             u32 wv[NCHT];
             if (plain) {
@@ -528,9 +525,9 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
                     if (dl == 0) {
                         const bool first = t == s2v[c];  // first column: no predecessor (falcon.c:434)
                         const int kprev = first ? ((5 << 3) | (1 << 14)) : ((pbv[c] << 3) | (pnv[c] << 6));
-                        const u32 wprev = first ? (1u << 24) : ((u32)(pnv[c] * 5 + pbv[c]) << 13);
+                        const u32 wprev = first ? (1u << LW_START_BIT) : ((u32)(pnv[c] * 5 + pbv[c]) << LW_PIDX_SHIFT);
                         key[c] = covd[c] ? (base0[c] | kprev) : -1;
-                        wv[c] = covd[c] ? (((u32)base0[c] << 10) | wprev) : 0u;
+                        wv[c] = covd[c] ? (((u32)base0[c] << LW_NB_SHIFT) | wprev) : 0u;
                         const bool upd = covd[c] && nins[c] == 0;
                         pbv[c] = upd ? base0[c] : pbv[c];
                         pnv[c] = upd ? 0 : pnv[c];
@@ -539,7 +536,7 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
                         const int b = (int)((wtag[c] >> (2 * (dl - 1))) & 3u);
                         const int pb = dl == 1 ? base0[c] : (int)((wtag[c] >> (2 * (dl - 2))) & 3u);
                         key[c] = part ? (b | (pb << 3) | ((dl - 1) << 6)) : -1;
-                        wv[c] = part ? (((u32)b << 10) | ((u32)((dl - 1) * 5 + pb) << 13)) : 0u;
+                        wv[c] = part ? (((u32)b << LW_NB_SHIFT) | ((u32)((dl - 1) * 5 + pb) << LW_PIDX_SHIFT)) : 0u;
                         const bool upd = part && nins[c] == dl;
                         pbv[c] = upd ? b : pbv[c];
                         pnv[c] = upd ? dl : pnv[c];
@@ -556,33 +553,33 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
                             if (t == s2v[c] && (t == 0 || !A.first_links_back)) {
                                 // first column: no predecessor (p_t_pos == -1, falcon.c:434)
                                 key[c] = base0[c] | (5 << 3) | (1 << 14);
-                                wv[c] = ((u32)base0[c] << 10) | (1u << 24);
+                                wv[c] = ((u32)base0[c] << LW_NB_SHIFT) | (1u << LW_START_BIT);
                             } else if (t == s2v[c]) {
                                 // unitig mode: get_align_tags adds the read's offset to its
                                 // initial p_t_pos of -1 (:140), so the first column of a read
                                 // placed at t > 0 links to (t - 1, delta 0) with the '.' base,
                                 // which the scorer reads as '-' (:431)
                                 key[c] = base0[c] | (4 << 3) | (0 << 6) | (1 << 15);
-                                wv[c] = ((u32)base0[c] << 10) | ((u32)4 << 13);
+                                wv[c] = ((u32)base0[c] << LW_NB_SHIFT) | ((u32)4 << LW_PIDX_SHIFT);
                             } else {
                                 key[c] = base0[c] | (pbv[c] << 3) | (pnv[c] << 6);
-                                wv[c] = ((u32)base0[c] << 10) | ((u32)(pnv[c] * 5 + pbv[c]) << 13);
+                                wv[c] = ((u32)base0[c] << LW_NB_SHIFT) | ((u32)(pnv[c] * 5 + pbv[c]) << LW_PIDX_SHIFT);
                             }
                         }
                     } else if (covd[c] && nins[c] >= dl) {
                         const int b = tag_ins_base(A, insoff[c], wtag[c], dl);
                         const int pb = dl == 1 ? base0[c] : tag_ins_base(A, insoff[c], wtag[c], dl - 1);
                         key[c] = b | (pb << 3) | ((dl - 1) << 6);
-                        wv[c] = ((u32)b << 10) | ((u32)((dl - 1) * 5 + pb) << 13);
+                        wv[c] = ((u32)b << LW_NB_SHIFT) | ((u32)((dl - 1) * 5 + pb) << LW_PIDX_SHIFT);
                         if (nocol && dl == 1) {
                             // the alignment's very first tag: no predecessor on the
                             // falcon_sense path, (t, delta 0, '.' read as '-') in unitig mode
                             if (A.first_links_back) {
                                 key[c] = b | (4 << 3) | (1 << 15);
-                                wv[c] = ((u32)b << 10) | ((u32)4 << 13);
+                                wv[c] = ((u32)b << LW_NB_SHIFT) | ((u32)4 << LW_PIDX_SHIFT);
                             } else {
                                 key[c] = b | (5 << 3) | (1 << 14);
-                                wv[c] = ((u32)b << 10) | (1u << 24);
+                                wv[c] = ((u32)b << LW_NB_SHIFT) | (1u << LW_START_BIT);
                             }
                         }
                         if (nins[c] == dl) { pbv[c] = b; pnv[c] = dl; }
@@ -805,6 +802,7 @@ static MsaArgs msa_args(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov
     A.first_links_back = m.first_links_back;
     A.force_generic = m.force_generic;
     A.only_redo = 0;
+    A.links_old = m.links_mode;
     return A;
 }
 
@@ -820,9 +818,10 @@ void fa_launch_msa_front(const FaBatchDev &b, const FaMsaDev &m, unsigned min_co
     if (ev_tags) (void)hipEventRecord(ev_tags, s);
     if (m.n_seg > 0) {
         // (the list heads)
-        for (int l = 0; l < 4; l++) (void)hipMemsetAsync(m.wide_count + l * (m.n_seg + 1), 0, sizeof(int), s);
-        hipLaunchKernelGGL(k_links<1>, dim3(m.n_seg), dim3(64), 0, s, A);
+        for (int l = 0; l < 5; l++) (void)hipMemsetAsync(m.wide_count + l * (m.n_seg + 1), 0, sizeof(int), s);
+        fa_launch_links2(A, s);
         const int wide_grid = m.n_seg < 8192 ? m.n_seg : 8192;
+        hipLaunchKernelGGL(k_links<1>, dim3(wide_grid), dim3(64), 0, s, A);
         hipLaunchKernelGGL(k_links<2>, dim3(wide_grid), dim3(64), 0, s, A);
         hipLaunchKernelGGL(k_links<4>, dim3(wide_grid), dim3(64), 0, s, A);
         hipLaunchKernelGGL(k_links<8>, dim3(wide_grid), dim3(64), 0, s, A);

@@ -83,9 +83,9 @@ __device__ __noinline__ void score_level_slow(int *s_io_v, int prev_h, u32 w_fir
     io.dg_h = s_io[192 + (lane & 7)]; io.dg_slot = s_io[200 + (lane & 7)]; io.dg_ck = s_io[208 + (lane & 7)];
     const bool have = lane < n_link;
     const u32 w = w_first;
-    const int cnt = (int)(w & 0x3ffu), nbase = (int)((w >> 10) & 7u);
-    const int pidx = (int)((w >> 13) & 0x7ffu);
-    const bool start = (w >> 24) & 1u;
+    const int cnt = (int)(w & LW_CNT_MASK), nbase = (int)((w >> LW_NB_SHIFT) & 7u);
+    const int pidx = (int)((w >> LW_PIDX_SHIFT) & 0x7ffu);
+    const bool start = (w >> LW_START_BIT) & 1u;
     (void)have;
     if (dl < SC_REG && n_link <= 64 &&
         // predecessors beyond the register-resident levels take the generic path
@@ -117,9 +117,9 @@ __device__ __noinline__ void score_level_slow(int *s_io_v, int prev_h, u32 w_fir
         const int n_here = min(64, n_link - c0);
         for (int l = 0; l < n_here; l++) {
             const u32 wl = (u32)__builtin_amdgcn_readlane((int)wc, l);
-            const int cnt_l = (int)(wl & 0x3ffu), nb_l = (int)((wl >> 10) & 7u);
-            const int pidx_l = (int)((wl >> 13) & 0x7ffu);
-            const bool start_l = (wl >> 24) & 1u;
+            const int cnt_l = (int)(wl & LW_CNT_MASK), nb_l = (int)((wl >> LW_NB_SHIFT) & 7u);
+            const int pidx_l = (int)((wl >> LW_PIDX_SHIFT) & 0x7ffu);
+            const bool start_l = (wl >> LW_START_BIT) & 1u;
             int ph = 0, pid = -1;
             if (!start_l) {
                 if (pidx_l < SC_REG * 5) {

@@ -35,7 +35,7 @@
 #define S2_NL 48              // levels per block
 #define S2_NK 320             // link records per block
 #define S2_RING 512           // node score slots (u32), slot = node id & 511
-#define S2_BIAS 2048u         // score + bias > 0: a link scores >= -2 - coverage (coverage <= 1023)
+#define S2_BIAS (1u << 17)     // score + bias > 0: a link scores >= -2 - coverage (coverage <= 65535)
 #define S2_FLOOR (S2_BIAS - 2u)   // the reference's -1, in half units
 // LDS layout, byte offsets
 #define S2_DUMP_B (S2_RING * 4)           // 64 words: one per lane, for the lanes beyond a level's links
@@ -179,10 +179,10 @@ __global__ __launch_bounds__(64) void k_score2(MsaArgs A) {
             if (k < nl) {
                 const u32 ra = S2_REC_B + 8u * (u32)(off + k);
                 const u32 w = s2_at(L, ra + 4u);
-                const int cnt = (int)(w & 0x3ffu);
-                const u32 nbase = (w >> 10) & 7u;
-                const u32 pidx = (w >> 13) & 0x7ffu;
-                const bool start = (w >> 24) & 1u;
+                const int cnt = (int)(w & LW_CNT_MASK);
+                const u32 nbase = (w >> LW_NB_SHIFT) & 7u;
+                const u32 pidx = (w >> LW_PIDX_SHIFT) & 0x7ffu;
+                const bool start = (w >> LW_START_BIT) & 1u;
                 const u32 src = start ? (u32)S2_ZERO_B : (((base5_s + pidx) & (S2_RING - 1u)) << 2);
                 const u32 dst = ((node5 + nbase) & (S2_RING - 1u)) << 2;
                 s2_at(L, ra) = src | (dst << 16);

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "k_msa.hip"
+#include "k_links2.hip"
 #include "k_score2.hip"
 
 #include <signal.h>
@@ -71,7 +72,8 @@ extern "C" int emu_msa(const u32 *words_in, u64 n_words, const FaSeq *seq_in, in
                        const FaRange *range_in, const FaAln *aln_in, const u32 *script_in, u64 n_script,
                        const u64 *script_off_in, unsigned min_cov, int first_links_back, char *out_seq, int *out_eqv,
                        u64 out_slots, FaPileOut *pile_out, FaScoreOut *score_out, FaNode *nodes_out, u64 nodes_cap,
-                       unsigned long long *n_sync_out, FaTInfo *tinfo_out, u32 *links_out, u64 links_cap, u16 *nlk_out) {
+                       unsigned long long *n_sync_out, FaTInfo *tinfo_out, u32 *links_out, u64 links_cap, u16 *nlk_out,
+                       int *todo_out) {
     struct sigaction sa;
     memset(&sa, 0, sizeof(sa));
     sa.sa_sigaction = on_segv;
@@ -129,7 +131,7 @@ extern "C" int emu_msa(const u32 *words_in, u64 n_words, const FaSeq *seq_in, in
     GBuf<FaAln> d_aln(n_seq);
     GBuf<u64> d_script_off(n_seq), d_t_off(n_pile + 1), d_link_off(n_pile), d_link_cap(n_pile);
     GBuf<FaTagAln> d_ta(n_ta + 1);
-    GBuf<int> d_tcov(n_ta + 1), d_tarr(tarr_ints + 8, 0), d_seg_pile(n_seg + 1), d_seg_t0(n_seg + 1), d_wide(4 * (n_seg + 1) + 1, 0);
+    GBuf<int> d_tcov(n_ta + 1), d_tarr(tarr_ints + 8, 0), d_seg_pile(n_seg + 1), d_seg_t0(n_seg + 1), d_wide(5 * (n_seg + 1) + 1, 0);
     GBuf<uint8_t> d_insb(ins_tot + 8);
     GBuf<FaTInfo> d_tinfo(t_tot + 8);
     GBuf<u16> d_lvl_nlink(node_off / 5 + 8);
@@ -174,8 +176,10 @@ extern "C" int emu_msa(const u32 *words_in, u64 n_words, const FaSeq *seq_in, in
     if (n_ta) simt::launch("k_tags", (unsigned)n_ta, [&] { k_tags(A); });
     simt::launch("k_tscan", (unsigned)n_pile, [&] { k_tscan(A); });
     if (n_seg) {
-        simt::launch("k_links<1>", (unsigned)n_seg, [&] { k_links<1>(A); });
+        A.links_old = getenv("EMU_MSA_LINKS1") ? 1 : 0;
+        simt::launch("k_links2", (unsigned)n_seg, [&] { k_links2(A); });
         const unsigned wide_grid = (unsigned)std::min<size_t>(n_seg, 64);
+        simt::launch("k_links<1>", wide_grid, [&] { k_links<1>(A); });
         simt::launch("k_links<2>", wide_grid, [&] { k_links<2>(A); });
         simt::launch("k_links<4>", wide_grid, [&] { k_links<4>(A); });
         simt::launch("k_links<8>", wide_grid, [&] { k_links<8>(A); });
@@ -190,6 +194,7 @@ extern "C" int emu_msa(const u32 *words_in, u64 n_words, const FaSeq *seq_in, in
     if (score_out) memcpy(score_out, d_score_out.get(), (size_t)n_pile * sizeof(FaScoreOut));
     if (nodes_out) memcpy(nodes_out, d_nodes.get(), node_off * sizeof(FaNode));
     if (n_sync_out) *n_sync_out = simt::g_wave.n_sync;
+    if (todo_out) for (int l = 0; l < 5; l++) todo_out[l] = d_wide.get()[l * (n_seg + 1)];  // segments each k_links instance took
     // (debug views of the graph: position records, link words -- piles back to back at
     // link_cap = columns + 8 each, as planned -- and the links per level slot)
     if (tinfo_out) memcpy(tinfo_out, d_tinfo.get(), t_tot * sizeof(FaTInfo));

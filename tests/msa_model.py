@@ -63,14 +63,14 @@ class Graph:
     def link_words(self, t, d, lvl_start):
         """The level's link words in k_links' order: first-insertion order over the whole level
         (which is insertion order inside every node, falcon.c:245-262; the nodes interleave):
-        count | base << 10 | (p_delta * 5 + p_base) << 13 | start << 24."""
+        count | base << 16 | (p_delta * 5 + p_base) << 19 | start << 30."""
         out = []
         for b, (pt, pd, pb) in self.order[(t, d)]:
             c = self.lv[(t, d)][b][(pt, pd, pb)]
             if pt == -1:
-                out.append(c | (b << 10) | (1 << 24))
+                out.append(c | (b << 16) | (1 << 30))
             else:
-                out.append(c | (b << 10) | ((pd * 5 + pb) << 13))
+                out.append(c | (b << 16) | ((pd * 5 + pb) << 19))
         return out
 
     def scores(self, lvl_start):

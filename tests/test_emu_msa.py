@@ -44,10 +44,13 @@ def model_of(st, pile):
     return G
 
 
-def check_stages(st, pile, min_cov):
-    """One pile through the emulated kernels; every intermediate product against the model."""
+def check_stages(st, pile, min_cov, todo=None):
+    """One pile through the emulated kernels; every intermediate product against the model.
+    todo (a list) receives the number of segments each k_links instance was handed."""
     graph = {}
     res, so, nodes, _pl = D.run(st, min_cov, want_nodes=True, graph=graph)
+    if todo is not None:
+        todo[:] = graph["todo"]
     G = model_of(st, pile)
     ls, ks, nlev, n_lvl, n_lnk = G.layout()
     ti = graph["tinfo"]
@@ -85,8 +88,22 @@ def test_smoke_pile_every_stage(port):
     s, rd = make_pile(5, S=4000, coverage=14, min_read=800, mean_read=2500, sd_read=800)
     pile = [codes_to_str(x) for x in pile_to_seqs(s, rd)]
     st = D.stage_piles([pile], port)
-    got = check_stages(st, pile, 4)
+    todo = []
+    got = check_stages(st, pile, 4, todo)
     assert got == tuple(port.generate_consensus(pile, 4, 8, 0.70))
+    assert todo == [0, 0, 0, 0, 0]  # k_links2 held every segment
+
+
+def test_k_links_takes_every_segment(port, monkeypatch):
+    """The fallback kernels (k_links<1..16>, lanes = alignments) on their own: k_links2 hands them
+    every segment (FALCON_AMD_LINKS1 in the product)."""
+    monkeypatch.setenv("EMU_MSA_LINKS1", "1")
+    for i, (pile, mc, idt) in enumerate(pile_cases(5)[:6]):
+        st = D.stage_piles([pile], port, min_idt=idt)
+        todo = []
+        got = check_stages(st, pile, mc, todo)
+        assert todo[0] == (len(pile[0]) + TSEG - 1) // TSEG
+        assert got == tuple(port.generate_consensus(pile, mc, 8, idt)), i
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
@@ -145,5 +162,7 @@ def test_long_insertion_runs(port):
     seed = codes_to_str(s)
     pile = [seed, seed] + reads
     st = D.stage_piles([pile], port)
-    got = check_stages(st, pile, 2)
+    todo = []
+    got = check_stages(st, pile, 2, todo)
     assert got == tuple(port.generate_consensus(pile, 2, 8, 0.70))
+    assert 0 < todo[0] < (len(seed) + TSEG - 1) // TSEG  # some segments outgrew k_links2's tables, not all

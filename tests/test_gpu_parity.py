@@ -472,10 +472,9 @@ def test_deep_piles_and_failures_stay_with_their_pile(engine, port):
 
 
 def test_score_generic_path_alone(engine, monkeypatch):
-    """k_score's generic path (what levels of more than 16 links, levels beyond the
-    register-resident ones and piles whose scores could outgrow the fast path's 25-bit key
-    take) on EVERY level of the golden piles: same strings and eqv as the fast path and the
-    reference (FALCON_AMD_SCORE_GENERIC pins it)."""
+    """k_score1 (the general score kernel: what k_score2 hands on) on EVERY level of the golden
+    piles: same strings and eqv as the default path and the reference (FALCON_AMD_SCORE_GENERIC
+    pins it)."""
     class Impl:
         def generate_consensus(self, seqs, min_cov, K, min_idt):
             return engine.consensus([seqs], min_cov, K, min_idt, want_eqv=True)[0]
@@ -484,6 +483,26 @@ def test_score_generic_path_alone(engine, monkeypatch):
     for c, f in zip(F4, fast):
         check_pile_case(Impl(), c)
         assert Impl().generate_consensus(c["seqs"], c["min_cov"], c["K"], c["min_idt"]) == f
+
+
+def test_fallback_kernels_alone(engine, monkeypatch):
+    """The kernels behind the default ones on EVERY pile and segment of the golden piles:
+    k_links (lanes = alignments) instead of k_links2 (FALCON_AMD_LINKS1), k_score1 instead of
+    k_score2 (FALCON_AMD_SCORE1), and both -- same strings and eqv as the default path and the
+    reference.  They take what the default kernels hand on (positions with long insertion runs,
+    the unitig mode, piles whose score bound outgrows 32 bits)."""
+    class Impl:
+        def generate_consensus(self, seqs, min_cov, K, min_idt):
+            return engine.consensus([seqs], min_cov, K, min_idt, want_eqv=True)[0]
+    fast = [Impl().generate_consensus(c["seqs"], c["min_cov"], c["K"], c["min_idt"]) for c in F4]
+    for env in (("FALCON_AMD_LINKS1",), ("FALCON_AMD_SCORE1",), ("FALCON_AMD_LINKS1", "FALCON_AMD_SCORE1")):
+        for e in env:
+            monkeypatch.setenv(e, "1")
+        for c, f in zip(F4, fast):
+            check_pile_case(Impl(), c)
+            assert Impl().generate_consensus(c["seqs"], c["min_cov"], c["K"], c["min_idt"]) == f
+        for e in env:
+            monkeypatch.delenv(e)
 
 
 def test_pipelined_submit_wait_equals_run(engine):
