@@ -14,25 +14,32 @@
 //   * the groups of a position live in lane-private LDS words.  The keys that make up nearly
 //     all links have a slot of their own -- delta 0 after a plain column (4 keys), delta 0 after
 //     a one-base insertion (8), delta 1 (8): a read-modify-write, no search; the others (deeper
-//     insertions, alignment starts, the unitig mode's first columns) go to a short list that
-//     is searched linearly;
+//     insertions, alignment starts, the unitig mode's first columns) go to a short linked list
+//     (entries from a pool the 64 positions share: a seed that lost two bases sees a dozen
+//     different two-base insertions at one position and none at its neighbours), searched
+//     linearly;
 //   * a group's rank among the links of its LEVEL is taken when it is created -- alignments
 //     come in read order, so that is the reference's first-insertion order (Q5) -- and with the
 //     groups per level of every lane known, a prefix sum over the lanes places every link word:
 //     the segment's links leave back to back, level by level inside a position, exactly where
 //     k_links puts them.
 //
-// A position with more groups than the list holds (runs of a dozen inserted bases) sends its
-// SEGMENT to k_links through a to-do list; so the tables stay small whatever the input.
+// 64 positions with more listed groups than the pool holds, or a level with more than 255
+// groups, send their SEGMENT to k_links through a to-do list; so the tables stay small whatever
+// the input.
 #include "k_msa.h"
 
-#define L2_DIR 20   // groups with a slot of their own, per position
-#define L2_RARE 8   // listed groups per position
+#define L2_DIR 20    // groups with a slot of their own, per position
+#define L2_POOL 256  // listed groups per 64 positions (entries of the lanes' linked lists)
+#define L2_NIL 0xffu
 
 // base `d` (1-based) of a tag's insertion run
 __device__ __forceinline__ u32 l2_ins_base(const MsaArgs &A, u32 ins_off, u32 w, int d) {
     if (tag_nins(w) <= INL) return (w >> (2 * (d - 1))) & 3u;
-    return (u32)A.insb[ins_off + (w & TAG_PAY_MASK) + (u32)(d - 1)];
+    // (a run too long for the tag word -- rare.  Waited for on the spot: a load still pending
+    // on one path into a join makes the compiler drain the memory queue at every later use,
+    // and with it the tag words requested ahead)
+    return fa_settled((u32)A.insb[ins_off + (w & TAG_PAY_MASK) + (u32)(d - 1)]);
 }
 // link word (without the count) of a group key: node base | previous base << 3 | previous depth << 6
 // | start << 14 (| 1 << 15: the unitig mode's first column, whose previous node reads as '-')
@@ -42,8 +49,10 @@ __device__ __forceinline__ u32 l2_word(u32 key) {
 }
 
 __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
-    __shared__ u32 dir[L2_DIR * 64];                    // count | rank in level << 16
-    __shared__ u32 rk[L2_RARE * 64], rc[L2_RARE * 64];  // level << 16 | key ; count | rank << 16
+    __shared__ u32 dir[L2_DIR * 64];               // count | rank in level << 16
+    // the listed groups: a pool shared by the wavefront's 64 positions, a linked list per lane
+    __shared__ u32 pk[L2_POOL], pc[L2_POOL];       // key | level << 16 | next << 24 ; count | rank << 16
+    __shared__ u32 pool_n;
     const int lane = fa_lane();
     const int sidx = blockIdx.x;
     if (sidx >= A.n_seg) return;
@@ -70,12 +79,16 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
         if (tin) x = ti[t];
         const u32 sb = tin ? fa_base_at(seedw, t) : 0u;
         const u32 sbp = (tin && t > 0) ? fa_base_at(seedw, t - 1) : 0u;
+        fa_wave_sync();  // (the half before is done with the tables)
 #pragma unroll
         for (int s = 0; s < L2_DIR; s++) dir[s * 64 + lane] = 0u;
-        int nrare = 0;
-        u32 lvln = 0;  // groups of levels 0..3, 8 bits each
+        pool_n = 0u;     // (every lane, the same word)
+        fa_wave_sync();
+        u32 head = L2_NIL;  // my list
+        u32 lvln = 0;       // groups of levels 0..3, 8 bits each
 
-        // rank of a new group among its level's links (levels 0..3 count in lvln)
+        // rank of a new group among its level's links (levels 0..3 count in lvln, the deeper
+        // ones only have listed groups)
         auto new_rank = [&](int dl) -> u32 {
             if (dl < 4) {
                 const u32 r = (lvln >> (8 * dl)) & 255u;
@@ -84,7 +97,7 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
                 return r;
             }
             u32 r = 0;
-            for (int e = 0; e < nrare; e++) r += (rk[e * 64 + lane] >> 16) == (u32)dl ? 1u : 0u;
+            for (u32 e = head; e != L2_NIL; e = pk[e] >> 24) r += ((pk[e] >> 16) & 255u) == (u32)dl ? 1u : 0u;
             return r;
         };
         auto add_group = [&](int dl, u32 key, int slot) {
@@ -94,15 +107,54 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
                 return;
             }
             const u32 k = ((u32)dl << 16) | key;
-            for (int e = 0; e < nrare; e++)
-                if (rk[e * 64 + lane] == k) { rc[e * 64 + lane] += 1u; return; }
-            if (nrare == L2_RARE || dl > 255) { overflow = true; return; }
-            rk[nrare * 64 + lane] = k;
-            rc[nrare * 64 + lane] = 1u | (new_rank(dl) << 16);
-            nrare++;
+            for (u32 e = head; e != L2_NIL; e = pk[e] >> 24)
+                if ((pk[e] & 0xffffffu) == k) { pc[e] += 1u; return; }
+            const u32 e = dl > 255 ? (u32)L2_POOL : atomicAdd(&pool_n, 1u);
+            if (e >= (u32)L2_POOL || e == L2_NIL) { overflow = true; return; }
+            pc[e] = 1u | (new_rank(dl) << 16);
+            pk[e] = k | (head << 24);
+            head = e;
+        };
+        // what a column of an alignment adds to my position: its tag word w, the tag word wp of
+        // the column before it (falcon.c:126-160)
+        auto add_column = [&](int u, int ld, u32 insoff, u32 w, u32 wp) {
+            const int nins = tag_nins(w);
+            const u32 base0 = (w & TAG_DEL) ? 4u : sb;
+            const bool nocol = ld != 0 && u == 0;  // only the leading insertion run, no delta-0 column
+            if (!nocol) {
+                if (u == 0) {
+                    // the alignment's first column: no previous node (p_t_pos == -1, falcon.c:434);
+                    // in the unitig mode a read placed at t > 0 links to (t - 1, delta 0) with the
+                    // '.' base, which the scorer reads as '-' (:140, :431)
+                    if (t == 0 || !unitig) add_group(0, base0 | (5u << 3) | (1u << 14), -1);
+                    else add_group(0, base0 | (4u << 3) | (1u << 15), -1);
+                } else {
+                    // the column before it: its last inserted base, or its base / '-'
+                    const u32 pn = (u32)tag_nins(wp);
+                    const u32 pb = pn > 0 ? l2_ins_base(A, insoff, wp, (int)pn) : ((wp & TAG_DEL) ? 4u : sbp);
+                    const int del = base0 == 4u ? 1 : 0;
+                    int slot = -1;
+                    if (pn == 0) slot = del * 2 + (pb == 4u ? 1 : 0);
+                    else if (pn == 1) slot = 4 + del * 4 + (int)pb;
+                    add_group(0, base0 | (pb << 3) | (pn << 6), slot);
+                }
+            }
+            for (int dl = 1; dl <= nins; dl++) {
+                const u32 b = l2_ins_base(A, insoff, w, dl);
+                if (nocol && dl == 1) {
+                    // the alignment's very first tag (see above)
+                    if (unitig) add_group(1, b | (4u << 3) | (1u << 15), -1);
+                    else add_group(1, b | (5u << 3) | (1u << 14), -1);
+                } else {
+                    const u32 pbb = dl == 1 ? base0 : l2_ins_base(A, insoff, w, dl - 1);
+                    const int slot = dl == 1 ? 12 + (base0 == 4u ? 4 : 0) + (int)b : -1;
+                    add_group(dl, b | (pbb << 3) | ((u32)(dl - 1) << 6), slot);
+                }
+            }
         };
 
-        // ---- the alignments, 64 at a time in the lanes, those overlapping the 64 positions one by one
+        // ---- the alignments, 64 at a time in the lanes; those overlapping the 64 positions one
+        // by one, the tag words of the next one requested before this one is worked in
         for (u32 c0 = a0; c0 < a1; c0 += 64) {
             const u32 ai = c0 + (u32)lane;
             int v_s2 = 0, v_tc = 0, v_ld = 0;
@@ -119,53 +171,39 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
                 v_ins = ta.ins_off;
                 ov = v_tc > v_ld && v_s2 < min(h0 + 64, t_hi) && v_s2 + v_tc > h0;
             }
-            for (u64 m = fa_ballot(ov); m; m &= m - 1) {
-                const int j = (int)__builtin_ctzll(m);
+            struct Col { int u, ld; u32 insoff, w, wp; bool on; };
+            auto request = [&](int j) -> Col {
+                Col c;
                 const int s2 = __builtin_amdgcn_readlane(v_s2, j);
                 const int tc = __builtin_amdgcn_readlane(v_tc, j);
-                const int ld = __builtin_amdgcn_readlane(v_ld, j);
-                const u32 insoff = (u32)__builtin_amdgcn_readlane((int)v_ins, j);
+                c.ld = __builtin_amdgcn_readlane(v_ld, j);
+                c.insoff = (u32)__builtin_amdgcn_readlane((int)v_ins, j);
                 const u64 doff = ((u64)(u32)__builtin_amdgcn_readlane((int)v_dhi, j) << 32) |
                                  (u64)(u32)__builtin_amdgcn_readlane((int)v_dlo, j);
                 const u32 *dptr = A.desc + doff;
-                const int u = t - s2;
-                if (tin && u >= 0 && u < tc) {  // the alignment has a column at my position
-                    const u32 w = dptr[u];
-                    const int nins = tag_nins(w);
-                    const u32 base0 = (w & TAG_DEL) ? 4u : sb;
-                    const bool nocol = ld != 0 && u == 0;  // only the leading insertion run, no delta-0 column
-                    if (!nocol) {
-                        if (u == 0) {
-                            // the alignment's first column: no previous node (p_t_pos == -1, falcon.c:434);
-                            // in the unitig mode a read placed at t > 0 links to (t - 1, delta 0) with the
-                            // '.' base, which the scorer reads as '-' (:140, :431)
-                            if (t == 0 || !unitig) add_group(0, base0 | (5u << 3) | (1u << 14), -1);
-                            else add_group(0, base0 | (4u << 3) | (1u << 15), -1);
-                        } else {
-                            // the column before it (falcon.c:129-160): its last inserted base, or its base / '-'
-                            const u32 wp = dptr[u - 1];
-                            const u32 pn = (u32)tag_nins(wp);
-                            const u32 pb = pn > 0 ? l2_ins_base(A, insoff, wp, (int)pn) : ((wp & TAG_DEL) ? 4u : sbp);
-                            const int del = base0 == 4u ? 1 : 0;
-                            int slot = -1;
-                            if (pn == 0) slot = del * 2 + (pb == 4u ? 1 : 0);
-                            else if (pn == 1) slot = 4 + del * 4 + (int)pb;
-                            add_group(0, base0 | (pb << 3) | (pn << 6), slot);
-                        }
-                    }
-                    for (int dl = 1; dl <= nins; dl++) {
-                        const u32 b = l2_ins_base(A, insoff, w, dl);
-                        if (nocol && dl == 1) {
-                            // the alignment's very first tag (see above)
-                            if (unitig) add_group(1, b | (4u << 3) | (1u << 15), -1);
-                            else add_group(1, b | (5u << 3) | (1u << 14), -1);
-                        } else {
-                            const u32 pbb = dl == 1 ? base0 : l2_ins_base(A, insoff, w, dl - 1);
-                            const int slot = dl == 1 ? 12 + (base0 == 4u ? 4 : 0) + (int)b : -1;
-                            add_group(dl, b | (pbb << 3) | ((u32)(dl - 1) << 6), slot);
-                        }
-                    }
-                }
+                c.u = t - s2;
+                c.on = tin && c.u >= 0 && c.u < tc;  // the alignment has a column at my position
+                // (both words from every lane, the index clamped into the alignment's words -- the
+                // word before the first one is the slot in front of them: a fixed number of loads
+                // per request lets the wait for THIS alignment's words leave the next one's in flight)
+                const int iu = min(max(c.u, 0), tc - 1);
+                c.w = dptr[iu];
+                c.wp = dptr[iu - 1];
+                return c;
+            };
+            u64 m = fa_ballot(ov);
+            if (m == 0ull) continue;
+            Col cur = request((int)__builtin_ctzll(m));
+            m &= m - 1;
+            int j_last = 0;
+            for (;;) {
+                const bool more = m != 0ull;
+                if (more) j_last = (int)__builtin_ctzll(m);
+                const Col nxt = request(j_last);  // (the last round requests its own words again)
+                m &= m - 1;
+                if (cur.on) add_column(cur.u, cur.ld, cur.insoff, cur.w, cur.wp);
+                if (!more) break;
+                cur = nxt;
             }
         }
 
@@ -174,46 +212,46 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
         const u32 n0 = lvln & 255u, n1 = (lvln >> 8) & 255u, n2 = (lvln >> 16) & 255u, n3 = lvln >> 24;
         const u32 sum4 = n0 + n1 + n2 + n3;
         u32 deep = 0;  // groups of levels >= 4
-        for (int e = 0; e < nrare; e++) deep += (rk[e * 64 + lane] >> 16) >= 4u ? 1u : 0u;
-        const u32 gtot = sum4 + deep;
+        for (u32 e = head; e != L2_NIL; e = pk[e] >> 24) deep += ((pk[e] >> 16) & 255u) >= 4u ? 1u : 0u;
+        const u32 gtot = (tin && x.cov != 0) ? sum4 + deep : 0u;  // (an uncovered position keeps no links, k_tscan)
         const u32 gsum = (u32)wave_incl_sum((int)gtot, lane);
         const u32 base = out + gsum - gtot;
         auto level_off = [&](u32 dl) -> u32 {
             if (dl < 4u) return dl == 0u ? 0u : dl == 1u ? n0 : dl == 2u ? n0 + n1 : n0 + n1 + n2;
             u32 o = sum4;
-            for (int e = 0; e < nrare; e++) {
-                const u32 de = rk[e * 64 + lane] >> 16;
+            for (u32 e = head; e != L2_NIL; e = pk[e] >> 24) {
+                const u32 de = (pk[e] >> 16) & 255u;
                 o += (de >= 4u && de < dl) ? 1u : 0u;
             }
             return o;
         };
+        if (gtot != 0u) {
 #pragma unroll
-        for (int s = 0; s < L2_DIR; s++) {
-            const u32 d = dir[s * 64 + lane];
-            if (d & 0xffffu) {
-                u32 key, dl;
-                if (s < 4) { key = ((s & 2) ? 4u : sb) | (((s & 1) ? 4u : sbp) << 3); dl = 0; }
-                else if (s < 12) { key = (((s - 4) & 4) ? 4u : sb) | ((u32)((s - 4) & 3) << 3) | (1u << 6); dl = 0; }
-                else { key = (u32)((s - 12) & 3) | ((((s - 12) & 4) ? 4u : sb) << 3); dl = 1; }
-                links[base + level_off(dl) + (d >> 16)] = l2_word(key) | (d & 0xffffu);
+            for (int s = 0; s < L2_DIR; s++) {
+                const u32 d = dir[s * 64 + lane];
+                if (d & 0xffffu) {
+                    u32 key, dl;
+                    if (s < 4) { key = ((s & 2) ? 4u : sb) | (((s & 1) ? 4u : sbp) << 3); dl = 0; }
+                    else if (s < 12) { key = (((s - 4) & 4) ? 4u : sb) | ((u32)((s - 4) & 3) << 3) | (1u << 6); dl = 0; }
+                    else { key = (u32)((s - 12) & 3) | ((((s - 12) & 4) ? 4u : sb) << 3); dl = 1; }
+                    links[base + level_off(dl) + (d >> 16)] = l2_word(key) | (d & 0xffffu);
+                }
             }
-        }
-        for (int e = 0; e < nrare; e++) {
-            const u32 k = rk[e * 64 + lane], c = rc[e * 64 + lane];
-            links[base + level_off(k >> 16) + (c >> 16)] = l2_word(k & 0xffffu) | (c & 0xffffu);
-        }
-        if (tin && x.cov != 0) {  // links per level slot
-            for (u32 dl = 0; dl < (u32)x.nlev; dl++) {
+            for (u32 e = head; e != L2_NIL; e = pk[e] >> 24) {
+                const u32 k = pk[e], c = pc[e];
+                links[base + level_off((k >> 16) & 255u) + (c >> 16)] = l2_word(k & 0xffffu) | (c & 0xffffu);
+            }
+            for (u32 dl = 0; dl < (u32)x.nlev; dl++) {  // links per level slot
                 u32 n = dl == 0u ? n0 : dl == 1u ? n1 : dl == 2u ? n2 : dl == 3u ? n3 : 0u;
                 if (dl >= 4u)
-                    for (int e = 0; e < nrare; e++) n += (rk[e * 64 + lane] >> 16) == dl ? 1u : 0u;
+                    for (u32 e = head; e != L2_NIL; e = pk[e] >> 24) n += ((pk[e] >> 16) & 255u) == dl ? 1u : 0u;
                 nlk[x.lvl_start + dl] = (u16)n;
             }
         }
         out += (u32)__builtin_amdgcn_readlane((int)gsum, 63);
     }
     if (fa_ballot(overflow)) {
-        // more groups at some position than the tables hold: k_links takes the segment
+        // more groups than the tables hold: k_links takes the segment
         if (lane == 0) {
             int *todo = A.wide_count;  // list 0
             todo[1 + atomicAdd(todo, 1)] = sidx;
