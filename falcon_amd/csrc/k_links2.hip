@@ -171,37 +171,46 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
                 v_ins = ta.ins_off;
                 ov = v_tc > v_ld && v_s2 < min(h0 + 64, t_hi) && v_s2 + v_tc > h0;
             }
-            struct Col { int u, ld; u32 insoff, w, wp; bool on; };
-            auto request = [&](int j) -> Col {
-                Col c;
-                const int s2 = __builtin_amdgcn_readlane(v_s2, j);
-                const int tc = __builtin_amdgcn_readlane(v_tc, j);
-                c.ld = __builtin_amdgcn_readlane(v_ld, j);
-                c.insoff = (u32)__builtin_amdgcn_readlane((int)v_ins, j);
-                const u64 doff = ((u64)(u32)__builtin_amdgcn_readlane((int)v_dhi, j) << 32) |
-                                 (u64)(u32)__builtin_amdgcn_readlane((int)v_dlo, j);
-                const u32 *dptr = A.desc + doff;
-                c.u = t - s2;
-                c.on = tin && c.u >= 0 && c.u < tc;  // the alignment has a column at my position
-                // (both words from every lane, the index clamped into the alignment's words -- the
-                // word before the first one is the slot in front of them: a fixed number of loads
-                // per request lets the wait for THIS alignment's words leave the next one's in flight)
-                const int iu = min(max(c.u, 0), tc - 1);
-                c.w = dptr[iu];
-                c.wp = dptr[iu - 1];
+            // the overlapping alignments four at a time: the tag words of the next four are
+            // under way while these four are worked in (one alignment ahead was not enough: a
+            // round of ~150 instructions is shorter than a trip to HBM)
+            struct Col4 { int u[4], ld[4]; u32 insoff[4], w[4], wp[4]; bool on[4], valid[4]; };
+            int j_last = 0;
+            auto request4 = [&](u64 &m) -> Col4 {
+                Col4 c;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    c.valid[q] = m != 0ull;
+                    if (c.valid[q]) j_last = (int)__builtin_ctzll(m);  // (else: the last one's words again)
+                    m &= m - 1;
+                    const int j = j_last;
+                    const int s2 = __builtin_amdgcn_readlane(v_s2, j);
+                    const int tc = __builtin_amdgcn_readlane(v_tc, j);
+                    c.ld[q] = __builtin_amdgcn_readlane(v_ld, j);
+                    c.insoff[q] = (u32)__builtin_amdgcn_readlane((int)v_ins, j);
+                    const u64 doff = ((u64)(u32)__builtin_amdgcn_readlane((int)v_dhi, j) << 32) |
+                                     (u64)(u32)__builtin_amdgcn_readlane((int)v_dlo, j);
+                    const u32 *dptr = A.desc + doff;
+                    c.u[q] = t - s2;
+                    c.on[q] = c.valid[q] && tin && c.u[q] >= 0 && c.u[q] < tc;  // the alignment has a column at my position
+                    // (both words from every lane, the index clamped into the alignment's words --
+                    // the word before the first one is the slot in front of them: a fixed number
+                    // of loads per request lets the wait for THESE words leave the next ones in flight)
+                    const int iu = min(max(c.u[q], 0), tc - 1);
+                    c.w[q] = dptr[iu];
+                    c.wp[q] = dptr[iu - 1];
+                }
                 return c;
             };
             u64 m = fa_ballot(ov);
             if (m == 0ull) continue;
-            Col cur = request((int)__builtin_ctzll(m));
-            m &= m - 1;
-            int j_last = 0;
+            Col4 cur = request4(m);
             for (;;) {
                 const bool more = m != 0ull;
-                if (more) j_last = (int)__builtin_ctzll(m);
-                const Col nxt = request(j_last);  // (the last round requests its own words again)
-                m &= m - 1;
-                if (cur.on) add_column(cur.u, cur.ld, cur.insoff, cur.w, cur.wp);
+                const Col4 nxt = request4(m);
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (cur.on[q]) add_column(cur.u[q], cur.ld[q], cur.insoff[q], cur.w[q], cur.wp[q]);
                 if (!more) break;
                 cur = nxt;
             }
