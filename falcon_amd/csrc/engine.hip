@@ -308,7 +308,9 @@ struct fa_batch {
     // MSA stage (k_msa.hip)
     DevBuf<FaTagAln> d_ta;
     DevBuf<u32> d_acc_first, d_desc, d_links;
-    DevBuf<int> d_tcov, d_tarr, d_score_ovf, d_seg_pile, d_seg_t0, d_wide;
+    DevBuf<int> d_tcov, d_seg_cnt, d_score_ovf, d_seg_pile, d_seg_t0, d_wide;
+    DevBuf<u32> d_seg_base, d_seg_first;
+    DevBuf<unsigned long long> d_bound;
     DevBuf<uint8_t> d_insb;
     DevBuf<u64> d_t_off, d_link_off, d_link_cap;
     DevBuf<FaTInfo> d_tinfo;
@@ -1269,10 +1271,12 @@ static int start_align(fa_batch *b, unsigned min_cov, double max_diff, int band,
     if (!b->msa_static) {
         std::vector<int> seg_pile, seg_t0;
         std::vector<u64> t_off(b->n_pile);
+        std::vector<u32> seg_first(b->n_pile + 1);
         seg_pile.reserve(n_seg); seg_t0.reserve(n_seg);
         u64 tt = 0;
         for (int p = 0; p < b->n_pile; p++) {
             t_off[p] = tt;
+            seg_first[p] = (u32)seg_pile.size();
             tt += (u64)b->pile[p].seed_len;
             for (int t0 = 0; t0 < b->pile[p].seed_len; t0 += TSEG) {
                 seg_pile.push_back(p);
@@ -1280,13 +1284,17 @@ static int start_align(fa_batch *b, unsigned min_cov, double max_diff, int band,
             }
         }
         if (b->d_seg_pile.alloc(n_seg + 1) || b->d_seg_t0.alloc(n_seg + 1) ||
-            b->d_wide.alloc(5 * (n_seg + 1) + 1) || b->d_t_off.alloc((size_t)b->n_pile + 1))
+            b->d_wide.alloc(5 * (n_seg + 1) + 1) || b->d_t_off.alloc((size_t)b->n_pile + 1) ||
+            b->d_seg_cnt.alloc(2 * n_seg + 2) || b->d_seg_base.alloc(2 * n_seg + 2) ||
+            b->d_seg_first.alloc((size_t)b->n_pile + 1) || b->d_bound.alloc((size_t)b->n_pile + 1))
             return -1;
         // (synchronous copies on the null stream; the context's streams are non-blocking,
         // so they do not wait for k_align)
         HIP_OK(hipMemcpy(b->d_seg_pile.p, seg_pile.data(), n_seg * sizeof(int), hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(b->d_seg_t0.p, seg_t0.data(), n_seg * sizeof(int), hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(b->d_t_off.p, t_off.data(), t_off.size() * sizeof(u64), hipMemcpyHostToDevice));
+        seg_first[b->n_pile] = (u32)seg_pile.size();
+        HIP_OK(hipMemcpy(b->d_seg_first.p, seg_first.data(), seg_first.size() * sizeof(u32), hipMemcpyHostToDevice));
         b->msa_static = true;
     }
     if (b->h_ta.resize((size_t)b->n_seq + 1) || b->h_acc_first.resize((size_t)b->n_pile + 1) ||
@@ -1387,7 +1395,6 @@ static int msa_stage(fa_batch *b) {
     }
     const u64 t_tot = b->run.t_tot;
     const size_t n_seg = b->run.n_seg;
-    const size_t tarr_ints = 3 * (size_t)(t_tot + (u64)b->n_pile);
     auto need = [&](auto &buf, size_t n) { return (buf.n < n) ? buf.alloc(n) : 0; };
     int rc2 = 0;
     rc2 |= need(b->d_ta, n_ta + 1);
@@ -1395,7 +1402,6 @@ static int msa_stage(fa_batch *b) {
     rc2 |= need(b->d_tcov, n_ta + 1);
     rc2 |= need(b->d_desc, (size_t)desc_tot + 8);
     rc2 |= need(b->d_insb, (size_t)ins_tot + 8);
-    rc2 |= need(b->d_tarr, tarr_ints + 8);
     rc2 |= need(b->d_tinfo, (size_t)t_tot + 8);
     rc2 |= need(b->d_links, (size_t)link_tot + 8);
     rc2 |= need(b->d_link_off, (size_t)b->n_pile);
@@ -1423,8 +1429,8 @@ static int msa_stage(fa_batch *b) {
     }
     FaMsaDev md;
     md.ta = b->d_ta.p; md.acc_first = b->d_acc_first.p; md.n_acc_total = (int)n_ta;
-    md.tcov = b->d_tcov.p; md.desc = b->d_desc.p; md.insb = b->d_insb.p; md.tarr = b->d_tarr.p;
-    md.tarr_bytes = tarr_ints * sizeof(int); md.t_off = b->d_t_off.p; md.tinfo = b->d_tinfo.p;
+    md.tcov = b->d_tcov.p; md.desc = b->d_desc.p; md.insb = b->d_insb.p; md.seg_cnt = b->d_seg_cnt.p;
+    md.seg_base = b->d_seg_base.p; md.seg_first = b->d_seg_first.p; md.bound = b->d_bound.p; md.t_off = b->d_t_off.p; md.tinfo = b->d_tinfo.p;
     md.links = b->d_links.p; md.link_off = b->d_link_off.p; md.link_cap = b->d_link_cap.p;
     md.lvl_nlink16 = b->d_lvl_nlink.p; md.score_ovf = b->d_score_ovf.p;
     md.score_out = b->d_score_out.p; md.seg_pile = b->d_seg_pile.p; md.seg_t0 = b->d_seg_t0.p;

@@ -158,8 +158,10 @@ struct FaMsaDev {
     int *tcov;
     u32 *desc;
     uint8_t *insb;
-    int *tarr;
-    size_t tarr_bytes;
+    int *seg_cnt;          // 2 ints per segment of TSEG positions (zeroed before k_tags)
+    u32 *seg_base;         // 2 per segment
+    const u32 *seg_first;  // [n_pile]
+    unsigned long long *bound;  // [n_pile]
     const u64 *t_off;
     FaTInfo *tinfo;
     u32 *links;

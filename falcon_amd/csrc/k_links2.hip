@@ -63,20 +63,24 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
     const int t_hi = min(T, t_lo + TSEG);
     if (A.score_out[p].err) return;
     const u32 *seedw = A.words + A.seq[pm.first].woff;
-    const FaTInfo *ti = A.tinfo + A.t_off[p];
+    FaTInfo *ti = A.tinfo + A.t_off[p];
     u32 *links = A.links + A.link_off[p];
     u16 *nlk = A.lvl_nlink16 + pm.node_off / 5;
     const u32 a0 = A.acc_first[p], a1 = A.acc_first[p + 1];
-    u32 out = fa_uni(ti[t_lo].link_start);
+    // the segment's first link slot and first level slot (k_sscan)
+    const u32 link0 = fa_uni(A.seg_base[2 * (size_t)sidx]);
+    u32 out = link0;
+    u32 lvl_next = fa_uni(A.seg_base[2 * (size_t)sidx + 1]);
     const bool unitig = A.first_links_back != 0;
-    bool overflow = A.links_old != 0;
+    const bool count_only = A.links_old != 0;  // k_links makes the links of every segment: only the position records here
+    bool overflow = false;
+    bool any_overflow = count_only;
+    unsigned long long bound = 0;  // sum of coverage x levels over my positions
 
-    for (int h0 = t_lo; h0 < t_hi && !A.links_old; h0 += 64) {
+    for (int h0 = t_lo; h0 < t_hi; h0 += 64) {
         const int t = h0 + lane;
         const bool tin = t < t_hi;
-        FaTInfo x;
-        x.lvl_start = 0; x.link_start = 0; x.cov = 0; x.nlev = 0;
-        if (tin) x = ti[t];
+        int cov = 0, maxn = 0;  // alignments with a column at my position, the longest insertion run behind one
         const u32 sb = tin ? fa_base_at(seedw, t) : 0u;
         const u32 sbp = (tin && t > 0) ? fa_base_at(seedw, t - 1) : 0u;
         fa_wave_sync();  // (the half before is done with the tables)
@@ -101,6 +105,7 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
             return r;
         };
         auto add_group = [&](int dl, u32 key, int slot) {
+            if (any_overflow) return;
             if (slot >= 0) {
                 const u32 d = dir[slot * 64 + lane];
                 dir[slot * 64 + lane] = (d & 0xffffu) ? d + 1u : (1u | (new_rank(dl) << 16));
@@ -121,6 +126,8 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
             const int nins = tag_nins(w);
             const u32 base0 = (w & TAG_DEL) ? 4u : sb;
             const bool nocol = ld != 0 && u == 0;  // only the leading insertion run, no delta-0 column
+            maxn = max(maxn, nins);
+            if (!nocol) cov++;  // (coverage counts delta-0 tags, falcon.c:357-360)
             if (!nocol) {
                 if (u == 0) {
                     // the alignment's first column: no previous node (p_t_pos == -1, falcon.c:434);
@@ -216,8 +223,22 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
             }
         }
 
-        // ---- a position's links: level by level, inside a level by rank
-        if (fa_ballot(overflow)) break;
+        // ---- the position's record (k_score1/2, k_backtrace and k_links read it): coverage,
+        // levels = 1 + its deepest insertion (slot 0 is always (t 0, delta 0); an uncovered
+        // position has none, and keeps no links), level slots in position order
+        const int nlev = cov > 0 ? 1 + maxn : (t == 0 && tin ? 1 : 0);
+        const int lsum = wave_incl_sum(nlev, lane);
+        FaTInfo x;
+        x.lvl_start = lvl_next + (u32)(lsum - nlev);
+        x.link_start = link0;
+        x.cov = (u16)min(cov, 65535);
+        x.nlev = (u16)nlev;
+        if (tin) ti[t] = x;
+        lvl_next += (u32)__builtin_amdgcn_readlane(lsum, 63);
+        bound += (unsigned long long)(min(cov, 65535) * nlev);
+        // ---- its links: level by level, inside a level by rank
+        any_overflow = any_overflow || fa_ballot(overflow) != 0ull;
+        if (any_overflow) continue;
         const u32 n0 = lvln & 255u, n1 = (lvln >> 8) & 255u, n2 = (lvln >> 16) & 255u, n3 = lvln >> 24;
         const u32 sum4 = n0 + n1 + n2 + n3;
         u32 deep = 0;  // groups of levels >= 4
@@ -259,7 +280,16 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
         }
         out += (u32)__builtin_amdgcn_readlane((int)gsum, 63);
     }
-    if (fa_ballot(overflow)) {
+    {   // what the pile's scores are bounded by
+        unsigned long long b = bound;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const u32 lo = (u32)__shfl((int)(u32)b, lane ^ o), hi = (u32)__shfl((int)(u32)(b >> 32), lane ^ o);
+            b += ((unsigned long long)hi << 32) | lo;
+        }
+        if (lane == 0) atomicAdd(&A.bound[p], b);
+    }
+    if (any_overflow) {
         // more groups than the tables hold: k_links takes the segment
         if (lane == 0) {
             int *todo = A.wide_count;  // list 0

@@ -47,7 +47,10 @@ struct MsaArgs {
     int *tcov;                 // [n_acc_total] covered target positions (k_tags)
     u32 *desc;                 // one tag word per covered target position
     uint8_t *insb;             // inserted bases of runs longer than INL (and all others)
-    int *tarr;                 // per pile 3 x (T+1): cov diff, max ins, sum ins
+    int *seg_cnt;              // per segment of TSEG positions: columns, inserted bases (k_tags)
+    u32 *seg_base;             // per segment: its first link slot, its first level slot (k_sscan)
+    const u32 *seg_first;      // [n_pile] a pile's first segment
+    unsigned long long *bound; // [n_pile] sum over the positions of coverage x levels: no score exceeds it (k_links2)
     const u64 *t_off;          // [n_pile] position offset of the pile's per-t arrays
     FaTInfo *tinfo;            // per target position
     u32 *links;                // link words

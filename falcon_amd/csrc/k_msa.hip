@@ -15,7 +15,7 @@
 //               array), each written exactly once.  Also accumulates, per target
 //               position, the coverage (difference array), the deepest insertion
 //               level and the number of tags.
-//   k_tscan     one wavefront per pile: prefix sums over target positions ->
+//   k_sscan     one wavefront per pile: prefix sums over the pile's segments ->
 //               level slot and link slot of every position (deterministic
 //               layout, node ids ascend in (t, delta) order).
 //   k_links     one wavefront per (pile, segment of 128 target positions):
@@ -80,9 +80,11 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
     const u32 *rw = A.words + A.seq[g].woff;
     u32 *desc = A.desc + ta.desc_off;
     uint8_t *insb = A.insb + ta.ins_off;
-    int *tarr = A.tarr + 3 * (A.t_off[ta.pile] + (u64)ta.pile);  // (T+1) entries per array
-    const int T1 = A.pile[ta.pile].seed_len + 1;
-    int *a_cov = tarr, *a_max = tarr + T1, *a_sum = tarr + 2 * T1;
+    // what the alignment adds to the segments of TSEG positions it touches: columns (delta 0
+    // tags) and inserted bases (tags of delta >= 1, counted at the position they hang off) --
+    // k_sscan sizes every segment's link and level slots from the two sums
+    int *segc = A.seg_cnt + 2 * (size_t)A.seg_first[ta.pile];
+    __shared__ u32 segl[16];  // inserted bases of a chunk, by segment
     const int dist = al.dist, te = al.t_e;
     // Tag words leave in whole lines: the target positions a chunk of 64 script rows
     // consumes are built in this LDS window (zeros, then the chunk's tags) and stored
@@ -190,6 +192,8 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
         __syncthreads();
         if (in_lds) { for (int i = lane; i < span; i += 64) win[i] = 0u; }
         else { for (int i = lane; i < span; i += 64) desc[w0 + i] = 0u; }
+        if (lane < 16) segl[lane] = 0u;
+        const int sg0 = max(0, rg.s2 + w0 - 1) / TSEG;  // the first segment a run of this chunk can hang off
         __syncthreads();
         // Every tag word has exactly one writer (no atomics): a deletion writes its
         // flag unless an insertion run hangs off the deleted base, in which case the
@@ -205,11 +209,17 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
             // (us == w0 - 1 lies in the window the previous chunk already stored: the
             // later store of the same wavefront to the same word wins)
             if (in_lds && us >= w0) win[us - w0] = word; else desc[us] = word;
-            atomicMax(&a_max[rg.s2 + us], delta);
-            atomicAdd(&a_sum[rg.s2 + us], delta);
+            // (rounds 1-3 kept the deepest run and the sum of the runs PER POSITION, two global
+            // atomics per run: 0.38 G per launch, two thirds of the kernel's HBM traffic.  The
+            // levels of a position are found by k_links2 now, and the slots only need sums per
+            // segment: the chunk's runs meet in LDS, a handful of atomics per chunk leave)
+            const int sg = (rg.s2 + us) / TSEG;
+            if (in_lds) atomicAdd(&segl[sg - sg0], (u32)delta);
+            else atomicAdd(&segc[2 * sg + 1], delta);
         }
         __syncthreads();
         if (in_lds) { for (int i = lane; i < span; i += 64) desc[w0 + i] = win[i]; }
+        if (lane < 16 && segl[lane] != 0u) atomicAdd(&segc[2 * (sg0 + lane) + 1], (int)segl[lane]);
         carry_t += __builtin_amdgcn_readlane(ts, 63);
         carry_q += __builtin_amdgcn_readlane(qs, 63);
         carry_i += __builtin_amdgcn_readlane(is, 63);
@@ -221,60 +231,58 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
     }
     // rows >= dcut are dropped: the alignment covers only what the kept rows consumed
     const int t_cov = (dcut <= dist) ? carry_t : te;
-    if (lane == 0) {
-        A.tcov[k] = t_cov | (lead ? TCOV_LEAD : 0);
-        atomicAdd(&a_cov[rg.s2], 1);
-        atomicAdd(&a_cov[rg.s2 + t_cov], -1);
+    if (lane == 0) A.tcov[k] = t_cov | (lead ? TCOV_LEAD : 0);
+    // its columns, per segment: positions [s2, s2 + t_cov)
+    if (t_cov > 0) {
+        const int sg_a = rg.s2 / TSEG, sg_b = (rg.s2 + t_cov - 1) / TSEG;
+        for (int sg = sg_a + lane; sg <= sg_b; sg += 64) {
+            const int lo = max(rg.s2, sg * TSEG), hi = min(rg.s2 + t_cov, (sg + 1) * TSEG);
+            atomicAdd(&segc[2 * sg], hi - lo);
+        }
     }
 }
 
 // ---------------------------------------------------------------------------
-// k_tscan: per pile prefix sums over target positions
+// k_sscan: per pile prefix sums over its segments of TSEG positions: where each segment's
+// links and levels begin.  A segment has room for every tag k_tags counted into it -- its
+// links are at most its tags; its levels at most its positions plus the inserted bases hanging
+// off them -- so the segments are independent of one another (k_links2 numbers the levels and
+// writes the links of a segment from these two starts; the gaps collect at the segments' ends).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_tscan(MsaArgs A) {
+__global__ __launch_bounds__(64) void k_sscan(MsaArgs A) {
     const int lane = fa_lane();
     const int p = blockIdx.x;
     if (p >= A.n_pile) return;
     const FaPile pm = A.pile[p];
-    const int T = pm.seed_len, T1 = T + 1;
-    const int *tarr = A.tarr + 3 * (A.t_off[p] + (u64)p);
-    const int *a_cov = tarr, *a_max = tarr + T1, *a_sum = tarr + 2 * T1;
-    FaTInfo *ti = A.tinfo + A.t_off[p];
-    int c_cov = 0;
+    const int T = pm.seed_len;
+    const u32 sf = A.seg_first[p];
+    const int n_sg = (T + TSEG - 1) / TSEG;
     u32 c_lvl = 0, c_link = 0;
-    long long score_bound = 0;  // no score exceeds the sum over levels of the coverage
-    for (int t0 = 0; t0 < T; t0 += 64) {
-        const int t = t0 + lane;
-        const bool have = t < T;
-        const int cd = have ? a_cov[t] : 0;
-        const int cov = c_cov + wave_incl_sum(cd, lane);
-        int nlev = 0, parts = 0;
-        if (have) {
-            nlev = cov > 0 ? 1 + a_max[t] : (t == 0 ? 1 : 0);  // slot 0 is always (t=0, delta=0)
-            parts = cov > 0 ? cov + a_sum[t] : 0;
+    for (int s0 = 0; s0 < n_sg; s0 += 64) {
+        const int sg = s0 + lane;
+        int links = 0, levels = 0;
+        if (sg < n_sg) {
+            const int cols = A.seg_cnt[2 * (size_t)(sf + (u32)sg)], ins = A.seg_cnt[2 * (size_t)(sf + (u32)sg) + 1];
+            links = cols + ins;
+            levels = min(TSEG, T - sg * TSEG) + ins;
         }
-        const int ls = wave_incl_sum(nlev, lane), ps = wave_incl_sum(parts, lane);
-        if (have) {
-            FaTInfo x;
-            x.lvl_start = c_lvl + (u32)(ls - nlev);
-            x.link_start = c_link + (u32)(ps - parts);
-            x.cov = (u16)min(cov, 65535);
-            x.nlev = (u16)nlev;
-            ti[t] = x;
+        const int ks = wave_incl_sum(links, lane), ls = wave_incl_sum(levels, lane);
+        if (sg < n_sg) {
+            A.seg_base[2 * (size_t)(sf + (u32)sg)] = c_link + (u32)(ks - links);
+            A.seg_base[2 * (size_t)(sf + (u32)sg) + 1] = c_lvl + (u32)(ls - levels);
         }
-        c_cov = __shfl(cov, 63);
+        c_link += (u32)__shfl(ks, 63);
         c_lvl += (u32)__shfl(ls, 63);
-        c_link += (u32)__shfl(ps, 63);
-        score_bound += (long long)__shfl(wave_incl_sum(min(cov, 65535) * nlev, lane), 63);
     }
     FaScoreOut so;
     so.g_node = -1; so.g_ck = 0; so.g_h = -2;
-    so.n_levels = (int)c_lvl;
+    so.n_levels = (int)c_lvl;   // (slots, not levels: k_links2 finds the levels)
     so.n_links = (int)c_link;
     so.err = ((u64)c_lvl * 5 > pm.node_cap || (u64)c_link > A.link_cap[p]) ? 1 : 0;
-    so.wide = score_bound >= SC_FAST_SCORE_MAX ? 1 : 0;
+    so.wide = 0;                // (k_score2 looks at the bound k_links2 sums up)
     so.redo = 0;
     A.score_out[p] = so;  // every lane stores the same record
+    A.bound[p] = 0ull;
 }
 // NCHT = 1: segments overlapped by <= 64 alignments (the normal case below 64x
 // coverage); wider segments put themselves on a to-do list that the NCHT = 8
@@ -792,7 +800,7 @@ static MsaArgs msa_args(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov
     A.words = b.words; A.seq = b.seq; A.pile = b.pile; A.range = b.range; A.aln = b.aln;
     A.script = b.script; A.script_off = b.script_off;
     A.ta = m.ta; A.acc_first = m.acc_first; A.n_acc_total = m.n_acc_total; A.n_pile = b.n_pile;
-    A.tcov = m.tcov; A.desc = m.desc; A.insb = m.insb; A.tarr = m.tarr; A.t_off = m.t_off;
+    A.tcov = m.tcov; A.desc = m.desc; A.insb = m.insb; A.seg_cnt = m.seg_cnt; A.seg_base = m.seg_base; A.seg_first = m.seg_first; A.bound = m.bound; A.t_off = m.t_off;
     A.tinfo = m.tinfo; A.links = m.links; A.link_off = m.link_off; A.link_cap = m.link_cap;
     A.lvl_nlink16 = m.lvl_nlink16; A.nodes = b.nodes;
     A.score_ovf = m.score_ovf; A.score_out = m.score_out;
@@ -812,9 +820,9 @@ void fa_launch_msa_front(const FaBatchDev &b, const FaMsaDev &m, unsigned min_co
                          hipEvent_t ev_tags, hipEvent_t ev_links) {
     if (b.n_pile == 0) return;
     MsaArgs A = msa_args(b, m, min_cov);
-    (void)hipMemsetAsync(m.tarr, 0, m.tarr_bytes, s);
+    (void)hipMemsetAsync(m.seg_cnt, 0, (size_t)m.n_seg * 2 * sizeof(int), s);
     if (m.n_acc_total > 0) hipLaunchKernelGGL(k_tags, dim3(m.n_acc_total), dim3(64), 0, s, A);
-    hipLaunchKernelGGL(k_tscan, dim3(b.n_pile), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(k_sscan, dim3(b.n_pile), dim3(64), 0, s, A);
     if (ev_tags) (void)hipEventRecord(ev_tags, s);
     if (m.n_seg > 0) {
         // (the list heads)

@@ -220,9 +220,13 @@ __global__ __launch_bounds__(64) void k_score1(MsaArgs A) {
         const int seg_end = (t0 / TSEG + 1) * TSEG;
         const bool fits = lane >= 1 && tl <= T && tl <= seg_end && (end_l - lvl0) <= SC_LEVELS &&
                           (end_k - lnk0) <= SC_LINKS;
-        int nb = __popcll(__ballot(fits));  // prefix sums are monotone, so is `fits`
-        const bool bulk = nb > 0;
-        if (!bulk) nb = 1;  // one oversized position: read straight from HBM
+        // (one position at a time, its link words read straight from HBM: the position records
+        // no longer carry a link slot per position -- only the segment's -- from which a block's
+        // extent in the link words could be bounded; this is the kernel behind k_score2, for
+        // the handful of piles that one hands on)
+        (void)fits;
+        const bool bulk = false;
+        int nb = 1;
         int nlk0 = 0;
         if ((t0 & (TSEG - 1)) == 0) lk_run = lnk0;
         lk_run = fa_uni(lk_run);

@@ -61,6 +61,8 @@ __global__ __launch_bounds__(64) void k_score2(MsaArgs A) {
     so.n_levels = fa_uni(so.n_levels); so.n_links = fa_uni(so.n_links);
     if (so.err) return;
     so.redo = 1;
+    // (no score exceeds the sum over the positions of coverage x levels, which k_links2 left)
+    so.wide = fa_uni((u32)(A.bound[p] >= (unsigned long long)SC_FAST_SCORE_MAX ? 1 : 0));
     if (so.wide || A.first_links_back) {
         A.score_out[p] = so;  // every lane stores the same record
         return;
@@ -82,7 +84,13 @@ __global__ __launch_bounds__(64) void k_score2(MsaArgs A) {
     }
     u32 best_s = S2_FLOOR;         // this lane's best node: biased score, node id, winning link
     int best_node = -1, best_ck = 0;
-    u32 carry_plvl = 0;            // first level slot of the position before the block
+    u32 carry_plvl = 0;            // first level slot of the position before the block,
+    u32 carry_nlev = 0;            // and its levels
+    // The scores' ring is addressed by a running count of the levels scored so far (times five,
+    // plus the base) -- NOT by the level slot: slots jump from segment to segment (every segment
+    // has room to spare behind its levels), the count does not, so the previous position's nodes
+    // and a block's own are 480 consecutive ring words wherever they lie in the node pool.
+    u32 rn = 0;                    // ring index of the block's first node
     u32 lk_run = 0;                // the block's first link word: k_links writes the links of a segment of TSEG
                                    // positions back to back from the segment's first link slot
     const bool slot0_empty = (tiw[2] & 0xffffu) == 0u;  // position 0 uncovered: its level slot has no links, and no count
@@ -119,7 +127,10 @@ __global__ __launch_bounds__(64) void k_score2(MsaArgs A) {
         const int seg_end = (t0 / TSEG + 1) * TSEG;
         int nl = (int)cur.nl;  // links of level slot lvl0 + lane
         const int nl_sum = wave_incl_sum(nl, lane);
-        const int lv_j = (int)(((tl < T) ? x_lvl : (u32)so.n_levels) - lvl0);  // levels of the first `lane` positions
+        // levels of the first `lane` positions: up to the end of the position before mine (the
+        // level slots of a segment are contiguous; behind its last position lies a gap)
+        const u32 end_j = x_lvl + (x_cn >> 16);
+        const int lv_j = (int)((u32)__builtin_amdgcn_update_dpp((int)lvl0, (int)end_j, 0x138, 0xf, 0xf, false) - lvl0);  // wave_shr:1
         const int lk_j = __shfl(nl_sum, max(0, min(lv_j, 64) - 1));               // and their links
         const bool fits = lane >= 1 && tl <= T && tl <= seg_end && lv_j <= S2_NL && (lv_j == 0 || lk_j <= S2_NK);
         const int nb = __popcll(__ballot(fits));  // prefix sums are monotone, so is `fits`
@@ -137,7 +148,8 @@ __global__ __launch_bounds__(64) void k_score2(MsaArgs A) {
             if (64 * q + lane < n_k) s2_at(L, S2_REC_B + 8u * (u32)(64 * q + lane) + 4u) = cur.lw[q];
         {   // the next block's extent is known: request its data
             const int t_nx = t0 + nb;
-            const u32 lvl_nx = lvl0 + (u32)n_l;
+            // (inside a segment the next block's levels follow this one's; a new segment has its own first slot)
+            const u32 lvl_nx = t_nx < T ? (u32)__builtin_amdgcn_readlane((int)x_lvl, nb & 63) : lvl0 + (u32)n_l;
             u32 lk_nx = lk_run + (u32)n_k;
             if ((t_nx & (TSEG - 1)) == 0) lk_nx = (u32)__builtin_amdgcn_readlane((int)x_link, nb & 63);  // (a new segment: its own link slot)
             cur = request(t_nx, lvl_nx, lk_nx);
@@ -160,11 +172,16 @@ __global__ __launch_bounds__(64) void k_score2(MsaArgs A) {
         const int cov_s = (int)(cn_s & 0xffffu);
         const int dl_s = (int)(lvl0 + (u32)lane - lvl_s);
         const u32 base5_s = (dl_s == 0 ? plvl_s : lvl_s) * 5u;  // node id of a link's predecessor = base5 + its index
+        // ... and its ring index = ring5 + that index: the position before the block's first
+        // one ends right below the block, whatever its slots are
+        const u32 ring5_s = rn + 5u * (dl_s == 0 ? (js == 0 ? 0u - carry_nlev : plvl_s - lvl0) : lvl_s - lvl0);
         const u32 upper_s = (u32)cov_s > min_cov ? 1u : 0u;     // falcon.c:498 (Q7)
-        const u32 node5 = (lvl0 + (u32)lane) * 5u;
+        const u32 node5 = (lvl0 + (u32)lane) * 5u;  // my level's first node, and its ring index
+        const u32 rnode5 = rn + 5u * (u32)lane;
         const int off = nl_sum - nl;  // (lanes < n_l)
         const int maxn = fa_wave_max(nl);
         carry_plvl = (u32)__builtin_amdgcn_readlane((int)x_lvl, nb - 1);
+        const u32 next_nlev = (u32)__builtin_amdgcn_readlane((int)x_cn, nb - 1) >> 16;
         if (maxn > 63) {
             A.score_out[p] = so;
             return;
@@ -173,7 +190,7 @@ __global__ __launch_bounds__(64) void k_score2(MsaArgs A) {
         // order inside a node: k_links).  Every node of the block starts at the floor.
         if (lane < n_l) {
 #pragma unroll
-            for (u32 b = 0; b < 5u; b++) s2_at(L, ((node5 + b) & (S2_RING - 1u)) << 2) = S2_FLOOR;
+            for (u32 b = 0; b < 5u; b++) s2_at(L, ((rnode5 + b) & (S2_RING - 1u)) << 2) = S2_FLOOR;
         }
         for (int k = 0; k < maxn; k++) {
             if (k < nl) {
@@ -183,8 +200,8 @@ __global__ __launch_bounds__(64) void k_score2(MsaArgs A) {
                 const u32 nbase = (w >> LW_NB_SHIFT) & 7u;
                 const u32 pidx = (w >> LW_PIDX_SHIFT) & 0x7ffu;
                 const bool start = (w >> LW_START_BIT) & 1u;
-                const u32 src = start ? (u32)S2_ZERO_B : (((base5_s + pidx) & (S2_RING - 1u)) << 2);
-                const u32 dst = ((node5 + nbase) & (S2_RING - 1u)) << 2;
+                const u32 src = start ? (u32)S2_ZERO_B : (((ring5_s + pidx) & (S2_RING - 1u)) << 2);
+                const u32 dst = ((rnode5 + nbase) & (S2_RING - 1u)) << 2;
                 s2_at(L, ra) = src | (dst << 16);
                 s2_at(L, ra + 4u) = (u32)(2 * cnt - cov_s);  // falcon.c:440-445, half units
             }
@@ -220,7 +237,6 @@ __global__ __launch_bounds__(64) void k_score2(MsaArgs A) {
         // ---- C: resolve.  Lane = level; its links in stored order.  A node's winner is the
         // first of its links that reaches the node's score, if that score beat the floor.
         {
-            const int lo = (int)(lvl0 * 5u) - 256;  // every node a record of this block names lies in [lo, lo + 512)
             u32 seen = 0;   // nodes (bit = base) met / resolved so far
             u32 won = 0;
             u32 cin = 0;    // links met per node, 6 bits each
@@ -229,7 +245,7 @@ __global__ __launch_bounds__(64) void k_score2(MsaArgs A) {
                     const u32 ra = S2_REC_B + 8u * (u32)(off + k);
                     const u32 w0 = s2_at(L, ra), cv = s2_at(L, ra + 4u);
                     const u32 src = w0 & 0xffffu, dst = w0 >> 16;
-                    const u32 nbase = ((dst >> 2) - node5) & (S2_RING - 1u);
+                    const u32 nbase = ((dst >> 2) - rnode5) & (S2_RING - 1u);
                     const u32 node = node5 + nbase;
                     const u32 bit = 1u << nbase;
                     const u32 sn = s2_at(L, dst);
@@ -241,7 +257,8 @@ __global__ __launch_bounds__(64) void k_score2(MsaArgs A) {
                     seen |= bit;
                     if (wins || stays) {
                         won |= bit;
-                        const int pid = (wins && src != (u32)S2_ZERO_B) ? lo + (int)(((src >> 2) - (u32)lo) & (S2_RING - 1u))
+                        // (the predecessor's node id from its ring index: its index at its position is the difference)
+                        const int pid = (wins && src != (u32)S2_ZERO_B) ? (int)(base5_s + (((src >> 2) - ring5_s) & (S2_RING - 1u)))
                                                                         : (wins ? -1 : 0);
                         s2_u32x2 r;
                         r.x = sn - S2_BIAS;
@@ -259,6 +276,8 @@ __global__ __launch_bounds__(64) void k_score2(MsaArgs A) {
         }
         t0 += nb;
         lk_run += (u32)n_k;
+        rn = (rn + 5u * (u32)n_l) & (S2_RING - 1u);
+        carry_nlev = next_nlev;
     }
     // global best = first strict maximum in (t, delta, base) order (falcon.c:464-469): the
     // highest score, among equals the lowest node id

@@ -84,6 +84,7 @@ extern "C" int emu_msa(const u32 *words_in, u64 n_words, const FaSeq *seq_in, in
     std::vector<u32> acc_first(n_pile + 1);
     std::vector<u64> link_off(n_pile), link_cap(n_pile), t_off(n_pile);
     std::vector<int> seg_pile, seg_t0;
+    std::vector<u32> seg_first(n_pile + 1);
     u64 node_off = 0, desc_tot = 4, ins_tot = 0, link_tot = 0, t_tot = 0, out = 0;
     for (int p = 0; p < n_pile; p++) {
         FaPile &pm = pile_io[p];
@@ -113,15 +114,16 @@ extern "C" int emu_msa(const u32 *words_in, u64 n_words, const FaSeq *seq_in, in
         link_cap[p] = cols;
         link_tot += cols;
         t_off[p] = t_tot;
+        seg_first[p] = (u32)seg_pile.size();
         t_tot += (u64)pm.seed_len;
         for (int t0 = 0; t0 < pm.seed_len; t0 += TSEG) { seg_pile.push_back(p); seg_t0.push_back(t0); }
         pm.out_off = out;
         out += 2 * (u64)pm.seed_len + 4;
     }
     acc_first[n_pile] = (u32)ta.size();
+    seg_first[n_pile] = (u32)seg_pile.size();
     if (out > out_slots || (nodes_out && node_off > nodes_cap)) return -2;
     const size_t n_ta = ta.size(), n_seg = seg_pile.size();
-    const size_t tarr_ints = 3 * (size_t)(t_tot + (u64)n_pile);
 
     // ---- "device" buffers
     GBuf<u32> d_words(n_words), d_script(n_script + 8), d_desc(desc_tot + 8), d_links(link_tot + 8), d_acc_first(n_pile + 1);
@@ -131,7 +133,9 @@ extern "C" int emu_msa(const u32 *words_in, u64 n_words, const FaSeq *seq_in, in
     GBuf<FaAln> d_aln(n_seq);
     GBuf<u64> d_script_off(n_seq), d_t_off(n_pile + 1), d_link_off(n_pile), d_link_cap(n_pile);
     GBuf<FaTagAln> d_ta(n_ta + 1);
-    GBuf<int> d_tcov(n_ta + 1), d_tarr(tarr_ints + 8, 0), d_seg_pile(n_seg + 1), d_seg_t0(n_seg + 1), d_wide(5 * (n_seg + 1) + 1, 0);
+    GBuf<int> d_tcov(n_ta + 1), d_seg_cnt(2 * n_seg + 2, 0), d_seg_pile(n_seg + 1), d_seg_t0(n_seg + 1), d_wide(5 * (n_seg + 1) + 1, 0);
+    GBuf<u32> d_seg_base(2 * n_seg + 2), d_seg_first(n_pile + 1);
+    GBuf<unsigned long long> d_bound(n_pile + 1);
     GBuf<uint8_t> d_insb(ins_tot + 8);
     GBuf<FaTInfo> d_tinfo(t_tot + 8);
     GBuf<u16> d_lvl_nlink(node_off / 5 + 8);
@@ -151,6 +155,7 @@ extern "C" int emu_msa(const u32 *words_in, u64 n_words, const FaSeq *seq_in, in
     memcpy(d_link_off.get(), link_off.data(), (size_t)n_pile * sizeof(u64));
     memcpy(d_link_cap.get(), link_cap.data(), (size_t)n_pile * sizeof(u64));
     memcpy(d_acc_first.get(), acc_first.data(), (size_t)(n_pile + 1) * sizeof(u32));
+    memcpy(d_seg_first.get(), seg_first.data(), (size_t)(n_pile + 1) * sizeof(u32));
     if (n_ta) memcpy(d_ta.get(), ta.data(), n_ta * sizeof(FaTagAln));
     if (n_seg) {
         memcpy(d_seg_pile.get(), seg_pile.data(), n_seg * sizeof(int));
@@ -162,7 +167,8 @@ extern "C" int emu_msa(const u32 *words_in, u64 n_words, const FaSeq *seq_in, in
     A.words = d_words.get(); A.seq = d_seq.get(); A.pile = d_pile.get(); A.range = d_range.get(); A.aln = d_aln.get();
     A.script = d_script.get(); A.script_off = d_script_off.get();
     A.ta = d_ta.get(); A.acc_first = d_acc_first.get(); A.n_acc_total = (int)n_ta; A.n_pile = n_pile;
-    A.tcov = d_tcov.get(); A.desc = d_desc.get(); A.insb = d_insb.get(); A.tarr = d_tarr.get(); A.t_off = d_t_off.get();
+    A.tcov = d_tcov.get(); A.desc = d_desc.get(); A.insb = d_insb.get(); A.seg_cnt = d_seg_cnt.get(); A.seg_base = d_seg_base.get();
+    A.seg_first = d_seg_first.get(); A.bound = d_bound.get(); A.t_off = d_t_off.get();
     A.tinfo = d_tinfo.get(); A.links = d_links.get(); A.link_off = d_link_off.get(); A.link_cap = d_link_cap.get();
     A.lvl_nlink16 = d_lvl_nlink.get(); A.nodes = d_nodes.get();
     A.score_ovf = nullptr; A.score_out = d_score_out.get();
@@ -174,7 +180,7 @@ extern "C" int emu_msa(const u32 *words_in, u64 n_words, const FaSeq *seq_in, in
 
     simt::g_wave.n_sync = 0;
     if (n_ta) simt::launch("k_tags", (unsigned)n_ta, [&] { k_tags(A); });
-    simt::launch("k_tscan", (unsigned)n_pile, [&] { k_tscan(A); });
+    simt::launch("k_sscan", (unsigned)n_pile, [&] { k_sscan(A); });
     if (n_seg) {
         A.links_old = getenv("EMU_MSA_LINKS1") ? 1 : 0;
         simt::launch("k_links2", (unsigned)n_seg, [&] { k_links2(A); });

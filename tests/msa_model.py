@@ -36,11 +36,14 @@ class Graph:
         self.lv = collections.defaultdict(lambda: collections.defaultdict(collections.OrderedDict))
         self.order = collections.defaultdict(list)  # (t, delta) -> [(base, link key)] in first-insertion order
         self.max_delta = [0] * T
+        self.ins_at = [0] * T   # inserted bases hanging off a position, over all alignments
 
     def add(self, tags):
         for (t, d, b, pt, pd, pb) in tags:
             if d == 0:
                 self.cov[t] += 1
+            else:
+                self.ins_at[t] += 1
             self.max_delta[t] = max(self.max_delta[t], d)
             node = self.lv[(t, d)][_B[b]]
             key = (pt, pd, _B[pb])
@@ -48,17 +51,28 @@ class Graph:
                 self.order[(t, d)].append((_B[b], key))
             node[key] = node.get(key, 0) + 1
 
-    def layout(self):
-        """Level slots and link offsets the way k_tscan lays them out."""
+    def layout(self, tseg=128):
+        """Level slots and link slots the way k_sscan / k_links2 lay them out: every segment of
+        `tseg` positions starts where the one before it would end if every tag were a link of
+        its own (links) and every inserted base a level of its own (levels); inside a segment
+        the levels follow one another in position order.  -> (first level slot per position,
+        the segment's first link slot per position, levels per position, level slots, link slots)"""
         lvl_start, link_start, nlev = [], [], []
-        ls = ks = 0
-        for t in range(self.T):
-            n = (1 + self.max_delta[t]) if self.cov[t] > 0 else (1 if t == 0 else 0)
-            parts = sum(sum(c for c in node.values()) for d in range(n) for node in self.lv.get((t, d), {}).values()) \
-                if self.cov[t] > 0 else 0
-            lvl_start.append(ls); link_start.append(ks); nlev.append(n)
-            ls += n; ks += parts
-        return lvl_start, link_start, nlev, ls, ks
+        seg_lvl = seg_link = 0
+        for s0 in range(0, self.T, tseg):
+            ts = range(s0, min(self.T, s0 + tseg))
+            ls = seg_lvl
+            for t in ts:
+                n = (1 + self.max_delta[t]) if self.cov[t] > 0 else (1 if t == 0 else 0)
+                lvl_start.append(ls); link_start.append(seg_link); nlev.append(n)
+                ls += n
+            ins = self._ins_tags(s0, min(self.T, s0 + tseg))
+            seg_lvl += len(ts) + ins
+            seg_link += sum(self.cov[t] for t in ts) + ins
+        return lvl_start, link_start, nlev, seg_lvl, seg_link
+
+    def _ins_tags(self, lo, hi):
+        return sum(self.ins_at[t] for t in range(lo, hi))
 
     def link_words(self, t, d, lvl_start):
         """The level's link words in k_links' order: first-insertion order over the whole level

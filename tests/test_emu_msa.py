@@ -54,7 +54,7 @@ def check_stages(st, pile, min_cov, todo=None):
     G = model_of(st, pile)
     ls, ks, nlev, n_lvl, n_lnk = G.layout()
     ti = graph["tinfo"]
-    for t in range(G.T):  # k_tags + k_tscan
+    for t in range(G.T):  # k_tags' segment sums + k_sscan + k_links2's position records
         assert (int(ti[t]["lvl_start"]), int(ti[t]["link_start"]), int(ti[t]["cov"]), int(ti[t]["nlev"])) == \
             (ls[t], ks[t], min(G.cov[t], 65535), nlev[t]), t
     assert (int(so[0]["n_levels"]), int(so[0]["n_links"])) == (n_lvl, n_lnk)
