@@ -105,7 +105,6 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
             return r;
         };
         auto add_group = [&](int dl, u32 key, int slot) {
-            if (any_overflow) return;
             if (slot >= 0) {
                 const u32 d = dir[slot * 64 + lane];
                 dir[slot * 64 + lane] = (d & 0xffffu) ? d + 1u : (1u | (new_rank(dl) << 16));
@@ -122,12 +121,13 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
         };
         // what a column of an alignment adds to my position: its tag word w, the tag word wp of
         // the column before it (falcon.c:126-160)
-        auto add_column = [&](int u, int ld, u32 insoff, u32 w, u32 wp) {
+        auto add_column = [&](int u, int ld, u32 insoff, u32 w, u32 wp, bool groups) {
             const int nins = tag_nins(w);
             const u32 base0 = (w & TAG_DEL) ? 4u : sb;
             const bool nocol = ld != 0 && u == 0;  // only the leading insertion run, no delta-0 column
             maxn = max(maxn, nins);
             if (!nocol) cov++;  // (coverage counts delta-0 tags, falcon.c:357-360)
+            if (!groups) return;
             if (!nocol) {
                 if (u == 0) {
                     // the alignment's first column: no previous node (p_t_pos == -1, falcon.c:434);
@@ -216,8 +216,43 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
                 const bool more = m != 0ull;
                 const Col4 nxt = request4(m);
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                    if (cur.on[q]) add_column(cur.u[q], cur.ld[q], cur.insoff[q], cur.w[q], cur.wp[q]);
+                for (int q = 0; q < 4; q++) {
+                    // Nearly every column is a plain one: not the alignment's first, at most one
+                    // inserted base behind it and behind the column before it.  Its one or two
+                    // groups have slots of their own; that path is written without a branch per
+                    // case (selects), the rest is behind one test.
+                    const u32 w = cur.w[q], wp = cur.wp[q];
+                    const u32 nins = (w >> TAG_NINS_SHIFT) & 0xffu, pn = (wp >> TAG_NINS_SHIFT) & 0xffu;
+                    const bool plain = cur.on[q] && cur.u[q] > 0 && nins <= 1u && pn <= 1u;
+                    if (plain) {
+                        const u32 del = w >> 31;
+                        const u32 pb = pn ? (wp & 3u) : ((wp >> 31) ? 4u : sbp);
+                        const u32 slot0 = pn ? 4u + del * 4u + pb : del * 2u + (pb >> 2);
+                        cov++;
+                        maxn = max(maxn, (int)nins);
+                        if (!any_overflow) {
+                            {
+                                const u32 d = dir[slot0 * 64u + (u32)lane];
+                                const bool fresh = (d & 0xffffu) == 0u;
+                                const u32 r = lvln & 255u;
+                                overflow = overflow || (fresh && r == 255u);
+                                dir[slot0 * 64u + (u32)lane] = fresh ? (1u | (r << 16)) : d + 1u;
+                                lvln += fresh ? 1u : 0u;
+                            }
+                            if (nins) {
+                                const u32 slot1 = 12u + del * 4u + (w & 3u);
+                                const u32 d = dir[slot1 * 64u + (u32)lane];
+                                const bool fresh = (d & 0xffffu) == 0u;
+                                const u32 r = (lvln >> 8) & 255u;
+                                overflow = overflow || (fresh && r == 255u);
+                                dir[slot1 * 64u + (u32)lane] = fresh ? (1u | (r << 16)) : d + 1u;
+                                lvln += fresh ? 256u : 0u;
+                            }
+                        }
+                    } else if (cur.on[q]) {
+                        add_column(cur.u[q], cur.ld[q], cur.insoff[q], w, wp, !any_overflow);
+                    }
+                }
                 if (!more) break;
                 cur = nxt;
             }
