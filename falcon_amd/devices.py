@@ -35,23 +35,33 @@ class DevicePool:
     # device: enough to keep the device busy, bounded however many producers there are
     MAX_QUEUED = 5
 
-    def __init__(self, engines):
+    def __init__(self, engines, grow=None):
+        """grow: optional callable -> a further engine or None; asked when every device has
+        MAX_QUEUED batches waiting (the single-stream worker starts on one GPU and takes another
+        one only when that one is the bottleneck AND the other one is nobody's)."""
         self.devices = [Device(e, i) for i, e in enumerate(engines)]
         self._lock = threading.Condition()
         self._next = 0
+        self._grow = grow
 
     def take(self) -> Device:
         """The device with the least work queued (round robin among equals); waits while
         every device has MAX_QUEUED batches waiting."""
         with self._lock:
-            n = len(self.devices)
             while True:
+                n = len(self.devices)
                 order = [self.devices[(self._next + i) % n] for i in range(n)]
                 dev = min(order, key=lambda d: d.queued)
                 if dev.queued < self.MAX_QUEUED:
                     break
+                if self._grow is not None:
+                    engine = self._grow()
+                    if engine is not None:
+                        self.devices.append(Device(engine, n))
+                        continue
+                    self._grow = None  # (nothing left to take: do not ask again at every batch)
                 self._lock.wait()
-            self._next = (dev.index + 1) % n
+            self._next = (dev.index + 1) % len(self.devices)
             dev.queued += 1
             dev.batches += 1
             return dev
@@ -66,18 +76,92 @@ class DevicePool:
             d.engine.close()
 
 
-def open_engines():
-    """One engine per visible GPU (FALCON_AMD_DEVICES narrows the list), times
-    FALCON_AMD_ENGINES_PER_DEVICE.  Raises without a HIP device: there is no CPU fallback."""
-    from falcon_amd.engine import Engine
+# ---- which GPU does a job take ------------------------------------------------------------
+# fc_run starts one consensus job per LA4Falcon block, several at a time
+# (falcon_kit/mains/consensus_split.py:55-85, run1.py:450), and the reference's worker sizes
+# itself from --n-core alone (consensus.py:258-264).  A job whose single ingest thread cannot
+# feed even one MI355X must not open a context -- arena, streams, planner thread -- on every
+# GPU of the node: by default it takes ONE, chosen so that jobs started together spread over
+# the node.  Advisory locks, no HIP call (looking at a device's memory would create the very
+# context this is about): slot k of device d is the file falcon_amd.dev<d>.slot<k>; a job
+# takes the first free (d, k) in the order k = 0, 1, ... and, inside a k, d from pid mod n on.
+# Eight jobs on eight GPUs hold eight different slot-0 locks; the ninth gets slot 1 somewhere.
+# The lock lives as long as the process (flock: the kernel drops it with the descriptor).
+_held_locks = []
+
+
+def _lock_dir():
+    d = os.environ.get("FALCON_AMD_LOCK_DIR") or os.path.join(os.environ.get("TMPDIR", "/tmp"), "falcon_amd.locks")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def _try_lock(dev, slot):
+    import fcntl
+    fd = os.open(os.path.join(_lock_dir(), "falcon_amd.dev%d.slot%d" % (dev, slot)), os.O_CREAT | os.O_RDWR, 0o666)
+    try:
+        fcntl.flock(fd, fcntl.LOCK_EX | fcntl.LOCK_NB)
+    except OSError:
+        os.close(fd)
+        return False
+    _held_locks.append(fd)
+    return True
+
+
+def choose_device(devices, max_slots=64, idle_only=False, skip=()):
+    """One of `devices` (device ids): the first whose slot is free, slots in the order above.
+    idle_only: only a device nobody holds (slot 0) -- None if there is none."""
+    n = len(devices)
+    first = os.getpid() % n
+    order = [devices[(first + i) % n] for i in range(n) if devices[(first + i) % n] not in skip]
+    for slot in range(1 if idle_only else max_slots):
+        for d in order:
+            if _try_lock(d, slot):
+                return d
+    return None if idle_only or not order else order[0]
+
+
+def visible_devices():
     from falcon_amd.lib import load
     n_dev = load().fa_device_count()
     if n_dev <= 0:
         raise RuntimeError("falcon_amd: no HIP device visible (there is no CPU fallback)")
+    return list(range(n_dev))
+
+
+def open_engines(all_devices=False):
+    """The engines of a worker.  FALCON_AMD_DEVICES=<ids> names them (one engine per id, times
+    FALCON_AMD_ENGINES_PER_DEVICE); FALCON_AMD_DEVICES=all or all_devices=True (the
+    multi-stream worker, which has the streams to feed them) takes every visible GPU; otherwise
+    ONE GPU, chosen so that jobs started together spread over the node (choose_device).
+    Raises without a HIP device: there is no CPU fallback."""
+    from falcon_amd.engine import Engine
+    devices = visible_devices()
     env = os.environ.get("FALCON_AMD_DEVICES")
-    devices = [int(x) for x in env.split(",")] if env else list(range(n_dev))
+    if env and env != "all":
+        devices = [int(x) for x in env.split(",")]
+    elif not (all_devices or env == "all"):
+        devices = [choose_device(devices)]
     per_gpu = max(1, int(os.environ.get("FALCON_AMD_ENGINES_PER_DEVICE", "1")))
     return [Engine(d) for d in devices for _ in range(per_gpu)]
+
+
+def open_pool():
+    """The single-stream worker's devices: one GPU (open_engines), and a way to a second one --
+    only an idle one, only when the first one's queue stays full (DevicePool.take)."""
+    engines = open_engines()
+    grow = None
+    if not os.environ.get("FALCON_AMD_DEVICES"):
+        from falcon_amd.engine import Engine
+        mine = [e.device for e in engines]
+
+        def grow():
+            d = choose_device(visible_devices(), idle_only=True, skip=mine)
+            if d is None:
+                return None
+            mine.append(d)
+            return Engine(d)
+    return DevicePool(engines, grow)
 
 
 class EngineBackend:

@@ -246,9 +246,10 @@ class GpuConsensus:
     consensus stage of one beside the index, chaining and alignment of the next."""
 
     def __init__(self, min_cov, min_idt, engines=None, batch_bases=400_000_000, backend=None):
-        from falcon_amd.devices import DevicePool, EngineBackend, SharedGpu, open_engines
-        engines = open_engines() if engines is None else engines
-        self.pool = DevicePool(engines)
+        from falcon_amd.devices import DevicePool, EngineBackend, SharedGpu, open_pool
+        # (no engines given: ONE GPU, chosen so that the jobs fc_run starts together spread over
+        # the node; another one only when this one's queue stays full and that one is idle)
+        self.pool = open_pool() if engines is None else DevicePool(engines)
         self.shared = SharedGpu(self.pool, backend or EngineBackend(min_cov, min_idt))
         self.engines = self.shared.engines
         self.parallel = self.shared.parallel

@@ -117,7 +117,7 @@ def run(args, pool=None, backend=None):
         # engines (contexts, each with its own streams and work slots) per GPU:
         # FALCON_AMD_ENGINES_PER_DEVICE (1: an engine already keeps two batches in flight, the
         # sequential stages of one beside the throughput stages of the next)
-        pool = DevicePool(open_engines())
+        pool = DevicePool(open_engines(all_devices=True))  # (several streams: they can feed every GPU)
     if backend is None:
         backend = EngineBackend(args.min_cov, args.min_idt)
     LOG.info("falcon_amd consensus: %d job(s) on %d GPU(s)", len(args.jobs), len(pool.devices))
