@@ -1284,7 +1284,7 @@ static int start_align(fa_batch *b, unsigned min_cov, double max_diff, int band,
             }
         }
         if (b->d_seg_pile.alloc(n_seg + 1) || b->d_seg_t0.alloc(n_seg + 1) ||
-            b->d_wide.alloc(5 * (n_seg + 1) + 1) || b->d_t_off.alloc((size_t)b->n_pile + 1) ||
+            b->d_wide.alloc(6 * (n_seg + 1) + 1) || b->d_t_off.alloc((size_t)b->n_pile + 1) ||
             b->d_seg_cnt.alloc(2 * n_seg + 2) || b->d_seg_base.alloc(2 * n_seg + 2) ||
             b->d_seg_first.alloc((size_t)b->n_pile + 1) || b->d_bound.alloc((size_t)b->n_pile + 1))
             return -1;

@@ -13,8 +13,8 @@ typedef uint16_t u16;
 #define FA_IDX_STRIDE 65540    // u32 per pile for the CSR table (65537 used, padded)
 #define FA_BAND 150            // falcon.c:624 INDEL_ALLOWENCE_2
 #define FA_ALIGN_MAXCH 3       // 64-lane chunks per band row (<= 191 diagonals)
-#define FA_CNS_MAX_ALN 1023    // accepted alignments per pile the MSA kernels handle (10-bit link counts,
-                               // 16 lane chunks in k_links); a deeper pile is reported, alone
+#define FA_CNS_MAX_ALN 65534   // accepted alignments per pile the MSA kernels handle (16-bit link counts, like
+                               // the reference's, falcon.c:86); a deeper pile is reported, alone
 
 struct FaSeq {
     u32 woff;   // offset into words[]

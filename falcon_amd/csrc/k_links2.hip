@@ -30,8 +30,10 @@
 #include "k_msa.h"
 
 #define L2_DIR 20    // groups with a slot of their own, per position
-#define L2_POOL 256  // listed groups per 64 positions (entries of the lanes' linked lists)
-#define L2_NIL 0xffu
+#define L2_POOL 256   // listed groups per 64 positions (entries of the lanes' linked lists)
+#define L2_POOL_BIG 4096  // ... of the second instance, which takes the segments the first cannot hold (piles of
+                          // a thousand reads list a few dozen groups at every position)
+#define L2_NIL 0xffffu
 
 // base `d` (1-based) of a tag's insertion run
 __device__ __forceinline__ u32 l2_ins_base(const MsaArgs &A, u32 ins_off, u32 w, int d) {
@@ -48,14 +50,14 @@ __device__ __forceinline__ u32 l2_word(u32 key) {
     return (nb << LW_NB_SHIFT) | (((key >> 14) & 1u) ? (1u << LW_START_BIT) : ((pd * 5u + pb) << LW_PIDX_SHIFT));
 }
 
-__global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
+template <int POOL>
+__device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
     __shared__ u32 dir[L2_DIR * 64];               // count | rank in level << 16
     // the listed groups: a pool shared by the wavefront's 64 positions, a linked list per lane
-    __shared__ u32 pk[L2_POOL], pc[L2_POOL];       // key | level << 16 | next << 24 ; count | rank << 16
+    __shared__ u32 pk[POOL], pc[POOL];             // key | level << 16 ; count | rank << 16
+    __shared__ u16 pnx[POOL];                      // the next entry of the list
     __shared__ u32 pool_n;
     const int lane = fa_lane();
-    const int sidx = blockIdx.x;
-    if (sidx >= A.n_seg) return;
     const int p = fa_uni(A.seg_pile[sidx]);
     const int t_lo = fa_uni(A.seg_t0[sidx]);
     const FaPile pm = A.pile[p];
@@ -72,9 +74,10 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
     u32 out = link0;
     u32 lvl_next = fa_uni(A.seg_base[2 * (size_t)sidx + 1]);
     const bool unitig = A.first_links_back != 0;
-    const bool count_only = A.links_old != 0;  // k_links makes the links of every segment: only the position records here
+    // (the second instance only runs what the first one handed on, which left the records)
+    const bool count_only = A.links_old != 0 && POOL == L2_POOL;  // k_links makes the links of every segment: only the position records here
     bool overflow = false;
-    bool any_overflow = count_only;
+    bool any_overflow = A.links_old != 0;
     unsigned long long bound = 0;  // sum of coverage x levels over my positions
 
     for (int h0 = t_lo; h0 < t_hi; h0 += 64) {
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
                 return r;
             }
             u32 r = 0;
-            for (u32 e = head; e != L2_NIL; e = pk[e] >> 24) r += ((pk[e] >> 16) & 255u) == (u32)dl ? 1u : 0u;
+            for (u32 e = head; e != L2_NIL; e = pnx[e]) r += ((pk[e] >> 16) & 255u) == (u32)dl ? 1u : 0u;
             return r;
         };
         auto add_group = [&](int dl, u32 key, int slot) {
@@ -111,12 +114,13 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
                 return;
             }
             const u32 k = ((u32)dl << 16) | key;
-            for (u32 e = head; e != L2_NIL; e = pk[e] >> 24)
-                if ((pk[e] & 0xffffffu) == k) { pc[e] += 1u; return; }
-            const u32 e = dl > 255 ? (u32)L2_POOL : atomicAdd(&pool_n, 1u);
-            if (e >= (u32)L2_POOL || e == L2_NIL) { overflow = true; return; }
+            for (u32 e = head; e != L2_NIL; e = pnx[e])
+                if (pk[e] == k) { pc[e] += 1u; return; }
+            const u32 e = dl > 255 ? (u32)POOL : atomicAdd(&pool_n, 1u);
+            if (e >= (u32)POOL) { overflow = true; return; }
             pc[e] = 1u | (new_rank(dl) << 16);
-            pk[e] = k | (head << 24);
+            pk[e] = k;
+            pnx[e] = (u16)head;
             head = e;
         };
         // what a column of an alignment adds to my position: its tag word w, the tag word wp of
@@ -277,14 +281,14 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
         const u32 n0 = lvln & 255u, n1 = (lvln >> 8) & 255u, n2 = (lvln >> 16) & 255u, n3 = lvln >> 24;
         const u32 sum4 = n0 + n1 + n2 + n3;
         u32 deep = 0;  // groups of levels >= 4
-        for (u32 e = head; e != L2_NIL; e = pk[e] >> 24) deep += ((pk[e] >> 16) & 255u) >= 4u ? 1u : 0u;
+        for (u32 e = head; e != L2_NIL; e = pnx[e]) deep += ((pk[e] >> 16) & 255u) >= 4u ? 1u : 0u;
         const u32 gtot = (tin && x.cov != 0) ? sum4 + deep : 0u;  // (an uncovered position keeps no links, k_tscan)
         const u32 gsum = (u32)wave_incl_sum((int)gtot, lane);
         const u32 base = out + gsum - gtot;
         auto level_off = [&](u32 dl) -> u32 {
             if (dl < 4u) return dl == 0u ? 0u : dl == 1u ? n0 : dl == 2u ? n0 + n1 : n0 + n1 + n2;
             u32 o = sum4;
-            for (u32 e = head; e != L2_NIL; e = pk[e] >> 24) {
+            for (u32 e = head; e != L2_NIL; e = pnx[e]) {
                 const u32 de = (pk[e] >> 16) & 255u;
                 o += (de >= 4u && de < dl) ? 1u : 0u;
             }
@@ -302,14 +306,14 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
                     links[base + level_off(dl) + (d >> 16)] = l2_word(key) | (d & 0xffffu);
                 }
             }
-            for (u32 e = head; e != L2_NIL; e = pk[e] >> 24) {
+            for (u32 e = head; e != L2_NIL; e = pnx[e]) {
                 const u32 k = pk[e], c = pc[e];
                 links[base + level_off((k >> 16) & 255u) + (c >> 16)] = l2_word(k & 0xffffu) | (c & 0xffffu);
             }
             for (u32 dl = 0; dl < (u32)x.nlev; dl++) {  // links per level slot
                 u32 n = dl == 0u ? n0 : dl == 1u ? n1 : dl == 2u ? n2 : dl == 3u ? n3 : 0u;
                 if (dl >= 4u)
-                    for (u32 e = head; e != L2_NIL; e = pk[e] >> 24) n += ((pk[e] >> 16) & 255u) == dl ? 1u : 0u;
+                    for (u32 e = head; e != L2_NIL; e = pnx[e]) n += ((pk[e] >> 16) & 255u) == dl ? 1u : 0u;
                 nlk[x.lvl_start + dl] = (u16)n;
             }
         }
@@ -325,16 +329,32 @@ __global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
         if (lane == 0) atomicAdd(&A.bound[p], b);
     }
     if (any_overflow) {
-        // more groups than the tables hold: k_links takes the segment
+        // more groups than the tables hold: the instance with the large pool takes the segment,
+        // and behind that one k_links
         if (lane == 0) {
-            int *todo = A.wide_count;  // list 0
+            int *todo = A.wide_count + (POOL == L2_POOL ? 0 : 1) * (A.n_seg + 1);
             todo[1 + atomicAdd(todo, 1)] = sidx;
         }
+    }
+}
+
+// one wavefront per segment
+__global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
+    if ((int)blockIdx.x < A.n_seg) links2_segment<L2_POOL>(A, (int)blockIdx.x);
+}
+// a fixed grid looping over the first instance's to-do list (usually empty)
+__global__ __launch_bounds__(64) void k_links2_big(MsaArgs A) {
+    const int *in = A.wide_count;
+    const int n_in = fa_uni(in[0]);
+    for (int i = (int)blockIdx.x; i < n_in; i += (int)gridDim.x) {
+        links2_segment<L2_POOL_BIG>(A, fa_uni(in[1 + i]));
+        __syncthreads();  // (the next segment reuses the LDS)
     }
 }
 
 #ifndef FA_EMU
 void fa_launch_links2(const MsaArgs &A, hipStream_t s) {
     hipLaunchKernelGGL(k_links2, dim3(A.n_seg), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(k_links2_big, dim3(A.n_seg < 2048 ? A.n_seg : 2048), dim3(64), 0, s, A);
 }
 #endif

@@ -5,7 +5,7 @@
 #include <type_traits>
 
 #define TSEG 128       // target positions per k_links wavefront
-#define MAXACT 1024    // alignments overlapping one segment (FA_CNS_MAX_ALN at most do)
+#define MAXACT 1024    // alignments overlapping one segment that k_links (the kernel behind k_links2) takes
 #define INL 11         // inserted bases stored inline in a tag
 #define BT_WIN 64      // levels per back-trace window
 
@@ -66,8 +66,8 @@ struct MsaArgs {
     const int *seg_pile;       // k_links work list
     const int *seg_t0;
     int n_seg;
-    int *wide_count;           // to-do lists of the k_links instances (5 lists of 1 + n_seg ints:
-    int *wide_list;            // [count, segments...]; the first is filled by k_links2)
+    int *wide_count;           // to-do lists (6 lists of 1 + n_seg ints: [count, segments...]): k_links2 ->
+    int *wide_list;            // k_links2_big -> k_links<1> -> <2> -> <4> -> <8> -> <16>
     unsigned min_cov;
     int first_links_back;      // unitig mode (falcon.c:668-773): see k_links
     int force_generic;         // k_score1: every level through the generic path (tests)

@@ -291,13 +291,14 @@ template <int NCHT>
 __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx);
 
 // The segments k_links2 (k_links2.hip: lanes = positions) could not hold, through to-do lists:
-// instance NCHT works off the list the one before it filled -- k_links2 fills the first -- and
+// instance NCHT works off the list the one before it filled -- k_links2's second instance fills
+// the first of them -- and
 // hands what is too wide for itself to the next (1 -> 2 -> 4 -> 8 -> 16 chunks of 64
 // alignments).  Fixed grids looping over their list (how long it is only the device knows;
 // usually it is empty).
 template <int NCHT>
 __global__ __launch_bounds__(64) void k_links(MsaArgs A) {
-    constexpr int LVL = NCHT == 1 ? 0 : NCHT == 2 ? 1 : NCHT == 4 ? 2 : NCHT == 8 ? 3 : 4;
+    constexpr int LVL = NCHT == 1 ? 1 : NCHT == 2 ? 2 : NCHT == 4 ? 3 : NCHT == 8 ? 4 : 5;
     const int *in = A.wide_count + LVL * (A.n_seg + 1);
     const int n_in = __builtin_amdgcn_readfirstlane(in[0]);
     for (int i = (int)blockIdx.x; i < n_in; i += (int)gridDim.x) {
@@ -312,7 +313,7 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
     // wavefront decides how many of these latency-bound wavefronts a CU holds)
     __shared__ int act[NCHT * 64];
     const int lane = fa_lane();
-    constexpr int LVL = NCHT == 1 ? 0 : NCHT == 2 ? 1 : NCHT == 4 ? 2 : NCHT == 8 ? 3 : 4;
+    constexpr int LVL = NCHT == 1 ? 1 : NCHT == 2 ? 2 : NCHT == 4 ? 3 : NCHT == 8 ? 4 : 5;
     const int lstride = A.n_seg + 1;
     const int p = __builtin_amdgcn_readfirstlane(A.seg_pile[sidx]);
     const int t_lo = __builtin_amdgcn_readfirstlane(A.seg_t0[sidx]);
@@ -342,7 +343,7 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
         n_act += __popcll(m);
     }
     __syncthreads();
-    if (n_act > MAXACT) {  // cannot happen: <= FA_CNS_MAX_ALN accepted alignments per pile
+    if (n_act > MAXACT) {  // (a segment that outgrew k_links2's tables AND lies under more than 1024 alignments)
         if (lane == 0) A.score_out[p].err = 2;
         return;
     }
@@ -826,7 +827,7 @@ void fa_launch_msa_front(const FaBatchDev &b, const FaMsaDev &m, unsigned min_co
     if (ev_tags) (void)hipEventRecord(ev_tags, s);
     if (m.n_seg > 0) {
         // (the list heads)
-        for (int l = 0; l < 5; l++) (void)hipMemsetAsync(m.wide_count + l * (m.n_seg + 1), 0, sizeof(int), s);
+        for (int l = 0; l < 6; l++) (void)hipMemsetAsync(m.wide_count + l * (m.n_seg + 1), 0, sizeof(int), s);
         fa_launch_links2(A, s);
         const int wide_grid = m.n_seg < 8192 ? m.n_seg : 8192;
         hipLaunchKernelGGL(k_links<1>, dim3(wide_grid), dim3(64), 0, s, A);

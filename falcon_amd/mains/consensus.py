@@ -666,9 +666,6 @@ def run(args, stdin=None, stdout=None, consensus_map=None):
 
 def main(argv=None):
     args = parse_args(sys.argv if argv is None else argv)
-    if args.max_n_read - 1 > 1023:
-        sys.stderr.write("falcon_amd: --max-n-read %d: piles with more than 1023 usable reads will be "
-                         "reported and left uncorrected (the GPU consensus stage's limit)\n" % args.max_n_read)
     run(args)
     if FAILED_PILES and not os.environ.get("FALCON_AMD_SKIP_FAILED_PILES"):
         sys.stderr.write("falcon_amd: %d pile(s) were not corrected (see above)\n" % len(FAILED_PILES))

@@ -175,8 +175,8 @@ int fa_batch_fetch(fa_batch *b, int want_eqv);
 /* Consensus of pile p: *seq is NUL terminated and owned by the batch. */
 int fa_batch_result(fa_batch *b, int pile, const char **seq, int *len, const int **eqv);
 int fa_batch_stats(fa_batch *b, fa_stats *out);
-/* Piles fail alone.  The consensus stage handles up to 1023 usable reads per pile (the
- * reference, falcon.c:597-647, any number; its driver's default --max-n-read is 500); a
+/* Piles fail alone.  The consensus stage handles up to 65534 usable reads per pile (16-bit
+ * link counts like the reference's, falcon.c:86; its driver's default --max-n-read is 500); a
  * deeper pile -- or one whose consensus stage reports a device error -- does not fail its
  * batch: fa_batch_run succeeds, fa_batch_result gives that pile an empty consensus, and this
  * returns why (0: the pile is fine; 2: too many usable reads; 1: device error; 3: one of its

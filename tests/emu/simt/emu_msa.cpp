@@ -133,7 +133,7 @@ extern "C" int emu_msa(const u32 *words_in, u64 n_words, const FaSeq *seq_in, in
     GBuf<FaAln> d_aln(n_seq);
     GBuf<u64> d_script_off(n_seq), d_t_off(n_pile + 1), d_link_off(n_pile), d_link_cap(n_pile);
     GBuf<FaTagAln> d_ta(n_ta + 1);
-    GBuf<int> d_tcov(n_ta + 1), d_seg_cnt(2 * n_seg + 2, 0), d_seg_pile(n_seg + 1), d_seg_t0(n_seg + 1), d_wide(5 * (n_seg + 1) + 1, 0);
+    GBuf<int> d_tcov(n_ta + 1), d_seg_cnt(2 * n_seg + 2, 0), d_seg_pile(n_seg + 1), d_seg_t0(n_seg + 1), d_wide(6 * (n_seg + 1) + 1, 0);
     GBuf<u32> d_seg_base(2 * n_seg + 2), d_seg_first(n_pile + 1);
     GBuf<unsigned long long> d_bound(n_pile + 1);
     GBuf<uint8_t> d_insb(ins_tot + 8);
@@ -184,6 +184,7 @@ extern "C" int emu_msa(const u32 *words_in, u64 n_words, const FaSeq *seq_in, in
     if (n_seg) {
         A.links_old = getenv("EMU_MSA_LINKS1") ? 1 : 0;
         simt::launch("k_links2", (unsigned)n_seg, [&] { k_links2(A); });
+        simt::launch("k_links2_big", (unsigned)std::min<size_t>(n_seg, 64), [&] { k_links2_big(A); });
         const unsigned wide_grid = (unsigned)std::min<size_t>(n_seg, 64);
         simt::launch("k_links<1>", wide_grid, [&] { k_links<1>(A); });
         simt::launch("k_links<2>", wide_grid, [&] { k_links<2>(A); });
@@ -200,7 +201,7 @@ extern "C" int emu_msa(const u32 *words_in, u64 n_words, const FaSeq *seq_in, in
     if (score_out) memcpy(score_out, d_score_out.get(), (size_t)n_pile * sizeof(FaScoreOut));
     if (nodes_out) memcpy(nodes_out, d_nodes.get(), node_off * sizeof(FaNode));
     if (n_sync_out) *n_sync_out = simt::g_wave.n_sync;
-    if (todo_out) for (int l = 0; l < 5; l++) todo_out[l] = d_wide.get()[l * (n_seg + 1)];  // segments each k_links instance took
+    if (todo_out) for (int l = 0; l < 6; l++) todo_out[l] = d_wide.get()[l * (n_seg + 1)];  // segments each k_links instance took
     // (debug views of the graph: position records, link words -- piles back to back at
     // link_cap = columns + 8 each, as planned -- and the links per level slot)
     if (tinfo_out) memcpy(tinfo_out, d_tinfo.get(), t_tot * sizeof(FaTInfo));

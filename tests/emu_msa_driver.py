@@ -114,7 +114,7 @@ def run(st, min_cov=4, first_links_back=0, want_nodes=False, graph=None):
     tinfo = np.zeros(int(pile["seed_len"].sum()) + 8, dtype=FaTInfo) if graph is not None else None
     links = np.zeros(links_cap, dtype=np.uint32) if graph is not None else None
     nlk = np.zeros(node_cap // 5 + 8, dtype=np.uint16) if graph is not None else None
-    todo = np.zeros(5, dtype=np.int32)
+    todo = np.zeros(6, dtype=np.int32)
     p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
     rc = lib().emu_msa(p(st["words"]), C.c_uint64(len(st["words"])), p(st["seq"]), C.c_int(n_seq), p(pile), C.c_int(n_pile),
                        p(st["rng"]), p(st["aln"]), p(st["script"]), C.c_uint64(len(st["script"])), p(st["script_off"]),

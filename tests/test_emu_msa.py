@@ -91,7 +91,7 @@ def test_smoke_pile_every_stage(port):
     todo = []
     got = check_stages(st, pile, 4, todo)
     assert got == tuple(port.generate_consensus(pile, 4, 8, 0.70))
-    assert todo == [0, 0, 0, 0, 0]  # k_links2 held every segment
+    assert todo == [0, 0, 0, 0, 0, 0]  # k_links2 held every segment
 
 
 def test_k_links_takes_every_segment(port, monkeypatch):
@@ -102,7 +102,7 @@ def test_k_links_takes_every_segment(port, monkeypatch):
         st = D.stage_piles([pile], port, min_idt=idt)
         todo = []
         got = check_stages(st, pile, mc, todo)
-        assert todo[0] == (len(pile[0]) + TSEG - 1) // TSEG
+        assert todo[0] == todo[1] == (len(pile[0]) + TSEG - 1) // TSEG
         assert got == tuple(port.generate_consensus(pile, mc, 8, idt)), i
 
 
@@ -178,4 +178,22 @@ def test_long_insertion_runs(port, clustered):
     got = check_stages(st, pile, 2, todo)
     assert got == tuple(port.generate_consensus(pile, 2, 8, 0.70))
     n_seg = (len(seed) + TSEG - 1) // TSEG
-    assert (0 < todo[0] < n_seg // 2) if clustered else todo[0] == 0, todo
+    # (the instance with the large pool holds what the first one hands on)
+    assert (0 < todo[0] < n_seg // 2 and todo[1] == 0) if clustered else todo[0] == 0, todo
+
+
+def test_pile_deeper_than_1023_alignments(port):
+    """~1200 accepted alignments on a 2.5 kb seed (--max-n-read 2000): k_links2 walks them 64 at
+    a time, link counts beyond 10 bits, coverage beyond 1023 in k_score2's biased scores
+    (rounds 1-3 reported such piles and left them uncorrected; falcon.c:597-647 loops over any
+    n_seq)."""
+    s, rd = make_pile(712, S=2500, coverage=830, e=0.08, min_read=1500, mean_read=2200, sd_read=200)
+    pile = [codes_to_str(x) for x in pile_to_seqs(s, rd, 5000)]
+    st = D.stage_piles([pile], port)
+    assert int(st["aln"]["accept"].sum()) > 1100
+    graph = {}
+    res, so, _n, _p = D.run(st, 4, graph=graph)
+    assert so[0]["redo"] == 0 and so[0]["err"] == 0
+    assert graph["todo"][0] > 0 and graph["todo"][1] == 0  # the large pool's instance took segments, k_links none
+    assert int(graph["links"].max() & 0xffff) > 1023
+    assert res[0] == tuple(port.generate_consensus(pile, 4, 8, 0.70))

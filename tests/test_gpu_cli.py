@@ -83,11 +83,13 @@ def test_overlay_exposes_reference_names():
     assert out.strip() == ("ACGT" * 300)[1:21]
 
 
-def test_a_pile_too_deep_for_the_gpu_fails_alone():
-    """--max-n-read 2000 lets a pile of ~1200 usable reads through: every other pile is printed
-    exactly as without it, the deep one is named on stderr, the exit status is 3 (0 with
-    FALCON_AMD_SKIP_FAILED_PILES=1) -- never a dead stream half way through."""
-    from falcon_amd.synth import make_pile, pile_to_la4falcon
+def test_a_deep_pile_is_corrected_like_any_other():
+    """--max-n-read 2000 lets a pile of ~1200 usable reads through (rounds 1-3 reported piles of
+    more than 1023 and left them uncorrected, exit status 3): it is printed where it belongs, with
+    the bytes the reference's own C makes of it (falcon.c:597-647 loops over any n_seq)."""
+    from falcon_amd.mains.consensus import fasta_records
+    from falcon_amd.synth import codes_to_str, make_pile, pile_to_la4falcon, pile_to_seqs
+    from oracle.pyoracle import Port, Ref, have_ref
     chunks = []
     for i in range(3):
         seed, rd = make_pile(1300 + i, S=2500, coverage=14, min_read=500, mean_read=1500, sd_read=400)
@@ -100,11 +102,14 @@ def test_a_pile_too_deep_for_the_gpu_fails_alone():
     env = dict(os.environ, PYTHONPATH=ROOT)
     text = chunks[0] + deep + chunks[1] + chunks[2] + "- -\n"
     p = subprocess.run(cmd, input=text, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
-    assert p.returncode == 3 and p.stdout == clean
-    assert "seed 000000007 is not corrected" in p.stderr and "1023" in p.stderr
-    p = subprocess.run(cmd, input=text, capture_output=True, text=True, cwd=ROOT, timeout=600,
-                       env=dict(env, FALCON_AMD_SKIP_FAILED_PILES="1"))
-    assert p.returncode == 0 and p.stdout == clean
+    pile = [codes_to_str(x) for x in pile_to_seqs(seed, rd, 2000)]
+    assert len(pile) > 1150
+    cns = (Ref() if have_ref() else Port()).generate_consensus(pile, 4, 8, 0.70)[0]
+    want = "".join(fasta_records("%09d" % 7, cns, False, True))
+    first = run_cmd(cmd, chunks[0] + "- -\n")
+    assert clean.startswith(first) and len(want) > 2000
+    assert p.returncode == 0, p.stderr[-400:]
+    assert p.stdout == first + want + clean[len(first):]
 
 
 def test_a_dirty_pile_in_the_stream_fails_alone():

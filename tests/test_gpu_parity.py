@@ -440,9 +440,9 @@ def test_batch_is_order_preserving_and_rerunnable(engine):
 def test_deep_piles_and_failures_stay_with_their_pile(engine, port):
     """The reference loops over any n_seq (falcon.c:597-647); its driver's default
     --max-n-read is 500.  Piles of ~700 and ~1000 usable reads (more than 64, 128, 256 and 512
-    alignments over a segment: every k_links instance) equal the oracle; a pile past the
-    consensus stage's 1023 fails ALONE -- its neighbours in the batch are corrected as if
-    it were not there, it is reported (fa_batch_pile_error) and gets the empty consensus."""
+    alignments over a segment) and of ~1200 (past the 1023 that rounds 1-3 stopped at: k_links2
+    walks any number of alignments, link counts are 16 bits) equal the oracle, in one batch
+    with ordinary piles, through the default kernels and through the ones behind them."""
     from falcon_amd.engine import FailedPile
     normal = [_synthetic(700 + i, S=3000, coverage=14, min_read=600, mean_read=1800, sd_read=500)
               for i in range(2)]
@@ -459,16 +459,19 @@ def test_deep_piles_and_failures_stay_with_their_pile(engine, port):
         st = b.stats()
     finally:
         b.free()
-    assert st.n_piles_failed == 1
-    for i in (0, 1, 3, 4):
-        want = port.generate_consensus(piles[i], 4, 8, 0.70)
-        assert got[i][0] == want[0] and got[i][1] == want[1], i
+    assert st.n_piles_failed == 0
+    want = [port.generate_consensus(p, 4, 8, 0.70) for p in piles]
+    for i in range(len(piles)):
+        assert got[i][0] == want[i][0] and got[i][1] == want[i][1], i
         assert not isinstance(got[i][0], FailedPile)
-    assert isinstance(got[2][0], FailedPile) and got[2][0] == "" and got[2][1] == []
-    assert "usable reads" in got[2][0].reason and "1023" in got[2][0].reason
-    # and alone in a batch: still no failure of the call
-    (only,) = engine.consensus([too_deep], 4, 8, 0.70)
-    assert isinstance(only, FailedPile)
+    # k_links (lanes = alignments, up to 1024 over a segment) instead of k_links2: the piles it holds
+    import os
+    os.environ["FALCON_AMD_LINKS1"] = "1"
+    try:
+        for i, r in zip((1, 3), engine.consensus([deep, deeper], 4, 8, 0.70, want_eqv=True)):
+            assert r[0] == want[i][0] and r[1] == want[i][1], i
+    finally:
+        del os.environ["FALCON_AMD_LINKS1"]
 
 
 def test_score_generic_path_alone(engine, monkeypatch):
