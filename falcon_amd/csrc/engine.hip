@@ -532,10 +532,11 @@ static int stage_reserve(fa_ctx *c, size_t bytes, bool device_twin) {
     return 0;
 }
 
-// Threads that copy a batch into the staging buffer: one per 32 MB, at most 8 (or
-// FALCON_AMD_STAGE_THREADS), never more than the cores there are.
+// Threads that pack a batch into the staging buffer: one per 32 MB, at most 16 (or
+// FALCON_AMD_STAGE_THREADS: a node of 8 GPUs has 16 cores per GPU), never more than the cores
+// there are.
 static int stage_threads(u64 bytes) {
-    int cap = 8;
+    int cap = 16;
     if (const char *e = getenv("FALCON_AMD_STAGE_THREADS")) cap = std::max(1, atoi(e));
     const unsigned hc = std::thread::hardware_concurrency();
     if (hc > 0) cap = std::min<int>(cap, (int)hc);

@@ -74,8 +74,7 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
     u32 out = link0;
     u32 lvl_next = fa_uni(A.seg_base[2 * (size_t)sidx + 1]);
     const bool unitig = A.first_links_back != 0;
-    // (the second instance only runs what the first one handed on, which left the records)
-    const bool count_only = A.links_old != 0 && POOL == L2_POOL;  // k_links makes the links of every segment: only the position records here
+    // (FALCON_AMD_LINKS1 -- k_links makes the links of every segment: only the position records here)
     bool overflow = false;
     bool any_overflow = A.links_old != 0;
     unsigned long long bound = 0;  // sum of coverage x levels over my positions

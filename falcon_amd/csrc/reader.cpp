@@ -34,7 +34,8 @@
 #include <fcntl.h>
 #include <poll.h>
 #include <sys/mman.h>
-#include <emmintrin.h>
+#include <sys/stat.h>
+#include <immintrin.h>
 #include <unistd.h>
 
 #include "../../include/falcon_amd.h"
@@ -88,35 +89,46 @@ struct fa_reader {
     // white-space bytes (<= 0x20) seen so far in the line being scanned
     size_t line_low = 0, line_first_low = 0;
     ~fa_reader() {
-        if (ahead.th.joinable()) {
-            {
-                std::lock_guard<std::mutex> g(ahead.mu);
-                ahead.quit = true;
-            }
-            ahead.cv.notify_all();
-            ahead.th.join();
+        {
+            std::lock_guard<std::mutex> g(ahead.mu);
+            ahead.quit = true;
         }
+        ahead.cv.notify_all();
+        for (std::thread &th : ahead.th)
+            if (th.joinable()) th.join();
         if (text) munmap(text, text_cap);
         for (const Shelf &o : shelf)
             if (o.text) munmap(o.text, o.text_cap);
     }
 
-    // Read-ahead: while the scanner works through one 4 MB piece, a helper thread has the
-    // next read() under way (the copy out of the page cache or the pipe is 2/3 of the
-    // reader's time).  One request at a time, always behind `filled`; the buffer only
-    // grows or changes hands while no request is in flight.
+    // Read-ahead: while the scanner works through one 4 MB piece, helper threads have the
+    // next ones under way (the copy out of the page cache or the pipe was 2/3 of the reader's
+    // time, and one thread's copy -- ~11 GB/s -- is what bounded the whole worker in round 3).
+    // A pipe has one helper and one read() at a time; a regular file has kSlots helpers, each
+    // with a pread() of its own piece at its own offset.  Pieces are handed out and taken in
+    // in stream order, always behind `filled`; the buffer only grows or changes hands while
+    // no request is in flight.
+    static constexpr int kSlots = 4;
     struct Ahead {
-        std::thread th;
+        std::thread th[kSlots];
         std::mutex mu;
         std::condition_variable cv;
-        enum { IDLE, REQUESTED, DONE } state = IDLE;
-        char *dst = nullptr;
-        size_t want = 0;
-        ssize_t n = 0;       // read()'s result, -1 with `err` = errno
-        int err = 0;
+        struct Slot {
+            enum { IDLE, REQUESTED, DONE } state = IDLE;
+            char *dst = nullptr;
+            size_t want = 0;
+            long long off = -1;  // file offset (pread), -1: read() at the descriptor's position
+            ssize_t n = 0;       // the result, -1 with `err` = errno
+            int err = 0;
+        } slot[kSlots];
         bool quit = false;
     } ahead;
-    bool in_flight = false;  // a request is out (scanner's side of ahead.state)
+    bool wide_scan = false;  // 64-byte compares (the host has AVX-512BW)
+    int n_slots = 1;         // 1: a pipe; kSlots: a regular file (file_off = where the next piece starts)
+    long long file_off = -1;
+    int in_flight = 0;       // requests out, slots (issue_at - in_flight .. issue_at - 1) mod n_slots
+    int issue_at = 0;
+    size_t pending = 0;      // bytes of the buffer behind `filled` that requests in flight will fill
 
     // pile in progress
     std::vector<Tok> pile;                  // seed, then reads in stream order
@@ -132,6 +144,27 @@ struct fa_reader {
 
 };
 
+// The scanner's inner loop with 64-byte compares (AVX-512BW, chosen at run time: the GPU
+// boxes' hosts have it, and one thread then looks at ~25 GB/s of text instead of 11): every
+// byte <= 0x20 is an event.  Returns where it stopped (a multiple of 64 bytes behind `i`, or
+// the event that closed the batch); the 16-byte loop takes what is left.
+template <class F>
+__attribute__((target("avx512f,avx512bw"))) static size_t scan64(const char *t, size_t i, size_t end, F &event,
+                                                                 bool &go) {
+    const __m512i lim = _mm512_set1_epi8(0x20);
+    while (go && i + 64 <= end) {
+        const __m512i v = _mm512_loadu_si512((const void *)(t + i));
+        unsigned long long m = _mm512_cmple_epu8_mask(v, lim);
+        for (; m; m &= m - 1)
+            if (!event(i + (size_t)__builtin_ctzll(m))) {
+                go = false;
+                break;
+            }
+        i += 64;
+    }
+    return i;
+}
+
 static char *map_text(char *old, size_t old_cap, size_t cap) {
     void *t = old ? mremap(old, old_cap, cap, MREMAP_MAYMOVE)
                   : mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
@@ -142,90 +175,127 @@ static char *map_text(char *old, size_t old_cap, size_t cap) {
     return (char *)t;
 }
 
-// the helper thread: one read() per request.  It polls first (in slices, looking at `quit`),
-// so that closing the reader never waits for a producer that went silent.
-static void ahead_main(fa_reader *r) {
+// a helper thread: serves its slot, one read() / pread() per request.  A pipe is polled first
+// (in slices, looking at `quit`), so that closing the reader never waits for a producer that
+// went silent.
+static void ahead_main(fa_reader *r, int k) {
     fa_reader::Ahead &a = r->ahead;
+    fa_reader::Ahead::Slot &sl = a.slot[k];
     std::unique_lock<std::mutex> lk(a.mu);
     for (;;) {
-        a.cv.wait(lk, [&] { return a.quit || a.state == fa_reader::Ahead::REQUESTED; });
+        a.cv.wait(lk, [&] { return a.quit || sl.state == fa_reader::Ahead::Slot::REQUESTED; });
         if (a.quit) return;
-        char *dst = a.dst;
-        const size_t want = a.want;
+        char *dst = sl.dst;
+        const size_t want = sl.want;
+        const long long off = sl.off;
         lk.unlock();
         ssize_t n = -1;
         int err = 0;
         for (;;) {
-            struct pollfd pfd = {r->fd, POLLIN, 0};
-            const int pr = poll(&pfd, 1, 50);
-            if (pr == 0 || (pr < 0 && errno == EINTR)) {
-                std::lock_guard<std::mutex> g(a.mu);
-                if (a.quit) return;
-                continue;
+            if (off < 0) {
+                struct pollfd pfd = {r->fd, POLLIN, 0};
+                const int pr = poll(&pfd, 1, 50);
+                if (pr == 0 || (pr < 0 && errno == EINTR)) {
+                    std::lock_guard<std::mutex> g(a.mu);
+                    if (a.quit) return;
+                    continue;
+                }
+                // (pr < 0 otherwise: not pollable -- just read)
             }
-            // (pr < 0 otherwise: not pollable -- just read)
             const auto t0 = std::chrono::steady_clock::now();
-            n = read(r->fd, dst, want);
+            if (off < 0) {
+                n = read(r->fd, dst, want);
+            } else {  // a regular file: the whole piece, or what is left of the file
+                size_t got = 0;
+                n = 0;
+                while (got < want) {
+                    const ssize_t m = pread(r->fd, dst + got, want - got, (off_t)(off + (long long)got));
+                    if (m < 0 && errno == EINTR) continue;
+                    if (m < 0) { n = -1; break; }
+                    if (m == 0) break;
+                    got += (size_t)m;
+                }
+                if (n >= 0) n = (ssize_t)got;
+            }
             err = errno;
-            r->read_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (n < 0 && (err == EINTR || err == EAGAIN)) continue;
+            lk.lock();
+            r->read_s += dt;
             break;
         }
-        lk.lock();
-        a.n = n;
-        a.err = err;
-        a.state = fa_reader::Ahead::DONE;
+        sl.n = n;
+        sl.err = err;
+        sl.state = fa_reader::Ahead::Slot::DONE;
         a.cv.notify_all();
     }
 }
 
-// ask for the next piece of the stream, behind `filled` (no request may be in flight)
+// ask for the next piece(s) of the stream, behind what is filled or already asked for
 static bool request_ahead(fa_reader *r) {
     const size_t want = 4u << 20;
-    if (r->text_cap < r->filled + want) {
-        const size_t cap = (std::max(r->text_cap * 2, r->filled + want) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
-        char *t = map_text(r->text, r->text_cap, cap);
-        if (!t) {
-            r->err = "falcon_amd: out of memory while reading the pile stream";
-            r->eof = true;
-            return false;
-        }
-        r->text = t;
-        r->text_cap = cap;
-    }
     fa_reader::Ahead &a = r->ahead;
-    if (!a.th.joinable()) a.th = std::thread(ahead_main, r);
-    {
-        std::lock_guard<std::mutex> g(a.mu);
-        a.dst = r->text + r->filled;
-        a.want = want;
-        a.state = fa_reader::Ahead::REQUESTED;
+    while (r->in_flight < r->n_slots) {
+        if (r->text_cap < r->filled + r->pending + want) {
+            if (r->in_flight > 0) break;  // (the buffer may move: not under a request's feet)
+            const size_t need = r->filled + (size_t)r->n_slots * want;
+            const size_t cap = (std::max(r->text_cap * 2, need) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+            char *t = map_text(r->text, r->text_cap, cap);
+            if (!t) {
+                r->err = "falcon_amd: out of memory while reading the pile stream";
+                r->eof = true;
+                return false;
+            }
+            r->text = t;
+            r->text_cap = cap;
+        }
+        const int k = r->issue_at;
+        if (!a.th[k].joinable()) a.th[k] = std::thread(ahead_main, r, k);
+        {
+            std::lock_guard<std::mutex> g(a.mu);
+            fa_reader::Ahead::Slot &sl = a.slot[k];
+            sl.dst = r->text + r->filled + r->pending;
+            sl.want = want;
+            sl.off = r->file_off;
+            sl.state = fa_reader::Ahead::Slot::REQUESTED;
+        }
+        if (r->file_off >= 0) r->file_off += (long long)want;
+        r->pending += want;
+        r->issue_at = (k + 1) % r->n_slots;
+        r->in_flight++;
+        a.cv.notify_all();
     }
-    r->in_flight = true;
-    a.cv.notify_all();
     return true;
 }
 
-// wait for the request in flight (if any) and take its bytes in; false: nothing came
+// wait for the OLDEST request in flight (if any) and take its bytes in; false: nothing came
 // (end of file or an error, see r->eof / r->err)
 static bool settle_ahead(fa_reader *r) {
-    if (!r->in_flight) return true;
-    r->in_flight = false;
+    if (r->in_flight == 0) return true;
     fa_reader::Ahead &a = r->ahead;
+    const int k = ((r->issue_at - r->in_flight) % r->n_slots + r->n_slots) % r->n_slots;
+    r->in_flight--;
     ssize_t n;
     int err;
+    size_t want;
     {
         std::unique_lock<std::mutex> lk(a.mu);
+        fa_reader::Ahead::Slot &sl = a.slot[k];
         const auto t0 = std::chrono::steady_clock::now();
-        a.cv.wait(lk, [&] { return a.state == fa_reader::Ahead::DONE; });
+        a.cv.wait(lk, [&] { return sl.state == fa_reader::Ahead::Slot::DONE; });
         r->wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        n = a.n;
-        err = a.err;
-        a.state = fa_reader::Ahead::IDLE;
+        n = sl.n;
+        err = sl.err;
+        want = sl.want;
+        sl.state = fa_reader::Ahead::Slot::IDLE;
     }
-    if (n > 0) {
+    r->pending -= want;
+    if (n > 0 && !r->eof) {
         r->filled += (size_t)n;
         r->read_bytes += (size_t)n;
+        // (a piece of a file that came short is the file's last one: the pieces asked for
+        // behind it start beyond the end and bring nothing)
+        if ((size_t)n < want && r->file_off >= 0) r->eof = true;
         return true;
     }
     r->eof = true;
@@ -233,15 +303,29 @@ static bool settle_ahead(fa_reader *r) {
     return false;
 }
 
+// every request in flight, in order (the buffer is about to change hands)
+static bool settle_all(fa_reader *r) {
+    bool ok = true;
+    while (r->in_flight > 0) ok = settle_ahead(r) && ok;
+    return ok;
+}
+
 static bool fill(fa_reader *r) {
     // More of the stream behind `filled`; false at end of file.  Pieces are 4 MB so that what
     // is read is scanned while it is still in the cache, and so that the tail a closed batch
     // leaves behind (copied over by the next call) stays small.  The piece after the one
     // returned is requested before the scanner gets this one.
-    if (r->eof) return false;
-    if (!r->in_flight && !request_ahead(r)) return false;
+    if (r->eof) {
+        (void)settle_all(r);
+        return false;
+    }
+    if (r->in_flight == 0 && !request_ahead(r)) return false;
     const size_t before = r->filled;
-    if (!settle_ahead(r) || r->filled == before) return false;
+    if (!settle_ahead(r) || r->filled == before) {
+        (void)settle_all(r);
+        return false;
+    }
+    if (r->eof) return true;  // (the file's last piece: nothing more to ask for)
     return request_ahead(r);
 }
 
@@ -343,6 +427,17 @@ extern "C" fa_reader *fa_reader_open(int fd, int min_n_read, int min_len_aln, in
     // a pipe from LA4Falcon: fewer, larger reads (refused for anything that is not a pipe)
     (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);
 #endif
+    r->wide_scan = __builtin_cpu_supports("avx512bw") && !getenv("FALCON_AMD_READER_SSE2");
+    // a regular file (a block's LA4Falcon output kept on disk, the benchmarks): several
+    // pread()s at a time from where the descriptor stands
+    struct stat st;
+    if (!getenv("FALCON_AMD_READER_SLOTS1") && fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+        const off_t at = lseek(fd, 0, SEEK_CUR);
+        if (at >= 0) {
+            r->file_off = (long long)at;
+            r->n_slots = fa_reader::kSlots;
+        }
+    }
     return r;
 }
 
@@ -371,8 +466,8 @@ extern "C" int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, 
         r->sel_name.clear();
         return r->err.empty() ? 0 : -1;
     }
-    // a piece requested during the previous call lands in the old buffer: take it along
-    if (!settle_ahead(r) && !r->err.empty()) return -1;
+    // pieces requested during the previous call land in the old buffer: take them along
+    if (!settle_all(r) && !r->err.empty()) return -1;
     // The batch handed out last stays where it is (its pointers live through this call);
     // the unparsed tail and the lines of the pile in progress move over to the other text
     // buffer, the one of the batch before it, and the stream continues there.
@@ -462,6 +557,7 @@ extern "C" int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, 
         const char *t = r->text;
         size_t i = r->scanned;
         bool go = true;
+        if (r->wide_scan) i = scan64(t, i, end, event, go);
         while (go && i + 16 <= end) {
             const __m128i v = _mm_loadu_si128((const __m128i *)(t + i));
             unsigned m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_min_epu8(v, lim), v));

@@ -348,3 +348,53 @@ def test_fuzzed_streams_match_the_python_parser():
         assert got == want
 
     check()
+
+
+def test_a_long_file_through_every_reading_mode(monkeypatch):
+    """45 MB of stream -- several 4 MB pieces in flight at once, the text buffer growing under
+    them -- read as a regular file (four pread() helpers, 64-byte compares where the host has
+    AVX-512), with one helper, with the 16-byte scanner, and through a pipe: the same piles,
+    and they are the stream's (consensus.py:161-209)."""
+    rng = random.Random(4)
+    base = _rand_seq(rng, 12000)
+    lines, want = [], []
+    for p in range(230):
+        n_read = rng.randint(15, 25)
+        names = ["%08d" % (1000 * p + i) for i in range(n_read)]
+        seqs = [base[rng.randint(0, 500):rng.randint(9000, 12000)] for _ in range(n_read)]
+        seqs[0] = base[:10000]
+        for nm, sq in zip(names, seqs):
+            lines.append("%s %s" % (nm, sq))
+        lines.append("+ +")
+        want.append((names[0], len(seqs[0]), n_read + 1))
+    lines.append("- -")
+    text = "\n".join(lines) + "\n"
+    assert len(text) > 40e6
+    ref, _ = _native(text, 1, 1, 0, 500, 0)
+    assert [(sid, len(p[0]), len(p)) for sid, p in ref] == want
+    monkeypatch.setenv("FALCON_AMD_READER_SLOTS1", "1")
+    assert _native(text, 1, 1, 0, 500, 0)[0] == ref
+    monkeypatch.setenv("FALCON_AMD_READER_SSE2", "1")
+    assert _native(text, 1, 1, 0, 500, 0, max_bases=30_000_000)[0] == ref
+    monkeypatch.delenv("FALCON_AMD_READER_SLOTS1")
+    assert _native(text, 1, 1, 0, 500, 0, max_piles=7)[0] == ref
+    monkeypatch.delenv("FALCON_AMD_READER_SSE2")
+    rd, wr = os.pipe()
+
+    def feed():
+        with os.fdopen(wr, "wb") as f:
+            f.write(text.encode("ascii"))
+    import threading
+    th = threading.Thread(target=feed)
+    th.start()
+    r = Reader(rd, 1, 1, 0, 500, 0)
+    got = []
+    while True:
+        ps = r.next(0, 0)
+        if ps is None:
+            break
+        got.extend(zip(ps.seed_ids, ps.piles()))
+    r.close()
+    th.join()
+    os.close(rd)
+    assert got == ref
