@@ -652,6 +652,9 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
                       "replacements_in_loop": int(getattr(st, "align_replacements", 0)),
                       "parkings": int(getattr(st, "align_parkings", 0)),
                       "handed_back": int(getattr(st, "align_handed_back", 0)),
+                      "handed_back_by_cause": {"tape": int(getattr(st, "align_handed_back_tape", 0)),
+                                               "wide_rows": int(getattr(st, "align_handed_back_wide", 0)),
+                                               "escape_list": int(getattr(st, "align_handed_back_escapes", 0))},
                       "relaunched": int(getattr(st, "align_relaunched", 0)),
                       "wide_rows": int(getattr(st, "align_wide_rows", 0)),
                       "band_rows": int(st.D)},

@@ -441,8 +441,8 @@ extern "C" fa_ctx *fa_create(int device) {
     HIP_OK_P(hipEventRecord(c->ev_redo, c->stream));
     HIP_OK_P(hipMalloc((void **)&c->arena.prof, 8 * sizeof(u64)));
     HIP_OK_P(hipMemset(c->arena.prof, 0, 8 * sizeof(u64)));
-    HIP_OK_P(hipMalloc((void **)&c->a2.stats, 8 * sizeof(unsigned long long)));
-    HIP_OK_P(hipMemset(c->a2.stats, 0, 8 * sizeof(unsigned long long)));
+    HIP_OK_P(hipMalloc((void **)&c->a2.stats, 12 * sizeof(unsigned long long)));
+    HIP_OK_P(hipMemset(c->a2.stats, 0, 12 * sizeof(unsigned long long)));
     c->a2.counter = c->arena.counter;  // (the front stream runs one alignment launch at a time)
     c->planner = std::thread(planner_main, c);
     return c;
@@ -1226,9 +1226,9 @@ static int start_align(fa_batch *b, unsigned min_cov, double max_diff, int band,
     b->run.links_mode = getenv("FALCON_AMD_LINKS1") ? 1 : 0;
     b->run.min_cov = min_cov; b->run.max_diff = max_diff; b->run.band = band;
     b->run.force_accept_g = force_accept_g; b->run.two_per_wave = two_per_wave;
-    if (b->h_aln.resize(b->n_seq) || b->h_a2_stats.resize(8)) return -1;
+    if (b->h_aln.resize(b->n_seq) || b->h_a2_stats.resize(12)) return -1;
     if (two_per_wave) {
-        (void)hipMemsetAsync(c->a2.stats, 0, 8 * sizeof(unsigned long long), s);
+        (void)hipMemsetAsync(c->a2.stats, 0, 12 * sizeof(unsigned long long), s);
         fa_launch_align2(d, c->a2, max_diff, band, b->order_dev(), b->n_seq, s);
     } else if (band + 1 > 64 * FA_ALIGN_MAXCH - 1) {
         fa_launch_align_wide(d, c->arena, max_diff, band, s);
@@ -1252,7 +1252,7 @@ static int start_align(fa_batch *b, unsigned min_cov, double max_diff, int band,
     HIP_OK(hipMemcpyAsync(b->h_aln.data(), b->d_aln.p, (size_t)b->n_seq * sizeof(FaAln),
                           hipMemcpyDeviceToHost, s));
     if (two_per_wave)
-        HIP_OK(hipMemcpyAsync(b->h_a2_stats.data(), c->a2.stats, 8 * sizeof(unsigned long long),
+        HIP_OK(hipMemcpyAsync(b->h_a2_stats.data(), c->a2.stats, 12 * sizeof(unsigned long long),
                               hipMemcpyDeviceToHost, s));
     HIP_OK(hipEventRecord(b->ev[12], s));
     b->stats.align_relaunched = 0;
@@ -1468,12 +1468,16 @@ static int msa_stage(fa_batch *b) {
         b->stats.align_handed_back = (long long)st[4];
         b->stats.align_wide_rows = (long long)st[5];
         b->stats.align_replacements = (long long)st[7];
+        b->stats.align_handed_back_tape = (long long)st[8];
+        b->stats.align_handed_back_wide = (long long)st[9];
+        b->stats.align_handed_back_escapes = (long long)st[10];
     } else {
         b->stats.align_arena_bytes = (long long)c->arena_cells_bytes + 2 * (long long)c->arena_rows_bytes +
                                      (long long)c->arena2_cells_bytes + 2 * (long long)c->arena2_rows_bytes;
         b->stats.align_pair_iterations = b->stats.align_single_iterations = b->stats.align_placements = 0;
         b->stats.align_parkings = b->stats.align_handed_back = b->stats.align_wide_rows = 0;
         b->stats.align_replacements = 0;
+        b->stats.align_handed_back_tape = b->stats.align_handed_back_wide = b->stats.align_handed_back_escapes = 0;
     }
     return 0;
 }

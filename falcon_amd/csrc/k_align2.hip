@@ -5,6 +5,7 @@
 // one atomic per alignment.
 //
 // Integer / latency / issue bound like the rest of the path; no MFMA.
+#include <algorithm>
 #include <cstdlib>
 #include "fa_wave.h"
 #include "k_align2_core.h"
@@ -56,6 +57,10 @@ void fa_launch_align2(const FaBatchDev &b, const FaAlign2Arena &a, double max_di
     {   // (FALCON_AMD_A2_DEBUG: timing experiments, see A2Args::debug -- results are not valid then)
         const char *e = getenv("FALCON_AMD_A2_DEBUG");
         A.debug = e ? atoi(e) : 0;
+        e = getenv("FALCON_AMD_ESC_CAP");           // (tests: force the escape-list exit)
+        A.esc_cap = e ? std::max(1, std::min(atoi(e), (int)A2_ESC_CAP)) : (int)A2_ESC_CAP;
+        e = getenv("FALCON_AMD_WIDE_PATIENCE");     // (tests: force the wide-rows exit)
+        A.wide_patience = e ? std::max(1, atoi(e)) : (int)A2_WIDE_PATIENCE;
     }
     (void)hipMemsetAsync(a.counter, 0, sizeof(int), s);
     // two alignments per wavefront: half as many wavefronts have work

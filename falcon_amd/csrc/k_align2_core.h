@@ -88,12 +88,20 @@ struct A2Args {
     FaAln *aln;
     int band;
     double max_diff;
-    unsigned long long *stats;  // 8 counters (see A2_STAT_*)
+    unsigned long long *stats;  // A2_STAT_N counters (see A2_STAT_*)
     int debug;                  // timing experiments only: 1 = no trace-back (the scripts stay unwritten)
+    // what the wavefront's event loop hands alignments back at: A2_ESC_CAP entries on the slot's
+    // escape list, A2_WIDE_PATIENCE wide rows beside a waiting neighbour -- lower in tests that
+    // force those exits (FALCON_AMD_ESC_CAP, FALCON_AMD_WIDE_PATIENCE)
+    int esc_cap, wide_patience;
 };
 // pair / single iterations, placements, parkings, hand-backs, wide rows, wide episodes, recenterings
 enum { A2_STAT_PAIR_IT = 0, A2_STAT_SINGLE_IT, A2_STAT_PLACE, A2_STAT_PARK, A2_STAT_BAIL,
-       A2_STAT_ESC, A2_STAT_EXT, A2_STAT_TRACKS };
+       A2_STAT_ESC, A2_STAT_EXT, A2_STAT_TRACKS,
+       // the hand-backs (A2_STAT_BAIL) by cause: the tape (an alignment whose rows do not fit the
+       // ring, at the queue or once its share is used up), wide rows (a band beyond 191 diagonals, or
+       // wide for longer than a waiting neighbour has patience), the slot's escape list full
+       A2_STAT_BAIL_TAPE, A2_STAT_BAIL_WIDE, A2_STAT_BAIL_ESC, A2_STAT_N };
 
 enum { A2_IDLE = 0, A2_RUN = 1, A2_PARKED = 2 };
 
@@ -313,6 +321,7 @@ struct A2Wave {    // wave-uniform
     u64 *esc;
     // statistics of this wavefront
     u32 st_pair, st_single, st_place, st_park, st_bail, st_tracks, st_wide, st_wide_rows, st_recenter;
+    u32 st_bail_tape, st_bail_wide, st_bail_esc;
 };
 
 W_FN void a2_result(const A2Args &A, int g, int err, int aligned, int dist, int q_e, int t_e, int n_ins,
@@ -356,6 +365,8 @@ W_FN bool a2_fetch(const A2Args &A, A2Track &t) {
         // that then goes on and on is handed back when the tape is used up)
         if ((u32)max_d + 192u > A.ring && (u32)max_d / 2u + A.ring / 8u > A.ring) {
             a2_result(A, g, 2, 0, 0, 0, 0, 0, 0);
+            w_stat_add(A.stats + A2_STAT_BAIL, 1ull);
+            w_stat_add(A.stats + A2_STAT_BAIL_TAPE, 1ull);
             continue;
         }
         t.state = A2_RUN;
@@ -1166,12 +1177,13 @@ W_FN void a2_wide(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Track &t, vi from, 
         w_lds_store(ring, (vu)(((d - 1) & 1) * A2_WIDE_RING) + ((vu)(kp >> 1) & (A2_WIDE_RING - 1u)), (vu)from);
         w_fence_block();
     }
-    bool done = false, dead = false, back = false;
+    bool done = false, dead = false, back = false, back_tape = false;
     int fin_x = 0, fin_k = 0, fin_j = 0, n_chunk_fin = 0;
     u32 it_row = 0;
     while (!done && !dead && !back) {
         if (d >= t.max_d || n - 1 > A.band) { dead = true; break; }  // DW_banded.c:183-186
-        if (n > 191 || (int)(w.it - t.it0) + 4 > (int)A.ring - 192 || row_budget-- <= 0) { back = true; break; }
+        if ((int)(w.it - t.it0) + 4 > (int)A.ring - 192) { back = back_tape = true; break; }
+        if (n > 191 || row_budget-- <= 0) { back = true; break; }
         if (n <= A2_MAX_N - 12) break;
         const int par = d & 1, max_k = min_k + 2 * (n - 1);
         u32 *Vcur = ring + par * A2_WIDE_RING;
@@ -1259,6 +1271,7 @@ W_FN void a2_wide(const A2Args &A, A2Wave &w, A2Lanes &wl, A2Track &t, vi from, 
         a2_result(A, t.g, 2, 0, 0, 0, 0, 0, 0);
         t.state = A2_IDLE;
         w.st_bail++;
+        if (back_tape) w.st_bail_tape++; else w.st_bail_wide++;
         return;
     }
     // narrow again: the last row back into registers, its hull around the middle of the wave
@@ -1305,6 +1318,7 @@ W_FN void a2_wave(const A2Args &A, int slot) {
     w.recs = w.cells + (u64)A.ring * 16u;
     w.esc = (u64 *)(w.recs + (u64)A.ring * 4u);
     w.st_pair = w.st_single = w.st_place = w.st_park = w.st_bail = w.st_tracks = w.st_wide = w.st_wide_rows = w.st_recenter = 0;
+    w.st_bail_tape = w.st_bail_wide = w.st_bail_esc = 0;
     for (;;) {
         // ---- fill the free tracks
         if (w.T0.state == A2_IDLE && w.more) { w.more = a2_fetch(A, w.T0); if (w.more) w.st_tracks++; }
@@ -1315,7 +1329,7 @@ W_FN void a2_wave(const A2Args &A, int slot) {
         // are in tape order)
         if (w.n_esc > 0 && (w.T0.state == A2_IDLE || w.T0.d == 0) && (w.T1.state == A2_IDLE || w.T1.d == 0))
             w.n_esc = 0;
-        if (w.n_esc > A2_ESC_CAP / 2) {
+        if (w.n_esc > A.esc_cap / 2) {
             const bool live0 = w.T0.state != A2_IDLE && w.T0.d > 0, live1 = w.T1.state != A2_IDLE && w.T1.d > 0;
             u32 oldest = live0 ? w.T0.it0 : w.T1.it0;
             if (live0 && live1 && (int)(w.T1.it0 - w.T0.it0) < 0) oldest = w.T1.it0;
@@ -1343,6 +1357,7 @@ W_FN void a2_wave(const A2Args &A, int slot) {
         const int tape_left = (int)A.ring - 192 - max(span0, span1);
         if (tape_left < 64) {
             if (span0 >= span1) a2_hand_back(A, w, w.T0); else a2_hand_back(A, w, w.T1);
+            w.st_bail_tape++;
             continue;
         }
 #ifdef A2_HOOK_TRIP
@@ -1355,20 +1370,20 @@ W_FN void a2_wave(const A2Args &A, int slot) {
             if (rc == 1) {
                 const vi from = w.T0.state == A2_PARKED ? wl.vpark : wl.vx;
                 if (w.T1.state == A2_RUN) { wl.vpark = wl.vx; w.T1.state = A2_PARKED; w.st_park++; }
-                a2_wide<0>(A, w, wl, w.T0, from, w.T1.state == A2_IDLE ? 0x7fffffff : A2_WIDE_PATIENCE);
+                a2_wide<0>(A, w, wl, w.T0, from, w.T1.state == A2_IDLE ? 0x7fffffff : A.wide_patience);
             } else {
                 const vi from = w.T1.state == A2_PARKED ? wl.vpark : wl.vx;
                 if (w.T0.state == A2_RUN) { wl.vpark = wl.vx; w.T0.state = A2_PARKED; w.st_park++; }
-                a2_wide<1>(A, w, wl, w.T1, from, w.T0.state == A2_IDLE ? 0x7fffffff : A2_WIDE_PATIENCE);
+                a2_wide<1>(A, w, wl, w.T1, from, w.T0.state == A2_IDLE ? 0x7fffffff : A.wide_patience);
             }
 #ifdef A2_HOOK_WIDE
             A2_HOOK_WIDE(w, wl, rc);
 #endif
             w.st_wide++;
             w.pair = 0;
-            if (w.n_esc > A2_ESC_CAP) {
-                if (w.T0.state != A2_IDLE) a2_hand_back(A, w, w.T0);
-                if (w.T1.state != A2_IDLE) a2_hand_back(A, w, w.T1);
+            if (w.n_esc > A.esc_cap) {
+                if (w.T0.state != A2_IDLE) { a2_hand_back(A, w, w.T0); w.st_bail_esc++; }
+                if (w.T1.state != A2_IDLE) { a2_hand_back(A, w, w.T1); w.st_bail_esc++; }
                 w.n_esc = 0;
             }
             continue;
@@ -1500,9 +1515,9 @@ W_FN void a2_wave(const A2Args &A, int slot) {
 #ifdef A2_HOOK_EXIT
         A2_HOOK_EXIT(w, h);
 #endif
-        if (w.n_esc > A2_ESC_CAP) {  // the escape list is full: everybody on the tape goes back
-            if (w.T0.state != A2_IDLE) a2_hand_back(A, w, w.T0);
-            if (w.T1.state != A2_IDLE) a2_hand_back(A, w, w.T1);
+        if (w.n_esc > A.esc_cap) {  // the escape list is full: everybody on the tape goes back
+            if (w.T0.state != A2_IDLE) { a2_hand_back(A, w, w.T0); w.st_bail_esc++; }
+            if (w.T1.state != A2_IDLE) { a2_hand_back(A, w, w.T1); w.st_bail_esc++; }
             w.n_esc = 0;
             continue;
         }
@@ -1530,5 +1545,8 @@ W_FN void a2_wave(const A2Args &A, int slot) {
         w_stat_add(A.stats + A2_STAT_TRACKS, w.st_recenter);
         w_stat_add(A.stats + A2_STAT_EXT, w.st_wide);
         w_stat_add(A.stats + A2_STAT_ESC, w.st_wide_rows);
+        w_stat_add(A.stats + A2_STAT_BAIL_TAPE, w.st_bail_tape);
+        w_stat_add(A.stats + A2_STAT_BAIL_WIDE, w.st_bail_wide);
+        w_stat_add(A.stats + A2_STAT_BAIL_ESC, w.st_bail_esc);
     }
 }

@@ -35,7 +35,9 @@ class FaStats(C.Structure):
                 ("align_pair_iterations", C.c_longlong), ("align_single_iterations", C.c_longlong),
                 ("align_placements", C.c_longlong), ("align_parkings", C.c_longlong),
                 ("align_handed_back", C.c_longlong), ("align_wide_rows", C.c_longlong),
-                ("align_replacements", C.c_longlong)]
+                ("align_replacements", C.c_longlong),
+                ("align_handed_back_tape", C.c_longlong), ("align_handed_back_wide", C.c_longlong),
+                ("align_handed_back_escapes", C.c_longlong)]
 
     def b_alg(self) -> int:
         """Algorithmic bytes: L/4 + 4C + 8D + 16A + 12T + 5O."""

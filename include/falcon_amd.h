@@ -145,6 +145,10 @@ typedef struct {
     long long align_arena_bytes;
     long long align_pair_iterations, align_single_iterations, align_placements, align_parkings,
         align_handed_back, align_wide_rows, align_replacements /* inside the row loop */;
+    /* align_handed_back by cause: the alignment's rows did not fit its tape ring; its band stayed
+     * wide (rows of more than 60 diagonals) for longer than a waiting neighbour has patience, or
+     * grew beyond 191 diagonals; the slot's list of snakes of >= 255 bases was full */
+    long long align_handed_back_tape, align_handed_back_wide, align_handed_back_escapes;
 } fa_stats;
 
 const char *fa_last_error(void);

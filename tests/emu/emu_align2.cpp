@@ -116,6 +116,8 @@ extern "C" int emu_align2(const u32 *words, u64 n_words, const FaSeq *seq, int n
     A.band = band; A.max_diff = max_diff;
     A.stats = stats;
     A.debug = 0;
+    A.esc_cap = getenv("EMU_A2_ESC_CAP") ? atoi(getenv("EMU_A2_ESC_CAP")) : (int)A2_ESC_CAP;
+    A.wide_patience = getenv("EMU_A2_WIDE_PATIENCE") ? atoi(getenv("EMU_A2_WIDE_PATIENCE")) : (int)A2_WIDE_PATIENCE;
     // the wavefronts of a launch run at the same time on the device and take work as they
     // go; here they run one after the other, wave w taking every n_wave-th chunk of the
     // queue is not needed for correctness -- any split of the queue is a legal schedule

@@ -76,7 +76,7 @@ def expand(script, dist, q, t):
 
 def align_pairs(pairs, band=150, ring=8192, order=None, max_diff=2.0, windows=None, n_wave=1):
     """pairs: [(query, target)].  windows: optional [(s1, e1, s2, e2)] per pair (default: the
-    whole strings).  Returns ([result dict per pair], stats[8]); a result has the keys of
+    whole strings).  Returns ([result dict per pair], stats[12]); a result has the keys of
     Port.align() plus `err`, `n_ins` and `accept`."""
     n = len(pairs)
     seqs, words, woff = [], [], 0
@@ -110,7 +110,7 @@ def align_pairs(pairs, band=150, ring=8192, order=None, max_diff=2.0, windows=No
         order = np.arange(2 * n, dtype=np.int32)
     order = np.ascontiguousarray(order, dtype=np.int32)
     in_queue = set(int(g) for g in order)
-    stats = np.zeros(8, dtype=np.uint64)
+    stats = np.zeros(12, dtype=np.uint64)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     rc = lib().emu_align2(p(words), C.c_uint64(len(words)), p(seq), C.c_int(2 * n), p(pile), C.c_int(n),
                           p(rng), p(order), C.c_int(len(order)), C.c_uint32(ring), C.c_int(n_wave),

@@ -32,4 +32,7 @@ def test_bench_self_parity_at_batch_scale(workload):
     assert line["config"]["piles_per_step_per_gpu"] == piles
     assert line["parity_checked_piles"] >= 256, line.get("cpu_baseline")
     assert line["parity_mismatches"] == 0, line.get("parity_mismatching_piles")
+    # (against the reference's own C, built by oracle/Makefile and shipped as oracle/_ref: a run
+    # that fell back to the repo's restatement would not be the check this test is named for)
+    assert line["parity_against"] == "reference", line["parity_against"]
     assert line["align"]["handed_back"] <= line["config"]["sequences_per_step_per_gpu"] // 50

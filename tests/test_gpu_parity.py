@@ -649,6 +649,58 @@ def test_outgrown_alignment_slots_are_redone(monkeypatch, port, kernel):
         eng.close()
 
 
+@pytest.mark.parametrize("cause", ["tape", "wide_rows", "escape_list"])
+def test_every_hand_back_cause_on_the_device(monkeypatch, port, cause):
+    """k_align2's three ways of giving an alignment back to the general kernel, each FORCED on
+    the GPU and counted by cause (fa_stats.align_handed_back_*) -- the lane emulator proves their
+    control logic, only the device runs the hand-scheduled row tail and the packed state calls
+    around them:
+      tape         a tape ring of 1024 iterations under alignments of up to ~3000 rows;
+      wide_rows    no patience with a neighbour whose band stays wider than 60 diagonals (reads
+                   at 25 % error beside ordinary ones);
+      escape_list  reads that copy the seed but for a base every ~300: snakes of >= 255 bases in
+                   every row, and a list that is declared full at 16 entries.
+    The consensus of every pile equals the oracle's (DW_banded.c:183-243)."""
+    from falcon_amd.engine import Engine
+    from falcon_amd.synth import codes_to_str, make_pile, pile_to_seqs
+    import random
+    if cause == "tape":
+        monkeypatch.setenv("FALCON_AMD_RING", "1024")
+        piles = [_synthetic(41, S=12000, coverage=20, min_read=1000, mean_read=7000, sd_read=3000)]
+    elif cause == "wide_rows":
+        monkeypatch.setenv("FALCON_AMD_WIDE_PATIENCE", "2")
+        piles = [_synthetic(42, S=8000, coverage=16, e=0.13, min_read=1000, mean_read=5000, sd_read=1500)]
+        s, rd = make_pile(43, S=8000, coverage=10, e=0.27, min_read=1000, mean_read=5000, sd_read=1500)
+        piles[0] = piles[0] + [codes_to_str(x) for x in rd]
+    else:
+        monkeypatch.setenv("FALCON_AMD_ESC_CAP", "16")
+        rng = random.Random(9)
+        s, _rd = make_pile(44, S=30000, coverage=1, e=0.0)
+        seed = codes_to_str(s)
+        reads = []
+        for k in range(24):
+            r = list(seed[rng.randrange(0, 3000):rng.randrange(24000, 30000)])
+            for at in range(rng.randrange(150, 300), len(r) - 10, rng.randrange(280, 330)):
+                r[at] = "ACGT"[("ACGT".index(r[at]) + 1 + rng.randrange(3)) % 4]
+            reads.append("".join(r))
+        piles = [[seed, seed] + reads]
+    want = [port.generate_consensus(p, 4, 8, 0.70) for p in piles]
+    eng = Engine(0)
+    try:
+        b = eng.batch(piles)
+        b.run(4, 8, 0.70).fetch(True)
+        st = b.stats()
+        got = [b.result(i) for i in range(len(piles))]
+        b.free()
+    finally:
+        eng.close()
+    by = {"tape": st.align_handed_back_tape, "wide_rows": st.align_handed_back_wide,
+          "escape_list": st.align_handed_back_escapes}
+    assert by[cause] > 0, (by, st.align_handed_back)
+    assert st.align_handed_back == sum(by.values()) == st.align_relaunched
+    assert [tuple(x) for x in got] == [tuple(x) for x in want]
+
+
 def test_long_insertion_runs_and_tag_cutoff(engine, port):
     """Insertion runs longer than a tag's 16 inline bases, and runs past the
     reference's 255-column cut-off (falcon.c:138-152; beyond the reference's own
