@@ -39,351 +39,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
-
-MIN_COV, K, MIN_IDT, MAX_N_READ = 4, 8, 0.70, 200
-
-# SURVEY.md 8d configs 2/3, 4, 5; the flags are the same cfg line in all three
-# (examples/fc_run_ecoli.cfg:33, fc_run_dmel.cfg:34, fc_run_arab.cfg:34)
-WORKLOADS = {
-    "ecoli": dict(S=20000, coverage=40.0, het=0.0, piles=3072,
-                  text="E. coli-like piles: ~20 kb seed x 40x coverage, e=0.13 "
-                       "(BASELINE.json configs[1]; falcon_amd/synth.py, SURVEY.md 8d)"),
-    "dmel": dict(S=30000, coverage=80.0, het=0.0, piles=1024,
-                 text="D. melanogaster-like piles: ~30 kb seed x 80x coverage, e=0.13, the "
-                      "200-read cap binding (BASELINE.json configs[3]; SURVEY.md 8d config 4)"),
-    "arab": dict(S=25000, coverage=60.0, het=0.005, piles=1536,
-                 text="Arabidopsis-like piles: ~25 kb seed x 60x coverage, e=0.13, two haplotypes "
-                      "0.5 % apart (BASELINE.json configs[4]; SURVEY.md 8d config 5)"),
-}
+# (the parts of this file live in benchlib/: the input, the CPU baseline, the end-to-end legs, the
+# HBM traffic on file; the names stay importable from here)
+from benchlib.cpu_baseline import cpu_baseline, host_cores  # noqa: E402,F401
+from benchlib.e2e import E2E_REPEATS, end_to_end, end_to_end_multi  # noqa: E402,F401
+from benchlib.traffic import _code_only, kernel_source_sha, measured_stream_rate, measured_traffic  # noqa: E402,F401
+from benchlib.workloads import (HBM_PEAK_GBS, K, MAX_N_READ, MIN_COV, MIN_IDT, WORKLOADS, _gen_pile,  # noqa: E402,F401
+                                gen_piles, write_la4falcon)
 
 
-def _gen_pile(job):
-    from falcon_amd.synth import codes_to_str, make_pile, pile_to_seqs
-    seed, S, cov, het = job
-    s, rd = make_pile(seed, S=S, coverage=cov, het=het)
-    return [codes_to_str(x).encode("ascii") for x in pile_to_seqs(s, rd, MAX_N_READ)]
-
-
-def gen_piles(seeds, procs, wl):
-    jobs = [(s, wl["S"], wl["coverage"], wl["het"]) for s in seeds]
-    if procs <= 1 or len(jobs) < 4:
-        return [_gen_pile(j) for j in jobs]
-    ctx = mp.get_context("fork")
-    with ctx.Pool(procs) as pool:
-        return pool.map(_gen_pile, jobs, chunksize=4)
-
-
-# ---- CPU baseline workers (own processes: the reference C is not re-entrant,
-# ---- falcon.c:338, and pays a one-off 0.9 GB workspace per process) ----------
-def _cpu_worker(args):
-    kind, piles = args
-    from oracle.pyoracle import Port, Ref
-    impl = Ref() if kind == "reference" else Port()
-    impl.generate_consensus(piles[0], MIN_COV, K, MIN_IDT)  # warm-up, untimed
-    t0 = time.perf_counter()
-    out = [impl.generate_consensus(p, MIN_COV, K, MIN_IDT)[0] for p in piles[1:]]
-    return out, time.perf_counter() - t0
-
-
-def host_cores():
-    """(logical cpus this process may use, physical cores of the host or None)."""
-    try:
-        logical = len(os.sched_getaffinity(0))
-    except AttributeError:
-        logical = os.cpu_count() or 1
-    try:
-        import psutil
-        phys = psutil.cpu_count(logical=False)
-    except Exception:
-        phys = None
-    return logical, phys
-
-
-def _mem_available_gb():
-    try:
-        with open("/proc/meminfo") as f:
-            for ln in f:
-                if ln.startswith("MemAvailable:"):
-                    return int(ln.split()[1]) / 1048576.0
-    except OSError:
-        pass
-    return None
-
-
-def _cpu_run(kind, piles, first, cores, per):
-    """`cores` worker processes, worker w on piles[first + w * per : first + (w + 1) * per]
-    (its first pile is the untimed warm-up).  -> (result object, {pile index: string})"""
-    jobs = [(kind, piles[first + i * per:first + (i + 1) * per]) for i in range(cores)]
-    ctx = mp.get_context("fork")
-    t0 = time.perf_counter()
-    with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, jobs)
-    wall = time.perf_counter() - t0
-    strings = {}
-    for w, (out, _) in enumerate(res):
-        for j, s in enumerate(out):
-            strings[first + w * per + 1 + j] = s
-    bases = sum(len(s) for s in strings.values())
-    busy = max(r[1] for r in res)  # workers run concurrently: timed span of the slowest
-    return {"cores": cores, "value": round(bases / busy, 1), "piles_per_sec": round(len(strings) / busy, 3),
-            "per_core_bases_per_sec": round(bases / sum(r[1] for r in res), 1), "piles": len(strings),
-            "wall_s": round(wall, 1)}, strings
-
-
-def cpu_baseline(piles, timed_per_worker=20, procs=None):
-    """-> (the cpu_baseline object, {pile index: consensus string} of the timed piles).
-
-    SURVEY.md 8d "CPU baseline timing": the reference C path in P worker processes = the
-    host's physical cores (never more than this process may run on, nor than memory allows:
-    the reference keeps a 0.9 GB workspace per process), one untimed warm-up pile per
-    worker, `timed_per_worker` timed piles each, taken from the front of this rank's batch.
-    The reference does not scale to a big host (every process sweeps its own 0.9 GB
-    workspace per pile: 128 processes were measured SLOWER than 16), so 16, 32 and 64
-    processes are timed as well and `value` is the best of them -- all are listed."""
-    from oracle.pyoracle import build, have_ref
-    try:
-        build()
-    except Exception:
-        pass
-    kind = "reference" if have_ref() else "port"
-    logical, phys = host_cores()
-    cores = max(1, min(logical, phys or logical))
-    mem = _mem_available_gb()
-    if mem is not None:
-        cores = max(1, min(cores, int(mem / 2.0)))  # 0.9 GB workspace + the piles + headroom
-    runs, strings, first = [], {}, 0
-    # 16, 32, 64 processes and the physical cores: where the host's best lies is measured,
-    # not assumed (the larger configurations time fewer piles per worker: ~10-30 s each)
-    for want in sorted({min(cores, int(x)) for x in procs} if procs else
-                       {min(cores, 16), min(cores, 32), min(cores, 64), cores}):
-        per = min((timed_per_worker if want <= 32 else max(4, timed_per_worker // 3)) + 1, len(piles))
-        c = max(1, min(want, (len(piles) - first) // per))
-        if (c < want and runs) or first + per > len(piles):
-            break  # (not enough piles left for another configuration)
-        r, got = _cpu_run(kind, piles, first, c, per)
-        runs.append(r)
-        strings.update(got)
-        first += c * per
-    best = max(runs, key=lambda r: r["value"])
-    cpu_model = ""
-    try:
-        with open("/proc/cpuinfo") as f:
-            for ln in f:
-                if ln.startswith("model name"):
-                    cpu_model = ln.split(":", 1)[1].strip()
-                    break
-    except OSError:
-        pass
-    return {
-        "value": best["value"], "unit": "bases/s", "cores": best["cores"], "kind": kind,
-        "piles_per_sec": best["piles_per_sec"],
-        "per_core_bases_per_sec": best["per_core_bases_per_sec"],
-        "host_cpu_count": logical, "host_physical_cores": phys, "host_cpu_model": cpu_model,
-        "runs": runs,
-        "sample": "piles of this workload from the front of the batch, %d timed per worker process (%d "
-                  "beyond 32 processes) + 1 untimed warm-up pile each; worker processes: %s (16, 32, 64 and "
-                  "the physical cores, capped by the cpus allowed and memory / 2 GB) -- `value` is the "
-                  "best of them: %d processes, %d piles"
-                  % (timed_per_worker, max(4, timed_per_worker // 3), ", ".join(str(r["cores"]) for r in runs),
-                     best["cores"], best["piles"]),
-    }, strings
-
-
-def write_la4falcon(piles, f, repeats=1):
-    """The LA4Falcon text a pile [seed, seed copy + reads by length] (falcon_amd.synth
-    pile_to_seqs) came from: the seed line, then the reads (the reader adds the seed's copy
-    itself, consensus.py:183-190).  `repeats`: the piles again under new seed ids, for a
-    stream as long as a .las block's."""
-    for rep in range(repeats):
-        for i, p in enumerate(piles):
-            lines, seen_copy = [b"%09d %s" % (rep * len(piles) + i, p[0])], False
-            for j, r in enumerate(p[1:]):
-                if not seen_copy and r == p[0]:
-                    seen_copy = True
-                    continue
-                lines.append(b"%09d %s" % (1000000 + 1000 * i + j, r))
-            f.write(b"\n".join(lines) + b"\n+ +\n")
-    f.write(b"- -\n")
-
-
-E2E_REPEATS = 10  # the end-to-end stream = the step's piles this many times: 30 720 piles, so
                   # that start-up is amortised the way a .las block's tens of thousands amortise it
-
-
-def end_to_end(piles, extra_args=(), expect=None, repeats=E2E_REPEATS):
-    """SURVEY.md 8d "end-to-end": LA4Falcon text on stdin -> FASTA on stdout through the
-    consensus worker (falcon_amd.mains.consensus: native reader, staging, GPU stages,
-    printing) in a process of its own, on the piles of this workload written out as text.
-    Reported beside `value` (kernel-only, inputs resident in HBM), never as it.
-    `expect`: consensus strings of these piles from the resident batch -- the FASTA must be
-    what the output rules (consensus.py:275-299) make of them, byte for byte."""
-    import subprocess
-    import tempfile
-    root = os.path.dirname(os.path.abspath(__file__))
-    with tempfile.TemporaryDirectory() as tmp:
-        src, dst = os.path.join(tmp, "piles.txt"), os.path.join(tmp, "cns.fasta")
-        # (as many repeats as the scratch directory holds with room to spare: ~0.83 MB of text per pile)
-        import shutil
-        per_repeat = sum(sum(len(x) + 10 for x in p) for p in piles) + 1
-        repeats = max(1, min(repeats, int(shutil.disk_usage(tmp).free * 0.6 // per_repeat)))
-        with open(src, "wb") as f:
-            write_la4falcon(piles, f, repeats)
-        size = os.path.getsize(src)
-        cmd = [sys.executable, "-m", "falcon_amd.mains.consensus", "--output-multi", "--min-idt",
-               "0.70", "--min-cov", "4", "--max-n-read", "200", "--n-core", "1"] + list(extra_args) + \
-            os.environ.get("FALCON_BENCH_E2E_ARGS", "").split()
-        # (a profiler wrapped around this process stays with this process: the worker's
-        # launches are at another batch size and would blur its per-kernel averages)
-        env = {k: v for k, v in os.environ.items()
-               if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTRACER", "HSA_TOOLS"))}
-        # three workers back to back, the median counts: fc_run starts one consensus process
-        # per .las block one after the other, so a worker that starts right behind one that
-        # released its VRAM (amdgpu wipes it) IS production (all three are listed)
-        walls, steady = [], []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            with open(src) as fin, open(dst, "w") as fout:
-                p = subprocess.run(cmd, stdin=fin, stdout=fout, stderr=subprocess.PIPE, check=True, cwd=root,
-                                   timeout=600, env=env, text=True)
-            walls.append(time.perf_counter() - t0)
-            for ln in p.stderr.split("\n"):  # the worker's own report (consensus._run_native)
-                if "steady state" in ln:
-                    steady.append(float(ln.split("steady state")[1].split()[0]))
-        wall = sorted(walls)[1]  # the MEDIAN of three back-to-back workers (all listed)
-        with open(dst) as f:
-            text = f.read()
-        bases = sum(len(ln) for ln in text.split("\n") if not ln.startswith(">"))
-    n = repeats * len(piles)
-    out = {"piles_per_sec": round(n / wall, 1), "text_MB_per_sec": round(size / 1e6 / wall, 1),
-           "fasta_bases_per_sec": round(bases / wall, 1), "wall_s": round(wall, 2),
-           "runs_wall_s": [round(w, 2) for w in walls],
-           "worker_steady_state_piles_per_sec": steady,
-           "what": "%d piles (the step's %d, %d times; %.0f MB of text from the page cache) -> FASTA, one "
-                   "worker process on one GPU, process start and HIP initialisation included; three workers "
-                   "back to back, the median wall time counts (`worker_steady_state_piles_per_sec`: what each "
-                   "worker reports between its first and its last batch printed)"
-                   % (n, len(piles), repeats, size / 1e6)}
-    if expect is not None:
-        from falcon_amd.mains.consensus import fasta_records
-        want = "".join(fasta_records("%09d" % (rep * len(piles) + i), c, False, True)
-                       for rep in range(repeats) for i, c in enumerate(expect))
-        out["fasta_identical_to_resident_batch"] = (want == text)
-        out["fasta_sha1"] = hashlib.sha1(text.encode()).hexdigest()[:16]
-    return out
-
-
-def end_to_end_multi(piles, n_streams, repeats=E2E_REPEATS):
-    """N > 1: the same text as `n_streams` jobs of ONE multi-stream worker process
-    (falcon_amd.mains.consensus_multi) over all visible GPUs -- how a node is fed: a single
-    stream has one reader and one staging thread, which one device's batches already keep
-    busy.  Every job's FASTA must equal what the single-stream worker prints
-    for the same text on one GPU (run afterwards, outside the timing)."""
-    root = os.path.dirname(os.path.abspath(__file__))
-    with tempfile.TemporaryDirectory() as tmp:
-        src = os.path.join(tmp, "piles.txt")
-        with open(src, "wb") as f:
-            write_la4falcon(piles, f, repeats)
-        size = os.path.getsize(src)
-        opts = ["--output-multi", "--min-idt", "0.70", "--min-cov", "4", "--max-n-read", "200", "--n-core", "1"]
-        env = {k: v for k, v in os.environ.items()
-               if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTRACER", "HSA_TOOLS"))
-               and k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-        env.pop("FALCON_AMD_DEVICES", None)
-        jobs = []
-        for j in range(n_streams):
-            jobs += ["--job", src, os.path.join(tmp, "cns_%d.fasta" % j)]
-        cmd = [sys.executable, "-m", "falcon_amd.mains.consensus_multi"] + opts + jobs
-        walls = []
-        for _ in range(2):
-            t0 = time.perf_counter()
-            subprocess.run(cmd, check=True, cwd=root, timeout=900, env=env)
-            walls.append(time.perf_counter() - t0)
-        ref = os.path.join(tmp, "single.fasta")
-        with open(src) as fin, open(ref, "w") as fout:
-            subprocess.run([sys.executable, "-m", "falcon_amd.mains.consensus"] + opts, stdin=fin, stdout=fout,
-                           check=True, cwd=root, timeout=900, env=dict(env, FALCON_AMD_DEVICES="0"))
-        want = open(ref).read()
-        same = all(open(os.path.join(tmp, "cns_%d.fasta" % j)).read() == want for j in range(n_streams))
-    n = repeats * len(piles) * n_streams
-    walls.sort()
-    wall = walls[len(walls) // 2]
-    return {"piles_per_sec": round(n / wall, 1), "text_MB_per_sec": round(size * n_streams / 1e6 / wall, 1),
-            "wall_s": round(wall, 2), "runs_wall_s": [round(w, 2) for w in walls], "streams": n_streams,
-            "every_stream_identical_to_the_single_stream_worker": bool(same),
-            "what": "%d streams of %d piles each (%.0f MB of text each, from the page cache) -> %d FASTA files, "
-                    "one multi-stream worker process over all visible GPUs, process start included; the slower "
-                    "of two runs counts" % (n_streams, repeats * len(piles), size / 1e6, n_streams)}
-
-
-def measured_stream_rate(torch, mib=1024, reps=5):
-    """GB/s (read + write) of a device-to-device copy of `mib` MiB: what HBM delivers to the
-    simplest streaming kernel on this box (outside the timed region; plumbing, not product)."""
-    try:
-        a = torch.empty(mib << 20, dtype=torch.uint8, device="cuda")
-        b = torch.empty_like(a)
-        b.copy_(a)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            b.copy_(a)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        del a, b
-        return round(2.0 * (mib << 20) / (ms * 1e-3) / 1e9, 1)
-    except Exception:  # informative only
-        return None
-
-
-KERNEL_SOURCE = {"k_align": ("k_align2.hip", "k_align2_core.h", "fa_wave.h", "k_align.hip"),
-                 "k_score": "k_msa.hip", "k_links": "k_msa.hip",
-                 "k_tags": "k_msa.hip", "k_backtrace": "k_msa.hip", "k_chain": "k_chain.hip",
-                 "k_seed_index": "k_pack_index.hip"}
-
-
-def _code_only(text):
-    """C++ source without comments and blank space: what the digest below is taken of (a
-    reworded comment does not make a measurement stale; string literals -- the inline asm --
-    are kept as they are)."""
-    import re
-    pat = re.compile(r'"(?:\\.|[^"\\])*"|\'(?:\\.|[^\'\\])*\'|//[^\n]*|/\*.*?\*/', re.S)
-    text = pat.sub(lambda m: m.group(0) if m.group(0)[0] in "\"'" else " ", text)
-    return "\n".join(" ".join(ln.split()) for ln in text.splitlines() if ln.strip())
-
-
-def kernel_source_sha(kernel):
-    """Digest of the code (comments and layout aside) of the source files a kernel lives in:
-    a PMC measurement is only presented as this build's when it was taken on this code."""
-    try:
-        names = KERNEL_SOURCE[kernel]
-        h = hashlib.sha1()
-        for name in ((names,) if isinstance(names, str) else names):
-            with open(os.path.join(ROOT, "falcon_amd", "csrc", name), "r", errors="replace") as f:
-                h.update(_code_only(f.read()).encode())
-        return h.hexdigest()[:16]
-    except (KeyError, OSError):
-        return None
-
-
-def measured_traffic(kernel, piles, workload):
-    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under
-    profiles/ (the TCC counters cannot be read from inside this process); None unless a
-    measurement of this kernel's CURRENT source, at this batch size and workload, is on file
-    (profiles/pmc_traffic.json, written by scripts/pmc_traffic_record.py)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            rec = json.load(f).get(kernel)
-        if not rec:
-            return None, "no PMC measurement of this kernel under profiles/"
-        if int(rec["piles_per_launch"]) != int(piles) or rec.get("workload", "ecoli") != workload:
-            return None, "the PMC measurement on file is of another batch size or workload"
-        if rec.get("source_sha") != kernel_source_sha(kernel):
-            return None, ("the PMC measurement on file (%s) was taken on an older source of this "
-                          "kernel" % rec.get("taken_on", "?"))
-        return int(rec["hbm_bytes_per_launch"]), rec.get("what", "")
-    except Exception as e:
-        return None, "profiles/pmc_traffic.json unreadable: %r" % (e,)
 
 
 def parse_args(argv=None):
@@ -396,9 +61,9 @@ def parse_args(argv=None):
                     help="piles per step per GPU (default: 3072 ecoli, 1024 dmel, 1536 arab)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-procs", default="",
-                    help="worker-process counts of the CPU baseline, comma separated (default: 16,32,64 and "
+                    help="worker-process counts of the CPU baseline, comma separated (default: 1,8,16,24,32,64 and "
                          "the physical cores)")
-    ap.add_argument("--cpu-baseline-timed", type=int, default=20,
+    ap.add_argument("--cpu-baseline-timed", type=int, default=12,
                     help="timed piles per CPU worker process (every one is also a parity check of the GPU's answer)")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--in-flight", type=int, default=3,

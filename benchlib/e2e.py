@@ -1,0 +1,120 @@
+"""bench.py, the end-to-end legs: LA4Falcon text in -> FASTA out through the consensus workers in processes of their own
+(SURVEY.md 8d "end-to-end"); reported beside `value`, never as it."""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+from benchlib.workloads import write_la4falcon
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+E2E_REPEATS = 10  # the end-to-end stream = the step's piles this many times: 30 720 piles, so
+
+
+def end_to_end(piles, extra_args=(), expect=None, repeats=E2E_REPEATS):
+    """SURVEY.md 8d "end-to-end": LA4Falcon text on stdin -> FASTA on stdout through the
+    consensus worker (falcon_amd.mains.consensus: native reader, staging, GPU stages,
+    printing) in a process of its own, on the piles of this workload written out as text.
+    Reported beside `value` (kernel-only, inputs resident in HBM), never as it.
+    `expect`: consensus strings of these piles from the resident batch -- the FASTA must be
+    what the output rules (consensus.py:275-299) make of them, byte for byte."""
+    root = ROOT
+    with tempfile.TemporaryDirectory() as tmp:
+        src, dst = os.path.join(tmp, "piles.txt"), os.path.join(tmp, "cns.fasta")
+        # (as many repeats as the scratch directory holds with room to spare: ~0.83 MB of text per pile)
+        import shutil
+        per_repeat = sum(sum(len(x) + 10 for x in p) for p in piles) + 1
+        repeats = max(1, min(repeats, int(shutil.disk_usage(tmp).free * 0.6 // per_repeat)))
+        with open(src, "wb") as f:
+            write_la4falcon(piles, f, repeats)
+        size = os.path.getsize(src)
+        cmd = [sys.executable, "-m", "falcon_amd.mains.consensus", "--output-multi", "--min-idt",
+               "0.70", "--min-cov", "4", "--max-n-read", "200", "--n-core", "1"] + list(extra_args) + \
+            os.environ.get("FALCON_BENCH_E2E_ARGS", "").split()
+        # (a profiler wrapped around this process stays with this process: the worker's
+        # launches are at another batch size and would blur its per-kernel averages)
+        env = {k: v for k, v in os.environ.items()
+               if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTRACER", "HSA_TOOLS"))}
+        # three workers back to back, the median counts: fc_run starts one consensus process
+        # per .las block one after the other, so a worker that starts right behind one that
+        # released its VRAM (amdgpu wipes it) IS production (all three are listed)
+        walls, steady = [], []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            with open(src) as fin, open(dst, "w") as fout:
+                p = subprocess.run(cmd, stdin=fin, stdout=fout, stderr=subprocess.PIPE, check=True, cwd=root,
+                                   timeout=600, env=env, text=True)
+            walls.append(time.perf_counter() - t0)
+            for ln in p.stderr.split("\n"):  # the worker's own report (consensus._run_native)
+                if "steady state" in ln:
+                    steady.append(float(ln.split("steady state")[1].split()[0]))
+        wall = sorted(walls)[1]  # the MEDIAN of three back-to-back workers (all listed)
+        with open(dst) as f:
+            text = f.read()
+        bases = sum(len(ln) for ln in text.split("\n") if not ln.startswith(">"))
+    n = repeats * len(piles)
+    out = {"piles_per_sec": round(n / wall, 1), "text_MB_per_sec": round(size / 1e6 / wall, 1),
+           "fasta_bases_per_sec": round(bases / wall, 1), "wall_s": round(wall, 2),
+           "runs_wall_s": [round(w, 2) for w in walls],
+           "worker_steady_state_piles_per_sec": steady,
+           "what": "%d piles (the step's %d, %d times; %.0f MB of text from the page cache) -> FASTA, one "
+                   "worker process on one GPU, process start and HIP initialisation included; three workers "
+                   "back to back, the median wall time counts (`worker_steady_state_piles_per_sec`: what each "
+                   "worker reports between its first and its last batch printed)"
+                   % (n, len(piles), repeats, size / 1e6)}
+    if expect is not None:
+        from falcon_amd.mains.consensus import fasta_records
+        want = "".join(fasta_records("%09d" % (rep * len(piles) + i), c, False, True)
+                       for rep in range(repeats) for i, c in enumerate(expect))
+        out["fasta_identical_to_resident_batch"] = (want == text)
+        out["fasta_sha1"] = hashlib.sha1(text.encode()).hexdigest()[:16]
+    return out
+
+
+def end_to_end_multi(piles, n_streams, repeats=E2E_REPEATS):
+    """N > 1: the same text as `n_streams` jobs of ONE multi-stream worker process
+    (falcon_amd.mains.consensus_multi) over all visible GPUs -- how a node is fed: a single
+    stream has one reader and one staging thread, which one device's batches already keep
+    busy.  Every job's FASTA must equal what the single-stream worker prints
+    for the same text on one GPU (run afterwards, outside the timing)."""
+    root = ROOT
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "piles.txt")
+        with open(src, "wb") as f:
+            write_la4falcon(piles, f, repeats)
+        size = os.path.getsize(src)
+        opts = ["--output-multi", "--min-idt", "0.70", "--min-cov", "4", "--max-n-read", "200", "--n-core", "1"]
+        env = {k: v for k, v in os.environ.items()
+               if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTRACER", "HSA_TOOLS"))
+               and k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        env.pop("FALCON_AMD_DEVICES", None)
+        jobs = []
+        for j in range(n_streams):
+            jobs += ["--job", src, os.path.join(tmp, "cns_%d.fasta" % j)]
+        cmd = [sys.executable, "-m", "falcon_amd.mains.consensus_multi"] + opts + jobs
+        walls = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            subprocess.run(cmd, check=True, cwd=root, timeout=900, env=env)
+            walls.append(time.perf_counter() - t0)
+        ref = os.path.join(tmp, "single.fasta")
+        with open(src) as fin, open(ref, "w") as fout:
+            subprocess.run([sys.executable, "-m", "falcon_amd.mains.consensus"] + opts, stdin=fin, stdout=fout,
+                           check=True, cwd=root, timeout=900, env=dict(env, FALCON_AMD_DEVICES="0"))
+        want = open(ref).read()
+        same = all(open(os.path.join(tmp, "cns_%d.fasta" % j)).read() == want for j in range(n_streams))
+    n = repeats * len(piles) * n_streams
+    walls.sort()
+    wall = walls[len(walls) // 2]
+    return {"piles_per_sec": round(n / wall, 1), "text_MB_per_sec": round(size * n_streams / 1e6 / wall, 1),
+            "wall_s": round(wall, 2), "runs_wall_s": [round(w, 2) for w in walls], "streams": n_streams,
+            "every_stream_identical_to_the_single_stream_worker": bool(same),
+            "what": "%d streams of %d piles each (%.0f MB of text each, from the page cache) -> %d FASTA files, "
+                    "one multi-stream worker process over all visible GPUs, process start included; the slower "
+                    "of two runs counts" % (n_streams, repeats * len(piles), size / 1e6, n_streams)}
