@@ -61,6 +61,34 @@ def _mem_available_gb():
     return None
 
 
+def _cgroup_cpu():
+    """(cpus the container's CPU quota allows or None, {throttled periods, throttled microseconds} so far)."""
+    quota, stat = None, {}
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                w = f.read().split()
+            if path.endswith("cpu.max"):
+                quota = None if w[0] == "max" else float(w[0]) / float(w[1])
+            else:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                    quota = None if int(w[0]) < 0 else float(w[0]) / float(g.read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            with open(path) as f:
+                for ln in f:
+                    k, v = ln.split()
+                    if k in ("nr_throttled", "throttled_usec", "throttled_time", "nr_periods"):
+                        stat[k] = int(v)
+            break
+        except (OSError, ValueError):
+            continue
+    return quota, stat
+
+
 def _placement():
     """The cpus workers are pinned to, in the order they are handed out: one logical cpu per
     physical core, the cores dealt round robin over the L3 domains (a CCD of an EPYC) and with them
@@ -104,10 +132,12 @@ def _cpu_run(kind, piles, first, cores, per, cpus):
     jobs = [(kind, piles[first + i * per:first + (i + 1) * per], cpus[i] if i < len(cpus) else None)
             for i in range(cores)]
     ctx = mp.get_context("fork")
+    _q, thr0 = _cgroup_cpu()
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
         res = pool.map(_cpu_worker, jobs)
     wall = time.perf_counter() - t0
+    _q, thr1 = _cgroup_cpu()
     strings = {}
     for w, (out, _, _u) in enumerate(res):
         for j, s in enumerate(out):
@@ -119,6 +149,8 @@ def _cpu_run(kind, piles, first, cores, per, cpus):
     return {"cores": cores, "value": round(bases / busy, 1), "piles_per_sec": round(len(strings) / busy, 3),
             "per_core_bases_per_sec": round(bases / sum(r[1] for r in res), 1), "piles": len(strings),
             "wall_s": round(wall, 1), "pinned": bool(cpus),
+            # the container's CPU quota at work: scheduler periods in which the workers were stopped, and for how long
+            "cgroup_throttled": {k: thr1.get(k, 0) - thr0.get(k, 0) for k in thr1},
             # per timed pile: seconds in user code / in the kernel, page faults
             "per_pile": {"user_s": round(use["user_s"] / n, 3), "sys_s": round(use["sys_s"] / n, 3),
                          "minor_faults": int(use["minor_faults"] / n), "major_faults": int(use["major_faults"] / n)}}, strings
@@ -148,6 +180,7 @@ def cpu_baseline(piles, timed_per_worker=12, procs=None):
     if mem is not None:
         cores = max(1, min(cores, int(mem / 2.0)))  # 0.9 GB workspace + the piles + headroom
     cpus = _placement()
+    quota, _thr = _cgroup_cpu()
     runs, strings, first = [], {}, 0
     # (the larger configurations time fewer piles per worker: every configuration ~5-20 s)
     wanted = sorted({min(cores, int(x)) for x in procs} if procs else
@@ -179,6 +212,9 @@ def cpu_baseline(piles, timed_per_worker=12, procs=None):
         "per_core_bases_per_sec": (one or best)["per_core_bases_per_sec"],
         "host_cpu_count": logical, "host_physical_cores": phys, "host_cpu_model": cpu_model,
         "workers_pinned_to_cores_over_l3_domains": bool(cpus),
+        # what the box lets this process group use at all: a container with a CPU quota runs 128
+        # workers no faster than `quota` of them (runs[].cgroup_throttled shows it happening)
+        "cgroup_cpu_quota_cores": quota,
         "runs": runs,
         "sample": "piles of this workload from the front of the batch, %d timed per worker process (%d "
                   "beyond 32 processes) + 1 untimed warm-up pile each; worker processes: %s (capped by the "

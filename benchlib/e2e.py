@@ -86,6 +86,10 @@ def end_to_end_multi(piles, n_streams, repeats=E2E_REPEATS):
     root = ROOT
     with tempfile.TemporaryDirectory() as tmp:
         src = os.path.join(tmp, "piles.txt")
+        # (as many repeats as the scratch directory holds with room to spare, like end_to_end)
+        import shutil
+        per_repeat = sum(sum(len(x) + 10 for x in p) for p in piles) + 1
+        repeats = max(1, min(repeats, int(shutil.disk_usage(tmp).free * 0.6 // per_repeat)))
         with open(src, "wb") as f:
             write_la4falcon(piles, f, repeats)
         size = os.path.getsize(src)
@@ -101,7 +105,7 @@ def end_to_end_multi(piles, n_streams, repeats=E2E_REPEATS):
         walls = []
         for _ in range(2):
             t0 = time.perf_counter()
-            subprocess.run(cmd, check=True, cwd=root, timeout=900, env=env)
+            subprocess.run(cmd, check=True, cwd=root, timeout=max(900, int(60 + n_streams * size / 2e8)), env=env)
             walls.append(time.perf_counter() - t0)
         ref = os.path.join(tmp, "single.fasta")
         with open(src) as fin, open(ref, "w") as fout:

@@ -338,8 +338,10 @@ struct fa_batch {
     u64 out_slots = 0;
     fa_stats stats = {};
     // events of the last run: 0..3 on the front stream (index, chain, align), 4..11 on the
-    // back stream (MSA stage), 12: alignment summaries on the host, 13: a repeat launch done
-    hipEvent_t ev[14] = {};
+    // back stream (MSA stage), 12: alignment summaries on the host, 13 / 14: around the repeat
+    // launch of the alignments k_align2 handed back (redo_timed: there was one in this run)
+    hipEvent_t ev[15] = {};
+    bool redo_timed = false;
     bool in_flight = false;  // fa_batch_submit done, fa_batch_wait pending
     // kernels of this batch were launched on the context's front stream (submit, pair and
     // unitig runs, also ones that failed half-way): fa_batch_free waits for that stream
@@ -938,6 +940,12 @@ static int ensure_arena(fa_ctx *c, const fa_batch *b, size_t lds_bytes, bool ful
             need_rows += need_rows / 4;
         }
     }
+    if (need_cells > c->arena_cells_bytes || need_rows > c->arena_rows_bytes) {
+        // (a pipeline drain, said out loud: submit no longer waits for the device, so the batch
+        // before this one may still have its alignment kernel queued on the arena that is about
+        // to be freed -- hipFree's implicit device-wide wait is not a contract to lean on)
+        (void)hipStreamSynchronize(c->stream);
+    }
     if (need_cells > c->arena_cells_bytes) {
         if (c->arena.cells) (void)hipFree(c->arena.cells);
         c->arena.cells = nullptr;
@@ -980,6 +988,8 @@ static int ensure_arena2(fa_ctx *c, const fa_batch *b, int n) {
         if ((u64)n_slot * per_slot > budget) n_slot = (int)std::max<u64>(1, budget / per_slot);
     }
     const size_t need_cells = (size_t)n_slot * cells * 4, need_rows = (size_t)n_slot * rows * sizeof(FaRowRec);
+    if (need_cells > c->arena2_cells_bytes || need_rows > c->arena2_rows_bytes)
+        (void)hipEventSynchronize(c->ev_redo);  // (a repeat launch of another batch may still use the arena)
     if (need_cells > c->arena2_cells_bytes) {
         if (c->arena2.cells) (void)hipFree(c->arena2.cells);
         c->arena2.cells = nullptr;
@@ -1042,6 +1052,7 @@ static int ensure_arena_a2(fa_ctx *c, const fa_batch *b) {
             n_slot = (int)fit;
         } else {
             if (need + need / 4 <= budget) need += need / 4;
+            (void)hipStreamSynchronize(c->stream);  // (the batch before may still run on the arena: a drain, see ensure_arena)
             if (c->a2.mem) (void)hipFree(c->a2.mem);
             c->a2.mem = nullptr;
             c->a2_bytes = 0;
@@ -1102,10 +1113,13 @@ static int redo_handed_back(fa_batch *b, double max_diff, int band, hipStream_t 
     if (ensure_arena2(c, b, (int)redo.size()) || b->d_redo.alloc(redo.size())) return -1;
     HIP_OK(hipStreamWaitEvent(s, c->ev_redo, 0));
     HIP_OK(hipMemcpyAsync(b->d_redo.p, redo.data(), redo.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_OK(hipEventRecord(b->ev[13], s));  // (the repeat launch's own span: added to ms_align, see fill of fa_stats)
     fa_launch_align_list(b->dev(), c->arena2, b->max_read_len, b->max_seed_len, max_diff, band, b->d_redo.p,
                          (int)redo.size(), s);
     HIP_OK(hipGetLastError());
     HIP_OK(hipEventRecord(c->ev_redo, s));
+    HIP_OK(hipEventRecord(b->ev[14], s));
+    b->redo_timed = true;
     b->stats.align_relaunched = (int)redo.size();
     // (the list must outlive the copy: fetch_aln synchronises the stream)
     int rc = fetch_aln(b, s);
@@ -1162,6 +1176,7 @@ extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double
         b->front_launched = true;
         b->fetched = b->fetched_eqv = false;
         b->have_range = b->have_aln = false;
+        b->redo_timed = false;
         const double max_diff = 1.0 - min_idt;  // falcon.c:580
         // (decided once per run: the arena sized here is the one start_align launches on)
         const bool two_per_wave = use_align2(b, FA_BAND);
@@ -1557,6 +1572,10 @@ static int finish_run(fa_batch *b, bool grace) {
     (void)hipEventElapsedTime(&st.ms_index, b->ev[0], b->ev[1]);
     (void)hipEventElapsedTime(&st.ms_chain, b->ev[1], b->ev[2]);
     (void)hipEventElapsedTime(&st.ms_align, b->ev[2], b->ev[3]);
+    if (b->redo_timed) {  // the alignments k_align2 handed back, repeated on the back stream
+        float ms_redo = 0;
+        if (hipEventElapsedTime(&ms_redo, b->ev[13], b->ev[14]) == hipSuccess) st.ms_align += ms_redo;
+    }
     (void)hipEventElapsedTime(&st.ms_tags, b->ev[4], b->ev[8]);
     (void)hipEventElapsedTime(&st.ms_links, b->ev[8], b->ev[9]);
     (void)hipEventElapsedTime(&st.ms_score, b->ev[7], b->ev[10]);
