@@ -340,6 +340,24 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
                 gpu_cns = [batch.result(p) for p in range(batch.n_pile)]
             except Exception:
                 gpu_cns = None
+        if world == 1:
+            # staging again, now that the context's pinned and device staging buffers exist:
+            # the steady-state cost of handing a batch of host buffers over (outside `value`)
+            try:
+                t_up2 = time.perf_counter()
+                again = eng.batch(piles)
+                t_up2 = time.perf_counter() - t_up2
+                again.free()
+                res["setup_s"]["stage_to_hbm_incl_pcie_again"] = round(t_up2, 2)
+            except Exception:  # informative; never lose the GPU line
+                pass
+        # the resident batches and the engine go before the end-to-end legs: their workers are
+        # processes of their own and find the GPU the way a job of fc_run finds it
+        for b in pair:
+            b.free()
+        pair = []
+        eng.close()
+        eng = None
         if world == 1 and not args.no_end_to_end:
             try:
                 res["end_to_end"] = end_to_end(piles, expect=gpu_cns)
@@ -352,19 +370,6 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
                 res["end_to_end"] = end_to_end_multi(piles, world)
             except Exception as e:
                 res["end_to_end"] = {"piles_per_sec": None, "what": "failed: %r" % (e,)}
-        if world == 1:
-            # staging again, now that the context's pinned and device staging buffers exist:
-            # the steady-state cost of handing a batch of host buffers over (outside `value`;
-            # after the end-to-end leg: amdgpu wipes released VRAM and a worker process
-            # starting right behind a large release waits for that)
-            try:
-                t_up2 = time.perf_counter()
-                again = eng.batch(piles)
-                t_up2 = time.perf_counter() - t_up2
-                again.free()
-                res["setup_s"]["stage_to_hbm_incl_pcie_again"] = round(t_up2, 2)
-            except Exception:  # informative; never lose the GPU line
-                pass
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"], cpu_cns = cpu_baseline(
@@ -383,7 +388,8 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
         print(json.dumps(res), file=out, flush=True)
     for b in pair:
         b.free()
-    eng.close()
+    if eng is not None:
+        eng.close()
     return res
 
 

@@ -450,6 +450,29 @@ extern "C" fa_ctx *fa_create(int device) {
     return c;
 }
 
+static int stage_reserve(fa_ctx *c, size_t bytes, bool device_twin);
+
+// What the first batch of a context would otherwise pay for on the spot: the pinned staging
+// buffer for batches of `batch_bases` bases, the code objects of the path's kernels, the first
+// host-to-device copy.  The workers call it from the thread that opens the engine, while the first
+// batches are being read (round 3's first batch waited 25 ms for the pinned buffer, 30 ms for its
+// upload and 39 ms for its first launches).
+extern "C" int fa_warm(fa_ctx *c, long long batch_bases) {
+    if (!c) return -1;
+    HIP_OK(hipSetDevice(c->device));
+    {
+        std::lock_guard<std::mutex> hold(c->stage_mu);
+        const size_t bytes = (size_t)std::max<long long>(batch_bases, 1 << 20) / 4 + (4u << 20);
+        if (stage_reserve(c, bytes, false)) return -1;
+        HIP_OK(hipMemsetAsync(c->d_first_bad, 0, sizeof(int), c->up_stream));
+        HIP_OK(hipMemcpyAsync(c->d_first_bad, c->h_stage, sizeof(int), hipMemcpyHostToDevice, c->up_stream));
+        HIP_OK(hipStreamSynchronize(c->up_stream));
+    }
+    fa_touch_index(); fa_touch_chain(); fa_touch_align2(); fa_touch_msa(); fa_touch_links2();
+    fa_touch_score1(); fa_touch_score2();
+    return 0;
+}
+
 extern "C" void fa_destroy(fa_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);

@@ -187,5 +187,13 @@ void fa_launch_msa_front(const FaBatchDev &b, const FaMsaDev &m, unsigned min_co
                          hipEvent_t ev_tags, hipEvent_t ev_links);
 void fa_launch_msa_back(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov, hipStream_t s,
                         hipEvent_t ev_score, hipEvent_t ev_backtrace);
+// fa_warm: one kernel of every file of the consensus path looked at, so that its code object is loaded
+void fa_touch_index();
+void fa_touch_chain();
+void fa_touch_align2();
+void fa_touch_msa();
+void fa_touch_links2();
+void fa_touch_score1();
+void fa_touch_score2();
 size_t fa_align_lds_bytes(int max_q_len, int max_t_len);
 int fa_align_blocks_per_cu(size_t lds_bytes);

@@ -68,3 +68,9 @@ void fa_launch_align2(const FaBatchDev &b, const FaAlign2Arena &a, double max_di
     if (grid > (n_work + 1) / 2) grid = (n_work + 1) / 2;
     hipLaunchKernelGGL(k_align2, dim3(grid), dim3(64), fa_align2_lds_bytes(), s, A);
 }
+
+// (fa_warm: the code object of this file is loaded when one of its kernels is first looked at)
+void fa_touch_align2() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_align2));
+}

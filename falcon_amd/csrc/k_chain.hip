@@ -361,3 +361,9 @@ void fa_launch_chain(const FaBatchDev &b, int max_bins, hipStream_t s) {
                                   (int)lds);
     hipLaunchKernelGGL(k_chain, dim3(b.n_chain), dim3(64), lds, s, A);
 }
+
+// (fa_warm: the code object of this file is loaded when one of its kernels is first looked at)
+void fa_touch_chain() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_chain));
+}

@@ -352,6 +352,10 @@ __global__ __launch_bounds__(64) void k_links2_big(MsaArgs A) {
 }
 
 #ifndef FA_EMU
+void fa_touch_links2() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_links2));
+}
 void fa_launch_links2(const MsaArgs &A, hipStream_t s) {
     hipLaunchKernelGGL(k_links2, dim3(A.n_seg), dim3(64), 0, s, A);
     hipLaunchKernelGGL(k_links2_big, dim3(A.n_seg < 2048 ? A.n_seg : 2048), dim3(64), 0, s, A);

@@ -795,6 +795,10 @@ __global__ __launch_bounds__(64) void k_backtrace(MsaArgs A) {
     A.pile_out[p] = po;  // every lane stores the same record
 }
 #ifndef FA_EMU  // (the host side below is not part of what the SIMT emulator of tests/emu/simt runs)
+void fa_touch_msa() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_tags));
+}
 // ---------------------------------------------------------------------------
 static MsaArgs msa_args(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov) {
     MsaArgs A;

@@ -297,6 +297,10 @@ __global__ __launch_bounds__(64) void k_score2(MsaArgs A) {
 }
 
 #ifndef FA_EMU
+void fa_touch_score2() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_score2));
+}
 void fa_launch_score2(const MsaArgs &A, hipStream_t s) {
     hipLaunchKernelGGL(k_score2, dim3(A.n_pile), dim3(64), 0, s, A);
 }

@@ -143,7 +143,15 @@ def open_engines(all_devices=False):
     elif not (all_devices or env == "all"):
         devices = [choose_device(devices)]
     per_gpu = max(1, int(os.environ.get("FALCON_AMD_ENGINES_PER_DEVICE", "1")))
-    return [Engine(d) for d in devices for _ in range(per_gpu)]
+    return [_warmed(Engine(d)) for d in devices for _ in range(per_gpu)]
+
+
+def _warmed(engine):
+    """(the workers open their engines while the first batches are read: the pinned staging buffer,
+    the kernels' code objects and the first upload are paid for there, not by the first batch)"""
+    if hasattr(engine, "warm"):
+        engine.warm(int(os.environ.get("FALCON_AMD_BATCH_BASES", "400000000")))
+    return engine
 
 
 def open_pool():
@@ -160,7 +168,7 @@ def open_pool():
             if d is None:
                 return None
             mine.append(d)
-            return Engine(d)
+            return _warmed(Engine(d))
     return DevicePool(engines, grow)
 
 

@@ -291,6 +291,11 @@ class Engine:
             raise FalconAmdError(last_error())
         self.device = device
 
+    def warm(self, batch_bases: int):
+        """Pay now what the first batch would pay for (pinned staging, code objects, first upload)."""
+        if self.lib.fa_warm(self.h, int(batch_bases)):
+            raise FalconAmdError(last_error())
+
     def batch(self, piles) -> Batch:
         return Batch(self, piles)
 

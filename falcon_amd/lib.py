@@ -66,6 +66,8 @@ def load() -> C.CDLL:
     lib = C.CDLL(SO_PATH)
     lib.fa_last_error.restype = C.c_char_p
     lib.fa_device_count.restype = C.c_int
+    lib.fa_warm.restype = C.c_int
+    lib.fa_warm.argtypes = [C.c_void_p, C.c_longlong]
     lib.fa_create.restype = C.c_void_p
     lib.fa_create.argtypes = [C.c_int]
     lib.fa_destroy.argtypes = [C.c_void_p]

@@ -154,6 +154,10 @@ typedef struct {
 const char *fa_last_error(void);
 int fa_device_count(void);
 fa_ctx *fa_create(int device);
+/* Optional: pay now what the context's first batch would pay for -- the pinned staging buffer for
+ * batches of `batch_bases` bases, the code objects of the path's kernels, the first upload.  The
+ * workers call it while their first batches are being read. */
+int fa_warm(fa_ctx *ctx, long long batch_bases);
 void fa_destroy(fa_ctx *ctx);
 
 /* Stage a batch: n_pile piles, pile p owns pile_n_seq[p] consecutive entries of
