@@ -227,7 +227,7 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
                     const u32 w = cur.w[q], wp = cur.wp[q];
                     const u32 nins = (w >> TAG_NINS_SHIFT) & 0xffu, pn = (wp >> TAG_NINS_SHIFT) & 0xffu;
                     const bool plain = cur.on[q] && cur.u[q] > 0 && nins <= 1u && pn <= 1u;
-                    if (plain) {
+                    if (plain && !(A.links_debug & 2)) {
                         const u32 del = w >> 31;
                         const u32 pb = pn ? (wp & 3u) : ((wp >> 31) ? 4u : sbp);
                         const u32 slot0 = pn ? 4u + del * 4u + pb : del * 2u + (pb >> 2);
@@ -252,7 +252,7 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
                                 lvln += fresh ? 256u : 0u;
                             }
                         }
-                    } else if (cur.on[q]) {
+                    } else if (cur.on[q] && !(A.links_debug & 1)) {
                         add_column(cur.u[q], cur.ld[q], cur.insoff[q], w, wp, !any_overflow);
                     }
                 }
@@ -293,7 +293,7 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
             }
             return o;
         };
-        if (gtot != 0u) {
+        if (gtot != 0u && !(A.links_debug & 4)) {
 #pragma unroll
             for (int s = 0; s < L2_DIR; s++) {
                 const u32 d = dir[s * 64 + lane];
