@@ -1136,13 +1136,16 @@ static int redo_handed_back(fa_batch *b, double max_diff, int band, hipStream_t 
     if (ensure_arena2(c, b, (int)redo.size()) || b->d_redo.alloc(redo.size())) return -1;
     HIP_OK(hipStreamWaitEvent(s, c->ev_redo, 0));
     HIP_OK(hipMemcpyAsync(b->d_redo.p, redo.data(), redo.size() * sizeof(int), hipMemcpyHostToDevice, s));
-    HIP_OK(hipEventRecord(b->ev[13], s));  // (the repeat launch's own span: added to ms_align, see fill of fa_stats)
+    const bool timed = b->ev[13] && b->ev[14];  // (runs of fa_align_pairs have no events)
+    if (timed) HIP_OK(hipEventRecord(b->ev[13], s));  // (the repeat launch's own span: added to ms_align, see fill of fa_stats)
     fa_launch_align_list(b->dev(), c->arena2, b->max_read_len, b->max_seed_len, max_diff, band, b->d_redo.p,
                          (int)redo.size(), s);
     HIP_OK(hipGetLastError());
     HIP_OK(hipEventRecord(c->ev_redo, s));
-    HIP_OK(hipEventRecord(b->ev[14], s));
-    b->redo_timed = true;
+    if (timed) {
+        HIP_OK(hipEventRecord(b->ev[14], s));
+        b->redo_timed = true;
+    }
     b->stats.align_relaunched = (int)redo.size();
     // (the list must outlive the copy: fetch_aln synchronises the stream)
     int rc = fetch_aln(b, s);
