@@ -360,7 +360,7 @@ struct fa_batch {
         int band = 0, force_accept_g = -1;
         bool two_per_wave = false;
         int score_mode = 0, force_generic = 0;  // FALCON_AMD_SCORE1 / _SCORE_GENERIC, read by the calling thread
-        int links_mode = 0, links_debug = 0;    // FALCON_AMD_LINKS1, FALCON_AMD_LINKS_DEBUG
+        int links_mode = 0;                     // FALCON_AMD_LINKS1
         size_t n_seg = 0;
         u64 t_tot = 0;
     } run;
@@ -1265,7 +1265,6 @@ static int start_align(fa_batch *b, unsigned min_cov, double max_diff, int band,
     b->run.score_mode = getenv("FALCON_AMD_SCORE1") ? 1 : 0;
     b->run.force_generic = getenv("FALCON_AMD_SCORE_GENERIC") ? 1 : 0;
     b->run.links_mode = getenv("FALCON_AMD_LINKS1") ? 1 : 0;
-    b->run.links_debug = getenv("FALCON_AMD_LINKS_DEBUG") ? atoi(getenv("FALCON_AMD_LINKS_DEBUG")) : 0;
     b->run.min_cov = min_cov; b->run.max_diff = max_diff; b->run.band = band;
     b->run.force_accept_g = force_accept_g; b->run.two_per_wave = two_per_wave;
     if (b->h_aln.resize(b->n_seq) || b->h_a2_stats.resize(12)) return -1;
@@ -1483,7 +1482,6 @@ static int msa_stage(fa_batch *b) {
     md.force_generic = b->run.force_generic;  // (tests: pins the generic path of k_score1)
     md.score_mode = b->run.score_mode;        // (FALCON_AMD_SCORE1: k_score1 for every pile)
     md.links_mode = b->run.links_mode;        // (FALCON_AMD_LINKS1: k_links for every segment)
-    md.links_debug = b->run.links_debug;
     const FaBatchDev d = b->dev();
     pt.mark("upload");
     HIP_OK(hipEventRecord(b->ev[4], sb));

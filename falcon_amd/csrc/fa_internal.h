@@ -177,7 +177,6 @@ struct FaMsaDev {
     int force_generic;     // k_score1: every level through the generic path (tests)
     int score_mode;        // 0: k_score2, k_score1 for what it hands on; 1: k_score1 for every pile
     int links_mode;        // 0: k_links2, k_links for what it hands on; 1: k_links for every segment
-    int links_debug;       // FALCON_AMD_LINKS_DEBUG (timing experiments inside k_links2; results are wrong with it)
     int *wide_count;
     int *wide_list;
 };

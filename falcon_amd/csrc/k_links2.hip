@@ -13,7 +13,8 @@
 //     inserted base -- the same keys k_links builds (falcon.c:126-160);
 //   * the groups of a position live in lane-private LDS words.  The keys that make up nearly
 //     all links have a slot of their own -- delta 0 after a plain column (4 keys), delta 0 after
-//     a one-base insertion (8), delta 1 (8): a read-modify-write, no search; the others (deeper
+//     a one-base insertion (8), delta 1 (8): a read-modify-write, no search, reached without the
+//     general column code for every column but an alignment's first; the others (deeper
 //     insertions, alignment starts, the unitig mode's first columns) go to a short linked list
 //     (entries from a pool the 64 positions share: a seed that lost two bases sees a dozen
 //     different two-base insertions at one position and none at its neighbours), searched
@@ -220,39 +221,52 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
                 const Col4 nxt = request4(m);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    // Nearly every column is a plain one: not the alignment's first, at most one
-                    // inserted base behind it and behind the column before it.  Its one or two
-                    // groups have slots of their own; that path is written without a branch per
-                    // case (selects), the rest is behind one test.
+                    // Every column but an alignment's first one (its start link, or the unitig mode's
+                    // leading run: add_column) takes this path: the group of its delta-0 tag has a
+                    // slot of its own unless the column before it carried two or more inserted bases,
+                    // the group of its first inserted base has one too; only the deeper levels --
+                    // and that one delta-0 case -- go to the list.  (The general add_column for every
+                    // column that was not "plain" cost 7.5 of the kernel's 12.7 ms: a few lanes per
+                    // alignment take it, so the wavefront did, nearly every time.)
                     const u32 w = cur.w[q], wp = cur.wp[q];
                     const u32 nins = (w >> TAG_NINS_SHIFT) & 0xffu, pn = (wp >> TAG_NINS_SHIFT) & 0xffu;
-                    const bool plain = cur.on[q] && cur.u[q] > 0 && nins <= 1u && pn <= 1u;
-                    if (plain && !(A.links_debug & 2)) {
-                        const u32 del = w >> 31;
-                        const u32 pb = pn ? (wp & 3u) : ((wp >> 31) ? 4u : sbp);
-                        const u32 slot0 = pn ? 4u + del * 4u + pb : del * 2u + (pb >> 2);
+                    if (cur.on[q] && cur.u[q] > 0) {
+                        const u32 del = w >> 31, base0 = del ? 4u : sb;
                         cov++;
                         maxn = max(maxn, (int)nins);
                         if (!any_overflow) {
-                            {
+                            // the column before it: its last inserted base, or its base / '-'
+                            const u32 pb = pn == 0u ? ((wp >> 31) ? 4u : sbp)
+                                                    : (pn == 1u ? (wp & 3u) : l2_ins_base(A, cur.insoff[q], wp, (int)pn));
+                            if (pn <= 1u) {
+                                const u32 slot0 = pn ? 4u + del * 4u + pb : del * 2u + (pb >> 2);
                                 const u32 d = dir[slot0 * 64u + (u32)lane];
                                 const bool fresh = (d & 0xffffu) == 0u;
                                 const u32 r = lvln & 255u;
                                 overflow = overflow || (fresh && r == 255u);
                                 dir[slot0 * 64u + (u32)lane] = fresh ? (1u | (r << 16)) : d + 1u;
                                 lvln += fresh ? 1u : 0u;
+                            } else {
+                                add_group(0, base0 | (pb << 3) | (pn << 6), -1);
                             }
                             if (nins) {
-                                const u32 slot1 = 12u + del * 4u + (w & 3u);
+                                const u32 b1 = nins <= (u32)INL ? (w & 3u) : l2_ins_base(A, cur.insoff[q], w, 1);
+                                const u32 slot1 = 12u + del * 4u + b1;
                                 const u32 d = dir[slot1 * 64u + (u32)lane];
                                 const bool fresh = (d & 0xffffu) == 0u;
                                 const u32 r = (lvln >> 8) & 255u;
                                 overflow = overflow || (fresh && r == 255u);
                                 dir[slot1 * 64u + (u32)lane] = fresh ? (1u | (r << 16)) : d + 1u;
                                 lvln += fresh ? 256u : 0u;
+                                u32 pbb = b1;
+                                for (int dl = 2; dl <= (int)nins; dl++) {
+                                    const u32 b = l2_ins_base(A, cur.insoff[q], w, dl);
+                                    add_group(dl, b | (pbb << 3) | ((u32)(dl - 1) << 6), -1);
+                                    pbb = b;
+                                }
                             }
                         }
-                    } else if (cur.on[q] && !(A.links_debug & 1)) {
+                    } else if (cur.on[q]) {
                         add_column(cur.u[q], cur.ld[q], cur.insoff[q], w, wp, !any_overflow);
                     }
                 }
@@ -293,7 +307,7 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
             }
             return o;
         };
-        if (gtot != 0u && !(A.links_debug & 4)) {
+        if (gtot != 0u) {
 #pragma unroll
             for (int s = 0; s < L2_DIR; s++) {
                 const u32 d = dir[s * 64 + lane];

@@ -73,8 +73,6 @@ struct MsaArgs {
     int force_generic;         // k_score1: every level through the generic path (tests)
     int only_redo;             // k_score1: only the piles k_score2 handed on (FaScoreOut.redo)
     int links_old;             // k_links2 hands every segment to k_links (A/B runs, tests of the fallback)
-    int links_debug;           // timing experiments (FALCON_AMD_LINKS_DEBUG; RESULTS ARE WRONG with it): 1 no columns
-                               // but plain ones, 2 no plain ones, 4 no link words written
 };
 
 // the links of every segment (k_links2.hip); what it cannot hold goes to k_links through A.wide_count

@@ -816,7 +816,6 @@ static MsaArgs msa_args(const FaBatchDev &b, const FaMsaDev &m, unsigned min_cov
     A.force_generic = m.force_generic;
     A.only_redo = 0;
     A.links_old = m.links_mode;
-    A.links_debug = m.links_debug;
     return A;
 }
 

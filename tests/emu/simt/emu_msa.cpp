@@ -183,7 +183,6 @@ extern "C" int emu_msa(const u32 *words_in, u64 n_words, const FaSeq *seq_in, in
     simt::launch("k_sscan", (unsigned)n_pile, [&] { k_sscan(A); });
     if (n_seg) {
         A.links_old = getenv("EMU_MSA_LINKS1") ? 1 : 0;
-        A.links_debug = 0;
         simt::launch("k_links2", (unsigned)n_seg, [&] { k_links2(A); });
         simt::launch("k_links2_big", (unsigned)std::min<size_t>(n_seg, 64), [&] { k_links2_big(A); });
         const unsigned wide_grid = (unsigned)std::min<size_t>(n_seg, 64);
