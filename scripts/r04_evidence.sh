@@ -22,17 +22,17 @@ python $R/scripts/rocpd_summary.py $(ls $O/kts/*/*.db $O/kts/*.db 2>/dev/null | 
 export FALCON_AMD_DEVICE_PACK=1
 B="python $R/bench.py --steps 1 --warmup 0 --no-pipeline --no-cpu-baseline --no-end-to-end"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 200 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "k_align|k_pack" --output-format csv -d $O/pmc/$c -o $c -- $B > $O/pmc/$c.log 2>&1; echo "pmc $c rc=$?"
+  timeout 420 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "k_align|k_pack" --output-format csv -d $O/pmc/$c -o $c -- $B > $O/pmc/$c.log 2>&1; echo "pmc $c rc=$?"
 done
 python $R/scripts/pmc_traffic_record.py $O/pmc k_align ecoli 1.0 > $O/pmc_traffic.txt 2>&1; tail -22 $O/pmc_traffic.txt
 cp $R/profiles/pmc_traffic.json $O/pmc_traffic.json
 i=0
 for ctrs in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
-  timeout 150 rocprofv3 --kernel-trace --pmc $ctrs --kernel-include-regex "k_align|k_links|k_score|k_tags|k_sscan|k_chain|k_backtrace|k_seed_index|k_pack" --output-format csv -d $O/pmc/p$i -o p$i -- $B > $O/pmc/p$i.log 2>&1; echo "pmc pass $i rc=$?"
+  timeout 420 rocprofv3 --kernel-trace --pmc $ctrs --kernel-include-regex "k_align|k_links|k_score|k_tags|k_sscan|k_chain|k_backtrace|k_seed_index|k_pack" --output-format csv -d $O/pmc/p$i -o p$i -- $B > $O/pmc/p$i.log 2>&1; echo "pmc pass $i rc=$?"
 done
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 200 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "k_tags|k_links2|k_score2|k_backtrace|k_sscan" --output-format csv -d $O/pmc/msa_$c -o msa_$c -- $B > $O/pmc/msa_$c.log 2>&1; echo "pmc msa $c rc=$?"
+  timeout 420 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "k_tags|k_links2|k_score2|k_backtrace|k_sscan" --output-format csv -d $O/pmc/msa_$c -o msa_$c -- $B > $O/pmc/msa_$c.log 2>&1; echo "pmc msa $c rc=$?"
 done
 python $R/scripts/pmc_table.py $O/pmc > $O/pmc_table.txt 2>&1
 find $O -name "*.db" -size +5M -delete
