@@ -71,18 +71,20 @@ struct fa_reader {
     // closed (it may grow), pointers afterwards
     char *text = nullptr;    // (mmap'ed: grown by remapping, never copied or zero-filled by us)
     size_t text_cap = 0;
-    // What a call hands out stays valid through the NEXT call (so that one thread can
-    // stage a batch while another reads the following one): two text buffers and two sets
-    // of pointer arrays alternate; `text` is the one being filled, `shelf` holds the
-    // other between calls.
+    // What a call hands out stays valid through the next n_keep - 1 calls (so that one thread
+    // can stage a batch while another reads the following ones): n_keep text buffers and sets
+    // of pointer arrays take turns (2 unless fa_reader_keep asked for more); `text` is the one
+    // being filled, `shelf` holds the others between calls.
     struct Shelf {
         char *text = nullptr;
         size_t text_cap = 0;
         std::vector<int> pile_n_seq, out_len;
         std::vector<const char *> out_seqs, out_ids;
-    } shelf[2];
-    int cur = 0;             // shelf[cur]: arrays of the batch handed out last (its text is
-                             // `text`, shelf[cur].text is null); shelf[cur ^ 1]: the batch before
+    };
+    std::vector<Shelf> shelf = std::vector<Shelf>(2);
+    bool handed_out = false; // fa_reader_next has been called (the ring keeps its size from then on)
+    int cur = 0;             // shelf[cur]: arrays of the batch handed out last (its text is `text`,
+                             // shelf[cur].text is null); shelf[cur + 1 (mod n_keep)]: the oldest one
     size_t parsed = 0;       // start of the line being scanned (all lines before it are split)
     size_t scanned = 0;      // bytes of `text` the scanner has looked at (>= parsed)
     size_t filled = 0;       // bytes of `text` holding stream data
@@ -441,6 +443,16 @@ extern "C" fa_reader *fa_reader_open(int fd, int min_n_read, int min_len_aln, in
     return r;
 }
 
+extern "C" int fa_reader_keep(fa_reader *r, int n_batches) {
+    if (!r || n_batches < 2 || n_batches > 64) return -1;
+    if (r->handed_out) {
+        r->err = "falcon_amd: fa_reader_keep after the first fa_reader_next";
+        return -1;
+    }
+    r->shelf.resize((size_t)n_batches);
+    return 0;
+}
+
 extern "C" void fa_reader_close(fa_reader *r) {
     if (r && getenv("FALCON_AMD_TIMING"))
         fprintf(stderr, "[falcon_amd] reader: %.1f MB, %.1f ms in fa_reader_next (%.1f ms of them waiting "
@@ -455,6 +467,7 @@ extern "C" int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, 
                               const char *const **seqs, const int **seq_len,
                               const char *const **seed_ids) {
     if (!r) return -1;
+    r->handed_out = true;
     struct Clock {
         fa_reader *r;
         std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -469,8 +482,8 @@ extern "C" int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, 
     // pieces requested during the previous call land in the old buffer: take them along
     if (!settle_all(r) && !r->err.empty()) return -1;
     // The batch handed out last stays where it is (its pointers live through this call);
-    // the unparsed tail and the lines of the pile in progress move over to the other text
-    // buffer, the one of the batch before it, and the stream continues there.
+    // the unparsed tail and the lines of the pile in progress move over to the text buffer of
+    // the OLDEST batch still on the shelves, and the stream continues there.
     {
         size_t keep_from = r->parsed;
         for (const Tok &t : r->pile) keep_from = std::min(keep_from, t.off);
@@ -478,7 +491,8 @@ extern "C" int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, 
         // (names of the pile in progress are owned copies)
         if (keep_from > 0) {
             const size_t tail = r->filled - keep_from;
-            fa_reader::Shelf &mine = r->shelf[r->cur], &other = r->shelf[r->cur ^ 1];
+            const int nxt = (r->cur + 1) % (int)r->shelf.size();
+            fa_reader::Shelf &mine = r->shelf[r->cur], &other = r->shelf[nxt];
             if (other.text_cap < tail) {
                 const size_t cap = std::max(r->text_cap,  // (untouched pages cost nothing)
                                             (tail + (4u << 20) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1));
@@ -497,7 +511,7 @@ extern "C" int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, 
             r->text_cap = other.text_cap;
             other.text = nullptr;
             other.text_cap = 0;
-            r->cur ^= 1;
+            r->cur = nxt;
             r->filled -= keep_from;
             r->parsed -= keep_from;
             r->scanned -= keep_from;
@@ -576,7 +590,7 @@ extern "C" int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, 
     // the batch is closed: offsets become pointers, tokens become C strings
     const size_t n_sel = r->sel.size(), n_pile = r->pile_n_seq.size();
     char *t = r->text;
-    fa_reader::Shelf &out = r->shelf[r->cur];  // (last used by the batch before the previous one)
+    fa_reader::Shelf &out = r->shelf[r->cur];  // (last used by the oldest batch, now given up)
     out.pile_n_seq = r->pile_n_seq;
     out.out_seqs.resize(n_sel);
     out.out_len.resize(n_sel);

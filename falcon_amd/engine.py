@@ -61,6 +61,11 @@ class Reader:
         if not self.h:
             raise FalconAmdError("fa_reader_open failed")
 
+    def keep(self, n_batches: int):
+        """What next() hands out lives through the next ``n_batches`` - 1 calls (default 2)."""
+        if self.lib.fa_reader_keep(self.h, int(n_batches)):
+            raise FalconAmdError("fa_reader_keep(%d) refused" % n_batches)
+
     def next(self, max_piles=0, max_bases=0):
         """The next PileSet, or None at the end of the stream."""
         cnt = C.POINTER(C.c_int)()

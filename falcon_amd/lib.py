@@ -114,6 +114,8 @@ def load() -> C.CDLL:
                                    C.POINTER(C.POINTER(C.c_char_p)),
                                    C.POINTER(C.POINTER(C.c_int)),
                                    C.POINTER(C.POINTER(C.c_char_p))]
+    lib.fa_reader_keep.restype = C.c_int
+    lib.fa_reader_keep.argtypes = [C.c_void_p, C.c_int]
     lib.fa_reader_error.restype = C.c_char_p
     lib.fa_reader_error.argtypes = [C.c_void_p]
     lib.fa_reader_close.argtypes = [C.c_void_p]

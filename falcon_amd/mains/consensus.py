@@ -390,6 +390,9 @@ def _stream_fd(stream):
 # kernels at a better rate, but the host buffers they need (text, pinned copy: page faults,
 # pinning) cost more than that buys, and small batches pipeline sooner.
 NATIVE_BATCH_BASES = 400_000_000
+# Batches of text the ingest thread may be ahead of the staging thread (8 x ~0.4 GB at most; the
+# devices take ~0.2 s to open, a file delivers ~4 GB in that time).
+NATIVE_READ_AHEAD = 8
 
 
 def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None):
@@ -423,10 +426,15 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None)
         failed.append(exc)
         stop.set()
 
-    # What the reader hands out lives through one further reader.next() (two text buffers
-    # alternate): `lease` counts the buffers the stager has not finished with.
-    raw = queue.Queue(maxsize=1)
-    lease = threading.Semaphore(2)
+    # What the reader hands out lives through the next `ahead` - 1 calls of reader.next() (that
+    # many text buffers take turns): `lease` counts the buffers the stager has not finished
+    # with.  The ingest thread runs ahead while the devices are still being opened and whenever
+    # the stream comes faster than the GPU takes it (a block's text in a file); a pipe from
+    # LA4Falcon never gets ahead, and buffers never filled are never touched.
+    ahead = max(2, min(64, int(os.environ.get("FALCON_AMD_READ_AHEAD", NATIVE_READ_AHEAD))))
+    reader.keep(ahead)
+    raw = queue.Queue(maxsize=ahead - 1)
+    lease = threading.Semaphore(ahead)
 
     def ingest():
         seq = 0

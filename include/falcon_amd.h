@@ -280,6 +280,11 @@ fa_reader *fa_reader_open(int fd, int min_n_read, int min_len_aln, int min_cov_a
  * while another reads batch n + 1), until the call after that or fa_reader_close(). */
 int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, const int **pile_n_seq,
                    const char *const **seqs, const int **seq_len, const char *const **seed_ids);
+/* How many batches stay valid at a time: what a fa_reader_next() hands out then lives through the
+ * next n_batches - 1 calls (default 2, at most 64; only before the first fa_reader_next; 0 or -1).
+ * A reader that runs ahead of the staging thread -- a block's text in a file, the devices still
+ * being opened -- holds up to n_batches batches of text in memory. */
+int fa_reader_keep(fa_reader *r, int n_batches);
 const char *fa_reader_error(const fa_reader *r);
 void fa_reader_close(fa_reader *r);
 

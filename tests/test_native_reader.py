@@ -119,6 +119,42 @@ def test_a_batch_outlives_one_further_call():
         os.unlink(path)
 
 
+@pytest.mark.parametrize("keep", [3, 8])
+def test_batches_outlive_as_many_calls_as_asked_for(keep):
+    """fa_reader_keep(n): a batch lives through the next n - 1 calls (the worker's ingest thread runs
+    that far ahead of the staging thread); every batch is read only when it is about to lapse."""
+    rng = random.Random(79)
+    text = _rand_stream(rng, 90, with_noise=True)
+    opts = (2, 0, 0, 500, 0)
+    want = _python(text, *opts)
+    with tempfile.NamedTemporaryFile("wb", delete=False) as f:
+        f.write(text.encode("ascii"))
+        path = f.name
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        for limits in ((1, 0), (3, 0), (0, 900)):
+            os.lseek(fd, 0, os.SEEK_SET)
+            r = Reader(fd, *opts)
+            r.keep(keep)
+            got, held = [], []
+            while True:
+                ps = r.next(*limits)
+                if ps is not None:
+                    held.append(ps)
+                while held and (ps is None or len(held) == keep):
+                    old = held.pop(0)  # handed out keep - 1 calls ago
+                    got.extend(zip(old.seed_ids, old.piles()))
+                if ps is None:
+                    break
+            with pytest.raises(Exception):
+                r.keep(2)  # only before the first batch
+            r.close()
+            assert got == want
+    finally:
+        os.close(fd)
+        os.unlink(path)
+
+
 def test_closing_the_reader_does_not_wait_for_a_silent_producer():
     """The reader keeps one read() ahead of the scanner on a helper thread (reader.cpp).  A
     producer that has delivered a batch and then says nothing (the pipe stays open) must not
