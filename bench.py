@@ -42,7 +42,7 @@ if ROOT not in sys.path:
 # (the parts of this file live in benchlib/: the input, the CPU baseline, the end-to-end legs, the
 # HBM traffic on file; the names stay importable from here)
 from benchlib.cpu_baseline import cpu_baseline, host_cores  # noqa: E402,F401
-from benchlib.e2e import E2E_REPEATS, end_to_end, end_to_end_multi  # noqa: E402,F401
+from benchlib.e2e import E2E_REPEATS, end_to_end, end_to_end_multi, end_to_end_workers  # noqa: E402,F401
 from benchlib.traffic import _code_only, kernel_source_sha, measured_stream_rate, measured_traffic  # noqa: E402,F401
 from benchlib.workloads import (HBM_PEAK_GBS, K, MAX_N_READ, MIN_COV, MIN_IDT, WORKLOADS, _gen_pile,  # noqa: E402,F401
                                 gen_piles, write_la4falcon)
@@ -370,6 +370,12 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
                 res["end_to_end"] = end_to_end_multi(piles, world)
             except Exception as e:
                 res["end_to_end"] = {"piles_per_sec": None, "what": "failed: %r" % (e,)}
+            # ... and the way fc_run feeds the node: N single-stream jobs at once, each on the GPU it
+            # finds for itself (per worker: device, wall time, piles/s, text rate)
+            try:
+                res["end_to_end_workers"] = end_to_end_workers(piles, world)
+            except Exception as e:
+                res["end_to_end_workers"] = {"piles_per_sec": None, "what": "failed: %r" % (e,)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"], cpu_cns = cpu_baseline(

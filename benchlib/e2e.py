@@ -122,3 +122,74 @@ def end_to_end_multi(piles, n_streams, repeats=E2E_REPEATS):
             "what": "%d streams of %d piles each (%.0f MB of text each, from the page cache) -> %d FASTA files, "
                     "one multi-stream worker process over all visible GPUs, process start included; the slower "
                     "of two runs counts" % (n_streams, repeats * len(piles), size / 1e6, n_streams)}
+
+
+def end_to_end_workers(piles, n_workers, repeats=E2E_REPEATS):
+    """N > 1, the way fc_run feeds a node: `n_workers` single-stream consensus jobs started at the same
+    moment (consensus_split.py:55-85 runs one per LA4Falcon block, several at a time), every one a
+    process of its own that finds a GPU for itself through the lock slots of falcon_amd/devices.py.
+    Per worker: the device it took, its wall time (process start to exit), piles/s and text rate; the
+    aggregate counts the slowest.  Every FASTA must be the same text."""
+    import re
+    root = ROOT
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "piles.txt")
+        import shutil
+        per_repeat = sum(sum(len(x) + 10 for x in p) for p in piles) + 1
+        repeats = max(1, min(repeats, int(shutil.disk_usage(tmp).free * 0.6 // per_repeat)))
+        with open(src, "wb") as f:
+            write_la4falcon(piles, f, repeats)
+        size = os.path.getsize(src)
+        cmd = [sys.executable, "-m", "falcon_amd.mains.consensus", "--output-multi", "--min-idt", "0.70",
+               "--min-cov", "4", "--max-n-read", "200", "--n-core", "1"]
+        env = {k: v for k, v in os.environ.items()
+               if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTRACER", "HSA_TOOLS"))
+               and k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                             "FALCON_AMD_DEVICES", "FALCON_AMD_DEVICE")}
+        env["FALCON_AMD_LOCK_DIR"] = os.path.join(tmp, "slots")  # (nobody else's jobs in this count)
+        os.makedirs(env["FALCON_AMD_LOCK_DIR"])
+        t0 = time.perf_counter()
+        procs = []
+        for j in range(n_workers):
+            fin, fout = open(src), open(os.path.join(tmp, "cns_%d.fasta" % j), "w")
+            ferr = open(os.path.join(tmp, "err_%d.txt" % j), "w+")
+            procs.append((subprocess.Popen(cmd, stdin=fin, stdout=fout, stderr=ferr, cwd=root, env=env), fin,
+                          fout, ferr))
+        wall = [None] * n_workers
+        deadline = t0 + max(900, 60 + n_workers * size / 2e8)
+        while any(w is None for w in wall):
+            for j, (p, *_f) in enumerate(procs):
+                if wall[j] is None and p.poll() is not None:
+                    wall[j] = time.perf_counter() - t0
+            if time.perf_counter() > deadline:
+                for p, *_f in procs:
+                    if p.poll() is None:
+                        p.kill()
+                raise RuntimeError("end_to_end_workers: a worker did not finish")
+            time.sleep(0.005)
+        workers, texts = [], []
+        for j, (p, fin, fout, ferr) in enumerate(procs):
+            fin.close()
+            fout.close()
+            ferr.seek(0)
+            log = ferr.read()
+            ferr.close()
+            if p.returncode != 0:
+                raise RuntimeError("end_to_end_workers: worker %d exited %d: %s" % (j, p.returncode, log[-400:]))
+            dev = re.search(r"device\(s\) ([0-9,]+)", log)
+            steady = re.search(r"steady state ([0-9.]+) piles/s", log)
+            texts.append(open(os.path.join(tmp, "cns_%d.fasta" % j)).read())
+            workers.append({"worker": j, "devices": dev.group(1) if dev else None, "wall_s": round(wall[j], 2),
+                            "piles_per_sec": round(repeats * len(piles) / wall[j], 1),
+                            "text_GB_per_sec": round(size / 1e9 / wall[j], 2),
+                            "steady_state_piles_per_sec": float(steady.group(1)) if steady else None})
+    n = repeats * len(piles) * n_workers
+    slowest = max(wall)
+    return {"piles_per_sec": round(n / slowest, 1), "text_MB_per_sec": round(size * n_workers / 1e6 / slowest, 1),
+            "wall_s": round(slowest, 2), "workers": workers,
+            "distinct_devices": len({w["devices"] for w in workers}),
+            "every_fasta_identical": all(t == texts[0] for t in texts) and len(texts[0]) > 0,
+            "what": "%d single-stream workers started together, %d piles each (%.0f MB of text each, from the page "
+                    "cache) -> %d FASTA files; every worker is a process of its own that takes a GPU through the "
+                    "lock slots (falcon_amd/devices.py), process start and HIP initialisation included; the "
+                    "aggregate counts the slowest worker" % (n_workers, repeats * len(piles), size / 1e6, n_workers)}

@@ -632,7 +632,8 @@ def run(args, stdin=None, stdout=None, consensus_map=None):
 
     def open_gpu():
         opened.append(GpuConsensus(args.min_cov, args.min_idt))
-        LOG.info("falcon_amd consensus on %d engine(s) (t=%.3f)", len(opened[0].engines), _clock())
+        LOG.info("falcon_amd consensus on %d engine(s), device(s) %s (t=%.3f)", len(opened[0].engines),
+                 ",".join(str(getattr(e, "device", "?")) for e in opened[0].engines), _clock())
         return opened[0]
 
     fd = _stream_fd(stdin)

@@ -205,3 +205,20 @@ def test_length_limits_through_the_command_line():
     for sid, pile in piles:
         want.append(cli.fasta_records(sid, port.generate_consensus(pile, 2, 8, 0.70)[0], False, True))
     assert out == "".join(want) and out.count(">") >= 2 and len(out) > 150000
+
+
+@pytest.mark.gpu
+def test_two_jobs_started_together_share_what_there_is():
+    """bench.py's N > 1 end-to-end leg (benchlib/e2e.py end_to_end_workers): single-stream jobs
+    started at the same moment, each taking a GPU through the lock slots -- on a one-GPU box both
+    land on device 0, and both print the same FASTA."""
+    sys.path.insert(0, ROOT)
+    from benchlib.e2e import end_to_end_workers
+    from benchlib.workloads import gen_piles
+    piles = gen_piles(range(40, 46), 1, dict(S=3000, coverage=20.0, het=0.0))
+    out = end_to_end_workers(piles, 2, repeats=3)
+    assert out["every_fasta_identical"] and len(out["workers"]) == 2, out
+    import torch
+    assert out["distinct_devices"] == min(2, torch.cuda.device_count()), out
+    for w in out["workers"]:
+        assert w["devices"] is not None and w["wall_s"] > 0, out
