@@ -33,7 +33,7 @@ def measured_stream_rate(torch, mib=1024, reps=5):
 KERNEL_SOURCE = {"k_align": ("k_align2.hip", "k_align2_core.h", "fa_wave.h", "k_align.hip"),
                  "k_score": ("k_score2.hip", "k_score1.hip", "k_msa.h"), "k_links": ("k_links2.hip", "k_msa.hip", "k_msa.h"),
                  "k_tags": ("k_msa.hip", "k_msa.h"), "k_backtrace": ("k_msa.hip", "k_msa.h"), "k_chain": "k_chain.hip",
-                 "k_seed_index": "k_pack_index.hip"}
+                 "k_seed_index": "k_seed_index.hip"}
 
 
 def _code_only(text):

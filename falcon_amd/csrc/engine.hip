@@ -1216,7 +1216,7 @@ extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double
         FaBatchDev d = b->dev();
 
         HIP_OK(hipEventRecord(b->ev[0], s));
-        fa_launch_index(d, s);
+        fa_launch_index(d, b->max_seed_len, s);
         HIP_OK(hipEventRecord(b->ev[1], s));
         trace_stage(s, "index");
         fa_launch_chain(d, b->max_bins, s);
@@ -1714,7 +1714,7 @@ extern "C" int fa_batch_trim_windows(fa_batch *b, unsigned K, int mask_threshold
     DevBuf<int> counter;
     if (counter.alloc(4)) return -1;
     const int n_slot = std::max(1, c->n_cu) * 4;  // 32 KB of LDS per wavefront
-    fa_launch_index(d, s);
+    fa_launch_index(d, b->max_seed_len, s);
     fa_launch_trimwin(d, n_slot, counter.p, nullptr, 0, mask_threshold, 1, s);
     if (b->h_range.resize(b->n_seq)) return -1;
     HIP_OK(hipMemcpyAsync(b->h_range.data(), b->d_range.p, (size_t)b->n_seq * sizeof(FaRange),

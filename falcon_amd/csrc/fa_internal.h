@@ -134,7 +134,7 @@ void fa_launch_align2(const FaBatchDev &b, const FaAlign2Arena &a, double max_di
 // other than upper-case A, C, G, T.  bad_pile (optional, n_pile ints, zeroed): 1 for every
 // pile with such a sequence
 void fa_launch_pack(const FaBatchDev &b, int *first_bad, int *bad_pile, hipStream_t s);
-void fa_launch_index(const FaBatchDev &b, hipStream_t s);
+void fa_launch_index(const FaBatchDev &b, int max_seed_len, hipStream_t s);
 void fa_launch_chain(const FaBatchDev &b, int max_bins, hipStream_t s);
 // general banded alignment for band tolerances beyond FA_ALIGN_MAXCH chunks (k_align_wide.hip)
 #define FA_WIDE_BAND_MAX 2000

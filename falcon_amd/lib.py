@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# (FALCON_AMD_LIB: another build of the same library -- kernel experiments, scripts/r03_variants.sh)
+# (FALCON_AMD_LIB: another build of the same library -- kernel experiments)
 SO_PATH = os.environ.get("FALCON_AMD_LIB") or os.path.join(HERE, "libfalcon_amd.so")
 
 

@@ -12,6 +12,11 @@
 
 inline int fa_lane() { return simt::lane(); }
 inline u32 fa_base_at(const u32 *w, int i) { return (w[i >> 4] >> ((i & 15) * 2)) & 3u; }
+inline u64 fa_window64(const u32 *w, int i) {
+    const u64 lo = w[i >> 4], hi = w[(i >> 4) + 1];
+    return ((hi << 32) | lo) >> ((i & 15) * 2);
+}
+inline u32 fa_kmer8(const u32 *w, int i) { return (u32)(fa_window64(w, i) & 0xFFFFu); }
 #define fa_ballot(p) simt::ballot((p), __LINE__)
 #define fa_uni(v) simt_uni((v), __LINE__)
 inline int simt_uni(int v, int site) { return simt::readfirstlane(v, site); }

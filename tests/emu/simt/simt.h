@@ -191,6 +191,8 @@ inline void launch(const char *name, unsigned grid, F kernel_call) {
 #define __builtin_amdgcn_mbcnt_hi(m, a) simt::mbcnt_hi((m), (a))
 #define __builtin_amdgcn_wave_barrier() simt::sync(__LINE__)
 
+#define __HIP_MEMORY_SCOPE_WORKGROUP 0
+#define __hip_atomic_load(p, order, scope) (*(p))
 template <class T> inline T atomicAdd(T *p, T v) { const T o = *p; *p = (T)(o + v); return o; }
 template <class T> inline T atomicMax(T *p, T v) { const T o = *p; if (v > o) *p = v; return o; }
 template <class T> inline T atomicMin(T *p, T v) { const T o = *p; if (v < o) *p = v; return o; }

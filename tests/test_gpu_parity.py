@@ -380,6 +380,52 @@ def test_hit_lists_and_tag_words_vs_reference(engine, port):
     assert n_hits > 20000 and n_tags > 250000 and n_long > 0
 
 
+def test_seed_index_in_the_lds_and_the_kernel_behind_it(engine, port, monkeypatch):
+    """k_seed_index keeps a pile's 8-mer table in the LDS with 16-bit cursors, which holds seeds of up to
+    65 543 bases; longer ones (< 100 000) go to k_seed_index_long in the same launch sequence.  One batch
+    with seeds of 6 000, exactly 65 543, 65 544 and 80 000 bases plus a low-complexity seed (8-mers many
+    times inside 64 consecutive positions): every read's hit list in the reference's order
+    (kmer_lookup.c:207-286) -- it is read straight off the index -- and the consensus; then the golden
+    piles with every pile forced through the kernel behind (FALCON_AMD_INDEX_LONG)."""
+    rng = np.random.default_rng(61)
+
+    def pile_on(seed_len, n_reads, read_len, lowc=False):
+        if lowc:
+            unit = "".join("ACGT"[c] for c in rng.integers(0, 4, 5))
+            seed = "".join(("ACGT"[c] if rng.random() < 0.03 else unit[i % 5]) for i, c in
+                           enumerate(rng.integers(0, 4, seed_len)))
+        else:
+            seed = "".join("ACGT"[c] for c in rng.integers(0, 4, seed_len))
+        reads = []
+        for _ in range(n_reads):
+            at = int(rng.integers(0, max(1, seed_len - read_len)))
+            r = [c for c in seed[at:at + read_len] if rng.random() > 0.04]
+            reads.append("".join(c if rng.random() > 0.05 else "ACGT"[rng.integers(0, 4)] for c in r))
+        return [seed, seed] + reads
+    piles = [pile_on(6000, 8, 3000), pile_on(65543, 6, 5000), pile_on(65544, 6, 5000), pile_on(80000, 6, 5000),
+             pile_on(3000, 8, 1500, lowc=True)]
+    b = engine.batch(piles)
+    b.run(2, 8, 0.70)
+    g0, n_hits = 0, 0
+    for p, pile in enumerate(piles):
+        for j in range(1, len(pile)):
+            hq, ht = port.find_hits(pile[0], pile[j])
+            assert b.debug_hits(g0 + j) == (hq, ht), (p, j)
+            n_hits += len(hq)
+        g0 += len(pile)
+    b.free()
+    assert n_hits > 30000
+    for p, got in zip(piles, engine.consensus(piles, 2, 8, 0.70, want_eqv=True)):
+        assert got == tuple(port.generate_consensus(p, 2, 8, 0.70))
+
+    class Impl:
+        def generate_consensus(self, seqs, min_cov, K, min_idt):
+            return engine.consensus([seqs], min_cov, K, min_idt, want_eqv=True)[0]
+    monkeypatch.setenv("FALCON_AMD_INDEX_LONG", "1")
+    for c in F4:
+        check_pile_case(Impl(), c)
+
+
 def test_device_side_packing_route_gives_the_same_answers(engine):
     """Batches are packed to 2 bits per base on the host (pack_host.cpp); round 2's route --
     the text uploaded and packed by k_pack -- is still there behind FALCON_AMD_DEVICE_PACK (the
