@@ -48,9 +48,9 @@ def table(d):
         if c.get("SQ_LDS_IDX_ACTIVE"):
             r.append("LDS bank-conflict cycles / LDS busy cycles = %.3f" % (c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"]))
         if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_INST_ANY" in c:
-            r.append("wave cycles waiting on an instruction result (s_waitcnt) = %.3f" % (c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]))
+            r.append("wave cycles stalled at issue (SQ_WAIT_INST_ANY: pipe busy, dependency) = %.3f" % (c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]))
         if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c:
-            r.append("wave cycles waiting for anything = %.3f" % (c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]))
+            r.append("wave cycles parked at s_waitcnt / a barrier (SQ_WAIT_ANY) = %.3f" % (c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]))
         if "TCC_HIT_sum" in c and c["TCC_HIT_sum"] + c.get("TCC_MISS_sum", 0) > 0:
             r.append("L2 hit rate = %.3f" % (c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])))
         if c.get("TCP_TOTAL_CACHE_ACCESSES_sum") and "TCP_TCC_READ_REQ_sum" in c:
