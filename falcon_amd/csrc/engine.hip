@@ -1909,15 +1909,17 @@ extern "C" int fa_batch_debug_hits(fa_batch *b, int g, int *q_pos, int *t_pos, i
     HIP_OK(hipMemcpy(pos.data(), b->d_kpos.p + pm.kpos_off, pos.size() * sizeof(u32), hipMemcpyDeviceToHost));
     long long n = 0;
     for (int p = 0; p < n_probe; p++) {
-        const u32 first = (u32)pr[p], cnt = (u32)(pr[p] >> 32);
+        // k_chain.hip's record: n = min(hits, 3); n <= 2: the hits themselves, n = 3: the bucket
+        const u32 nn = (u32)pr[p] & 3u, fa = (u32)(pr[p] >> 2) & 0x1ffffu, fb = (u32)(pr[p] >> 19) & 0x1ffffu;
+        const u32 cnt = nn == 3 ? fb : nn;
         for (u32 e = 0; e < cnt; e++, n++) {
             if (n < cap) {
-                if (first + e >= pos.size()) {
+                if (nn == 3 && fa + e >= pos.size()) {
                     set_err("falcon_amd: probe %d of sequence %d points outside its pile's index", p, g);
                     return -1;
                 }
                 q_pos[n] = 4 * p;
-                t_pos[n] = (int)pos[first + e];
+                t_pos[n] = (int)(nn == 3 ? pos[fa + e] : e == 0 ? fa : fb);
             }
         }
     }

@@ -89,7 +89,7 @@ struct FaBatchDev {
     const int *order;      // sequence indices, longest first (k_align work queue)
     const int *chain_order;  // k_chain work list: pile-major, 8 interleaved streams (-1 = padding)
     int n_chain;
-    u64 *probe;            // k_chain: per probe {bucket start, size}
+    u64 *probe;            // k_chain: one record per probe (k_chain.hip, CH_REC)
     const u64 *probe_off;  // [n_seq]
     FaRange *range;
     FaAln *aln;

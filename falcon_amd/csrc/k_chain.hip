@@ -10,7 +10,9 @@
 //   the range sanity filter of generate_consensus (src/c/falcon.c:613-619).
 //
 // Mapping: one wavefront per read, lane <-> probe (query offsets 0,4,8,..).
-//   pass A  bucket bounds of every probe -> diagonal extent (wave min/max)
+//   pass A  bucket bounds of every probe -> diagonal extent (wave min/max), and a RECORD per probe
+//           for the later passes: the probe's first and last hit themselves when it has at most
+//           two (98 % of the probes of the bench piles), its bucket otherwise
 //   pass B  diagonal histogram in LDS (ds atomics) + per bin the order key of
 //           its first hit, so "first fullest bin in hit order" (:360-366) is a
 //           reduction over bins instead of a second walk over the hits
@@ -38,7 +40,7 @@ struct ChainArgs {
     int n_seq;
     int lds_bins;
     FaRange *out;
-    uint2 *probe;            // per probe {first bucket entry, bucket size}: written by pass A
+    u64 *probe;              // per probe: the record of pass A (CH_REC_*)
     const u64 *probe_off;    // [n_seq]
 };
 
@@ -48,8 +50,22 @@ typedef long long i64;
 
 // The chain stage is a string of dependent random reads (packed read -> bucket bounds
 // -> seed positions); a wavefront that walks its probes 64 at a time spends its life
-// waiting for them (measured: 85 % of wave cycles in s_waitcnt).  Every pass therefore
-// issues the loads of CH_U chunks back to back before using any of them.
+// waiting for them (measured: 74-85 % of wave cycles parked at an s_waitcnt).  Every pass
+// therefore issues the loads of CH_U chunks back to back before using any of them, and only
+// pass A walks the whole string: it already holds every probe's first and last hit (for the
+// diagonal extent), and a probe with one or two hits has no others.  Rounds 1-3 kept the
+// bucket bounds in the record, and passes B and D went back to P for every probe, one
+// dependent load per hit: three to five exposed latencies per step of 256 probes in pass B,
+// two to four per 64 probes in pass D.
+//
+// The record: bits 1..0 n = min(hits, 3);
+//   n = 1, 2: bits 18..2 the first hit (seed position), bits 35..19 the last one
+//   n = 3:    bits 18..2 the first bucket entry, bits 35..19 the bucket's size (>= 3)
+// (seed positions and bucket sizes are < 100 000 < 2^17: fa_batch_create refuses longer seeds)
+#define CH_REC(n, a, b) ((u64)(n) | ((u64)(a) << 2) | ((u64)(b) << 19))
+#define CH_REC_N(r) ((u32)(r) & 3u)
+#define CH_REC_A(r) ((u32)((r) >> 2) & 0x1ffffu)
+#define CH_REC_B(r) ((u32)((r) >> 19) & 0x1ffffu)
 
 // inclusive wave scan of the maps r -> max(u, r + v), composed left to right
 // (64-bit, LDS crossbar: the fallback for reads with huge k-mer buckets)
@@ -91,7 +107,11 @@ __device__ __forceinline__ int wave_sum(int s) {
 }
 
 __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
+#ifdef FA_EMU  // (tests/emu/simt: the launcher there hands the block its dynamic LDS)
+    u32 *smem = (u32 *)simt::g_dyn_lds;
+#else
     extern __shared__ __attribute__((aligned(16))) u32 smem[];
+#endif
     u32 *bin_cnt = smem;
     u32 *bin_key = smem + A.lds_bins;
     const int lane = fa_lane();
@@ -112,8 +132,8 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
     const u32 *T = A.kidx + pm.kidx_off;
     const u32 *P = A.kpos + pm.kpos_off;
     const int n_probe = (sq.len > FA_K) ? (sq.len - FA_K + 3) / 4 : 0;  // i = 4p < len-K
-    uint2 *pr = A.probe + A.probe_off[g];  // the two later passes re-read the bucket bounds
-                                           // coalesced instead of repeating the random lookups
+    u64 *pr = A.probe + A.probe_off[g];  // the two later passes read the records coalesced
+                                         // instead of repeating the random lookups
 
     // ---- pass A: diagonal extent and hit count
     int d_min = 0x7fffffff, d_max = -0x7fffffff;
@@ -144,7 +164,8 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
             const int p = p0 + 64 * u + lane;
             if (p < n_probe) {
                 const int i = 4 * p;
-                pr[p] = make_uint2(lo[u], hi[u] - lo[u]);
+                const u32 cnt = hi[u] - lo[u];
+                pr[p] = cnt == 0 ? 0ull : cnt <= 2 ? CH_REC(cnt, tl[u], th[u]) : CH_REC(3u, lo[u], cnt);
                 if (hi[u] > lo[u]) {
                     n_hit += (int)(hi[u] - lo[u]);
                     cnt_max = max(cnt_max, hi[u] - lo[u]);
@@ -176,26 +197,41 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
     __syncthreads();
 
     // ---- pass B: histogram + first-hit order key per bin (:350-366)
+    auto count_hit = [&](int p, u32 j, int t) {
+        const int b = (4 * p - t - d_min) / CH_BIN;
+        atomicAdd(&bin_cnt[b], 1u);
+        atomicMin(&bin_key[b], ((u32)p << 17) | j);
+    };
     for (int p0 = 0; p0 < n_probe; p0 += 64 * CH_U) {
-        uint2 v[CH_U];
-        u32 t0[CH_U];
+        u64 v[CH_U];
 #pragma unroll
         for (int u = 0; u < CH_U; u++) {
             const int p = p0 + 64 * u + lane;
-            v[u] = make_uint2(0u, 0u);
-            if (p < n_probe) v[u] = pr[p];
+            v[u] = pr[min(p, n_probe - 1)];
+            if (p >= n_probe) v[u] = 0;
         }
 #pragma unroll
-        for (int u = 0; u < CH_U; u++) t0[u] = P[v[u].y ? v[u].x : 0u];  // first hit of the probe
-#pragma unroll
         for (int u = 0; u < CH_U; u++) {
             const int p = p0 + 64 * u + lane;
-            const int i = 4 * p;
-            for (u32 j = 0; j < v[u].y; j++) {
-                const int t = (int)(j == 0 ? t0[u] : P[v[u].x + j]);
-                const int b = (i - t - d_min) / CH_BIN;
-                atomicAdd(&bin_cnt[b], 1u);
-                atomicMin(&bin_key[b], ((u32)p << 17) | j);
+            const u32 n = CH_REC_N(v[u]);
+            if (n == 1 || n == 2) count_hit(p, 0, (int)CH_REC_A(v[u]));
+            if (n == 2) count_hit(p, 1, (int)CH_REC_B(v[u]));
+        }
+#pragma unroll
+        for (int u = 0; u < CH_U; u++) {  // the probes with larger buckets: four entries per round trip
+            const int p = p0 + 64 * u + lane;
+            const bool heavy = CH_REC_N(v[u]) == 3;
+            if (!fa_ballot(heavy)) continue;
+            const u32 lo = CH_REC_A(v[u]), cnt = heavy ? CH_REC_B(v[u]) : 0u;
+            for (u32 j0 = 0; fa_ballot(j0 < cnt) != 0; j0 += 4) {
+                if (j0 < cnt) {
+                    u32 t[4];
+#pragma unroll
+                    for (u32 q = 0; q < 4; q++) t[q] = P[lo + min(j0 + q, cnt - 1u)];
+#pragma unroll
+                    for (u32 q = 0; q < 4; q++)
+                        if (j0 + q < cnt) count_hit(p, j0 + q, (int)t[q]);
+                }
             }
         }
     }
@@ -235,31 +271,52 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
         i64 carry_run = 0, best = 0;
         int carry_prev_q = -1;             // q of the last kept group so far (-1: none yet)
         int carry_start_q = 0, carry_start_t = 0;
-        // software pipeline: bucket bounds two chunks ahead, first hits one chunk ahead
-        uint2 v_nx = make_uint2(0u, 0u), v_n2 = make_uint2(0u, 0u);
-        u32 t0_nx = 0;
-        if (lane < n_probe) v_nx = pr[lane];
-        if (lane + 64 < n_probe) v_n2 = pr[lane + 64];
-        t0_nx = P[v_nx.y ? v_nx.x : 0u];
+        // software pipeline: records two chunks ahead; one chunk ahead the first four bucket
+        // entries of the probes that have more than two hits (the index clamped, so that every
+        // chunk has the same loads in flight)
+        auto record_at = [&](int p) {
+            const u64 v = pr[min(p, n_probe - 1)];
+            return p < n_probe ? v : 0ull;
+        };
+        auto entry = [&](u64 v, u32 j) {  // entry min(j, size - 1) of a large bucket, P[0] for the others
+            const bool heavy = CH_REC_N(v) == 3;
+            return P[heavy ? CH_REC_A(v) + min(j, CH_REC_B(v) - 1u) : 0u];
+        };
+        u64 v_nx = record_at(lane), v_n2 = record_at(lane + 64);
+        u32 e_nx[4];
+#pragma unroll
+        for (u32 j = 0; j < 4; j++) e_nx[j] = entry(v_nx, j);
         for (int p0 = 0; p0 < n_probe; p0 += 64) {
             const int p = p0 + lane;
-            const uint2 v = v_nx;
-            const u32 t0 = t0_nx;
+            const u64 v = v_nx;
+            u32 e[4];
+#pragma unroll
+            for (u32 j = 0; j < 4; j++) e[j] = e_nx[j];
             v_nx = v_n2;
-            t0_nx = P[v_nx.y ? v_nx.x : 0u];
-            v_n2 = make_uint2(0u, 0u);
-            if (p + 128 < n_probe) v_n2 = pr[p + 128];
+#pragma unroll
+            for (u32 j = 0; j < 4; j++) e_nx[j] = entry(v_nx, j);
+            v_n2 = record_at(p + 128);
             int m = 0, t_first = 0, t_last = 0;
             const int q = 4 * p;
-            for (u32 j = 0; j < v.y; j++) {  // (v.y == 0 beyond the last probe)
-                const int t = (int)(j == 0 ? t0 : P[v.x + j]);
-                const int b = (q - t - d_min) / CH_BIN;
+            auto take = [&](bool there, int t) {  // one hit, in order: the +-5 bin filter (:369-383)
+                const int b = there ? (q - t - d_min) / CH_BIN : 0;
                 int db = b - top_bin;
                 if (db < 0) db = -db;
-                if (db > 5 || (int)bin_cnt[b] <= CH_TH) continue;
-                if (m == 0) t_first = t;
-                t_last = t;
-                m++;
+                const bool keep = there && db <= 5 && (int)bin_cnt[b] > CH_TH;
+                if (keep && m == 0) t_first = t;
+                if (keep) t_last = t;
+                m += keep ? 1 : 0;
+            };
+            const u32 n = CH_REC_N(v);
+            const bool heavy = n == 3;
+            const u32 cnt = heavy ? CH_REC_B(v) : n;  // (0 beyond the last probe)
+            take(cnt >= 1, (int)(heavy ? e[0] : CH_REC_A(v)));
+            take(cnt >= 2, (int)(heavy ? e[1] : CH_REC_B(v)));
+            if (fa_ballot(heavy) != 0) {
+                take(cnt >= 3, (int)e[2]);
+                take(cnt >= 4, (int)e[3]);
+                if (fa_ballot(cnt > 4) != 0)
+                    for (u32 j = 4; j < cnt; j++) take(true, (int)P[CH_REC_A(v) + j]);
             }
             const bool has = m > 0;
             const u64 hm = fa_ballot(m > 0);
@@ -348,12 +405,13 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
     A.out[g] = r;
 }
 
+#ifndef FA_EMU
 void fa_launch_chain(const FaBatchDev &b, int max_bins, hipStream_t s) {
     if (b.n_seq == 0 || b.n_chain == 0) return;
     ChainArgs A;
     A.words = b.words; A.seq = b.seq; A.pile = b.pile; A.kidx = b.kidx; A.kpos = b.kpos;
     A.order = b.chain_order; A.n_seq = b.n_seq; A.out = b.range;
-    A.probe = (uint2 *)b.probe; A.probe_off = b.probe_off;
+    A.probe = b.probe; A.probe_off = b.probe_off;
     A.lds_bins = (max_bins + 3) & ~3;
     size_t lds = (size_t)A.lds_bins * 2 * sizeof(u32);
     if (lds > 48 * 1024)
@@ -367,3 +425,4 @@ void fa_touch_chain() {
     hipFuncAttributes a;
     (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_chain));
 }
+#endif  // FA_EMU

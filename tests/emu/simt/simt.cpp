@@ -5,6 +5,7 @@
 
 namespace simt {
 Wave g_wave;
+void *g_dyn_lds = nullptr;
 
 // x86-64 SysV stack switch: callee-saved registers on the old stack, stack pointers swapped.
 asm(R"(

@@ -53,6 +53,8 @@ extern Wave g_wave;
 extern "C" void simt_switch(void **save_sp, void *load_sp);
 void run_block(Wave &w);
 
+// dynamic `extern __shared__` memory of the running block (the launcher sets it)
+extern void *g_dyn_lds;
 inline int lane() { return g_wave.cur; }
 inline Dim3 tidx() { return Dim3{(unsigned)g_wave.cur, 0, 0}; }
 inline Dim3 bidx() { return Dim3{g_wave.block, 0, 0}; }
@@ -83,15 +85,23 @@ inline uint64_t ballot(bool p, int site) {
         if (((x.act >> l) & 1ull) && x.v[l]) m |= 1ull << l;
     return m;
 }
-inline int shfl(int v, int src, int site) {
-    const X x = xchg((uint32_t)v, site);
-    return (int)(uint32_t)x.v[src & 63];
+// (32- and 64-bit operands alike: a slot holds 64 bits; a lane that left reads as 0)
+template <class T> inline T shfl(T v, int src, int site) {
+    static_assert(sizeof(T) <= 8, "shfl operand");
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    const X x = xchg(bits, site);
+    const uint64_t r = ((x.act >> (src & 63)) & 1ull) ? x.v[src & 63] : 0;
+    T out;
+    memcpy(&out, &r, sizeof(T));
+    return out;
 }
-inline int shfl_up(int v, int delta, int site) {
-    const X x = xchg((uint32_t)v, site);
+template <class T> inline T shfl_up(T v, int delta, int site) {
     const int me = lane();
-    return me >= delta ? (int)(uint32_t)x.v[me - delta] : v;
+    const T r = shfl(v, me >= delta ? me - delta : me, site);
+    return me >= delta ? r : v;
 }
+template <class T> inline T shfl_xor(T v, int mask, int site) { return shfl(v, lane() ^ mask, site); }
 inline int readlane(int v, int l, int site) {
     const X x = xchg((uint32_t)v, site);
     return (int)(uint32_t)x.v[l & 63];
@@ -175,8 +185,11 @@ inline void launch(const char *name, unsigned grid, F kernel_call) {
 #define __syncthreads() simt::sync(__LINE__)
 #define __threadfence_block() simt::sync(__LINE__)
 #define __ballot(p) simt::ballot((p), __LINE__)
-#define __shfl(v, s) simt::shfl((int)(v), (int)(s), __LINE__)
-#define __shfl_up(v, d) simt::shfl_up((int)(v), (int)(d), __LINE__)
+#define __shfl(v, s) simt::shfl((v), (int)(s), __LINE__)
+#define __shfl_up(v, d) simt::shfl_up((v), (int)(d), __LINE__)
+#define __shfl_xor(v, m) simt::shfl_xor((v), (int)(m), __LINE__)
+#define __clzll(x) __builtin_clzll((unsigned long long)(x))
+#define __ffsll(x) __builtin_ffsll((long long)(x))
 #define __popcll(x) __builtin_popcountll(x)
 #define __popc(x) __builtin_popcount(x)
 #define __builtin_amdgcn_ballot_w64(p) simt::ballot((p), __LINE__)
