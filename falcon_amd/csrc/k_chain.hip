@@ -46,7 +46,8 @@ struct ChainArgs {
 
 typedef long long i64;
 
-#define CH_U 4  // probe chunks (of 64) whose dependent loads are issued together
+#define CH_U 4   // probe chunks (of 64) whose dependent loads are issued together
+#define CH_UA 5  // ... in pass A, where three loads depend on one another (5: still 64 VGPRs, 8 wavefronts per SIMD)
 
 // The chain stage is a string of dependent random reads (packed read -> bucket bounds
 // -> seed positions); a wavefront that walks its probes 64 at a time spends its life
@@ -139,20 +140,20 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
     int d_min = 0x7fffffff, d_max = -0x7fffffff;
     int n_hit = 0;
     u32 cnt_max = 0;  // largest bucket a probe of this read hits
-    for (int p0 = 0; p0 < n_probe; p0 += 64 * CH_U) {
-        u32 km[CH_U], lo[CH_U], hi[CH_U], tl[CH_U], th[CH_U];
+    for (int p0 = 0; p0 < n_probe; p0 += 64 * CH_UA) {
+        u32 km[CH_UA], lo[CH_UA], hi[CH_UA], tl[CH_UA], th[CH_UA];
 #pragma unroll
-        for (int u = 0; u < CH_U; u++) {
+        for (int u = 0; u < CH_UA; u++) {
             const int p = p0 + 64 * u + lane;
             km[u] = (p < n_probe) ? fa_kmer8(w, 4 * p) : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < CH_U; u++) {
+        for (int u = 0; u < CH_UA; u++) {
             lo[u] = T[km[u]];
             hi[u] = T[km[u] + 1];
         }
 #pragma unroll
-        for (int u = 0; u < CH_U; u++) {
+        for (int u = 0; u < CH_UA; u++) {
             const int p = p0 + 64 * u + lane;
             if (p >= n_probe) hi[u] = lo[u];
             const bool any = hi[u] > lo[u];
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
             th[u] = P[any ? hi[u] - 1u : 0u];
         }
 #pragma unroll
-        for (int u = 0; u < CH_U; u++) {
+        for (int u = 0; u < CH_UA; u++) {
             const int p = p0 + 64 * u + lane;
             if (p < n_probe) {
                 const int i = 4 * p;
