@@ -105,10 +105,14 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
         return;
     }
 
-    // pre-pass: tagging stops at the first column whose insertion depth reaches
-    // 255 (falcon.c:138-152); dcut = that row (dist + 1 if none)
-    int dcut = dist + 1;
-    {
+    // Tagging stops at the first column whose insertion depth reaches 255 (falcon.c:138-152):
+    // dcut = that row (dist + 1 if none).  Rounds 1-3 walked the whole script once to find it
+    // before the pass that writes the tags.  Such a run is 254 consecutive all-zero script words
+    // (insertion, empty snake), which hold at least two whole chunks of 64 rows -- and the
+    // first of them starts 191 rows or more before dcut, so nothing written up to there depends
+    // on where the tagging ends.  The main pass therefore only looks for an all-zero chunk, and
+    // the exact walk happens when it meets one (practically never).
+    auto exact_dcut = [&]() {
         int carry_open = 0, first_bad = 0x7fffffff;
         u32 e_nx = (lane <= dist) ? scr[lane] : 1u, e_last = 1u;
         for (int d0 = 0; d0 <= dist; d0 += 64) {
@@ -127,24 +131,47 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
             carry_open = __builtin_amdgcn_readlane(delta, 63);
         }
         first_bad = fa_wave_min(first_bad);
-        if (first_bad <= dist) dcut = first_bad;
-    }
-    __threadfence_block();
+        return first_bad <= dist ? first_bad : dist + 1;
+    };
+    int dcut = dist + 1;
+    bool dcut_known = false;
+    fa_wave_sync();
 
-    // main pass over rows 0 .. dlast
-    const int dlast = min(dist, dcut - 1);
+    // main pass over rows 0 .. dlast.  What a chunk needs from global memory is requested at the
+    // END of the chunk before it, behind that chunk's stores (the counter a wait looks at
+    // counts loads and stores alike, in order): the script words of the chunk after the next
+    // one (the next chunk's are in registers already: a chunk's last row looks at its
+    // successor), and 64 packed words of the read from the next chunk's first query base on,
+    // out of which the inserted bases are taken with a lane shuffle.
+    int dlast = dist;
     int carry_t = 0, carry_q = rg.s1, carry_i = 0, carry_open = 0, carry_run_i = 0;
     int carry_start_row = 0;
     u32 carry_inl = 0, carry_es = 0;
-    u32 e_nx = (lane <= dlast) ? scr[lane] : 1u, e_last = 1u;
-    for (int d0 = 0; d0 <= dlast; d0 += 64) {
+    const int rw_last = (A.seq[g].len + 15) / 16;  // (two zero words follow every sequence)
+    // (every request unconditional, the index clamped: rows beyond dlast are masked where they are
+    // used -- a load under a branch makes the compiler wait for it on the spot)
+    // The registers take turns instead of being copied (a copy of a register a load is still under way
+    // for is a wait for that load -- and for every store issued before it): a chunk's script words
+    // are in `e_cur`, the next chunk's in `e_nx`; when the chunk is done, e_cur's register takes the
+    // words of the chunk after the next, and the two swap names.  Likewise the read words.
+    u32 e_a = scr[min(lane, dist)], e_b = scr[min(lane + 64, dist)], e_last = 1u;
+    int rw_base = rg.s1 >> 4;
+    u32 rw_a = rw[min(rw_base + lane, rw_last)], rw_b = 0;
+    int d0 = 0;
+    auto chunk = [&](u32 &e_cur, u32 &e_nx, u32 &rwn, u32 &rwn_nx) {
         const int d = d0 + lane;
+        if (!dcut_known && d0 + 63 <= dlast && fa_ballot(e_cur != 0u) == 0) {  // (wave-uniform)
+            dcut = exact_dcut();
+            dlast = min(dist, dcut - 1);
+            dcut_known = true;
+        }
         const bool have = d <= dlast;
-        const u32 e_cur = e_nx;
-        e_nx = (d + 64 <= dlast) ? scr[d + 64] : 1u;  // rows beyond dlast read as "deletion, no snake"
-        const ScrChunk sc = scr_chunk(e_cur, e_last, (u32)__builtin_amdgcn_readfirstlane((int)e_nx), lane);
+        // rows beyond dlast read as "deletion, no snake"
+        ScrChunk sc;
+        sc.e = have ? e_cur : 1u;
+        sc.ep = (u32)__builtin_amdgcn_update_dpp((int)e_last, (int)sc.e, 0x138, 0xf, 0xf, false);  // wave_shr:1
         const u32 e_last_prev = e_last;
-        e_last = (u32)__builtin_amdgcn_readlane((int)e_cur, 63);
+        e_last = (u32)__builtin_amdgcn_readlane((int)sc.e, 63);
         const u32 e = sc.e;
         const int m = have ? (int)(e >> 1) : 0;
         const bool is_edit = have && d >= 1;
@@ -156,6 +183,9 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
         const int tpos = carry_t + ts - tc;     // target index of this row's edit
         const int qpos = carry_q + qs - qc;     // query index of this row's inserted base
         const int iidx = carry_i + is - (is_ins ? 1 : 0);
+        // the read words the NEXT chunk takes its inserted bases from: its first query base is known
+        const int q_next = carry_q + __builtin_amdgcn_readlane(qs, 63);
+        rwn_nx = rw[min((q_next >> 4) + lane, rw_last)];
         bool cont;
         int start_row = 0;
         const int delta = chunk_delta(d >= 2 ? sc.ep : 1u, d, d0, is_ins, lane, carry_open, cont, start_row);
@@ -163,9 +193,6 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
         if (from_prev_chunk) start_row = carry_start_row;
         // index (in the alignment's insertion list) of the first base of my run
         const int run_i = is_ins ? (from_prev_chunk ? carry_run_i : iidx - (delta - 1)) : 0;
-        // the run ends here unless the next row continues it
-        const u32 en = (d + 1 <= dlast) ? sc.en : 1u;
-        const bool ends = is_ins && (m > 0 || (en & 1u) != 0u);
         // the column before my run (decides whether the run hangs off a deleted base):
         // a lane of this chunk, the last row of the previous one, or -- for a run that
         // began in an earlier chunk -- what that chunk found
@@ -174,9 +201,19 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
         if (from_prev_chunk) es = carry_es;
         if (start_row < 2) es = 0u;
         // inline bases of my run so far: OR of b << 2(delta-1) over the run's rows
+        // (the inserted base: out of the 64 read words requested a chunk ago; a chunk whose
+        // snakes carry it more than ~1000 query bases goes to memory itself)
         u32 b = 0, inl = 0;
+        {
+            const int wi = (qpos >> 4) - rw_base;
+            if (fa_ballot(is_ins && wi >= 64) != 0) {
+                if (is_ins) b = fa_settled(fa_base_at(rw, qpos));  // (waited for inside this rare branch)
+            } else {
+                const u32 word = (u32)__shfl((int)rwn, is_ins ? wi : 0);
+                b = (word >> ((qpos & 15) * 2)) & 3u;
+            }
+        }
         if (is_ins) {
-            b = fa_base_at(rw, qpos);
             insb[iidx] = (uint8_t)b;
             if (delta <= INL) inl = b << (2 * (delta - 1));
         }
@@ -186,15 +223,26 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
             if (is_ins && delta - 1 >= off && lane >= off) inl |= o;
         }
         if (from_prev_chunk) inl |= carry_inl;
+        // the run ends here unless the next row continues it (the last lane looks at the next
+        // chunk's first row: the registers requested at the end of the chunk before this one --
+        // their first use, this far down, is what the wait for them lands in front of)
+        sc.en = (u32)__builtin_amdgcn_update_dpp(
+            (int)(d0 + 64 <= dlast ? (u32)__builtin_amdgcn_readfirstlane((int)e_nx) : 1u), (int)sc.e, 0x130, 0xf, 0xf,
+            false);  // wave_shl:1
+        const u32 en = (d + 1 <= dlast) ? sc.en : 1u;
+        const bool ends = is_ins && (m > 0 || (en & 1u) != 0u);
         // the chunk's window of target positions [w0, w0 + span)
         const int w0 = carry_t, span = __builtin_amdgcn_readlane(ts, 63);
         const bool in_lds = span <= TG_WIN;  // (a very long match run: straight to HBM)
-        __syncthreads();
+        // (one wavefront: its LDS operations execute in order, so the zeros, the tags and the
+        // reads of the store-out need no barrier between them -- a __syncthreads() here also
+        // waited for the previous chunk's stores to be acknowledged, three times per chunk)
+        fa_wave_sync();
         if (in_lds) { for (int i = lane; i < span; i += 64) win[i] = 0u; }
         else { for (int i = lane; i < span; i += 64) desc[w0 + i] = 0u; }
         if (lane < 16) segl[lane] = 0u;
         const int sg0 = max(0, rg.s2 + w0 - 1) / TSEG;  // the first segment a run of this chunk can hang off
-        __syncthreads();
+        fa_wave_sync();
         // Every tag word has exactly one writer (no atomics): a deletion writes its
         // flag unless an insertion run hangs off the deleted base, in which case the
         // run's last row writes the whole word.
@@ -217,17 +265,30 @@ __global__ __launch_bounds__(64) void k_tags(MsaArgs A) {
             if (in_lds) atomicAdd(&segl[sg - sg0], (u32)delta);
             else atomicAdd(&segc[2 * sg + 1], delta);
         }
-        __syncthreads();
-        if (in_lds) { for (int i = lane; i < span; i += 64) desc[w0 + i] = win[i]; }
+        fa_wave_sync();
+        if (in_lds) {  // (four stores per trip: unrolled further, their addresses alone take 32 registers)
+            u32 *dp = desc + w0 + lane;
+#pragma unroll 4
+            for (int i = lane; i < span; i += 64, dp += 64) *dp = win[i];
+        }
         if (lane < 16 && segl[lane] != 0u) atomicAdd(&segc[2 * (sg0 + lane) + 1], (int)segl[lane]);
         carry_t += __builtin_amdgcn_readlane(ts, 63);
         carry_q += __builtin_amdgcn_readlane(qs, 63);
+        // the request for the chunk after the next one, into the register this chunk is done with
+        e_cur = scr[min(d + 128, dist)];
+        rw_base = q_next >> 4;
         carry_i += __builtin_amdgcn_readlane(is, 63);
         carry_open = __builtin_amdgcn_readlane(delta, 63);
         carry_run_i = __builtin_amdgcn_readlane(run_i, 63);
         carry_start_row = __builtin_amdgcn_readlane(start_row, 63);
         carry_inl = (u32)__builtin_amdgcn_readlane((int)inl, 63);
         carry_es = (u32)__builtin_amdgcn_readlane((int)es, 63);
+        d0 += 64;
+    };
+    while (d0 <= dlast) {
+        chunk(e_a, e_b, rw_a, rw_b);
+        if (d0 > dlast) break;
+        chunk(e_b, e_a, rw_b, rw_a);
     }
     // rows >= dcut are dropped: the alignment covers only what the kept rows consumed
     const int t_cov = (dcut <= dist) ? carry_t : te;

@@ -46,7 +46,7 @@ def script_of(q_aln, t_aln):
     return rows
 
 
-def stage_piles(piles, port, min_idt=0.70, accept_all=False):
+def stage_piles(piles, port, min_idt=0.70, accept_all=False, band=150, whole=False, forced=None):
     """(arrays for emu_msa) from piles = [[seed, read, ...], ...] and an oracle Port."""
     seqs, words, woff = [], [], 0
     n_seq = sum(len(p) for p in piles)
@@ -72,11 +72,23 @@ def stage_piles(piles, port, min_idt=0.70, accept_all=False):
             if j > 0:
                 hq, ht = port.find_hits(seed, s)
                 s1, e1, s2, e2, score = port.best_range(hq, ht)
+                if whole:  # (the windows of unitig consensus: whole sequences)
+                    s1, e1, s2, e2 = 0, len(s), 0, len(seed)
                 ok = not (e1 - s1 < 100 or e2 - s2 < 100 or
                           abs((e1 - s1) - (e2 - s2)) > int(0.5 * 0.10 * (e1 - s1 + e2 - s2)))  # falcon.c:613-619
                 rng[g] = (s1, e1, s2, e2, 1 if ok else 0, len(hq), score)
+                if forced and (p, j) in forced:  # a hand-made alignment of the whole read to the whole seed
+                    qa, ta = forced[(p, j)]
+                    assert qa.replace("-", "") == s and ta.replace("-", "") == seed and len(qa) == len(ta)
+                    s1, e1, s2, e2, ok = 0, len(s), 0, len(seed), True
+                    rng[g] = (s1, e1, s2, e2, 1, len(hq), score)
                 if ok:
-                    a = port.align(s[s1:e1], seed[s2:e2])
+                    if forced and (p, j) in forced:
+                        dist = sum(1 for x, y in zip(qa, ta) if x == "-" or y == "-")
+                        a = dict(aln_str_size=len(qa), q_aln_str=qa, t_aln_str=ta, dist=dist, aln_q_e=len(s),
+                                 aln_t_e=len(seed), cells=0)
+                    else:
+                        a = port.align(s[s1:e1], seed[s2:e2], band)
                     size = a["aln_str_size"]
                     rows = script_of(a["q_aln_str"], a["t_aln_str"])
                     assert len(rows) == a["dist"] + 1
