@@ -7,7 +7,7 @@
 #define TSEG 128       // target positions per k_links wavefront
 #define MAXACT 1024    // alignments overlapping one segment that k_links (the kernel behind k_links2) takes
 #define INL 11         // inserted bases stored inline in a tag
-#define BT_WIN 64      // levels per back-trace window
+#define BT_WIN 128     // levels per back-trace window (a multiple of 64)
 
 // tag word of one covered target position (one u32, written exactly once):
 //   bit 31      the alignment deletes the target base

@@ -741,7 +741,13 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
 // the scalar unit: 7.2 ms per 3072 piles, five times the chase).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_backtrace(MsaArgs A) {
-    __shared__ __attribute__((aligned(8))) u32 win[2 * 5 * BT_WIN];
+    // A window of BT_WIN levels (5 node records each) and, per node of it, the node 1, 2, 4, .. 32
+    // steps down the path that starts there (a local index, BT_OUT once the path has left the
+    // window or ended)
+    constexpr int NW = 5 * BT_WIN;
+    constexpr u16 BT_OUT = 0xffffu;
+    __shared__ __attribute__((aligned(8))) u32 win[2 * NW];
+    __shared__ u16 jump[6][NW];
     const int lane = fa_lane();
     const int p = blockIdx.x;
     if (p >= A.n_pile) return;
@@ -760,79 +766,99 @@ __global__ __launch_bounds__(64) void k_backtrace(MsaArgs A) {
         const unsigned lim = (unsigned)T * 2u;
         unsigned index = 0;                // characters written so far
         int win_lo = 0, n_win = 0;         // node ids [win_lo, win_lo + n_win) are in LDS
-        int pf_lo = 0, pf_n = 0;           // ... and these are on their way, five records per lane
-        uint2 pf[5];
+        int pf_lo = 0, pf_n = 0;           // ... and these are on their way, BT_PF records per lane
+        constexpr int BT_PF = NW / 64;
+        uint2 pf[BT_PF];
 #pragma unroll
-        for (int q = 0; q < 5; q++) { pf[q].x = 0; pf[q].y = 0; }
-        auto request_below = [&](int first_node) {  // the 64 levels under the window
+        for (int q = 0; q < BT_PF; q++) { pf[q].x = 0; pf[q].y = 0; }
+        auto request_below = [&](int first_node) {  // the BT_WIN levels under the window
             const int lvl_hi = first_node / 5 - 1;
             const int lvl_lo = max(0, lvl_hi - (BT_WIN - 1));
             pf_lo = lvl_lo * 5;
             pf_n = lvl_hi < 0 ? 0 : (lvl_hi - lvl_lo + 1) * 5;
 #pragma unroll
-            for (int q = 0; q < 5; q++) {
+            for (int q = 0; q < BT_PF; q++) {
                 const int i = lane + 64 * q;
-                if (i < pf_n) pf[q] = nodes[pf_lo + i];
+                pf[q] = nodes[pf_lo + min(i, max(pf_n, 1) - 1)];  // (unconditional, the index clamped)
             }
         };
-        auto fetch = [&](int node) -> FaNode {
-            if ((unsigned)(node - win_lo) >= (unsigned)n_win) {
-                fa_wave_sync();
-                if ((unsigned)(node - pf_lo) < (unsigned)pf_n) {  // the usual case: the window below
-                    win_lo = pf_lo;
-                    n_win = pf_n;
+        // The walk along the best-predecessor pointers is a chain of dependent reads, one node per
+        // LDS round trip however it is written (rounds 1-4: ~430 clocks per node, 4 ms for 3072
+        // piles and 20 ms for 1024 deeper ones).  But the nodes of a window are all there, so the
+        // chain is walked by pointer doubling instead: jump[j][v] = the node 2^j steps below v, six
+        // data-parallel passes over the window, and lane s then finds the path's s-th node in six
+        // reads (the bits of s) -- 64 nodes for a dozen round trips.
+        auto window_at = [&](int node) {  // node (wave-uniform) becomes the top of the window
+            fa_wave_sync();
+            if ((unsigned)(node - pf_lo) < (unsigned)pf_n) {  // the usual case: the window below
+                win_lo = pf_lo;
+                n_win = pf_n;
 #pragma unroll
-                    for (int q = 0; q < 5; q++) {
-                        const int i = lane + 64 * q;
-                        if (i < pf_n) { win[2 * i] = pf[q].x; win[2 * i + 1] = pf[q].y; }
-                    }
-                } else {  // the first window, and the jump of a zero back pointer (Q4)
-                    const int lvl_hi = node / 5;
-                    const int lvl_lo = max(0, lvl_hi - (BT_WIN - 1));
-                    win_lo = lvl_lo * 5;
-                    n_win = (lvl_hi - lvl_lo + 1) * 5;
-                    for (int i = lane; i < n_win; i += 64) {
-                        const uint2 v = nodes[win_lo + i];
-                        win[2 * i] = v.x;
-                        win[2 * i + 1] = v.y;
-                    }
+                for (int q = 0; q < BT_PF; q++) {
+                    const int i = lane + 64 * q;
+                    if (i < pf_n) { win[2 * i] = pf[q].x; win[2 * i + 1] = pf[q].y; }
                 }
-                fa_wave_sync();
-                win_lo = fa_uni(win_lo);  // (wave-uniform: the window test of every step stays on the scalar unit)
-                n_win = fa_uni(n_win);
-                request_below(win_lo);
-                pf_lo = fa_uni(pf_lo);
-                pf_n = fa_uni(pf_n);
+            } else {  // the first window, and the jump of a zero back pointer (Q4)
+                const int lvl_hi = node / 5;
+                const int lvl_lo = max(0, lvl_hi - (BT_WIN - 1));
+                win_lo = lvl_lo * 5;
+                n_win = (lvl_hi - lvl_lo + 1) * 5;
+                for (int i = lane; i < n_win; i += 64) {
+                    const uint2 v = nodes[win_lo + i];
+                    win[2 * i] = v.x;
+                    win[2 * i + 1] = v.y;
+                }
             }
-            // (one 8-byte LDS read at a wave-uniform address; the walk itself is scalar)
-            const uint2 v = *reinterpret_cast<const uint2 *>(&win[2 * (node - win_lo)]);
-            FaNode r;
-            r.score_h = __builtin_amdgcn_readfirstlane((int)v.x);
-            r.link = __builtin_amdgcn_readfirstlane((int)v.y);
-            return r;
+            win_lo = fa_uni(win_lo);
+            n_win = fa_uni(n_win);
+            request_below(win_lo);
+            pf_lo = fa_uni(pf_lo);
+            pf_n = fa_uni(pf_n);
+            fa_wave_sync();
+            for (int v = lane; v < n_win; v += 64) {  // one step: the back pointer, if it stays inside
+                const int prev = (int)(win[2 * v + 1] >> 1) - 1 - win_lo;
+                jump[0][v] = (prev >= 0 && prev < n_win) ? (u16)prev : BT_OUT;
+            }
+#pragma unroll
+            for (int j = 1; j < 6; j++) {
+                fa_wave_sync();
+                for (int v = lane; v < n_win; v += 64) {
+                    const u16 h = jump[j - 1][v];
+                    jump[j][v] = h == BT_OUT ? BT_OUT : jump[j - 1][h];
+                }
+            }
+            fa_wave_sync();
         };
         int node = so.g_node;
-        FaNode rec = fetch(node);
+        window_at(node);
         bool first = true;  // the round holds the path's first node, whose character comes from g_ck (Q2)
         for (;;) {
-            // ---- collect up to 64 nodes: lane s keeps the s-th
-            int my_node = 0, my_score = 0, my_link = 0;
-            int n = 0;
-            bool last = false;  // the round's last node has no predecessor: the path ends
-            for (int s = 0; s < 64; s++) {
-                if (lane == s) { my_node = node; my_score = rec.score_h; my_link = rec.link; }
-                n = s + 1;
-                const int prev = (rec.link >> 1) - 1;
-                if (prev < 0) { last = true; break; }
-                node = prev;
-                rec = fetch(node);
+            // ---- lane s: the path's s-th node from `node` on, while the path stays in the window
+            u32 cur = (u32)(node - win_lo);
+#pragma unroll
+            for (int j = 5; j >= 0; j--) {
+                const u32 nx = jump[j][min(cur, (u32)(NW - 1))];
+                if ((lane >> j) & 1) cur = cur == BT_OUT ? cur : nx;
             }
+            const bool in = cur != BT_OUT;
+            const int n = __popcll(fa_ballot(in));  // (a prefix of the lanes, lane 0 always)
+            int my_node = 0, my_score = 0, my_link = 0;
+            if (in) {
+                my_node = win_lo + (int)cur;
+                my_score = (int)win[2 * cur];
+                my_link = (int)win[2 * cur + 1];
+            }
+            // what follows the round's last node: nothing (the path ends), or the next round's first
+            const int prev = (__builtin_amdgcn_readlane(my_link, n - 1) >> 1) - 1;
+            const bool last = prev < 0;
+            if (!last && (unsigned)(prev - win_lo) >= (unsigned)n_win) window_at(prev);
+            const int after_score = last ? 0 : (int)win[2 * (prev - win_lo)];
             // ---- what the reference does per node, for all of them (falcon.c:494-528): node i
             // yields a character unless it is the path's last one (:517-519, Q1), the character
             // is skipped when it is '-'; eqv = (int)score - (int)next node's score (Q6)
             const int n_out = last ? n - 1 : n;
-            int next_score = __builtin_amdgcn_update_dpp(rec.score_h, my_score, 0x130, 0xf, 0xf, false);  // wave_shl:1
-            if (lane == n - 1) next_score = rec.score_h;  // (the node the next round starts with)
+            int next_score = __builtin_amdgcn_update_dpp(after_score, my_score, 0x130, 0xf, 0xf, false);  // wave_shl:1
+            if (lane == n - 1) next_score = after_score;  // (the node the next round starts with)
             const int ck = (first && lane == 0) ? so.g_ck : my_node % 5;
             const u32 letters = (my_link & 1) ? 0x54474341u /* "ACGT" */ : 0x74676361u /* "acgt" */;
             // 0..3: the base, upper case where the coverage allowed; 4: '-'; a link index >= 5
@@ -849,6 +875,7 @@ __global__ __launch_bounds__(64) void k_backtrace(MsaArgs A) {
             index = min(lim, index + (unsigned)__popcll(m));
             first = false;
             if (last || index >= lim) break;
+            node = prev;
         }
         po.len = (int)index;
         po.start = (int)(lim - index);
