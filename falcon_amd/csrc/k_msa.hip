@@ -815,16 +815,31 @@ __global__ __launch_bounds__(64) void k_backtrace(MsaArgs A) {
             pf_lo = fa_uni(pf_lo);
             pf_n = fa_uni(pf_n);
             fa_wave_sync();
-            for (int v = lane; v < n_win; v += 64) {  // one step: the back pointer, if it stays inside
-                const int prev = (int)(win[2 * v + 1] >> 1) - 1 - win_lo;
-                jump[0][v] = (prev >= 0 && prev < n_win) ? (u16)prev : BT_OUT;
+            // (every pass reads all of a lane's BT_PF nodes, then all of their targets, then writes:
+            // two LDS round trips per pass -- a loop over the nodes made it two per NODE)
+            const int top = n_win - 1;
+            {  // one step: the back pointer, if it stays inside
+                u32 lk[BT_PF];
+#pragma unroll
+                for (int q = 0; q < BT_PF; q++) lk[q] = win[2 * min(lane + 64 * q, top) + 1];
+#pragma unroll
+                for (int q = 0; q < BT_PF; q++) {
+                    const int v = lane + 64 * q, prev = (int)(lk[q] >> 1) - 1 - win_lo;
+                    if (v < n_win) jump[0][v] = (prev >= 0 && prev < n_win) ? (u16)prev : BT_OUT;
+                }
             }
 #pragma unroll
             for (int j = 1; j < 6; j++) {
                 fa_wave_sync();
-                for (int v = lane; v < n_win; v += 64) {
-                    const u16 h = jump[j - 1][v];
-                    jump[j][v] = h == BT_OUT ? BT_OUT : jump[j - 1][h];
+                u16 h[BT_PF], g[BT_PF];
+#pragma unroll
+                for (int q = 0; q < BT_PF; q++) h[q] = jump[j - 1][min(lane + 64 * q, top)];
+#pragma unroll
+                for (int q = 0; q < BT_PF; q++) g[q] = jump[j - 1][min((int)h[q], top)];
+#pragma unroll
+                for (int q = 0; q < BT_PF; q++) {
+                    const int v = lane + 64 * q;
+                    if (v < n_win) jump[j][v] = h[q] == BT_OUT ? BT_OUT : g[q];
                 }
             }
             fa_wave_sync();
