@@ -404,7 +404,9 @@ extern "C" int fa_device_count(void) {
 static void planner_main(fa_ctx *c);
 
 extern "C" fa_ctx *fa_create(int device) {
+    PhaseTimer pt("fa_create");
     int n = fa_device_count();
+    pt.mark("device-count");
     if (n <= 0) {
         set_err("falcon_amd: no HIP device visible -- this library has no CPU fallback");
         return nullptr;
@@ -416,6 +418,7 @@ extern "C" fa_ctx *fa_create(int device) {
     HIP_OK_P(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_OK_P(hipGetDeviceProperties(&prop, device));
+    pt.mark("set-device+properties");
     fa_ctx *c = new fa_ctx();
     c->device = device;
     {
@@ -436,6 +439,7 @@ extern "C" fa_ctx *fa_create(int device) {
     }
     HIP_OK_P(hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
     HIP_OK_P(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+    pt.mark("streams");
     HIP_OK_P(hipMalloc((void **)&c->arena.counter, sizeof(int)));
     HIP_OK_P(hipMalloc((void **)&c->d_first_bad, sizeof(int)));
     HIP_OK_P(hipMalloc((void **)&c->d_counter2, sizeof(int)));
@@ -447,6 +451,7 @@ extern "C" fa_ctx *fa_create(int device) {
     HIP_OK_P(hipMemset(c->a2.stats, 0, 12 * sizeof(unsigned long long)));
     c->a2.counter = c->arena.counter;  // (the front stream runs one alignment launch at a time)
     c->planner = std::thread(planner_main, c);
+    pt.mark("small-buffers");
     return c;
 }
 
@@ -459,17 +464,21 @@ static int stage_reserve(fa_ctx *c, size_t bytes, bool device_twin);
 // upload and 39 ms for its first launches).
 extern "C" int fa_warm(fa_ctx *c, long long batch_bases) {
     if (!c) return -1;
+    PhaseTimer pt("fa_warm");
     HIP_OK(hipSetDevice(c->device));
     {
         std::lock_guard<std::mutex> hold(c->stage_mu);
         const size_t bytes = (size_t)std::max<long long>(batch_bases, 1 << 20) / 4 + (4u << 20);
         if (stage_reserve(c, bytes, false)) return -1;
+        pt.mark("pinned-staging");
         HIP_OK(hipMemsetAsync(c->d_first_bad, 0, sizeof(int), c->up_stream));
         HIP_OK(hipMemcpyAsync(c->d_first_bad, c->h_stage, sizeof(int), hipMemcpyHostToDevice, c->up_stream));
         HIP_OK(hipStreamSynchronize(c->up_stream));
+        pt.mark("first-copy");
     }
     fa_touch_index(); fa_touch_chain(); fa_touch_align2(); fa_touch_msa(); fa_touch_links2();
     fa_touch_score1(); fa_touch_score2();
+    pt.mark("code-objects");
     return 0;
 }
 

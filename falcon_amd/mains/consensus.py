@@ -588,9 +588,11 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None)
         stop.set()
         raise
     finally:
+        LOG.debug("t=%.3f runners done", _clock())
         done.put(END)   # (behind everything the runners delivered)
         t_out.join()
         stop.set()
+        LOG.debug("t=%.3f printer done", _clock())
         # the reader may only be closed once the ingest and staging threads have left it;
         # what they had staged meanwhile is released
         while t_in.is_alive() or t_stage.is_alive():
@@ -675,7 +677,11 @@ def run(args, stdin=None, stdout=None, consensus_map=None):
 
 def main(argv=None):
     args = parse_args(sys.argv if argv is None else argv)
+    LOG.debug("t=%.3f arguments parsed", _clock())
+    if os.environ.get("FALCON_AMD_T_LAUNCH"):  # (scripts/exp_e2e.py: when the parent started this process)
+        LOG.debug("t=0 was %.3f s after the launch", time.time() - _clock() - float(os.environ["FALCON_AMD_T_LAUNCH"]))
     run(args)
+    LOG.debug("t=%.3f run() returned", _clock())
     if FAILED_PILES and not os.environ.get("FALCON_AMD_SKIP_FAILED_PILES"):
         sys.stderr.write("falcon_amd: %d pile(s) were not corrected (see above)\n" % len(FAILED_PILES))
         sys.exit(3)

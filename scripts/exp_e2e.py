@@ -44,7 +44,8 @@ for env in SETTINGS:
     t = time.time()
     with open(path) as fin, open(path + ".fa", "w") as fout, open(path + ".err", "w") as ferr:
         subprocess.run([sys.executable, "-m", "falcon_amd.mains.consensus", "-v", "1"] + opts, stdin=fin,
-                       stdout=fout, stderr=ferr, check=True, cwd=ROOT, env=dict(os.environ, **env))
+                       stdout=fout, stderr=ferr, check=True, cwd=ROOT,
+                       env=dict(os.environ, FALCON_AMD_T_LAUNCH=repr(t), **env))
     dt = time.time() - t
     sha = hashlib.sha1(open(path + ".fa", "rb").read()).hexdigest()[:12]
     ref_sha = ref_sha or sha
