@@ -395,7 +395,7 @@ NATIVE_BATCH_BASES = 400_000_000
 NATIVE_READ_AHEAD = 8
 
 
-def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None):
+def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None, leave_open=False):
     """The worker's pipeline, records leaving in input order (``failed_piles``: where the
     seeds of piles that failed alone are collected, default the process-wide list):
 
@@ -602,7 +602,8 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None)
                 continue
             if item is not END:
                 getattr(item[2], "free", lambda: None)()
-        reader.close()
+        if not (leave_open and not failed):  # (leave_open: the process is about to end -- _leave)
+            reader.close()
     LOG.debug("t=%.3f stream finished", _clock())
     if len(printed) >= 3:
         # the worker's own steady state: from the first batch leaving to the last one (what
@@ -617,7 +618,7 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None)
         raise failed[0]
 
 
-def run(args, stdin=None, stdout=None, consensus_map=None):
+def run(args, stdin=None, stdout=None, consensus_map=None, leave_open=False):
     """``consensus_map`` (tests) replaces the GPU map: iterable of piles -> iterable of
     consensus strings."""
     stdin = sys.stdin if stdin is None else stdin
@@ -640,13 +641,16 @@ def run(args, stdin=None, stdout=None, consensus_map=None):
 
     fd = _stream_fd(stdin)
     if consensus_map is None and not args.trim and fd is not None:
+        ok = False
         try:
-            _run_native(args, cfg, fd, open_gpu, stdout)
+            _run_native(args, cfg, fd, open_gpu, stdout, leave_open=leave_open)
+            ok = True
         finally:
             stdout.flush()
-            for g in opened:
-                g.close()
-            LOG.debug("t=%.3f engines closed", _clock())
+            if not (leave_open and ok):
+                for g in opened:
+                    g.close()
+                LOG.debug("t=%.3f engines closed", _clock())
         return
     if consensus_map is None:
         gpu = open_gpu()
@@ -680,11 +684,31 @@ def main(argv=None):
     LOG.debug("t=%.3f arguments parsed", _clock())
     if os.environ.get("FALCON_AMD_T_LAUNCH"):  # (scripts/exp_e2e.py: when the parent started this process)
         LOG.debug("t=0 was %.3f s after the launch", time.time() - _clock() - float(os.environ["FALCON_AMD_T_LAUNCH"]))
-    run(args)
+    fast = not os.environ.get("FALCON_AMD_SLOW_EXIT") and "pytest" not in sys.modules
+    run(args, leave_open=fast)
     LOG.debug("t=%.3f run() returned", _clock())
+    code = 0
     if FAILED_PILES and not os.environ.get("FALCON_AMD_SKIP_FAILED_PILES"):
         sys.stderr.write("falcon_amd: %d pile(s) were not corrected (see above)\n" % len(FAILED_PILES))
-        sys.exit(3)
+        code = 3
+    _leave(code)
+
+
+def _leave(code):
+    """The console command's exit: everything is written and flushed, and the process is its own --
+    so it ends here, without the interpreter's and the HIP runtime's teardown (threads, module
+    finalisers, unmapping gigabytes of text buffers the kernel frees anyway: ~0.15 s of a block's
+    1.6 s).  FALCON_AMD_SLOW_EXIT=1: the ordinary way out."""
+    if os.environ.get("FALCON_AMD_SLOW_EXIT") or "pytest" in sys.modules:  # (the same test as in main)
+        if code:
+            sys.exit(code)
+        return
+    try:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        logging.shutdown()
+    finally:
+        os._exit(code)
 
 
 if __name__ == "__main__":
