@@ -152,34 +152,27 @@ __device__ __forceinline__ void si_fill(u32 *cur, const u32 *w, u32 *P, int n_po
     }
 }
 
-// One pile, thread `tid` of its workgroup.  ONE_PHASE: only phase `phase` (0 .. 4) and no barrier --
-// how tests/emu/simt/emu_index.cpp runs the phases, wavefront after wavefront, on an emulator that
-// holds one wavefront at a time (the phases only meet through the LDS and T).
-template <bool ONE_PHASE>
-__device__ __forceinline__ void si_pile(int phase, u32 *cur, u32 *wtot, u32 *sw, const u32 *seed_words, int len,
-                                        u32 *T, u32 *P, int tid) {
+// One pile, thread `tid` of its workgroup.
+__device__ __forceinline__ void si_pile(u32 *cur, u32 *wtot, u32 *sw, const u32 *seed_words, int len, u32 *T, u32 *P,
+                                        int tid) {
     const int n_pos = max(0, len - FA_K), lane = tid & 63, wv = tid >> 6;
-    if (!ONE_PHASE || phase == 0) si_zero(cur, sw, seed_words, len, tid);
-    if (!ONE_PHASE) __syncthreads();
-    if (!ONE_PHASE || phase == 1) si_histogram(cur, sw, n_pos, tid);
-    if (!ONE_PHASE) __syncthreads();
+    si_zero(cur, sw, seed_words, len, tid);
+    __syncthreads();
+    si_histogram(cur, sw, n_pos, tid);
+    __syncthreads();
     SiScan S;
-    int total = 0;
-    if (!ONE_PHASE || phase == 2 || phase == 3) total = si_scan_load(cur, wv, lane, S);
-    if ((!ONE_PHASE || phase == 2) && lane == 0) wtot[wv] = (u32)total;
-    if (!ONE_PHASE) __syncthreads();
-    if (!ONE_PHASE || phase == 3) {
-        u32 carry = 0;
+    const int total = si_scan_load(cur, wv, lane, S);
+    if (lane == 0) wtot[wv] = (u32)total;
+    __syncthreads();
+    u32 carry = 0;
 #pragma unroll
-        for (int q = 0; q < SI_NW; q++) carry += q < wv ? wtot[q] : 0u;
-        si_scan_store(cur, T, wv, lane, S, carry);
-        if (tid == 0) T[FA_NKMER] = (u32)n_pos;
-    }
-    if (!ONE_PHASE) __syncthreads();
-    if ((!ONE_PHASE || phase == 4) && wv == 0) si_fill(cur, sw, P, n_pos, lane);
+    for (int q = 0; q < SI_NW; q++) carry += q < wv ? wtot[q] : 0u;
+    si_scan_store(cur, T, wv, lane, S, carry);
+    if (tid == 0) T[FA_NKMER] = (u32)n_pos;
+    __syncthreads();
+    if (wv == 0) si_fill(cur, sw, P, n_pos, lane);
 }
 
-#ifndef FA_EMU
 __global__ __launch_bounds__(SI_NT) void k_seed_index(const u32 *__restrict__ words, const FaSeq *__restrict__ seq,
                                                       const FaPile *__restrict__ pile, u32 *__restrict__ kidx,
                                                       u32 *__restrict__ kpos) {
@@ -189,7 +182,7 @@ __global__ __launch_bounds__(SI_NT) void k_seed_index(const u32 *__restrict__ wo
     const FaPile pm = pile[blockIdx.x];
     const FaSeq sd = seq[pm.first];
     if (sd.len - FA_K > SI_MAX_POS) return;  // k_seed_index_long's
-    si_pile<false>(0, cur, wtot, sw, words + sd.woff, sd.len, kidx + pm.kidx_off, kpos + pm.kpos_off, threadIdx.x);
+    si_pile(cur, wtot, sw, words + sd.woff, sd.len, kidx + pm.kidx_off, kpos + pm.kpos_off, threadIdx.x);
 }
 
 // --------------------------------------------------------------------------
@@ -301,6 +294,7 @@ __global__ __launch_bounds__(SL_NT) void k_seed_index_long(const u32 *__restrict
     }
 }
 
+#ifndef FA_EMU
 // max_seed_len: the batch's longest seed (the kernel behind is only launched when a seed needs it);
 // FALCON_AMD_INDEX_LONG=1: every pile through the kernel behind (tests, A/B runs)
 void fa_launch_index(const FaBatchDev &b, int max_seed_len, hipStream_t s) {

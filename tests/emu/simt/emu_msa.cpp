@@ -49,7 +49,7 @@ struct Guarded {
 // a kernel that leaves its buffers: say which kernel, block, lane and buffer
 static void on_segv(int, siginfo_t *si, void *) {
     const char *a = (const char *)si->si_addr;
-    fprintf(stderr, "emu_msa: %s block %u lane %d touched %p", simt::g_wave.kernel, simt::g_wave.block, simt::g_wave.cur, (void *)a);
+    fprintf(stderr, "emu_msa: %s block %u lane %d touched %p", simt::g_cw->kernel, simt::g_cw->block, simt::g_cw->cur, (void *)a);
     for (int i = 0; i < g_nbufs; i++) {
         const Guarded *g = g_bufs[i];
         if (a >= g->map && a < g->map + g->map_bytes)

@@ -14,7 +14,10 @@
 //   * lanes that talk through memory (LDS or global) put a rendezvous between the write and
 //     the read -- fa_wave_sync() where the hardware needs nothing because the lanes run in
 //     lockstep; __syncthreads() and __threadfence_block() are rendezvous as well.
-// Blocks run one after the other (a `__shared__` array is a function-local static).
+// Blocks run one after the other (a `__shared__` array is a function-local static).  A block of
+// several wavefronts (launch_waves) runs them one after the other as well: each until it has
+// returned or every live lane of it waits at a __syncthreads(), which lets go when all the block's
+// live wavefronts are there (a wavefront that has returned is not waited for, as on the hardware).
 // Never compiled into the product; nothing under falcon_amd/ includes it.
 #pragma once
 #include <stdint.h>
@@ -47,19 +50,26 @@ struct Wave {
     std::function<void()> body;
     const char *kernel = "";
     unsigned long long n_sync = 0;
+    int index = 0;            // wavefront of its block
+    bool at_barrier = false;  // every live lane waits at a __syncthreads()
 };
-extern Wave g_wave;
+constexpr int MAX_WAVES = 16;
+constexpr int BLOCK_SITE = 1 << 30;  // site flag of a rendezvous of the whole block
+extern Wave g_wave;            // wavefront 0 (and the counters the drivers read)
+extern Wave *g_cw;             // the wavefront that is running
+extern int g_nwaves;           // wavefronts per block of the running launch
 
 extern "C" void simt_switch(void **save_sp, void *load_sp);
 void run_block(Wave &w);
+void run_block_waves(const char *name, unsigned block, unsigned grid, int n_waves, const std::function<void()> &body);
 
 // dynamic `extern __shared__` memory of the running block (the launcher sets it)
 extern void *g_dyn_lds;
-inline int lane() { return g_wave.cur; }
-inline Dim3 tidx() { return Dim3{(unsigned)g_wave.cur, 0, 0}; }
-inline Dim3 bidx() { return Dim3{g_wave.block, 0, 0}; }
-inline Dim3 gdim() { return Dim3{g_wave.grid, 1, 1}; }
-inline Dim3 bdim() { return Dim3{(unsigned)W, 1, 1}; }
+inline int lane() { return g_cw->cur; }
+inline Dim3 tidx() { return Dim3{(unsigned)(g_cw->index * W + g_cw->cur), 0, 0}; }
+inline Dim3 bidx() { return Dim3{g_cw->block, 0, 0}; }
+inline Dim3 gdim() { return Dim3{g_cw->grid, 1, 1}; }
+inline Dim3 bdim() { return Dim3{(unsigned)(W * g_nwaves), 1, 1}; }
 
 struct X {
     const uint64_t *v;
@@ -67,7 +77,7 @@ struct X {
 };
 // deposit `mine`, wait for the other live lanes, return everybody's operands
 inline X xchg(uint64_t mine, int site) {
-    Wave &w = g_wave;
+    Wave &w = *g_cw;
     const int me = w.cur;
     const unsigned g = w.gen & 1u;
     w.slot[g][me] = mine;
@@ -111,6 +121,7 @@ inline int readfirstlane(int v, int site) {
     return (int)(uint32_t)x.v[__builtin_ctzll(x.act)];
 }
 inline void sync(int site) { (void)xchg(0, site); }
+inline void sync_block(int site) { (void)xchg(0, site | BLOCK_SITE); }
 
 // DPP: which lane does `me` read under control `ctrl` (-1: no source lane)
 inline int dpp_src(int me, int ctrl) {
@@ -158,14 +169,14 @@ inline uint32_t mbcnt_hi(uint32_t m, uint32_t add) {
 // ---- launching ---------------------------------------------------------------------------
 template <class F>
 inline void launch(const char *name, unsigned grid, F kernel_call) {
-    Wave &w = g_wave;
-    w.kernel = name;
-    w.grid = grid;
-    w.body = kernel_call;
-    for (unsigned b = 0; b < grid; b++) {
-        w.block = b;
-        run_block(w);
-    }
+    const std::function<void()> body = kernel_call;
+    for (unsigned b = 0; b < grid; b++) run_block_waves(name, b, grid, 1, body);
+}
+// blocks of n_waves wavefronts (threadIdx.x = 64 * wavefront + lane)
+template <class F>
+inline void launch_waves(const char *name, unsigned grid, int n_waves, F kernel_call) {
+    const std::function<void()> body = kernel_call;
+    for (unsigned b = 0; b < grid; b++) run_block_waves(name, b, grid, n_waves, body);
 }
 }  // namespace simt
 
@@ -182,7 +193,7 @@ inline void launch(const char *name, unsigned grid, F kernel_call) {
 #define gridDim (simt::gdim())
 #define blockDim (simt::bdim())
 
-#define __syncthreads() simt::sync(__LINE__)
+#define __syncthreads() simt::sync_block(__LINE__)
 #define __threadfence_block() simt::sync(__LINE__)
 #define __ballot(p) simt::ballot((p), __LINE__)
 #define __shfl(v, s) simt::shfl((v), (int)(s), __LINE__)

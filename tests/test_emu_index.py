@@ -22,7 +22,7 @@ def lib():
         subprocess.run(["make", "-s", "-C", EMU_DIR, "libemu_index.so"], check=True)
         _lib = C.CDLL(os.path.join(EMU_DIR, "libemu_index.so"))
         _lib.emu_seed_index.restype = C.c_longlong
-        _lib.emu_seed_index.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _lib.emu_seed_index.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     return _lib
 
 
@@ -49,18 +49,18 @@ def expected(codes):
     return T, P
 
 
-def run(codes):
+def run(codes, use_long=0):
     codes = np.asarray(codes, dtype=np.uint32)
     words = pack(codes)
     T = np.zeros(NKMER + 1, dtype=np.uint32)
     P = np.zeros(max(1, len(codes)), dtype=np.uint32)
-    n = lib().emu_seed_index(words.ctypes.data, len(codes), T.ctypes.data, P.ctypes.data)
+    n = lib().emu_seed_index(words.ctypes.data, len(codes), T.ctypes.data, P.ctypes.data, use_long)
     assert n >= 0
     return T, P[:max(0, len(codes) - 8)]
 
 
-def check(codes):
-    T, P = run(codes)
+def check(codes, use_long=0):
+    T, P = run(codes, use_long)
     eT, eP = expected(codes)
     assert np.array_equal(T, eT)
     assert np.array_equal(P, eP)
@@ -104,7 +104,14 @@ def test_the_longest_seed_the_lds_table_takes():
     check(rng.integers(0, 4, 65543))
     check(np.zeros(65543, dtype=np.uint32))
     check(np.full(65543, 3, dtype=np.uint32))
-    codes = np.zeros(65544, dtype=np.uint32)  # one more: the kernel behind takes it
-    T = np.zeros(NKMER + 1, dtype=np.uint32)
-    P = np.zeros(len(codes), dtype=np.uint32)
-    assert lib().emu_seed_index(pack(codes).ctypes.data, len(codes), T.ctypes.data, P.ctypes.data) == -1
+    check(np.zeros(65544, dtype=np.uint32))  # one more: the kernel behind takes it
+    check(rng.integers(0, 4, 70001))
+
+
+def test_the_kernel_behind_on_short_seeds_too():
+    """k_seed_index_long (the table in global memory: rounds 1-3's kernel) with every_pile set, as
+    FALCON_AMD_INDEX_LONG runs it."""
+    rng = np.random.default_rng(9)
+    check(rng.integers(0, 4, 5000), use_long=1)
+    check([1] * 900, use_long=1)
+    check(rng.integers(0, 4, 7), use_long=1)
