@@ -192,7 +192,7 @@ extern "C" int emu_msa(const u32 *words_in, u64 n_words, const FaSeq *seq_in, in
         simt::launch("k_links<8>", wide_grid, [&] { k_links<8>(A); });
         simt::launch("k_links<16>", wide_grid, [&] { k_links<16>(A); });
     }
-    simt::launch("k_score2", (unsigned)n_pile, [&] { k_score2(A); });
+    simt::launch_waves("k_score2", (unsigned)n_pile, 2, [&] { k_score2(A); });
     if (!getenv("EMU_MSA_NO_BACKTRACE")) simt::launch("k_backtrace", (unsigned)n_pile, [&] { k_backtrace(A); });
 
     memcpy(out_seq, d_out_seq.get(), out);
