@@ -181,40 +181,54 @@ __global__ __launch_bounds__(128) void k_score2(MsaArgs A) {
         return a;
     };
     // ---- C: resolve a block.  Lane = level; its links in stored order.  A node's winner is the
-    // first of its links that reaches the node's score, if that score beat the floor.
+    // first of its links that reaches the node's score, if that score beat the floor.  Four links
+    // at a time: their records, then the two scores each of them names, then the four in order
+    // (one link at a time was two LDS round trips per link with nothing to do meanwhile).
     auto resolve = [&](const S2Block &g, u32 rec_b) {
         u32 seen = 0;   // nodes (bit = base) met / resolved so far
         u32 won = 0;
         u32 cin = 0;    // links met per node, 6 bits each
-        for (int k = 0; k < g.maxn; k++) {
-            if (k < g.nl) {
-                const u32 ra = rec_b + 8u * (u32)(g.off + k);
-                const u32 w0 = s2_at(L, ra), cv = s2_at(L, ra + 4u);
-                const u32 src = w0 & 0xffffu, dst = w0 >> 16;
-                const u32 nbase = ((dst >> 2) - g.rnode5) & (S2_RING - 1u);
-                const u32 node = g.node5 + nbase;
-                const u32 bit = 1u << nbase;
-                const u32 sn = s2_at(L, dst);
-                const u32 h = s2_at(L, src) + cv;
-                const u32 ck = (cin >> (6u * nbase)) & 63u;
-                cin += 1u << (6u * nbase);
-                const bool wins = !(won & bit) && sn > S2_FLOOR && h == sn;
-                const bool stays = !(seen & bit) && sn <= S2_FLOOR;  // no link beats the floor: the zero back pointer (Q4)
-                seen |= bit;
-                if (wins || stays) {
-                    won |= bit;
-                    // (the predecessor's node id from its ring index: its index at its position is the difference)
-                    const int pid = (wins && src != (u32)S2_ZERO_B) ? (int)(g.base5_s + (((src >> 2) - g.ring5_s) & (S2_RING - 1u)))
-                                                                    : (wins ? -1 : 0);
-                    s2_u32x2 r;
-                    r.x = sn - S2_BIAS;
-                    r.y = (u32)((pid + 1) << 1) | g.upper_s;
-                    nodes[node] = r;
-                    // the first strict maximum in (t, delta, base) order: among equals the lowest node
-                    if (sn > best_s || (sn == best_s && sn > S2_FLOOR && (int)node < best_node)) {
-                        best_s = sn;
-                        best_node = (int)node;
-                        best_ck = wins ? (int)ck : 0;
+        for (int k0 = 0; k0 < g.maxn; k0 += 4) {
+            s2_u32x2 rec[4];
+            u32 sn[4], hs[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)  // (a lane beyond its links reads some record of the set: never used)
+                rec[q] = *reinterpret_cast<const s2_u32x2 *>(&s2_at(L, rec_b + 8u * (u32)(k0 + q < g.nl ? g.off + k0 + q : lane)));
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const bool on = k0 + q < g.nl;
+                sn[q] = s2_at(L, on ? rec[q].x >> 16 : (u32)S2_ZERO_B);
+                hs[q] = s2_at(L, on ? rec[q].x & 0xffffu : (u32)S2_ZERO_B);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (k0 + q < g.nl) {
+                    const u32 w0 = rec[q].x, cv = rec[q].y;
+                    const u32 src = w0 & 0xffffu, dst = w0 >> 16;
+                    const u32 nbase = ((dst >> 2) - g.rnode5) & (S2_RING - 1u);
+                    const u32 node = g.node5 + nbase;
+                    const u32 bit = 1u << nbase;
+                    const u32 h = hs[q] + cv;
+                    const u32 ck = (cin >> (6u * nbase)) & 63u;
+                    cin += 1u << (6u * nbase);
+                    const bool wins = !(won & bit) && sn[q] > S2_FLOOR && h == sn[q];
+                    const bool stays = !(seen & bit) && sn[q] <= S2_FLOOR;  // no link beats the floor: the zero back pointer (Q4)
+                    seen |= bit;
+                    if (wins || stays) {
+                        won |= bit;
+                        // (the predecessor's node id from its ring index: its index at its position is the difference)
+                        const int pid = (wins && src != (u32)S2_ZERO_B) ? (int)(g.base5_s + (((src >> 2) - g.ring5_s) & (S2_RING - 1u)))
+                                                                        : (wins ? -1 : 0);
+                        s2_u32x2 r;
+                        r.x = sn[q] - S2_BIAS;
+                        r.y = (u32)((pid + 1) << 1) | g.upper_s;
+                        nodes[node] = r;
+                        // the first strict maximum in (t, delta, base) order: among equals the lowest node
+                        if (sn[q] > best_s || (sn[q] == best_s && sn[q] > S2_FLOOR && (int)node < best_node)) {
+                            best_s = sn[q];
+                            best_node = (int)node;
+                            best_ck = wins ? (int)ck : 0;
+                        }
                     }
                 }
             }
@@ -306,18 +320,26 @@ __global__ __launch_bounds__(128) void k_score2(MsaArgs A) {
 #pragma unroll
                     for (u32 bb = 0; bb < 5u; bb++) s2_at(L, ((g.rnode5 + bb) & (S2_RING - 1u)) << 2) = S2_FLOOR;
                 }
-                for (int kk = 0; kk < maxn; kk++) {
-                    if (kk < nl) {
-                        const u32 ra = rec_b + 8u * (u32)(g.off + kk);
-                        const u32 w = s2_at(L, ra + 4u);
-                        const int cnt = (int)(w & LW_CNT_MASK);
-                        const u32 nbase = (w >> LW_NB_SHIFT) & 7u;
-                        const u32 pidx = (w >> LW_PIDX_SHIFT) & 0x7ffu;
-                        const bool start = (w >> LW_START_BIT) & 1u;
-                        const u32 src = start ? (u32)S2_ZERO_B : (((g.ring5_s + pidx) & (S2_RING - 1u)) << 2);
-                        const u32 dst = ((g.rnode5 + nbase) & (S2_RING - 1u)) << 2;
-                        s2_at(L, ra) = src | (dst << 16);
-                        s2_at(L, ra + 4u) = (u32)(2 * cnt - cov_s);  // falcon.c:440-445, half units
+                for (int k0 = 0; k0 < maxn; k0 += 4) {  // (four link words per LDS round trip)
+                    u32 w4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) w4[q] = s2_at(L, rec_b + 8u * (u32)(k0 + q < nl ? g.off + k0 + q : lane) + 4u);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        if (k0 + q < nl) {
+                            const u32 ra = rec_b + 8u * (u32)(g.off + k0 + q);
+                            const u32 w = w4[q];
+                            const int cnt = (int)(w & LW_CNT_MASK);
+                            const u32 nbase = (w >> LW_NB_SHIFT) & 7u;
+                            const u32 pidx = (w >> LW_PIDX_SHIFT) & 0x7ffu;
+                            const bool start = (w >> LW_START_BIT) & 1u;
+                            const u32 src = start ? (u32)S2_ZERO_B : (((g.ring5_s + pidx) & (S2_RING - 1u)) << 2);
+                            const u32 dst = ((g.rnode5 + nbase) & (S2_RING - 1u)) << 2;
+                            s2_u32x2 r;
+                            r.x = src | (dst << 16);
+                            r.y = (u32)(2 * cnt - cov_s);  // falcon.c:440-445, half units
+                            *reinterpret_cast<s2_u32x2 *>(&s2_at(L, ra)) = r;
+                        }
                     }
                 }
                 t0 += nb;
