@@ -39,6 +39,20 @@ find $O -name "*.db" -size +5M -delete
 find $O -name "*.csv" -size +2M -delete
 cd $R
 unset FALCON_AMD_DEVICE_PACK
-FALCON_AMD_TIMING=1 timeout 600 python scripts/exp_e2e.py 3072 3 FALCON_AMD_NOTHING=1 FALCON_AMD_NOTHING=2 > $O/e2e.txt 2>&1
+FALCON_AMD_TIMING=1 timeout 600 python scripts/exp_e2e.py 3072 10 FALCON_AMD_NOTHING=1 FALCON_AMD_NOTHING=2 > $O/e2e.txt 2>&1
 grep -i "steady" /tmp/e2e_stream.txt.err | tail -1 >> $O/e2e.txt
+grep -v "printer:\|ingest:\|stager:\|runner:\|fa_batch_create\|msa stage\|align launch\|fa_batch_submit" /tmp/e2e_stream.txt.err | head -30 | cut -c1-250 > $O/e2e_timeline_marks.txt
 tail -4 $O/e2e.txt | cut -c1-220
+bash scripts/r04_exp6.sh $TAG/batch_size > /dev/null 2>&1; python - <<EOF
+import json
+out = ["# python bench.py --piles N [--no-pipeline] --no-cpu-baseline --no-end-to-end: step time against batch size, final kernels"]
+for n in (473, 946, 1536, 3072):
+    for suf in ("", "_serial"):
+        try:
+            d = json.loads(open("$O/batch_size/bench_%d%s.json.txt" % (n, suf)).read().strip().splitlines()[-1])
+            out.append("%5d piles %-10s ms_per_step %6.2f  us_per_pile %5.2f  piles/s %6.0f  kernel_ms %s" % (n, suf[1:] or "pipelined", d["ms_per_step"], 1e3 * d["ms_per_step"] / n, d["piles_per_sec"], d["kernel_ms"]))
+        except Exception as e:
+            out.append("%d %s unreadable: %r" % (n, suf, e))
+open("$O/step_vs_batch_size.txt", "w").write("\n".join(out) + "\n")
+EOF
+cut -c1-110 $O/step_vs_batch_size.txt
