@@ -29,6 +29,7 @@ from collections import namedtuple
 
 LOG = logging.getLogger("falcon_amd.consensus")
 _T0 = time.perf_counter()  # (debug lines carry seconds since the module was loaded)
+_LEFT_OPEN = []             # what run(leave_open=True) did not close: kept from the garbage collector until _leave
 
 
 def _clock():
@@ -602,7 +603,9 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None,
                 continue
             if item is not END:
                 getattr(item[2], "free", lambda: None)()
-        if not (leave_open and not failed):  # (leave_open: the process is about to end -- _leave)
+        if leave_open and not failed:  # (the process is about to end, _leave: nothing is unmapped or freed first --
+            _LEFT_OPEN.append(reader)   # not by a destructor either)
+        else:
             reader.close()
     LOG.debug("t=%.3f stream finished", _clock())
     if len(printed) >= 3:
@@ -647,7 +650,9 @@ def run(args, stdin=None, stdout=None, consensus_map=None, leave_open=False):
             ok = True
         finally:
             stdout.flush()
-            if not (leave_open and ok):
+            if leave_open and ok:
+                _LEFT_OPEN.extend(opened)
+            else:
                 for g in opened:
                     g.close()
                 LOG.debug("t=%.3f engines closed", _clock())
