@@ -684,19 +684,29 @@ def run(args, stdin=None, stdout=None, consensus_map=None, leave_open=False):
     stdout.flush()
 
 
-def main(argv=None):
+def main(argv=None, own_process=False):
+    """The reference's entry point (falcon_kit/mains/consensus.py:302, setup.py:51).  own_process: the
+    caller IS the process (``console_main``) -- reader and engines are then left as they are and the
+    process ends without tearing anything down."""
     args = parse_args(sys.argv if argv is None else argv)
     LOG.debug("t=%.3f arguments parsed", _clock())
-    if os.environ.get("FALCON_AMD_T_LAUNCH"):  # (scripts/exp_e2e.py: when the parent started this process)
-        LOG.debug("t=0 was %.3f s after the launch", time.time() - _clock() - float(os.environ["FALCON_AMD_T_LAUNCH"]))
-    fast = not os.environ.get("FALCON_AMD_SLOW_EXIT") and "pytest" not in sys.modules
+    fast = own_process and not os.environ.get("FALCON_AMD_SLOW_EXIT")
     run(args, leave_open=fast)
     LOG.debug("t=%.3f run() returned", _clock())
     code = 0
     if FAILED_PILES and not os.environ.get("FALCON_AMD_SKIP_FAILED_PILES"):
         sys.stderr.write("falcon_amd: %d pile(s) were not corrected (see above)\n" % len(FAILED_PILES))
         code = 3
-    _leave(code)
+    if fast:
+        _leave(code)
+    if code:
+        sys.exit(code)
+
+
+def console_main(argv=None):
+    """``python -m falcon_amd.mains.consensus``, ``bin/fc_consensus``, the drop-in's
+    ``python -m falcon_kit.mains.consensus``: main() in a process of its own."""
+    main(argv, own_process=True)
 
 
 def _leave(code):
@@ -704,10 +714,6 @@ def _leave(code):
     so it ends here, without the interpreter's and the HIP runtime's teardown (threads, module
     finalisers, unmapping gigabytes of text buffers the kernel frees anyway: ~0.15 s of a block's
     1.6 s).  FALCON_AMD_SLOW_EXIT=1: the ordinary way out."""
-    if os.environ.get("FALCON_AMD_SLOW_EXIT") or "pytest" in sys.modules:  # (the same test as in main)
-        if code:
-            sys.exit(code)
-        return
     try:
         sys.stdout.flush()
         sys.stderr.flush()
@@ -717,4 +723,4 @@ def _leave(code):
 
 
 if __name__ == "__main__":
-    main(sys.argv)
+    console_main(sys.argv)
