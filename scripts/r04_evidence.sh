@@ -43,7 +43,7 @@ FALCON_AMD_TIMING=1 timeout 600 python scripts/exp_e2e.py 3072 10 FALCON_AMD_NOT
 grep -i "steady" /tmp/e2e_stream.txt.err | tail -1 >> $O/e2e.txt
 grep -v "printer:\|ingest:\|stager:\|runner:\|fa_batch_create\|msa stage\|align launch\|fa_batch_submit" /tmp/e2e_stream.txt.err | head -30 | cut -c1-250 > $O/e2e_timeline_marks.txt
 tail -4 $O/e2e.txt | cut -c1-220
-bash scripts/r04_exp6.sh $TAG/batch_size > /dev/null 2>&1; python - <<EOF
+bash scripts/r04_step_vs_batch_size.sh $TAG/batch_size > /dev/null 2>&1; python - <<EOF
 import json
 out = ["# python bench.py --piles N [--no-pipeline] --no-cpu-baseline --no-end-to-end: step time against batch size, final kernels"]
 for n in (473, 946, 1536, 3072):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scripts/r04_exp6.sh <tag> : step time against batch size (pipelined, resident inputs)
+# usage: scripts/r04_step_vs_batch_size.sh <tag> : step time against batch size (pipelined, resident inputs)
 TAG=${1:-r04q}; R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 for n in 473 946 1536 3072; do
   timeout 300 python bench.py --piles $n --no-cpu-baseline --no-end-to-end --steps 12 --warmup 3 > $O/bench_$n.json.txt 2> $O/bench_$n.err
