@@ -374,6 +374,13 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
             # finds for itself (per worker: device, wall time, piles/s, text rate)
             try:
                 res["end_to_end_workers"] = end_to_end_workers(piles, world)
+                # (worker i is not rank i -- ranks hold resident batches, workers are processes of their
+                # own -- but there are as many, one per GPU if the lock slots did their job)
+                for row, w in zip(res["per_rank"], res["end_to_end_workers"].get("workers", [])):
+                    row["e2e_worker_device"] = w["devices"]
+                    row["e2e_worker_wall_s"] = w["wall_s"]
+                    row["e2e_worker_piles_per_sec"] = w["piles_per_sec"]
+                    row["e2e_worker_text_GB_per_sec"] = w["text_GB_per_sec"]
             except Exception as e:
                 res["end_to_end_workers"] = {"piles_per_sec": None, "what": "failed: %r" % (e,)}
         if world == 1 and not args.no_cpu_baseline:
