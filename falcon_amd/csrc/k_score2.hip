@@ -54,14 +54,11 @@
 #define S2_REC_B(b) (S2_ZERO_B + 64 + (b) * S2_REC_SZ)   // two sets: the chain's and the other wavefront's
 #define S2_MARK_B S2_REC_B(2)             // 64 words: level slot -> position of the block
 #define S2_NLV_B(b) (S2_MARK_B + 64 * 4 + (b) * 64 * 4)  // links of the block's levels, two sets
-#define S2_PRM_B(b) (S2_NLV_B(2) + (b) * 64 * 8)         // per level: what the resolve phase needs of its position
-#define S2_CTL_B(b) (S2_PRM_B(2) + (b) * 32)             // per set: levels, go / none, first level slot, ring index, longest level
+#define S2_CTL_B(b) (S2_NLV_B(2) + (b) * 16)             // per set: levels of the block, what to do with it
 #define S2_DONE_B S2_CTL_B(2)
 #define S2_LDS_WORDS ((S2_DONE_B + 16) / 4)
 #define S2_GO 1u
 #define S2_NONE 0u
-#define S2_FINISHED 1u
-#define S2_BAIL 2u
 
 __device__ __forceinline__ u32 &s2_at(u32 *L, u32 byte) {
     return *reinterpret_cast<u32 *>(reinterpret_cast<char *>(L) + byte);
@@ -103,64 +100,6 @@ __device__ __forceinline__ void s2_chain(u32 *L, u32 rec_b, int n_l, int nl, int
     }
 }
 
-// ---- C: resolve a block (wavefront 0, behind the block's chain).  Lane = level; its links in
-// stored order.  A node's winner is the first of its links that reaches the node's score, if that
-// score beat the floor.  Four links at a time: their records, then the two scores each of them
-// names, then the four in order (one link at a time was two LDS round trips per link with nothing
-// to do meanwhile).
-struct S2Best { u32 s; int node, ck; };
-__device__ __forceinline__ void s2_resolve(u32 *L, const S2Block &g, u32 rec_b, s2_u32x2 *nodes, S2Best &best, int lane) {
-    u32 seen = 0;   // nodes (bit = base) met / resolved so far
-    u32 won = 0;
-    u32 cin = 0;    // links met per node, 6 bits each
-    for (int k0 = 0; k0 < g.maxn; k0 += 4) {
-        s2_u32x2 rec[4];
-        u32 sn[4], hs[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++)  // (a lane beyond its links reads some record of the set: never used)
-            rec[q] = *reinterpret_cast<const s2_u32x2 *>(&s2_at(L, rec_b + 8u * (u32)(k0 + q < g.nl ? g.off + k0 + q : lane)));
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const bool on = k0 + q < g.nl;
-            sn[q] = s2_at(L, on ? rec[q].x >> 16 : (u32)S2_ZERO_B);
-            hs[q] = s2_at(L, on ? rec[q].x & 0xffffu : (u32)S2_ZERO_B);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (k0 + q < g.nl) {
-                const u32 w0 = rec[q].x, cv = rec[q].y;
-                const u32 src = w0 & 0xffffu, dst = w0 >> 16;
-                const u32 nbase = ((dst >> 2) - g.rnode5) & (S2_RING - 1u);
-                const u32 node = g.node5 + nbase;
-                const u32 bit = 1u << nbase;
-                const u32 h = hs[q] + cv;
-                const u32 ck = (cin >> (6u * nbase)) & 63u;
-                cin += 1u << (6u * nbase);
-                const bool wins = !(won & bit) && sn[q] > S2_FLOOR && h == sn[q];
-                const bool stays = !(seen & bit) && sn[q] <= S2_FLOOR;  // no link beats the floor: the zero back pointer (Q4)
-                seen |= bit;
-                if (wins || stays) {
-                    won |= bit;
-                    // (the predecessor's node id from its ring index: its index at its position is the difference)
-                    const int pid = (wins && src != (u32)S2_ZERO_B) ? (int)(g.base5_s + (((src >> 2) - g.ring5_s) & (S2_RING - 1u)))
-                                                                    : (wins ? -1 : 0);
-                    s2_u32x2 r;
-                    r.x = sn[q] - S2_BIAS;
-                    r.y = (u32)((pid + 1) << 1) | g.upper_s;
-                    nodes[node] = r;
-                    // the first strict maximum in (t, delta, base) order: among equals the lowest node
-                    if (sn[q] > best.s || (sn[q] == best.s && sn[q] > S2_FLOOR && (int)node < best.node)) {
-                        best.s = sn[q];
-                        best.node = (int)node;
-                        best.ck = wins ? (int)ck : 0;
-                    }
-                }
-            }
-        }
-    }
-    (void)lane;
-}
-
 __global__ __launch_bounds__(128) void k_score2(MsaArgs A) {
     __shared__ __attribute__((aligned(8))) u32 L[S2_LDS_WORDS];
     const int lane = fa_lane();
@@ -179,57 +118,24 @@ __global__ __launch_bounds__(128) void k_score2(MsaArgs A) {
         if (role == 1) A.score_out[p] = so;  // every lane stores the same record
         return;
     }
-    s2_u32x2 *nodes = reinterpret_cast<s2_u32x2 *>(A.nodes + pm.node_off);
     if (role == 0) {
-        // ======== wavefront 0: in step k the chain of block k - 1, on the records the other
-        // wavefront decoded in step k - 1, and then that block's resolve phase
-        S2Best best;
-        best.s = S2_FLOOR; best.node = -1; best.ck = 0;  // this lane's best node: biased score, node id, winning link
-        u32 how = 0;
+        // ======== wavefront 0: the chain of block k - 1 in step k, on the records the other
+        // wavefront decoded in step k - 1
         for (u32 k = 0;; k++) {
             const u32 b = (k + 1u) & 1u;  // (block k - 1's set)
-            if (k >= 1u && fa_uni(s2_at(L, S2_CTL_B(b) + 4u)) == S2_GO) {
-                S2Block g;
-                g.n_l = (int)fa_uni(s2_at(L, S2_CTL_B(b)));
-                g.nl = (int)s2_at(L, S2_NLV_B(b) + 4u * (u32)lane);
-                s2_chain(L, S2_REC_B(b), g.n_l, g.nl, lane);
-                g.off = wave_incl_sum(g.nl, lane) - g.nl;
-                g.maxn = (int)fa_uni(s2_at(L, S2_CTL_B(b) + 16u));
-                g.node5 = (fa_uni(s2_at(L, S2_CTL_B(b) + 8u)) + (u32)lane) * 5u;
-                g.rnode5 = fa_uni(s2_at(L, S2_CTL_B(b) + 12u)) + 5u * (u32)lane;
-                const s2_u32x2 prm = *reinterpret_cast<const s2_u32x2 *>(&s2_at(L, S2_PRM_B(b) + 8u * (u32)lane));
-                g.ring5_s = prm.x;
-                g.base5_s = prm.y & 0x7fffffffu;
-                g.upper_s = prm.y >> 31;
-                s2_resolve(L, g, S2_REC_B(b), nodes, best, lane);
-            }
+            if (k >= 1u && fa_uni(s2_at(L, S2_CTL_B(b) + 4u)) == S2_GO)
+                s2_chain(L, S2_REC_B(b), (int)fa_uni(s2_at(L, S2_CTL_B(b))), (int)s2_at(L, S2_NLV_B(b) + 4u * (u32)lane), lane);
             __syncthreads();
-            how = fa_uni(s2_at(L, S2_DONE_B));
-            if (how != 0u) break;
+            if (fa_uni(s2_at(L, S2_DONE_B)) != 0u) return;
         }
-        if (how == S2_BAIL) return;  // (the other wavefront hands the pile on)
-        // global best = first strict maximum in (t, delta, base) order (falcon.c:464-469): the
-        // highest score, among equals the lowest node id
-        const u32 top = (u32)fa_wave_max((int)best.s);
-        const int cand = (best.s == top && best.node >= 0) ? best.node : 0x7fffffff;
-        const int g_node = fa_wave_min(cand);
-        const u64 who = fa_ballot(cand == g_node);
-        so.redo = 0;
-        if (g_node == 0x7fffffff) {
-            so.g_h = -2; so.g_node = -1; so.g_ck = 0;
-        } else {
-            so.g_h = (int)(top - S2_BIAS);
-            so.g_node = g_node;
-            so.g_ck = __builtin_amdgcn_readlane(best.ck, (int)__builtin_ctzll(who));
-        }
-        A.score_out[p] = so;  // every lane stores the same record
-        return;
     }
-    // ======== wavefront 1: in step k, stage and decode block k into the set of records block k - 2 left
+    // ======== wavefront 1: in step k, resolve block k - 2 (its chain ran in step k - 1), then
+    // stage and decode block k into the set that block's records just left
     const int T = pm.seed_len;
     const u32 *tiw = reinterpret_cast<const u32 *>(A.tinfo + A.t_off[p]);  // 3 words per position
     const u32 *links = A.links + A.link_off[p];
     const u16 *nlk = A.lvl_nlink16 + pm.node_off / 5;
+    s2_u32x2 *nodes = reinterpret_cast<s2_u32x2 *>(A.nodes + pm.node_off);
     const u32 min_cov = A.min_cov;
 
     s2_at(L, S2_ZERO_B) = S2_BIAS;  // (every lane, the same word)
@@ -243,6 +149,8 @@ __global__ __launch_bounds__(128) void k_score2(MsaArgs A) {
         r.x = (u32)-2; r.y = (u32)(((0 + 1) << 1) | (((tiw[2] & 0xffffu) > min_cov) ? 1 : 0));
         nodes[lane] = r;
     }
+    u32 best_s = S2_FLOOR;         // this lane's best node: biased score, node id, winning link
+    int best_node = -1, best_ck = 0;
     u32 carry_plvl = 0;            // first level slot of the position before the block,
     u32 carry_nlev = 0;            // and its levels
     // The scores' ring is addressed by a running count of the levels scored so far (times five,
@@ -272,11 +180,69 @@ __global__ __launch_bounds__(128) void k_score2(MsaArgs A) {
         }
         return a;
     };
+    // ---- C: resolve a block.  Lane = level; its links in stored order.  A node's winner is the
+    // first of its links that reaches the node's score, if that score beat the floor.  Four links
+    // at a time: their records, then the two scores each of them names, then the four in order
+    // (one link at a time was two LDS round trips per link with nothing to do meanwhile).
+    auto resolve = [&](const S2Block &g, u32 rec_b) {
+        u32 seen = 0;   // nodes (bit = base) met / resolved so far
+        u32 won = 0;
+        u32 cin = 0;    // links met per node, 6 bits each
+        for (int k0 = 0; k0 < g.maxn; k0 += 4) {
+            s2_u32x2 rec[4];
+            u32 sn[4], hs[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)  // (a lane beyond its links reads some record of the set: never used)
+                rec[q] = *reinterpret_cast<const s2_u32x2 *>(&s2_at(L, rec_b + 8u * (u32)(k0 + q < g.nl ? g.off + k0 + q : lane)));
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const bool on = k0 + q < g.nl;
+                sn[q] = s2_at(L, on ? rec[q].x >> 16 : (u32)S2_ZERO_B);
+                hs[q] = s2_at(L, on ? rec[q].x & 0xffffu : (u32)S2_ZERO_B);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (k0 + q < g.nl) {
+                    const u32 w0 = rec[q].x, cv = rec[q].y;
+                    const u32 src = w0 & 0xffffu, dst = w0 >> 16;
+                    const u32 nbase = ((dst >> 2) - g.rnode5) & (S2_RING - 1u);
+                    const u32 node = g.node5 + nbase;
+                    const u32 bit = 1u << nbase;
+                    const u32 h = hs[q] + cv;
+                    const u32 ck = (cin >> (6u * nbase)) & 63u;
+                    cin += 1u << (6u * nbase);
+                    const bool wins = !(won & bit) && sn[q] > S2_FLOOR && h == sn[q];
+                    const bool stays = !(seen & bit) && sn[q] <= S2_FLOOR;  // no link beats the floor: the zero back pointer (Q4)
+                    seen |= bit;
+                    if (wins || stays) {
+                        won |= bit;
+                        // (the predecessor's node id from its ring index: its index at its position is the difference)
+                        const int pid = (wins && src != (u32)S2_ZERO_B) ? (int)(g.base5_s + (((src >> 2) - g.ring5_s) & (S2_RING - 1u)))
+                                                                        : (wins ? -1 : 0);
+                        s2_u32x2 r;
+                        r.x = sn[q] - S2_BIAS;
+                        r.y = (u32)((pid + 1) << 1) | g.upper_s;
+                        nodes[node] = r;
+                        // the first strict maximum in (t, delta, base) order: among equals the lowest node
+                        if (sn[q] > best_s || (sn[q] == best_s && sn[q] > S2_FLOOR && (int)node < best_node)) {
+                            best_s = sn[q];
+                            best_node = (int)node;
+                            best_ck = wins ? (int)ck : 0;
+                        }
+                    }
+                }
+            }
+        }
+    };
     int t0 = 0;
     Ahead cur = request(0, 0u, tiw[1]);
+    S2Block g_prev, g_last;  // blocks k - 2 and k - 1 of step k
+    g_prev.maxn = g_last.maxn = 0; g_prev.nl = g_last.nl = 0;
+    bool have_prev = false, have_last = false;
     bool bail = false;
     for (u32 k = 0;; k++) {
         const u32 b = k & 1u;  // block k's set = block k - 2's
+        if (have_prev) resolve(g_prev, S2_REC_B(b));
         S2Block g;
         g.maxn = 0; g.nl = 0; g.n_l = 0; g.off = 0; g.node5 = g.rnode5 = g.ring5_s = g.base5_s = g.upper_s = 0;
         bool have = false;
@@ -307,6 +273,7 @@ __global__ __launch_bounds__(128) void k_score2(MsaArgs A) {
             } else {
                 // ---- stage the link words (the high word of each record), null records behind them
                 const u32 rec_b = S2_REC_B(b);
+                fa_wave_sync();  // (the resolve phase above is done with this set of records)
 #pragma unroll
                 for (int q = 0; q < S2_NK / 64; q++)
                     if (64 * q + lane < n_k) s2_at(L, rec_b + 8u * (u32)(64 * q + lane) + 4u) = cur.lw[q];
@@ -323,9 +290,6 @@ __global__ __launch_bounds__(128) void k_score2(MsaArgs A) {
                 s2_at(L, S2_MARK_B + 4u * (u32)lane) = (u32)-1;
                 s2_at(L, S2_NLV_B(b) + 4u * (u32)lane) = (u32)nl;
                 s2_at(L, S2_CTL_B(b)) = (u32)n_l;
-                s2_at(L, S2_CTL_B(b) + 8u) = lvl0;
-                s2_at(L, S2_CTL_B(b) + 12u) = rn;
-                s2_at(L, S2_CTL_B(b) + 16u) = (u32)maxn;
                 fa_wave_sync();
                 // ---- which position does level slot lvl0 + lane belong to: every position with levels
                 // marks its first slot, the slots take the last mark at or below them
@@ -347,12 +311,6 @@ __global__ __launch_bounds__(128) void k_score2(MsaArgs A) {
                 g.node5 = (lvl0 + (u32)lane) * 5u;  // my level's first node, and its ring index
                 g.rnode5 = rn + 5u * (u32)lane;
                 g.off = nl_sum - nl;  // (lanes < n_l)
-                {   // what the resolve phase (the other wavefront, a step later) needs of my level's position
-                    s2_u32x2 prm;
-                    prm.x = g.ring5_s;
-                    prm.y = g.base5_s | (g.upper_s << 31);
-                    *reinterpret_cast<s2_u32x2 *>(&s2_at(L, S2_PRM_B(b) + 8u * (u32)lane)) = prm;
-                }
                 g.nl = nl; g.maxn = maxn; g.n_l = n_l;
                 carry_plvl = (u32)__builtin_amdgcn_readlane((int)x_lvl, nb - 1);
                 carry_nlev = (u32)__builtin_amdgcn_readlane((int)x_cn, nb - 1) >> 16;
@@ -391,14 +349,34 @@ __global__ __launch_bounds__(128) void k_score2(MsaArgs A) {
             }
         }
         s2_at(L, S2_CTL_B(b) + 4u) = have ? S2_GO : S2_NONE;
-        // the last step: nothing left to decode (the other wavefront finishes block k - 1 in this
-        // step) -- or a block that does not fit this kernel
-        const bool done = bail || !have;
-        if (done) s2_at(L, S2_DONE_B) = bail ? S2_BAIL : S2_FINISHED;
+        // the last step: nothing decoded now or in the step before (its chain had nothing to run),
+        // block k - 2 resolved just now -- or a block that does not fit this kernel
+        const bool done = bail || (!have && !have_last);
+        if (done) s2_at(L, S2_DONE_B) = 1u;
         __syncthreads();
         if (done) break;
+        g_prev = g_last; have_prev = have_last;
+        g_last = g; have_last = have;
     }
-    if (bail) A.score_out[p] = so;  // (redo: k_score1 scores the whole pile again)
+    if (bail) {
+        A.score_out[p] = so;  // (redo: k_score1 scores the whole pile again)
+        return;
+    }
+    // global best = first strict maximum in (t, delta, base) order (falcon.c:464-469): the
+    // highest score, among equals the lowest node id
+    const u32 top = (u32)fa_wave_max((int)best_s);
+    const int cand = (best_s == top && best_node >= 0) ? best_node : 0x7fffffff;
+    const int g_node = fa_wave_min(cand);
+    const u64 who = fa_ballot(cand == g_node);
+    so.redo = 0;
+    if (g_node == 0x7fffffff) {
+        so.g_h = -2; so.g_node = -1; so.g_ck = 0;
+    } else {
+        so.g_h = (int)(top - S2_BIAS);
+        so.g_node = g_node;
+        so.g_ck = __builtin_amdgcn_readlane(best_ck, (int)__builtin_ctzll(who));
+    }
+    A.score_out[p] = so;  // every lane stores the same record
 }
 
 #ifndef FA_EMU
