@@ -12,12 +12,14 @@
 //               edit script turn it into position-major tags: one 4-byte word
 //               per covered target position {deleted?, insertion-run length,
 //               up to 11 inserted bases inline} (longer runs spill to a byte
-//               array), each written exactly once.  Also accumulates, per target
-//               position, the coverage (difference array), the deepest insertion
-//               level and the number of tags.
+//               array), each written exactly once, staged through an LDS window
+//               and stored in whole lines.  Also counts, per SEGMENT of 128
+//               positions, the columns and the inserted bases (the pools' sizes).
 //   k_sscan     one wavefront per pile: prefix sums over the pile's segments ->
-//               level slot and link slot of every position (deterministic
-//               layout, node ids ascend in (t, delta) order).
+//               every segment's first link slot and first level slot.
+//   k_links2    (k_links2.hip) one wavefront per segment, lanes = positions: the
+//               links of every level, coverage, levels and level slots of every
+//               position.  k_links<1..16> below is the kernel behind it:
 //   k_links     one wavefront per (pile, segment of 128 target positions):
 //               lanes = alignments overlapping the segment (compacted, in read
 //               order).  For every (t, delta) level the lanes holding the same
@@ -25,15 +27,13 @@
 //               (update_col, falcon.c:232-263): grouped with ballots, group
 //               size = link count, groups visited in lowest-lane order = the
 //               reference's first-insertion order (Q5).  Emits one u32 per link.
-//   k_score     one wavefront per pile: the score recurrence (falcon.c:405-475)
-//               over the link words, -1 floor, strict '>', first maximum; the
-//               scores of the previous and current target position live in two
-//               VGPRs (lane = delta * 5 + base); writes the 8-byte node records
-//               and the global best.
-//   k_backtrace one wavefront per pile: collects the best path 64 nodes at a time out of a
-//               64-level LDS window of node records, then turns the 64 nodes into characters
-//               and eqv values at once, written right-aligned (falcon.c:494-528, no reversal
-//               pass).
+//   k_score2    (k_score2.hip; k_score1.hip behind it) the score recurrence
+//               (falcon.c:405-475) over the link words, -1 floor, strict '>', first
+//               maximum; writes the 8-byte node records and the global best.
+//   k_backtrace one wavefront per pile: the best path by pointer doubling inside a
+//               128-level LDS window of node records (64 nodes per round), then the 64
+//               nodes become characters and eqv values at once, written right-aligned
+//               (falcon.c:494-528, no reversal pass).
 //
 // Integer only; per-column reduction over aligned bases; no MFMA.
 #include "k_msa.h"

@@ -1,5 +1,6 @@
-"""The consensus-stage kernels' SOURCE (k_msa.hip: k_tags, k_tscan, k_links, k_backtrace;
-k_score2.hip: k_score2) on the host-side SIMT emulator of tests/emu/simt, against the CPU oracle
+"""The consensus-stage kernels' SOURCE (k_msa.hip: k_tags, k_sscan, k_links, k_backtrace;
+k_links2.hip: k_links2; k_score2.hip: k_score2, a workgroup of two wavefronts) on the host-side SIMT
+emulator of tests/emu/simt, against the CPU oracle
 and, stage by stage, against the plain-python graph model of tests/msa_model.py.  No GPU: this is
 what pins the kernels' logic here, in the dev container; the GPU suite then only has to confirm
 that the hardware runs the same source the same way.  (src/c/falcon.c:106-162, :232-263,
