@@ -124,7 +124,7 @@ def end_to_end_multi(piles, n_streams, repeats=E2E_REPEATS):
                     "of two runs counts" % (n_streams, repeats * len(piles), size / 1e6, n_streams)}
 
 
-def end_to_end_workers(piles, n_workers, repeats=E2E_REPEATS):
+def end_to_end_workers(piles, n_workers, repeats=E2E_REPEATS, worker_cmd=None):
     """N > 1, the way fc_run feeds a node: `n_workers` single-stream consensus jobs started at the same
     moment (consensus_split.py:55-85 runs one per LA4Falcon block, several at a time), every one a
     process of its own that finds a GPU for itself through the lock slots of falcon_amd/devices.py.
@@ -140,8 +140,9 @@ def end_to_end_workers(piles, n_workers, repeats=E2E_REPEATS):
         with open(src, "wb") as f:
             write_la4falcon(piles, f, repeats)
         size = os.path.getsize(src)
-        cmd = [sys.executable, "-m", "falcon_amd.mains.consensus", "--output-multi", "--min-idt", "0.70",
-               "--min-cov", "4", "--max-n-read", "200", "--n-core", "1"]
+        # (worker_cmd: a stand-in for the worker, tests/test_bench_ranks.py -- the plumbing runs without a GPU)
+        cmd = worker_cmd or [sys.executable, "-m", "falcon_amd.mains.consensus", "--output-multi", "--min-idt", "0.70",
+                             "--min-cov", "4", "--max-n-read", "200", "--n-core", "1"]
         env = {k: v for k, v in os.environ.items()
                if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTRACER", "HSA_TOOLS"))
                and k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",

@@ -143,3 +143,32 @@ def test_traffic_record_digest_ignores_comments_not_code():
     assert bench._code_only(a) == bench._code_only(b)
     assert bench._code_only(a) != bench._code_only(c)
     assert bench._code_only(a) != bench._code_only(d)
+
+
+def test_the_concurrent_workers_leg_with_stand_in_workers():
+    """bench.py --gpus N, `end_to_end_workers`: N single-stream jobs started together, every one a
+    process of its own that takes a GPU through the lock slots (falcon_amd/devices.py).  Stand-in
+    workers (no GPU: they take a slot among four pretended devices, say so the way the worker does,
+    and print a digest of the text as their FASTA): four jobs -> four different devices, per worker a
+    wall time and rates, identical outputs; a fifth doubles up."""
+    import sys
+    from benchlib.e2e import end_to_end_workers
+    stand_in = [sys.executable, "-c", """
+import hashlib, sys, time
+sys.path.insert(0, %r)
+from falcon_amd.devices import choose_device
+d = choose_device([0, 1, 2, 3])
+sys.stderr.write("INFO:falcon_amd.consensus:falcon_amd consensus on 1 engine(s), device(s) %%d (t=0.010)\\n" %% d)
+text = sys.stdin.buffer.read()
+time.sleep(0.4)   # (holds its slot while the others choose)
+sys.stdout.write(">digest\\n%%s\\n" %% hashlib.sha1(text).hexdigest())
+sys.stderr.write("INFO:falcon_amd.consensus:falcon_amd consensus: 6 piles in 3 batches; steady state 1234 piles/s (x)\\n")
+""" % ROOT]
+    piles = [[b"ACGT" * 300, b"ACGT" * 300, b"ACGA" * 250] for _ in range(6)]
+    out = end_to_end_workers(piles, 4, repeats=2, worker_cmd=stand_in)
+    assert out["distinct_devices"] == 4 and out["every_fasta_identical"], out
+    assert sorted(w["devices"] for w in out["workers"]) == ["0", "1", "2", "3"]
+    for w in out["workers"]:
+        assert w["wall_s"] >= 0.4 and w["piles_per_sec"] > 0 and w["steady_state_piles_per_sec"] == 1234.0
+    out5 = end_to_end_workers(piles, 5, repeats=1, worker_cmd=stand_in)
+    assert out5["distinct_devices"] == 4 and len(out5["workers"]) == 5
