@@ -31,7 +31,7 @@
 #include "k_msa.h"
 
 #define L2_DIR 20    // groups with a slot of their own, per position
-#define L2_POOL 256   // listed groups per 64 positions (entries of the lanes' linked lists)
+#define L2_POOL 128   // listed groups per 64 positions (entries of the lanes' linked lists): 6.4 KB of LDS per wavefront, 6 per SIMD
 #define L2_POOL_BIG 4096  // ... of the second instance, which takes the segments the first cannot hold (piles of
                           // a thousand reads list a few dozen groups at every position)
 #define L2_NIL 0xffffu

@@ -182,7 +182,8 @@ def test_long_insertion_runs(port, clustered):
     assert got == tuple(port.generate_consensus(pile, 2, 8, 0.70))
     n_seg = (len(seed) + TSEG - 1) // TSEG
     # (the instance with the large pool holds what the first one hands on)
-    assert (0 < todo[0] < n_seg // 2 and todo[1] == 0) if clustered else todo[0] == 0, todo
+    # (scattered, one segment of the 24 may still meet three runs in its 64 positions: 128 listed groups)
+    assert (0 < todo[0] < n_seg // 2 and todo[1] == 0) if clustered else (todo[0] <= 1 and todo[1] == 0), todo
 
 
 def test_pile_deeper_than_1023_alignments(port):
