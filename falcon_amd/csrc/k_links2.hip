@@ -28,13 +28,15 @@
 // 64 positions with more listed groups than the pool holds, or a level with more than 255
 // groups, send their SEGMENT to k_links through a to-do list; so the tables stay small whatever
 // the input.
+#include <type_traits>
+
 #include "k_msa.h"
 
 #define L2_DIR 20    // groups with a slot of their own, per position
-#define L2_POOL 128   // listed groups per 64 positions (entries of the lanes' linked lists): 6.4 KB of LDS per wavefront, 6 per SIMD
+#define L2_POOL 128   // listed groups per 64 positions (entries of the lanes' linked lists): with 3-byte slots 5.1 KB of
+                      // LDS per wavefront, 8 per SIMD
 #define L2_POOL_BIG 4096  // ... of the second instance, which takes the segments the first cannot hold (piles of
                           // a thousand reads list a few dozen groups at every position)
-#define L2_NIL 0xffffu
 
 // base `d` (1-based) of a tag's insertion run
 __device__ __forceinline__ u32 l2_ins_base(const MsaArgs &A, u32 ins_off, u32 w, int d) {
@@ -53,10 +55,14 @@ __device__ __forceinline__ u32 l2_word(u32 key) {
 
 template <int POOL>
 __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
-    __shared__ u32 dir[L2_DIR * 64];               // count | rank in level << 16
+    __shared__ u16 dcnt[L2_DIR * 64];              // the slots of their own: a group's count ...
+    __shared__ uint8_t drnk[L2_DIR * 64];          // ... and its rank in its level (3 bytes, not 4: 8 wavefronts per SIMD fit)
     // the listed groups: a pool shared by the wavefront's 64 positions, a linked list per lane
     __shared__ u32 pk[POOL], pc[POOL];             // key | level << 16 ; count | rank << 16
-    __shared__ u16 pnx[POOL];                      // the next entry of the list
+    // (the next entry of the list: a byte for the small pool -- with it the tables are 4996 bytes)
+    typedef typename std::conditional<(POOL <= 255), uint8_t, u16>::type pnx_t;
+    constexpr u32 L2_NIL = POOL <= 255 ? 0xffu : 0xffffu;
+    __shared__ pnx_t pnx[POOL];
     __shared__ u32 pool_n;
     const int lane = fa_lane();
     const int p = fa_uni(A.seg_pile[sidx]);
@@ -88,7 +94,7 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
         const u32 sbp = (tin && t > 0) ? fa_base_at(seedw, t - 1) : 0u;
         fa_wave_sync();  // (the half before is done with the tables)
 #pragma unroll
-        for (int s = 0; s < L2_DIR; s++) dir[s * 64 + lane] = 0u;
+        for (int s = 0; s < L2_DIR; s++) dcnt[s * 64 + lane] = 0;
         pool_n = 0u;     // (every lane, the same word)
         fa_wave_sync();
         u32 head = L2_NIL;  // my list
@@ -109,8 +115,9 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
         };
         auto add_group = [&](int dl, u32 key, int slot) {
             if (slot >= 0) {
-                const u32 d = dir[slot * 64 + lane];
-                dir[slot * 64 + lane] = (d & 0xffffu) ? d + 1u : (1u | (new_rank(dl) << 16));
+                const u32 c = dcnt[slot * 64 + lane];
+                dcnt[slot * 64 + lane] = (u16)(c + 1u);
+                if (c == 0u) drnk[slot * 64 + lane] = (uint8_t)new_rank(dl);
                 return;
             }
             const u32 k = ((u32)dl << 16) | key;
@@ -120,7 +127,7 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
             if (e >= (u32)POOL) { overflow = true; return; }
             pc[e] = 1u | (new_rank(dl) << 16);
             pk[e] = k;
-            pnx[e] = (u16)head;
+            pnx[e] = (pnx_t)head;
             head = e;
         };
         // what a column of an alignment adds to my position: its tag word w, the tag word wp of
@@ -240,11 +247,12 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
                                                     : (pn == 1u ? (wp & 3u) : l2_ins_base(A, cur.insoff[q], wp, (int)pn));
                             if (pn <= 1u) {
                                 const u32 slot0 = pn ? 4u + del * 4u + pb : del * 2u + (pb >> 2);
-                                const u32 d = dir[slot0 * 64u + (u32)lane];
-                                const bool fresh = (d & 0xffffu) == 0u;
+                                const u32 c = dcnt[slot0 * 64u + (u32)lane];
+                                const bool fresh = c == 0u;
                                 const u32 r = lvln & 255u;
                                 overflow = overflow || (fresh && r == 255u);
-                                dir[slot0 * 64u + (u32)lane] = fresh ? (1u | (r << 16)) : d + 1u;
+                                dcnt[slot0 * 64u + (u32)lane] = (u16)(c + 1u);
+                                if (fresh) drnk[slot0 * 64u + (u32)lane] = (uint8_t)r;
                                 lvln += fresh ? 1u : 0u;
                             } else {
                                 add_group(0, base0 | (pb << 3) | (pn << 6), -1);
@@ -252,11 +260,12 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
                             if (nins) {
                                 const u32 b1 = nins <= (u32)INL ? (w & 3u) : l2_ins_base(A, cur.insoff[q], w, 1);
                                 const u32 slot1 = 12u + del * 4u + b1;
-                                const u32 d = dir[slot1 * 64u + (u32)lane];
-                                const bool fresh = (d & 0xffffu) == 0u;
+                                const u32 c = dcnt[slot1 * 64u + (u32)lane];
+                                const bool fresh = c == 0u;
                                 const u32 r = (lvln >> 8) & 255u;
                                 overflow = overflow || (fresh && r == 255u);
-                                dir[slot1 * 64u + (u32)lane] = fresh ? (1u | (r << 16)) : d + 1u;
+                                dcnt[slot1 * 64u + (u32)lane] = (u16)(c + 1u);
+                                if (fresh) drnk[slot1 * 64u + (u32)lane] = (uint8_t)r;
                                 lvln += fresh ? 256u : 0u;
                                 u32 pbb = b1;
                                 for (int dl = 2; dl <= (int)nins; dl++) {
@@ -310,7 +319,7 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
         if (gtot != 0u) {
 #pragma unroll
             for (int s = 0; s < L2_DIR; s++) {
-                const u32 d = dir[s * 64 + lane];
+                const u32 d = (u32)dcnt[s * 64 + lane] | ((u32)drnk[s * 64 + lane] << 16);
                 if (d & 0xffffu) {
                     u32 key, dl;
                     if (s < 4) { key = ((s & 2) ? 4u : sb) | (((s & 1) ? 4u : sbp) << 3); dl = 0; }
