@@ -134,3 +134,44 @@ def test_native_output_rules_equal_the_python_ones():
             n_out += bool(want)
     assert n_out > 100
     assert lib.fa_fasta_records(b"x", b"ACGT", 4, 3, buf, 10) < 0  # unknown mode
+
+
+def test_console_main_leaves_without_teardown_and_keeps_the_exit_status(tmp_path):
+    """`python -m falcon_amd.mains.consensus` / bin/fc_consensus end through console_main: once run() has
+    returned, output is flushed and the process leaves with os._exit (0, or 3 when piles failed alone) --
+    no interpreter teardown, so nothing registered with atexit runs; main() called by a host program
+    returns (or raises SystemExit(3)) as it always did; FALCON_AMD_SLOW_EXIT=1 restores that for the
+    console command too."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = """
+import atexit, os, sys
+sys.path.insert(0, %r)
+import falcon_amd.mains.consensus as c
+atexit.register(lambda: sys.stderr.write("ATEXIT RAN\\n"))
+def fake_run(args, leave_open=False, **kw):
+    sys.stdout.write(">r\\nACGT\\n")          # (left in the buffer: _leave has to flush it)
+    sys.stderr.write("leave_open=%%s\\n" %% leave_open)
+    if os.environ.get("FAIL_ONE"):
+        c.FAILED_PILES.append("000000007")
+c.run = fake_run
+getattr(c, sys.argv[1])(["prog", "--n-core", "1"])
+sys.stderr.write("RETURNED\\n")
+""" % ROOT
+
+    def go(entry, **env):
+        e = dict(os.environ, **env)
+        e.pop("FALCON_AMD_SLOW_EXIT", None) if "FALCON_AMD_SLOW_EXIT" not in env else None
+        return subprocess.run([sys.executable, "-c", prog, entry], capture_output=True, text=True, env=e, timeout=120)
+    p = go("console_main")
+    assert (p.returncode, p.stdout) == (0, ">r\nACGT\n") and "leave_open=True" in p.stderr
+    assert "ATEXIT RAN" not in p.stderr and "RETURNED" not in p.stderr
+    p = go("console_main", FAIL_ONE="1")
+    assert p.returncode == 3 and p.stdout == ">r\nACGT\n" and "1 pile(s) were not corrected" in p.stderr
+    p = go("console_main", FALCON_AMD_SLOW_EXIT="1")
+    assert p.returncode == 0 and "leave_open=False" in p.stderr and "RETURNED" in p.stderr and "ATEXIT RAN" in p.stderr
+    p = go("main")
+    assert p.returncode == 0 and "leave_open=False" in p.stderr and "RETURNED" in p.stderr and "ATEXIT RAN" in p.stderr
+    p = go("main", FAIL_ONE="1")
+    assert p.returncode == 3 and "RETURNED" not in p.stderr and "ATEXIT RAN" in p.stderr
