@@ -1,0 +1,60 @@
+"""What the kernels' launch shapes rely on, read off the compiler's output (hipcc -S for gfx950, no GPU):
+LDS bytes and VGPRs per wavefront decide how many wavefronts a SIMD holds, and several kernels were sized
+for that on purpose -- a table that grows by a few bytes would silently cost a
+wavefront per SIMD.  160 KB of LDS per CU, 512 VGPRs per SIMD lane, at most 8 wavefronts per SIMD."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "falcon_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+LDS_PER_CU = 160 * 1024
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+
+
+def resources(src):
+    """{kernel name: (LDS bytes, VGPRs)} of a .hip file."""
+    asm = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", "-",
+                          os.path.join(CSRC, src)], capture_output=True, text=True, check=True, cwd=CSRC).stdout
+    out = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", asm, re.S):
+        name, body = m.group(1), m.group(2)
+        lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", body).group(1))
+        v = re.search(r"\.set %s\.num_vgpr, (\d+)" % re.escape(name), asm)
+        out[name] = (lds, int(v.group(1)) if v else None)
+    return out
+
+
+def waves_per_simd(lds, vgpr, waves_per_group=1):
+    by_lds = (LDS_PER_CU // max(lds, 1)) * waves_per_group // 4
+    by_vgpr = 512 // (-(-vgpr // 8) * 8)
+    return min(8, by_lds, by_vgpr)
+
+
+def test_k_links2_holds_eight_wavefronts_per_simd():
+    r = resources("k_links2.hip")
+    (name, (lds, vgpr)), = [(k, v) for k, v in r.items() if "k_links2" in k and "big" not in k]
+    assert lds <= 5120 and vgpr <= 64, (name, lds, vgpr)   # 10.65 -> 9.34 ms came from exactly this
+    assert waves_per_simd(lds, vgpr) == 8
+
+
+def test_per_pile_kernels_hold_a_bench_batch_at_once():
+    """k_score2 (two wavefronts per pile) and k_backtrace run a pile per workgroup from start to end: the
+    3072 piles of a bench batch are 12 workgroups per CU, which must all be resident."""
+    (lds, vgpr), = [v for k, v in resources("k_score2.hip").items() if "k_score2" in k]
+    assert LDS_PER_CU // lds >= 12 and 12 * 2 <= 4 * (512 // (-(-vgpr // 8) * 8)), (lds, vgpr)
+    (lds, vgpr), = [v for k, v in resources("k_msa.hip").items() if "k_backtrace" in k]
+    assert LDS_PER_CU // lds >= 12 and 12 <= 4 * (512 // (-(-vgpr // 8) * 8)), (lds, vgpr)
+    (lds, vgpr), = [v for k, v in resources("k_msa.hip").items() if "k_tags" in k]
+    assert waves_per_simd(lds, vgpr) == 8, (lds, vgpr)
+
+
+def test_the_seed_index_table_fits_one_cu():
+    r = resources("k_seed_index.hip")
+    (lds, vgpr), = [v for k, v in r.items() if "k_seed_index" in k and "long" not in k]
+    assert 128 * 1024 < lds <= LDS_PER_CU and 4 * (-(-vgpr // 8) * 8) <= 512, (lds, vgpr)   # 16 wavefronts of one workgroup
