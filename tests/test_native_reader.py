@@ -220,6 +220,49 @@ def test_pipe_with_ragged_writes_and_control_bytes():
         assert got == want
 
 
+def test_a_pipe_with_eight_batches_kept():
+    """The worker keeps 8 batches alive (fa_reader_keep) whatever the stream is -- a pipe from
+    LA4Falcon in production: ragged writes, small batches, every batch read only when it is about to
+    lapse."""
+    import threading
+    rng = random.Random(6)
+    text = _rand_stream(rng, 80, with_noise=True)
+    data = text.encode("latin-1")
+    opts = (2, 0, 0, 500, 0)
+    want = _python(text, *opts)
+    rd, wr = os.pipe()
+
+    def feed():
+        i = 0
+        try:
+            while i < len(data):
+                n = rng.choice([1, 5, 16, 63, 64, 65, 300, 5000])
+                os.write(wr, data[i:i + n])
+                i += n
+        except BrokenPipeError:
+            pass
+        os.close(wr)
+
+    t = threading.Thread(target=feed)
+    t.start()
+    r = Reader(rd, *opts)
+    r.keep(8)
+    got, held = [], []
+    while True:
+        ps = r.next(2, 0)
+        if ps is not None:
+            held.append(ps)
+        while held and (ps is None or len(held) == 8):
+            old = held.pop(0)
+            got.extend(zip(old.seed_ids, old.piles()))
+        if ps is None:
+            break
+    r.close()
+    os.close(rd)
+    t.join()
+    assert got == want
+
+
 def test_long_sequences_are_cut_and_stream_end_variants():
     big = "A" * 100001
     edge = "C" * 100000
