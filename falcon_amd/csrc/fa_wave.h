@@ -14,6 +14,8 @@ typedef int vi;    // one int per lane
 typedef u32 vu;    // one u32 per lane
 typedef bool vb;   // one predicate per lane (feed ONE comparison to w_ballot)
 
+// the row loop of k_align2 as a hand-scheduled instruction stream (k_align2_rows.h)
+#define W_ROWS_ASM 1
 #define W_FN __device__ __forceinline__
 #define W_NOINLINE __device__ __noinline__
 // the lanes of mask `m` execute the block (the others keep their values)
@@ -64,6 +66,21 @@ W_FN vu w_prefix_max(vu v) {
                  "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
                  "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
                  "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "=&v"(t)
+                 : "v"(v));
+    return t;
+}
+
+// inclusive prefix sum over the lanes: the same six steps (lanes without a source add 0)
+W_FN vu w_prefix_add(vu v) {
+    vu t;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_u32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
                  : "=&v"(t)
                  : "v"(v));
     return t;

@@ -10,6 +10,8 @@
 #include "fa_wave.h"
 #include "k_align2_core.h"
 
+void fa_launch_align2_shadow(const A2Args &A, int grid, size_t lds, hipStream_t s);
+
 __global__ __launch_bounds__(64, 8) void k_align2(A2Args A) {
     a2_wave(A, (int)blockIdx.x);
 }
@@ -66,6 +68,10 @@ void fa_launch_align2(const FaBatchDev &b, const FaAlign2Arena &a, double max_di
     // two alignments per wavefront: half as many wavefronts have work
     int grid = a.n_slot;
     if (grid > (n_work + 1) / 2) grid = (n_work + 1) / 2;
+    if (getenv("FALCON_AMD_A2_SHADOW")) {  // (tests: k_align2_shadow.hip)
+        fa_launch_align2_shadow(A, grid, fa_align2_lds_bytes(), s);
+        return;
+    }
     hipLaunchKernelGGL(k_align2, dim3(grid), dim3(64), fa_align2_lds_bytes(), s, A);
 }
 

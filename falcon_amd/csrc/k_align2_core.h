@@ -44,6 +44,10 @@
 
 #define A2_NEG (-(1 << 29))      // "x" of the lanes outside a band's hull: loses every comparison
 #define A2_INVALID 0x80000000u  // tape record: the track computed no row in this iteration
+// what track 1's band-filter keys (x + y) carry on top of track 0's, so that one prefix maximum over
+// the lanes serves both: above every real key (x + y < 2^18), and small enough that a lane
+// outside the bands -- x = A2_NEG + 1 there, its key 2 A2_NEG + .. -- stays negative with it
+#define A2_TOP 0x20000000u
 #define A2_CONT 0x80000001u     // ... or: cells 64.. of the row the iteration before began (wide rows)
 #define A2_WIDE_RING 256        // LDS ring of a wide row's V values, per row parity (<= 191 live diagonals)
 #define A2_LDS_WORDS (256 + 2 * A2_WIDE_RING)  // (256 spare words) + the two rings
@@ -180,7 +184,7 @@ struct A2HotV {   // per lane
     vi vnegk;         // -(diagonal the lane computes in an even iteration)
     vu vqb, vtb;      // window starts
     vi vqlen, vtlen;
-    vu vtop;          // 0x80000000 in track 1's lanes (PAIR), else 0
+    vu vtop;          // A2_TOP in track 1's lanes (PAIR), else 0
     vu vacc;          // the cell bytes of up to 4 iterations
     vu rc_mlo, rc_mhi;  // ring of the last <= 64 iterations' from_above masks (lane = it & 63)
     vu vm;            // the snake lengths of the last row
@@ -208,6 +212,9 @@ struct A2Hot {    // wave-uniform
 template <int P, int J, bool PAIR>
 W_FN u64 a2_row(A2Hot &h, A2HotV &hv, const u32 *words, u64 *esc, int band, u32 byte_sel = 0u) {
     const u64 act = h.act;
+    // (the cells of a row are counted where the row is computed)
+    if (PAIR) { h.cells0 += (u32)w_popc(act & ~h.zone1); h.cells1 += (u32)w_popc(act & h.zone1); }
+    else h.cells0 += (u32)w_popc(act);
     // V[k-1] + 1 and V[k+1] of the previous row (DW_banded.c:190-196)
     vi a1, b;
     if (P == 0) {
@@ -271,20 +278,20 @@ W_FN u64 a2_row(A2Hot &h, A2HotV &hv, const u32 *words, u64 *esc, int band, u32 
         h.best0 = max(h.best0, (int)w_readlaneu(pm, 63));
         in = w_ballot(keyb >= (vu)h.best0) & act;
     }
+#ifdef A2_HOOK_IN
+    A2_HOOK_IN(PAIR, in, h.zone1, m, act);
+#endif
     // the next row's bands: the hulls, one diagonal wider on either side -- in lanes: one
     // lane down before an odd row, one lane up before an even one.  (Lane numbers never
-    // become registers here: masks only; the band's cells are counted as it is laid out.)
+    // become registers here: masks only.)
     u64 hull;
     if (PAIR) {
         const u64 in0 = in & ~h.zone1, in1 = in & h.zone1;
         const int span0 = w_span(in0), span1 = w_span(in1);
         hull = w_lanes(w_lowest(in0), span0) | w_lanes(w_lowest(in1), span1);
-        h.cells0 += (u32)(span0 + 1);
-        h.cells1 += (u32)(span1 + 1);
     } else {
         const int span0 = w_span(in);
         hull = w_lanes(w_lowest(in), span0);
-        h.cells0 += (u32)(span0 + 1);
     }
     // (the two hulls keep a lane's distance from the boundary between the tracks, so one
     // shift of the whole mask widens both; a hull on the wave's first or last lane loses the
@@ -503,7 +510,7 @@ W_FN int a2_place(A2Wave &w, A2Lanes &wl) {
     wl.vtlen = w_sel(zone1, w.T0.t_len, w.T1.t_len);
     wl.vqb = w_selu(zone1, w.T0.qb, w.T1.qb);
     wl.vtb = w_selu(zone1, w.T0.tb, w.T1.tb);
-    wl.vtop = pair ? w_selu(zone1, 0u, 0x80000000u) : (vu)0u;
+    wl.vtop = pair ? w_selu(zone1, 0u, A2_TOP) : (vu)0u;
     // the tape says from here on which tracks take part and where their lane 0 is
     const u64 ahead = ~0ull << (w.it & 63u);
     wl.rc_k0 = w_selu(ahead, wl.rc_k0, run0 ? (u32)kb0 : A2_INVALID);
@@ -705,7 +712,7 @@ W_FN bool a2_replace(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, const A2TrackCo
         hv.vtlen = w_sel(h.zone1, tc.t_len0, tc.t_len1);
         hv.vqb = w_selu(h.zone1, tc.qb0, tc.qb1);
         hv.vtb = w_selu(h.zone1, tc.tb0, tc.tb1);
-        hv.vtop = w_selu(h.zone1, 0u, 0x80000000u);
+        hv.vtop = w_selu(h.zone1, 0u, A2_TOP);
         rc_k0 = w_selu(ahead, rc_k0, h.kb0);
         rc_k1 = w_selu(ahead, rc_k1, h.kb1);
         h.act = w_lanes(nl0, n0) | w_lanes(nl1, n1);
@@ -800,14 +807,14 @@ W_FN bool a2_park(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, const A2TrackConst
     w_pack_put<A2_SC_P_KC>(r.sc, (u32)((int)(park0 ? h.kb0 : h.kb1) - 1 + p_last));
     w_pack_put<A2_SC_P_LI>(r.sc, (u32)p_li);
     w_pack_put<A2_SC_P_HIN>(r.sc, (u32)p_hin);
-    w_pack_put<A2_SC_P_BEST>(r.sc, park0 ? (u32)h.best0 : (u32)h.best1 - 0x80000000u);
-    w_pack_put<A2_SC_P_CELLS>(r.sc, (park0 ? h.cells0 : h.cells1) - (u32)(p_hin - p_li + 2));
+    w_pack_put<A2_SC_P_BEST>(r.sc, park0 ? (u32)h.best0 : (u32)h.best1 - A2_TOP);
+    w_pack_put<A2_SC_P_CELLS>(r.sc, park0 ? h.cells0 : h.cells1);
     w_pack_put<A2_SC_PARKED>(r.sc, park0 ? 1u : 2u);
     r.vpark = hv.vx;
     const u64 ahead = ~0ull << (h.it & 63u);
     // the runner plays "track 0" of the single loop, whichever it is
     if (park0) {
-        h.best0 = (int)((u32)h.best1 - 0x80000000u);
+        h.best0 = (int)((u32)h.best1 - A2_TOP);
         h.cells0 = h.cells1;
         h.kb0 = A2_INVALID;
         rc_k0 = w_selu(ahead, rc_k0, A2_INVALID);
@@ -867,9 +874,9 @@ W_FN bool a2_join(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, const A2TrackConst
     h.kb0 = run_is0 ? kb_r : kb_p;
     h.kb1 = run_is0 ? kb_p : kb_r;
     const u32 best_r = (u32)h.best0, best_p = w_pack_get<A2_SC_P_BEST>(r.sc);  // (the runner played track 0)
-    const u32 cells_r = h.cells0, cells_p = w_pack_get<A2_SC_P_CELLS>(r.sc) + (u32)np;
+    const u32 cells_r = h.cells0, cells_p = w_pack_get<A2_SC_P_CELLS>(r.sc);
     h.best0 = (int)(run_is0 ? best_r : best_p);
-    h.best1 = (int)((run_is0 ? best_p : best_r) + 0x80000000u);
+    h.best1 = (int)((run_is0 ? best_p : best_r) + A2_TOP);
     h.cells0 = run_is0 ? cells_r : cells_p;
     h.cells1 = run_is0 ? cells_p : cells_r;
     hv.vnegk = w_sel(h.zone1, 1 - (int)h.kb0, 1 - (int)h.kb1) - 2 * lane;
@@ -877,7 +884,7 @@ W_FN bool a2_join(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, const A2TrackConst
     hv.vtlen = w_sel(h.zone1, tc.t_len0, tc.t_len1);
     hv.vqb = w_selu(h.zone1, tc.qb0, tc.qb1);
     hv.vtb = w_selu(h.zone1, tc.tb0, tc.tb1);
-    hv.vtop = w_selu(h.zone1, 0u, 0x80000000u);
+    hv.vtop = w_selu(h.zone1, 0u, A2_TOP);
     const u64 ahead = ~0ull << (h.it & 63u);
     rc_k0 = w_selu(ahead, rc_k0, h.kb0);
     rc_k1 = w_selu(ahead, rc_k1, h.kb1);
@@ -894,6 +901,112 @@ W_FN bool a2_join(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, const A2TrackConst
     A2_HOOK_DRIVE(1);
 #endif
     return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// The rows between two events: at least one, until a row raises an event (h.ev != 0, h.act_row =
+// the lanes that held a cell in it) or iteration `it_end` is reached.  Every fourth iteration
+// the cell bytes go to the tape, every 64th the records.  This is the statement of what the
+// row loop does; the product runs it as one hand-scheduled instruction stream
+// (k_align2_rows.h: W_ROWS_ASM), the lane emulator runs this.
+// ---------------------------------------------------------------------------------------
+template <bool PAIR>
+W_FN void a2_rows_c(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, const u32 *words, u64 *esc, u32 *cells, u32 *recs,
+                    u32 ring, int band, u32 it_end) {
+    const vi lane = w_lane();
+    // the cell byte of an iteration is byte it & 3 of the lane's word: v_perm selectors that
+    // put it there, alternating between (0, 1) and (2, 3) with every pair of rows
+    u32 sel_even = (h.it & 2u) ? 0x03040100u : 0x03020104u;
+    u32 sel_odd = (h.it & 2u) ? 0x04020100u : 0x03020400u;
+    for (;;) {
+        if ((h.it & 1u) == 0u) {  // (a stretch may begin at an odd iteration: then with the odd row)
+            const u64 lanes_ = a2_row<0, -1, PAIR>(h, hv, words, esc, band, sel_even);
+            if (h.ev) { h.act_row = lanes_; return; }
+            if (h.it == it_end) return;
+        }
+        const u64 lanes_ = a2_row<1, -1, PAIR>(h, hv, words, esc, band, sel_odd);
+        if ((h.it & 3u) == 0u)
+            w_store32(cells, (((h.it >> 2) - 1u) & ((ring >> 2) - 1u)) * 64u + (vu)lane, hv.vacc);
+        if ((h.it & 63u) == 0u) {
+            w_store_x4(recs, ((h.it - 64u) & (ring - 1u)) + (vu)lane, hv.rc_mlo, hv.rc_mhi, rc_k0, rc_k1);
+            rc_k0 = h.kb0;
+            rc_k1 = h.kb1;
+        }
+        sel_even ^= 0x03040100u ^ 0x03020104u;
+        sel_odd ^= 0x04020100u ^ 0x03020400u;
+        if (h.ev) { h.act_row = lanes_; return; }
+        if (h.it == it_end) return;
+    }
+}
+
+#if defined(W_ROWS_ASM) && !defined(A2_ROWS_C)
+#include "k_align2_rows.h"
+#else
+// (without the hand-written stream the rows count their cells themselves: nothing to fold)
+struct A2RowsV { vi tdn, tup; vu vcnt; };
+template <bool PAIR>
+W_FN void a2_fold_cells(A2Hot &, vu &) {}
+#endif
+
+#if defined(A2_SHADOW)
+// one log entry: what differed (bit per field), where, and both values of the first scalar that did
+W_FN void a2_shadow_log(u32 what, u32 it_in, u32 it_c, u32 it_a, u64 a, u64 b, u64 c, u64 d, int pair);
+template <bool PAIR>
+W_FN void a2_rows_shadow(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, const u32 *words, u64 *esc,
+                         u32 *cells, u32 *recs, u32 ring, int band, u32 it_end) {
+    A2Hot hc = h;
+    A2HotV hvc = hv;
+    vu k0c = rc_k0, k1c = rc_k1;
+    const u32 it_in = h.it;
+    a2_rows_c<PAIR>(hc, hvc, k0c, k1c, words, esc, cells, recs, ring, band, it_end);
+    A2Hot ha = h;
+    A2HotV hva = hv;
+    vu k0a = rc_k0, k1a = rc_k1;
+    A2RowsV rva = rv;
+    rva.vcnt = 0u;
+    a2_rows_asm<PAIR>(ha, hva, k0a, k1a, rva, words, cells, recs, ring, band, it_end);
+    a2_fold_cells<PAIR>(ha, rva.vcnt);
+    u32 what = 0;
+    if (ha.it != hc.it) what |= 1u;
+    if (ha.act != hc.act) what |= 2u;
+    if (ha.in != hc.in) what |= 4u;
+    if (ha.fin != hc.fin) what |= 8u;
+    if (ha.big != hc.big) what |= 16u;
+    if ((ha.ev != 0ull) != (hc.ev != 0ull)) what |= 32u;
+    if (ha.best0 != hc.best0) what |= 64u;
+    if (PAIR && ha.best1 != hc.best1) what |= 128u;
+    if (hc.ev && ha.act_row != hc.act_row) what |= 256u;
+    const u64 dx = w_ballot(hva.vx != hvc.vx);
+    if (dx) what |= 512u;
+    if (w_ballot(k0a != k0c) | w_ballot(k1a != k1c)) what |= 1024u;
+    if (ha.cells0 != hc.cells0 || (PAIR && ha.cells1 != hc.cells1)) what |= 2048u;
+    if (hc.big && (w_ballot(hva.vm != hvc.vm) & hc.big)) what |= 4096u;
+    if (what) {
+        const int l = dx ? w_lowest(dx) : 0;
+        a2_shadow_log(what, it_in, hc.it, ha.it, (what & 4u) ? hc.in : (what & 2u) ? hc.act : hc.fin,
+                      (what & 4u) ? ha.in : (what & 2u) ? ha.act : ha.fin,
+                      ((u64)(u32)hc.best0 << 32) | (u32)ha.best0,
+                      dx ? (((u64)(u32)w_readlane(hvc.vx, l) << 32) | (u32)w_readlane(hva.vx, l)) | 0ull
+                         : (((u64)hc.cells0 << 32) | ha.cells0),
+                      (PAIR ? 1 : 0) | (l << 8) | ((int)(h.split & 0xff) << 16));
+    }
+    h = hc; hv = hvc; rc_k0 = k0c; rc_k1 = k1c;
+    rv.tdn = rva.tdn; rv.tup = rva.tup;
+}
+#endif
+
+template <bool PAIR>
+W_FN void a2_rows(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, const u32 *words, u64 *esc, u32 *cells,
+                  u32 *recs, u32 ring, int band, u32 it_end) {
+#if defined(A2_SHADOW)
+    // (k_align2_shadow.hip, tests only: both renderings of the rows from the same state, every
+    // difference logged, the statement's result kept)
+    a2_rows_shadow<PAIR>(h, hv, rc_k0, rc_k1, rv, words, esc, cells, recs, ring, band, it_end);
+#elif defined(W_ROWS_ASM) && !defined(A2_ROWS_C)
+    a2_rows_asm<PAIR>(h, hv, rc_k0, rc_k1, rv, words, cells, recs, ring, band, it_end);
+#else
+    a2_rows_c<PAIR>(h, hv, rc_k0, rc_k1, words, esc, cells, recs, ring, band, it_end);
+#endif
 }
 
 template <bool PAIR>
@@ -931,38 +1044,15 @@ W_NOINLINE A2Regs a2_fast(A2Regs r) {
     h.in = ((u64)w_pack_get<A2_SC_IN_HI>(r.sc) << 32) | w_pack_get<A2_SC_IN_LO>(r.sc);
     h.fin = 0ull; h.ev = 0ull; h.act_row = 0ull; h.big = 0ull;
     hv.vm = 0u;
-    const vi lane = w_lane();
-    // the cell byte of an iteration is byte it & 3 of the lane's word: v_perm selectors that
-    // put it there, alternating between (0, 1) and (2, 3) with every pair of rows
-    u32 sel_even = (h.it & 2u) ? 0x03040100u : 0x03020104u;
-    u32 sel_odd = (h.it & 2u) ? 0x04020100u : 0x03020400u;
     // (`it_end`: where to look up from the rows -- the end of the tracks' rows `it_last`, or,
     // with a neighbour parked, every A2_LOOK_EVERY iterations: when the running band has
     // become narrow enough (<= join_at lanes) the loop leaves, for the neighbour to join)
+    A2RowsV rv;
+    rv.tdn = A2_NEG; rv.tup = A2_NEG; rv.vcnt = 0u;
     for (;;) {
-        if ((h.it & 1u) == 0u) {  // (a call may begin at an odd iteration: then with the odd row)
-            const u64 lanes_ = a2_row<0, -1, PAIR>(h, hv, words, esc, band, sel_even);
-            if (h.ev) {
-                h.act_row = lanes_;
-                if (!a2_replace<PAIR>(h, hv, rc_k0, rc_k1, tc)) break;
-            }
-            if (h.it == it_end) {
-                if (PAIR || it_end == it_last || w_span(h.in) + 1 <= join_at) break;
-                it_end = ((int)(it_last - it_end) > A2_LOOK_EVERY) ? it_end + A2_LOOK_EVERY : it_last;
-            }
-        }
-        const u64 lanes_ = a2_row<1, -1, PAIR>(h, hv, words, esc, band, sel_odd);
-        if ((h.it & 3u) == 0u)
-            w_store32(cells, (((h.it >> 2) - 1u) & ((ring >> 2) - 1u)) * 64u + (vu)lane, hv.vacc);
-        if ((h.it & 63u) == 0u) {
-            w_store_x4(recs, ((h.it - 64u) & (ring - 1u)) + (vu)lane, hv.rc_mlo, hv.rc_mhi, rc_k0, rc_k1);
-            rc_k0 = h.kb0;
-            rc_k1 = h.kb1;
-        }
-        sel_even ^= 0x03040100u ^ 0x03020104u;
-        sel_odd ^= 0x04020100u ^ 0x03020400u;
+        a2_rows<PAIR>(h, hv, rc_k0, rc_k1, rv, words, esc, cells, recs, ring, band, it_end);
         if (h.ev) {
-            h.act_row = lanes_;
+            if (PAIR) a2_fold_cells<true>(h, rv.vcnt);  // (the boundary between the tracks is about to move)
             if (!a2_replace<PAIR>(h, hv, rc_k0, rc_k1, tc)) break;
         }
         if (h.it == it_end) {
@@ -970,6 +1060,8 @@ W_NOINLINE A2Regs a2_fast(A2Regs r) {
             it_end = ((int)(it_last - it_end) > A2_LOOK_EVERY) ? it_end + A2_LOOK_EVERY : it_last;
         }
     }
+    a2_fold_cells<PAIR>(h, rv.vcnt);
+    const vi lane = w_lane();
     if (h.big) {
         // the last row had snakes of >= 255 bases: their lengths to the escape list, 255 into
         // their cell bytes (the row put the low byte of the length there) -- and into the
@@ -1405,17 +1497,15 @@ W_FN void a2_wave(const A2Args &A, int slot) {
         h.kb0 = run0 ? (u32)(w.T0.kc + p) : A2_INVALID;
         h.kb1 = run1 ? (u32)(w.T1.kc + p) : A2_INVALID;
         int budget, join_at = 0;
-        // (the rows count a band's cells when they lay it out: the first bands are counted here,
-        // and the bands laid out for the row after the last one are taken off again below)
         if (w.pair) {
             a2_next_band(w.T0, p, h.lo0, h.hi0);
             a2_next_band(w.T1, p, h.lo1, h.hi1);
             if (w.T0.d == 0) h.lo0 = h.hi0 = -(w.T0.kc + (p ? 1 : -1)) / 2;  // diagonal 0's lane
             if (w.T1.d == 0) h.lo1 = h.hi1 = -(w.T1.kc + (p ? 1 : -1)) / 2;
             h.best0 = w.T0.best;
-            h.best1 = (int)((u32)w.T1.best + 0x80000000u);
-            h.cells0 = w.T0.cells + (u32)(h.hi0 - h.lo0 + 1);
-            h.cells1 = w.T1.cells + (u32)(h.hi1 - h.lo1 + 1);
+            h.best1 = (int)((u32)w.T1.best + A2_TOP);
+            h.cells0 = w.T0.cells;
+            h.cells1 = w.T1.cells;
             h.act = w_lanes(h.lo0, h.hi0 - h.lo0 + 1) | w_lanes(h.lo1, h.hi1 - h.lo1 + 1);
             h.in = 0ull;
             budget = min(min(w.T0.max_d - w.T0.d, w.T1.max_d - w.T1.d), tape_left);
@@ -1435,7 +1525,7 @@ W_FN void a2_wave(const A2Args &A, int slot) {
             }
             h.lo1 = h.hi1 = 0;
             h.best0 = run0 ? w.T0.best : w.T1.best; h.best1 = 0;
-            h.cells0 = (run0 ? w.T0.cells : w.T1.cells) + (u32)(h.hi0 - h.lo0 + 1); h.cells1 = 0;
+            h.cells0 = run0 ? w.T0.cells : w.T1.cells; h.cells1 = 0;
             h.act = w_lanes(h.lo0, h.hi0 - h.lo0 + 1);
             h.in = 0ull;
             budget = min((run0 ? w.T0.max_d : w.T1.max_d) - t_d, tape_left);
@@ -1485,13 +1575,13 @@ W_FN void a2_wave(const A2Args &A, int slot) {
             w.T0.li = w_lowest(in0); w.T0.hin = w_highest(in0);
             w.T1.li = w_lowest(in1); w.T1.hin = w_highest(in1);
             w.T0.best = h.best0;
-            w.T1.best = (int)((u32)h.best1 - 0x80000000u);
-            w.T0.cells = h.cells0 - (u32)(w.T0.hin - w.T0.li + 2);
-            w.T1.cells = h.cells1 - (u32)(w.T1.hin - w.T1.li + 2);
+            w.T1.best = (int)((u32)h.best1 - A2_TOP);
+            w.T0.cells = h.cells0;
+            w.T1.cells = h.cells1;
             w.T0.state = A2_RUN; w.T1.state = A2_RUN;
         } else {
             const int n_li = w_lowest(h.in), n_hin = w_highest(h.in);
-            const u32 n_cells = h.cells0 - (u32)(n_hin - n_li + 2);
+            const u32 n_cells = h.cells0;
             if (ran0) {
                 w.T0.d += dr.d0; w.T0.kc = (int)h.kb0 - 1 + p_last; w.T0.li = n_li; w.T0.hin = n_hin;
                 w.T0.best = h.best0; w.T0.cells = n_cells;

@@ -1,0 +1,347 @@
+// k_align2_rows.h -- the row loop of k_align2 as ONE hand-scheduled gfx950 instruction stream.
+//
+// What it computes is stated by a2_rows_c (k_align2_core.h): rows of up to two tracks -- the
+// furthest-reaching points of DW_banded.c:183-243 -- from h.it on, until a row raises an event
+// (a cell reached an end of a sequence, a band hull reached a forbidden lane, a snake does not
+// fit its cell byte) or iteration `it_end` is reached; the cell bytes of every fourth and the
+// records of every 64th iteration go to the tape on the way.  The lane emulator (tests/emu)
+// runs a2_rows_c; the device runs this.  Why by hand: k_align2 is bound by instruction issue,
+// and the compiler's rendering of a2_rows_c was 48 vector + 50 scalar instructions per
+// iteration (profiles/r04_pmc_table.txt) -- half of the scalar ones the state machine it made
+// of the loop's exits, the hull algebra and the bookkeeping.  This one is 39 + 2 memory + 24:
+//
+//   * x = max(V[k-1] + 1, V[k+1]): the lanes outside a band's hull hold A2_NEG, so the maximum IS
+//     the reference's choice (from above at min_k, from below at max_k) and the from_above bit
+//     is only needed for the tape.  The lane below lane 0 / above lane 63 is A2_NEG too: the
+//     DPP shifts leave lane 0 of `tdn` / lane 63 of `tup` alone, and those hold A2_NEG for good.
+//   * per-lane constants fold the diagonal: query address x + cq, target address x + ct, the
+//     bases left min(q_len - x, t_len - y) = L - x, the key x + y = 2 x + ck (L and ck one
+//     register per row parity).  A cell has reached an end of a sequence iff x >= L.
+//   * keys are signed: a lane outside the bands computes x = A2_NEG + 1 and a negative key all
+//     by itself -- no masks on the vector side; the loads alone run under exec = act.
+//   * best_m by one prefix maximum for both tracks (track 1's keys carry A2_TOP), the filter as
+//     two compares against the two scalars.
+//   * the hull of the lanes that pass the filter: 99 % of the rows they are contiguous per track
+//     (measured on the lane emulator) -- then the hull IS the mask; the test costs five scalar
+//     instructions, the general hull algebra (out of line) thirteen.
+//   * the cells of a track are counted per LANE (one v_add under exec = act), summed when the
+//     lanes change hands (a2_fold_cells).
+//   * the snake beyond 16 bases (a fifth of the rows), snakes of >= 255 bases, the tape stores:
+//     out of line.  Two `act` registers take turns, so a row never copies a mask.
+//   * exits: one label.  Which row left and why is worked out by the caller from what the
+//     stream hands back (the row's masks, the iteration counter).
+//
+// Hazards kept by hand (the assembler does not insert wait states): VALU write -> DPP read of
+// the same VGPR: 2 wait states; VALU write -> v_readlane of it: 1; VALU writes an SGPR -> use
+// as a lane select: none here (selects come from the scalar unit).
+#pragma once
+
+// ---- the first 16 bases of a snake: x in %[x], leaves min(matching bases, bases left, 16) in DST
+// TA: the instruction that forms the target address, LIM: the register with L of this row parity
+#define A2R_SNAKE16(TA, LIM, MID)                                  \
+    "v_add_u32 %[qa], %[x], %[cq]\n\t"                             \
+    TA                                                             \
+    "v_lshrrev_b32 %[t1], 2, %[qa]\n\t"                            \
+    "v_lshrrev_b32 %[t2], 2, %[ta]\n\t"                            \
+    "v_and_b32 %[t1], -4, %[t1]\n\t"                               \
+    "v_and_b32 %[t2], -4, %[t2]\n\t"                               \
+    "global_load_dwordx2 v[52:53], %[t1], %[words]\n\t"            \
+    "global_load_dwordx2 v[54:55], %[t2], %[words]\n\t"            \
+    MID                                                            \
+    "v_lshlrev_b32 %[qa], 1, %[qa]\n\t"                            \
+    "v_lshlrev_b32 %[ta], 1, %[ta]\n\t"                            \
+    "v_sub_u32 %[t1], " LIM ", %[x]\n\t"                           \
+    "s_waitcnt vmcnt(1)\n\t"                                       \
+    "v_alignbit_b32 v52, v53, v52, %[qa]\n\t"                      \
+    "s_waitcnt vmcnt(0)\n\t"                                       \
+    "v_alignbit_b32 v54, v55, v54, %[ta]\n\t"                      \
+    "v_xor_b32 v52, v52, v54\n\t"                                  \
+    "v_ffbl_b32 v52, v52\n\t"                                      \
+    "v_lshrrev_b32 v52, 1, v52\n\t"
+
+#define A2R_TA_EVEN "v_add_u32 %[ta], %[x], %[ct]\n\t"
+#define A2R_TA_ODD "v_add3_u32 %[ta], %[x], %[ct], -1\n\t"
+
+// ---- best_m and the lanes that pass the band filter, into %[in]
+#define A2R_BEST_PAIR                                              \
+    "v_readlane_b32 %[p0], %[pm], %[ln0]\n\t"                      \
+    "v_readlane_b32 %[p1], %[pm], 63\n\t"                          \
+    "s_max_i32 %[b0], %[b0], %[p0]\n\t"                            \
+    "s_max_i32 %[b1], %[b1], %[p1]\n\t"                            \
+    "v_cmp_le_i32 vcc, %[b0], %[k2]\n\t"                           \
+    "v_cmp_le_i32 %[c1], %[b1], %[k2]\n\t"                         \
+    "s_andn2_b64 %[in], vcc, %[z1]\n\t"                            \
+    "s_or_b64 %[in], %[in], %[c1]\n\t"
+#define A2R_BEST_SINGLE                                            \
+    "v_readlane_b32 %[p1], %[pm], 63\n\t"                          \
+    "s_max_i32 %[b0], %[b0], %[p1]\n\t"                            \
+    "v_cmp_le_i32 %[in], %[b0], %[k2]\n\t"
+
+// ---- the general hull of %[in] into %[c1] (out of line)
+#define A2R_HULL_PAIR                                              \
+    "s_andn2_b64 %[c1], %[in], %[z1]\n\t"                          \
+    "s_ff1_i32_b64 %[p0], %[c1]\n\t"                               \
+    "s_flbit_i32_b64 %[p1], %[c1]\n\t"                             \
+    "s_lshl_b64 %[t], -1, %[p0]\n\t"                               \
+    "s_lshr_b64 %[c1], -1, %[p1]\n\t"                              \
+    "s_and_b64 %[c1], %[c1], %[t]\n\t"                             \
+    "s_and_b64 %[t], %[in], %[z1]\n\t"                             \
+    "s_ff1_i32_b64 %[p0], %[t]\n\t"                                \
+    "s_flbit_i32_b64 %[p1], %[t]\n\t"                              \
+    "s_lshl_b64 %[t], -1, %[p0]\n\t"                               \
+    "s_lshr_b64 %[u], -1, %[p1]\n\t"                               \
+    "s_and_b64 %[t], %[t], %[u]\n\t"                               \
+    "s_or_b64 %[c1], %[c1], %[t]\n\t"
+#define A2R_HULL_SINGLE                                            \
+    "s_ff1_i32_b64 %[p0], %[in]\n\t"                               \
+    "s_flbit_i32_b64 %[p1], %[in]\n\t"                             \
+    "s_lshl_b64 %[t], -1, %[p0]\n\t"                               \
+    "s_lshr_b64 %[c1], -1, %[p1]\n\t"                              \
+    "s_and_b64 %[c1], %[c1], %[t]\n\t"
+
+// ---- one row.  J: the iteration's byte in the cell word (= it & 3), its parity the row's phase.
+//   DPP:   the shift of the previous row into tdn / tup      A1: V[k-1] + 1 into %[x]
+//   FA:    from_above into vcc                               MX: x = max(V[k-1] + 1, V[k+1])
+//   TA / LIM / CK: target address, L and key constant of this parity
+//   RD / WR: the act register the row reads / writes         SH: s_lshr_b64 (even) / s_lshl_b64 (odd)
+//   FORB:  the lanes the hull may not reach in this row      SEL: the v_perm selector of byte J
+//   F1 / F2: what fills the wait states of the second and third DPP step (two each)
+//   BEST / HULL / NRUN: pair or single
+#define A2R_ROW(J, DPP, A1, FA, MX, TA, LIM, CK, RD, WR, SH, FORB, SEL, F1, F2, BEST, HULL, NRUN)         \
+    ".La2r_r" J "_%=:\n\t"                                                                               \
+    DPP                                                                                                  \
+    A1                                                                                                   \
+    FA                                                                                                   \
+    MX                                                                                                   \
+    "s_mov_b64 exec, " RD "\n\t"                                                                         \
+    "v_add_u32 %[cnt], 1, %[cnt]\n\t"                                                                    \
+    A2R_SNAKE16(TA, LIM,                                                                                 \
+                "v_writelane_b32 %[mlo], vcc_lo, m0\n\t"                                                 \
+                "v_writelane_b32 %[mhi], vcc_hi, m0\n\t")                                                \
+    "v_min3_u32 %[vm], v52, %[t1], 16\n\t"                                                               \
+    "v_cmp_eq_u32 vcc, 16, %[vm]\n\t"                                                                    \
+    "v_add_u32 %[x], %[x], %[vm]\n\t"                                                                    \
+    "s_cbranch_vccnz .La2r_x" J "_%=\n"                                                                  \
+    ".La2r_b" J "_%=:\n\t"                                                                               \
+    "s_mov_b64 exec, -1\n\t"                                                                             \
+    "v_lshl_add_u32 %[key], %[x], 1, " CK "\n\t"                                                         \
+    "v_perm_b32 %[acc], %[vm], %[acc], " SEL "\n\t"                                                      \
+    "s_add_u32 m0, m0, 1\n\t"                                                                            \
+    "v_max_i32_dpp %[pm], %[key], %[key] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"          \
+    "v_add_u32 %[k2], %[band], %[key]\n\t"                                                               \
+    "v_cmp_ge_i32 %[fin], %[x], " LIM "\n\t"                                                             \
+    "v_max_i32_dpp %[pm], %[pm], %[pm] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                         \
+    F1                                                                                                   \
+    "v_max_i32_dpp %[pm], %[pm], %[pm] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                         \
+    F2                                                                                                   \
+    "v_max_i32_dpp %[pm], %[pm], %[pm] row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                         \
+    "s_nop 1\n\t"                                                                                        \
+    "v_max_i32_dpp %[pm], %[pm], %[pm] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                      \
+    "s_nop 1\n\t"                                                                                        \
+    "v_max_i32_dpp %[pm], %[pm], %[pm] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                      \
+    "s_nop 1\n\t"                                                                                        \
+    BEST                                                                                                 \
+    SH " %[t], %[in], 1\n\t"                                                                             \
+    "s_andn2_b64 %[c1], %[in], %[t]\n\t"                                                                 \
+    "s_bcnt1_i32_b64 %[p0], %[c1]\n\t"                                                                   \
+    "s_cmp_lg_u32 %[p0], " NRUN "\n\t"                                                                   \
+    "s_cbranch_scc1 .La2r_s" J "_%=\n\t"                                                                 \
+    "v_cndmask_b32 %[vx], %[neg], %[x], %[in]\n\t"                                                       \
+    "s_or_b64 " WR ", %[in], %[t]\n"                                                                     \
+    ".La2r_h" J "_%=:\n\t"                                                                               \
+    "s_and_b64 %[t], %[in], " FORB "\n\t"                                                                \
+    "s_or_b64 %[t], %[t], %[fin]\n\t"                                                                    \
+    "s_cbranch_scc1 .La2r_out_%=\n\t"                                                                    \
+    "s_sub_u32 %[rem], %[rem], 1\n\t"                                                                    \
+    "s_cbranch_scc1 .La2r_out_%=\n\t"
+
+// ---- what a row keeps out of line: the snake beyond 16 bases (then: snakes of >= 255 bases end
+// the stretch with this row), the hull of a filter mask with holes
+#define A2R_ROW_FAR(J, TA, LIM, RD, WR, SH, HULL)                                                        \
+    ".La2r_x" J "_%=:\n\t"                                                                               \
+    "s_mov_b64 %[t], vcc\n"                                                                              \
+    ".La2r_xl" J "_%=:\n\t"                                                                              \
+    "s_mov_b64 exec, %[t]\n\t"                                                                           \
+    A2R_SNAKE16(TA, LIM, "")                                                                             \
+    "v_min3_u32 v52, v52, %[t1], 16\n\t"                                                                 \
+    "v_add_u32 %[x], %[x], v52\n\t"                                                                      \
+    "v_add_u32 %[vm], %[vm], v52\n\t"                                                                    \
+    "v_cmp_eq_u32 vcc, 16, v52\n\t"                                                                      \
+    "s_and_b64 %[t], vcc, exec\n\t"                                                                      \
+    "s_cbranch_scc1 .La2r_xl" J "_%=\n\t"                                                                \
+    "s_mov_b64 exec, " RD "\n\t"                                                                         \
+    "v_cmp_lt_u32 vcc, 0xfe, %[vm]\n\t"                                                                  \
+    "s_mov_b64 %[big], vcc\n\t"                                                                          \
+    "s_cmp_eq_u64 %[big], 0\n\t"                                                                         \
+    "s_cbranch_scc1 .La2r_b" J "_%=\n\t"                                                                 \
+    "s_mov_b32 %[rem], 0\n\t"                                                                            \
+    "s_branch .La2r_b" J "_%=\n"                                                                         \
+    ".La2r_s" J "_%=:\n\t"                                                                               \
+    HULL                                                                                                 \
+    "v_cndmask_b32 %[vx], %[neg], %[x], %[c1]\n\t"                                                       \
+    SH " %[t], %[c1], 1\n\t"                                                                             \
+    "s_or_b64 " WR ", %[c1], %[t]\n\t"                                                                   \
+    "s_branch .La2r_h" J "_%=\n"
+
+#define A2R_EVEN(J, SEL, F1, F2, BEST, HULL, NRUN)                                                       \
+    A2R_ROW(J, "v_mov_b32_dpp %[tdn], %[vx] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t",                  \
+            "v_add_u32 %[x], 1, %[tdn]\n\t",                                                             \
+            "v_cmp_lt_i32 vcc, %[tdn], %[vx]\n\t",                                                       \
+            "v_max_i32 %[x], %[x], %[vx]\n\t",                                                           \
+            A2R_TA_EVEN, "%[le]", "%[cke]", "%[sa]", "%[sb]", "s_lshr_b64", "%[f1]", SEL, F1, F2, BEST, HULL, NRUN)
+#define A2R_ODD(J, SEL, F1, F2, BEST, HULL, NRUN)                                                        \
+    A2R_ROW(J, "v_mov_b32_dpp %[tup], %[vx] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t",                  \
+            "v_add_u32 %[x], 1, %[vx]\n\t",                                                              \
+            "v_cmp_lt_i32 vcc, %[vx], %[tup]\n\t",                                                       \
+            "v_max_i32 %[x], %[x], %[tup]\n\t",                                                          \
+            A2R_TA_ODD, "%[lo]", "%[cko]", "%[sb]", "%[sa]", "s_lshl_b64", "%[f0]", SEL, F1, F2, BEST, HULL, NRUN)
+#define A2R_EVEN_FAR(J, HULL) A2R_ROW_FAR(J, A2R_TA_EVEN, "%[le]", "%[sa]", "%[sb]", "s_lshr_b64", HULL)
+#define A2R_ODD_FAR(J, HULL) A2R_ROW_FAR(J, A2R_TA_ODD, "%[lo]", "%[sb]", "%[sa]", "s_lshl_b64", HULL)
+
+#define A2R_NOP2 "s_nop 1\n\t"
+// the fourth row of a group: its two fillers send the lanes' cell words to the tape and look
+// whether the block of 64 iterations is complete (m0 counts the iteration already)
+#define A2R_F1_STORE                                                                                     \
+    "v_add_u32 %[t2], %[coff], %[l4]\n\t"                                                                \
+    "s_add_u32 %[coff], %[coff], 0x100\n\t"
+#define A2R_F2_STORE                                                                                     \
+    "global_store_dword %[t2], %[acc], %[cells]\n\t"                                                     \
+    "s_and_b32 %[coff], %[coff], %[cmaskb]\n\t"                                                          \
+    "s_cmp_eq_u32 m0, 64\n\t"                                                                            \
+    "s_cbranch_scc1 .La2r_rec_%=\n"                                                                      \
+    ".La2r_recb_%=:\n\t"
+
+// the records of a complete block of 64 iterations to the tape; the K fields start over
+#define A2R_REC                                                                                          \
+    ".La2r_rec_%=:\n\t"                                                                                  \
+    "v_lshl_add_u32 %[t2], %[l4], 2, %[roff]\n\t"                                                        \
+    "global_store_dword %[t2], %[mlo], %[recs]\n\t"                                                      \
+    "global_store_dword %[t2], %[mhi], %[recs] offset:4\n\t"                                             \
+    "global_store_dword %[t2], %[k0], %[recs] offset:8\n\t"                                              \
+    "global_store_dword %[t2], %[k1], %[recs] offset:12\n\t"                                             \
+    "s_add_u32 %[roff], %[roff], 0x400\n\t"                                                              \
+    "s_and_b32 %[roff], %[roff], %[rmaskb]\n\t"                                                          \
+    "s_add_u32 %[itb], %[itb], 64\n\t"                                                                   \
+    "s_mov_b32 m0, 0\n\t"                                                                                \
+    "v_mov_b32 %[k0], %[kb0]\n\t"                                                                        \
+    "v_mov_b32 %[k1], %[kb1]\n\t"                                                                        \
+    "s_branch .La2r_recb_%=\n"
+
+#define A2R_BODY(BEST, HULL, NRUN)                                                                       \
+    "s_nop 1\n\t"                                                                                        \
+    "s_and_b32 m0, %[it], 63\n\t"                                                                        \
+    "s_andn2_b32 %[itb], %[it], 63\n\t"                                                                  \
+    "s_mov_b64 %[sb], %[sa]\n\t"                                                                         \
+    "s_mov_b64 %[big], 0\n\t"                                                                            \
+    "s_and_b32 %[p0], %[it], 3\n\t"                                                                      \
+    "s_cmp_eq_u32 %[p0], 1\n\t"                                                                          \
+    "s_cbranch_scc1 .La2r_r1_%=\n\t"                                                                     \
+    "s_cmp_eq_u32 %[p0], 2\n\t"                                                                          \
+    "s_cbranch_scc1 .La2r_r2_%=\n\t"                                                                     \
+    "s_cmp_eq_u32 %[p0], 3\n\t"                                                                          \
+    "s_cbranch_scc1 .La2r_r3_%=\n"                                                                       \
+    A2R_EVEN("0", "%[sel0]", A2R_NOP2, A2R_NOP2, BEST, HULL, NRUN)                                       \
+    A2R_ODD("1", "%[sel1]", A2R_NOP2, A2R_NOP2, BEST, HULL, NRUN)                                        \
+    A2R_EVEN("2", "%[sel2]", A2R_NOP2, A2R_NOP2, BEST, HULL, NRUN)                                       \
+    A2R_ODD("3", "%[sel3]", A2R_F1_STORE, A2R_F2_STORE, BEST, HULL, NRUN)                                \
+    "s_branch .La2r_r0_%=\n"                                                                             \
+    A2R_EVEN_FAR("0", HULL)                                                                              \
+    A2R_ODD_FAR("1", HULL)                                                                               \
+    A2R_EVEN_FAR("2", HULL)                                                                              \
+    A2R_ODD_FAR("3", HULL)                                                                               \
+    A2R_REC                                                                                              \
+    ".La2r_out_%=:\n\t"                                                                                  \
+    "s_add_u32 %[it], %[itb], m0\n\t"
+
+// the sums of the lanes' cell counters over the two tracks' lanes into h.cells0 / h.cells1; the
+// counters start over.  (Wherever the lanes change hands: a2_replace, the end of a2_fast.)
+template <bool PAIR>
+W_FN void a2_fold_cells(A2Hot &h, vu &vcnt) {
+    const vu ps = w_prefix_add(vcnt);
+    const u32 all = w_readlaneu(ps, 63);
+    if (PAIR) {
+        const u32 low = w_readlaneu(ps, (h.split - 1) & 63);
+        h.cells0 += low;
+        h.cells1 += all - low;
+    } else {
+        h.cells0 += all;
+    }
+    vcnt = 0u;
+}
+
+// State of the stream that outlives a stretch
+struct A2RowsV {
+    vi tdn, tup;   // the previous row shifted one lane up / down; lane 0 / lane 63 hold A2_NEG for good
+    vu vcnt;       // cells per lane since the last a2_fold_cells
+};
+
+template <bool PAIR>
+W_FN void a2_rows_asm(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, const u32 *words, u32 *cells,
+                      u32 *recs, u32 ring, int band, u32 it_end) {
+    const vi lane = w_lane();
+    // the per-lane constants of the rows (even rows: y = x + vnegk, odd ones: y = x + vnegk - 1)
+    const vu cq = hv.vqb;
+    const vu ct = hv.vtb + (vu)hv.vnegk;
+    const vi tn = hv.vtlen - hv.vnegk;
+    const vi le = w_min(hv.vqlen, tn), lo = w_min(hv.vqlen, tn + 1);
+    const vu cke = (vu)hv.vnegk + hv.vtop, cko = cke - 1u;
+    const vu l4 = (vu)lane << 2;
+    const vi neg = A2_NEG;
+    u64 sa = h.act, sb, in, fin, big, t, c1, u;
+    u32 b0 = (u32)h.best0, b1 = (u32)h.best1;
+    u32 rem = it_end - h.it - 1u, it = h.it, itb, p0, p1;
+    u32 coff = ((it >> 2) & ((ring >> 2) - 1u)) << 8;            // byte offset of the current group of 4's cell words
+    u32 roff = ((it & ~63u) & (ring - 1u)) << 4;                 // ... of the current block of 64's records
+    const u32 cmaskb = ((ring >> 2) << 8) - 1u, rmaskb = (ring << 4) - 1u;
+    const u32 ln0 = w_uniu((u32)(h.split - 1) & 63u);  // (the compiler keeps `split` on the vector unit)
+    vu vm, x, qa, ta, t1, t2, key, pm, k2;
+    if (PAIR) {
+        asm volatile(A2R_BODY(A2R_BEST_PAIR, A2R_HULL_PAIR, "2")
+                     : [vx] "+v"(hv.vx), [acc] "+v"(hv.vacc), [mlo] "+v"(hv.rc_mlo), [mhi] "+v"(hv.rc_mhi),
+                       [k0] "+v"(rc_k0), [k1] "+v"(rc_k1), [cnt] "+v"(rv.vcnt), [tdn] "+v"(rv.tdn), [tup] "+v"(rv.tup),
+                       [vm] "=&v"(vm), [x] "=&v"(x), [qa] "=&v"(qa), [ta] "=&v"(ta), [t1] "=&v"(t1), [t2] "=&v"(t2),
+                       [key] "=&v"(key), [pm] "=&v"(pm), [k2] "=&v"(k2),
+                       [sa] "+s"(sa), [b0] "+s"(b0), [b1] "+s"(b1), [rem] "+s"(rem), [it] "+s"(it),
+                       [coff] "+s"(coff), [roff] "+s"(roff),
+                       [sb] "=&s"(sb), [in] "=&s"(in), [fin] "=&s"(fin), [big] "=&s"(big), [t] "=&s"(t),
+                       [c1] "=&s"(c1), [u] "=&s"(u), [p0] "=&s"(p0), [p1] "=&s"(p1), [itb] "=&s"(itb)
+                     : [cq] "v"(cq), [ct] "v"(ct), [le] "v"(le), [lo] "v"(lo), [cke] "v"(cke), [cko] "v"(cko),
+                       [l4] "v"(l4), [neg] "v"(neg),
+                       [z1] "s"(h.zone1), [f0] "s"(h.forbid_to0), [f1] "s"(h.forbid_to1), [band] "s"(band),
+                       [ln0] "s"(ln0), [words] "s"(words), [cells] "s"(cells), [recs] "s"(recs),
+                       [cmaskb] "s"(cmaskb), [rmaskb] "s"(rmaskb), [kb0] "s"(h.kb0), [kb1] "s"(h.kb1),
+                       [sel0] "s"(0x03020104u), [sel1] "s"(0x03020400u), [sel2] "s"(0x03040100u),
+                       [sel3] "s"(0x04020100u)
+                     : "vcc", "scc", "memory", "v52", "v53", "v54", "v55");
+    } else {
+        asm volatile(A2R_BODY(A2R_BEST_SINGLE, A2R_HULL_SINGLE, "1")
+                     : [vx] "+v"(hv.vx), [acc] "+v"(hv.vacc), [mlo] "+v"(hv.rc_mlo), [mhi] "+v"(hv.rc_mhi),
+                       [k0] "+v"(rc_k0), [k1] "+v"(rc_k1), [cnt] "+v"(rv.vcnt), [tdn] "+v"(rv.tdn), [tup] "+v"(rv.tup),
+                       [vm] "=&v"(vm), [x] "=&v"(x), [qa] "=&v"(qa), [ta] "=&v"(ta), [t1] "=&v"(t1), [t2] "=&v"(t2),
+                       [key] "=&v"(key), [pm] "=&v"(pm), [k2] "=&v"(k2),
+                       [sa] "+s"(sa), [b0] "+s"(b0), [rem] "+s"(rem), [it] "+s"(it),
+                       [coff] "+s"(coff), [roff] "+s"(roff),
+                       [sb] "=&s"(sb), [in] "=&s"(in), [fin] "=&s"(fin), [big] "=&s"(big), [t] "=&s"(t),
+                       [c1] "=&s"(c1), [p0] "=&s"(p0), [p1] "=&s"(p1), [itb] "=&s"(itb)
+                     : [cq] "v"(cq), [ct] "v"(ct), [le] "v"(le), [lo] "v"(lo), [cke] "v"(cke), [cko] "v"(cko),
+                       [l4] "v"(l4), [neg] "v"(neg),
+                       [f0] "s"(h.forbid_to0), [f1] "s"(h.forbid_to1), [band] "s"(band),
+                       [words] "s"(words), [cells] "s"(cells), [recs] "s"(recs),
+                       [cmaskb] "s"(cmaskb), [rmaskb] "s"(rmaskb), [kb0] "s"(h.kb0), [kb1] "s"(h.kb1),
+                       [sel0] "s"(0x03020104u), [sel1] "s"(0x03020400u), [sel2] "s"(0x03040100u),
+                       [sel3] "s"(0x04020100u)
+                     : "vcc", "scc", "memory", "v52", "v53", "v54", "v55");
+        (void)u; (void)b1; (void)ln0;
+    }
+    // what the stream hands back: the last row was an even one (it read `sa`, wrote `sb`) or an
+    // odd one (the other way round)
+    const bool last_even = ((it - 1u) & 1u) == 0u;
+    h.it = it;
+    h.act = last_even ? sb : sa;
+    h.act_row = last_even ? sa : sb;
+    h.in = in; h.fin = fin; h.big = big;
+    h.best0 = (int)b0;
+    if (PAIR) h.best1 = (int)b1;
+    h.ev = fin | big | (in & (last_even ? h.forbid_to1 : h.forbid_to0));
+    hv.vm = vm;
+}

@@ -1,0 +1,51 @@
+// k_align2_shadow.hip -- TESTS ONLY: k_align2 with both renderings of its row loop run side by
+// side -- a2_rows_c, the statement, and a2_rows_asm, the hand-scheduled stream (k_align2_rows.h)
+// -- from the same state, stretch by stretch.  Whatever differs between them goes to a log in
+// device memory (FALCON_AMD_A2_SHADOW=1: fa_launch_align2 launches this kernel, waits, and
+// prints the log to stderr); the statement's result is what the kernel goes on with, so a run
+// completes and its answers are those of the compiler's rendering.
+#include <cstdio>
+#include "fa_wave.h"
+
+#define A2_SHADOW 1
+#define A2_SHADOW_CAP 64
+__device__ u32 g_a2_shadow_n;
+__device__ u32 g_a2_shadow[A2_SHADOW_CAP * 16];
+
+#include "k_align2_core.h"
+
+W_FN void a2_shadow_log(u32 what, u32 it_in, u32 it_c, u32 it_a, u64 a, u64 b, u64 c, u64 d, int pair) {
+    const u32 i = (u32)w_uni((int)atomicAdd(&g_a2_shadow_n, fa_lane() == 0 ? 1u : 0u));
+    if (i >= A2_SHADOW_CAP) return;
+    if (fa_lane() == 0) {
+        u32 *e = g_a2_shadow + i * 16;
+        e[0] = what; e[1] = it_in; e[2] = it_c; e[3] = it_a;
+        e[4] = (u32)a; e[5] = (u32)(a >> 32); e[6] = (u32)b; e[7] = (u32)(b >> 32);
+        e[8] = (u32)c; e[9] = (u32)(c >> 32); e[10] = (u32)d; e[11] = (u32)(d >> 32);
+        e[12] = (u32)pair; e[13] = blockIdx.x;
+    }
+}
+
+__global__ __launch_bounds__(64, 4) void k_align2_shadow(A2Args A) {
+    a2_wave(A, (int)blockIdx.x);
+}
+
+void fa_launch_align2_shadow(const A2Args &A, int grid, size_t lds, hipStream_t s) {
+    u32 zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_a2_shadow_n), &zero, sizeof(zero));
+    hipLaunchKernelGGL(k_align2_shadow, dim3(grid), dim3(64), lds, s, A);
+    (void)hipStreamSynchronize(s);
+    u32 n = 0;
+    static u32 log[A2_SHADOW_CAP * 16];
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_a2_shadow_n), sizeof(n));
+    (void)hipMemcpyFromSymbol(log, HIP_SYMBOL(g_a2_shadow), sizeof(log));
+    fprintf(stderr, "a2_shadow: %u stretches differ\n", n);
+    for (u32 i = 0; i < n && i < A2_SHADOW_CAP && i < 24; i++) {
+        const u32 *e = log + i * 16;
+        fprintf(stderr,
+                "  [%u] what=%04x pair=%u split=%u wave=%u it_in=%u it_c=%u it_a=%u mask_c=%08x%08x mask_a=%08x%08x "
+                "best0 c=%d a=%d lane=%u vx/cells c=%d a=%d\n",
+                i, e[0], e[12] & 1u, (e[12] >> 16) & 0xffu, e[13], e[1], e[2], e[3], e[5], e[4], e[7], e[6],
+                (int)e[9], (int)e[8], (e[12] >> 8) & 0xffu, (int)e[11], (int)e[10]);
+    }
+}

@@ -105,6 +105,11 @@ W_FN vu w_prefix_max(const vu &v) {
     for (int l = 0; l < 64; l++) { m = std::max(m, v.v[l]); r.v[l] = m; }
     return r;
 }
+W_FN vu w_prefix_add(const vu &v) {
+    vu r; u32 m = 0;
+    for (int l = 0; l < 64; l++) { m += v.v[l]; r.v[l] = m; }
+    return r;
+}
 W_FN vu w_row_tail(const vu &key, const vi &x, const vi &qlen, const vi &y, const vi &tlen, const vu &m, u64 act,
                    u32 band, u64 fa, int slot, vu &rc_lo, vu &rc_hi, u64 &fin, u64 &big, vu &keyb) {
     fin = 0; big = 0;
