@@ -953,7 +953,7 @@ W_FN void a2_fold_cells(A2Hot &, vu &) {}
 W_FN void a2_shadow_log(u32 what, u32 it_in, u32 it_c, u32 it_a, u64 a, u64 b, u64 c, u64 d, int pair);
 template <bool PAIR>
 W_FN void a2_rows_shadow(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, const u32 *words, u64 *esc,
-                         u32 *cells, u32 *recs, u32 ring, int band, u32 it_end) {
+                         u32 *cells, u32 *recs, u32 ring, int band, u32 it_end, bool head) {
     A2Hot hc = h;
     A2HotV hvc = hv;
     vu k0c = rc_k0, k1c = rc_k1;
@@ -964,7 +964,7 @@ W_FN void a2_rows_shadow(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
     vu k0a = rc_k0, k1a = rc_k1;
     A2RowsV rva = rv;
     rva.vcnt = 0u;
-    a2_rows_asm<PAIR>(ha, hva, k0a, k1a, rva, words, cells, recs, ring, band, it_end);
+    a2_rows_asm<PAIR>(ha, hva, k0a, k1a, rva, words, cells, recs, ring, band, it_end, head);
     a2_fold_cells<PAIR>(ha, rva.vcnt);
     u32 what = 0;
     if (ha.it != hc.it) what |= 1u;
@@ -997,13 +997,13 @@ W_FN void a2_rows_shadow(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
 
 template <bool PAIR>
 W_FN void a2_rows(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, const u32 *words, u64 *esc, u32 *cells,
-                  u32 *recs, u32 ring, int band, u32 it_end) {
+                  u32 *recs, u32 ring, int band, u32 it_end, bool head) {
 #if defined(A2_SHADOW)
     // (k_align2_shadow.hip, tests only: both renderings of the rows from the same state, every
     // difference logged, the statement's result kept)
-    a2_rows_shadow<PAIR>(h, hv, rc_k0, rc_k1, rv, words, esc, cells, recs, ring, band, it_end);
+    a2_rows_shadow<PAIR>(h, hv, rc_k0, rc_k1, rv, words, esc, cells, recs, ring, band, it_end, head);
 #elif defined(W_ROWS_ASM) && !defined(A2_ROWS_C)
-    a2_rows_asm<PAIR>(h, hv, rc_k0, rc_k1, rv, words, cells, recs, ring, band, it_end);
+    a2_rows_asm<PAIR>(h, hv, rc_k0, rc_k1, rv, words, cells, recs, ring, band, it_end, head);
 #else
     a2_rows_c<PAIR>(h, hv, rc_k0, rc_k1, words, esc, cells, recs, ring, band, it_end);
 #endif
@@ -1049,8 +1049,11 @@ W_NOINLINE A2Regs a2_fast(A2Regs r) {
     // become narrow enough (<= join_at lanes) the loop leaves, for the neighbour to join)
     A2RowsV rv;
     rv.tdn = A2_NEG; rv.tup = A2_NEG; rv.vcnt = 0u;
+    bool head = true;
+#pragma clang loop unroll(disable)
     for (;;) {
-        a2_rows<PAIR>(h, hv, rc_k0, rc_k1, rv, words, esc, cells, recs, ring, band, it_end);
+        a2_rows<PAIR>(h, hv, rc_k0, rc_k1, rv, words, esc, cells, recs, ring, band, it_end, head);
+        head = false;
         if (h.ev) {
             if (PAIR) a2_fold_cells<true>(h, rv.vcnt);  // (the boundary between the tracks is about to move)
             if (!a2_replace<PAIR>(h, hv, rc_k0, rc_k1, tc)) break;

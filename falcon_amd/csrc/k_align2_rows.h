@@ -275,9 +275,11 @@ struct A2RowsV {
     vu vcnt;       // cells per lane since the last a2_fold_cells
 };
 
+// One stretch of rows through the stream: from h.it until a row raises an event or `it_end`.
+// `xrow`: x of every lane after the last row (what hv.vx holds of it inside the hull).
 template <bool PAIR>
-W_FN void a2_rows_asm(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, const u32 *words, u32 *cells,
-                      u32 *recs, u32 ring, int band, u32 it_end) {
+W_FN void a2_rows_stream(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, const u32 *words, u32 *cells,
+                         u32 *recs, u32 ring, int band, u32 it_end, vi &xrow) {
     const vi lane = w_lane();
     // the per-lane constants of the rows (even rows: y = x + vnegk, odd ones: y = x + vnegk - 1)
     const vu cq = hv.vqb;
@@ -344,4 +346,37 @@ W_FN void a2_rows_asm(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, c
     if (PAIR) h.best1 = (int)b1;
     h.ev = fin | big | (in & (last_even ? h.forbid_to1 : h.forbid_to0));
     hv.vm = vm;
+    xrow = (vi)x;
+}
+
+// The rows of a stretch.  `head`: the first stretch after the wavefront's event loop placed the
+// tracks -- the only one that can begin with a track's row 0.  That row is the one case in which
+// a lane OUTSIDE the bands computes a plausible x: before it the track's lanes hold a single 0
+// (V[1] of the reference's zeroed array, DW_banded.c:153) that is no hull, and the lane above
+// it reads it as its V[k-1].  The stream does not mask the filter with the row's lanes, so a
+// row 0 runs alone and what it hands back is cut to the row's lanes here.
+template <bool PAIR>
+W_FN void a2_rows_asm(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, const u32 *words, u32 *cells,
+                      u32 *recs, u32 ring, int band, u32 it_end, bool head) {
+    bool row0 = false;
+    if (head)
+        row0 = PAIR ? (w_popc(h.act & ~h.zone1) == 1 || w_popc(h.act & h.zone1) == 1) : w_popc(h.act) == 1;
+    vi x;
+    a2_rows_stream<PAIR>(h, hv, rc_k0, rc_k1, rv, words, cells, recs, ring, band, row0 ? h.it + 1u : it_end, x);
+    if (row0) {  // (the caller's loop goes on from here)
+        const bool even = ((h.it - 1u) & 1u) == 0u;
+        const u64 in = h.in & h.act_row;
+        u64 hull;
+        if (PAIR) {
+            const u64 in0 = in & ~h.zone1, in1 = in & h.zone1;
+            hull = w_lanes(w_lowest(in0), w_span(in0)) | w_lanes(w_lowest(in1), w_span(in1));
+        } else {
+            hull = w_lanes(w_lowest(in), w_span(in));
+        }
+        hv.vx = w_sel(hull, A2_NEG, x);
+        h.act = even ? (hull | (hull >> 1)) : (hull | (hull << 1));
+        h.in = in;
+        h.fin &= h.act_row;
+        h.ev = h.fin | h.big | (in & (even ? h.forbid_to1 : h.forbid_to0));
+    }
 }
