@@ -951,6 +951,7 @@ W_FN void a2_fold_cells(A2Hot &, vu &) {}
 #if defined(A2_SHADOW)
 // one log entry: what differed (bit per field), where, and both values of the first scalar that did
 W_FN void a2_shadow_log(u32 what, u32 it_in, u32 it_c, u32 it_a, u64 a, u64 b, u64 c, u64 d, int pair);
+W_FN bool a2_shadow_adopt();
 template <bool PAIR>
 W_FN void a2_rows_shadow(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, const u32 *words, u64 *esc,
                          u32 *cells, u32 *recs, u32 ring, int band, u32 it_end, bool head) {
@@ -965,6 +966,9 @@ W_FN void a2_rows_shadow(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
     A2RowsV rva = rv;
     rva.vcnt = 0u;
     a2_rows_asm<PAIR>(ha, hva, k0a, k1a, rva, words, cells, recs, ring, band, it_end, head);
+    // (a track's row 0 comes back alone: the caller's loop would go on from there)
+    if (head && !ha.ev && ha.it != it_end)
+        a2_rows_asm<PAIR>(ha, hva, k0a, k1a, rva, words, cells, recs, ring, band, it_end, false);
     a2_fold_cells<PAIR>(ha, rva.vcnt);
     u32 what = 0;
     if (ha.it != hc.it) what |= 1u;
@@ -990,7 +994,11 @@ W_FN void a2_rows_shadow(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
                          : (((u64)hc.cells0 << 32) | ha.cells0),
                       (PAIR ? 1 : 0) | (l << 8) | ((int)(h.split & 0xff) << 16));
     }
-    h = hc; hv = hvc; rc_k0 = k0c; rc_k1 = k1c;
+    if (a2_shadow_adopt()) {  // (FALCON_AMD_A2_SHADOW=2: go on with the stream's state, as the product does)
+        h = ha; hv = hva; rc_k0 = k0a; rc_k1 = k1a;
+    } else {
+        h = hc; hv = hvc; rc_k0 = k0c; rc_k1 = k1c;
+    }
     rv.tdn = rva.tdn; rv.tup = rva.tup;
 }
 #endif

@@ -5,11 +5,13 @@
 // prints the log to stderr); the statement's result is what the kernel goes on with, so a run
 // completes and its answers are those of the compiler's rendering.
 #include <cstdio>
+#include <cstdlib>
 #include "fa_wave.h"
 
 #define A2_SHADOW 1
 #define A2_SHADOW_CAP 64
 __device__ u32 g_a2_shadow_n;
+__device__ u32 g_a2_shadow_adopt;
 __device__ u32 g_a2_shadow[A2_SHADOW_CAP * 16];
 
 #include "k_align2_core.h"
@@ -26,6 +28,8 @@ W_FN void a2_shadow_log(u32 what, u32 it_in, u32 it_c, u32 it_a, u64 a, u64 b, u
     }
 }
 
+W_FN bool a2_shadow_adopt() { return w_uniu(g_a2_shadow_adopt) != 0u; }
+
 __global__ __launch_bounds__(64, 4) void k_align2_shadow(A2Args A) {
     a2_wave(A, (int)blockIdx.x);
 }
@@ -33,6 +37,9 @@ __global__ __launch_bounds__(64, 4) void k_align2_shadow(A2Args A) {
 void fa_launch_align2_shadow(const A2Args &A, int grid, size_t lds, hipStream_t s) {
     u32 zero = 0;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_a2_shadow_n), &zero, sizeof(zero));
+    const char *mode = getenv("FALCON_AMD_A2_SHADOW");
+    const u32 adopt = (mode && atoi(mode) == 2) ? 1u : 0u;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_a2_shadow_adopt), &adopt, sizeof(adopt));
     hipLaunchKernelGGL(k_align2_shadow, dim3(grid), dim3(64), lds, s, A);
     (void)hipStreamSynchronize(s);
     u32 n = 0;
