@@ -950,7 +950,8 @@ W_FN void a2_fold_cells(A2Hot &, vu &) {}
 
 #if defined(A2_SHADOW)
 // one log entry: what differed (bit per field), where, and both values of the first scalar that did
-W_FN void a2_shadow_log(u32 what, u32 it_in, u32 it_c, u32 it_a, u64 a, u64 b, u64 c, u64 d, int pair);
+W_FN void a2_shadow_log2(u32 what, u32 it_in, u32 it_c, u32 it_a, const u64 *v, u32 xc, u32 xa, u32 flags, u32 cc,
+                         u32 ca);
 W_FN bool a2_shadow_adopt();
 template <bool PAIR>
 W_FN void a2_rows_shadow(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, const u32 *words, u64 *esc,
@@ -987,12 +988,10 @@ W_FN void a2_rows_shadow(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
     if (hc.big && (w_ballot(hva.vm != hvc.vm) & hc.big)) what |= 4096u;
     if (what) {
         const int l = dx ? w_lowest(dx) : 0;
-        a2_shadow_log(what, it_in, hc.it, ha.it, (what & 4u) ? hc.in : (what & 2u) ? hc.act : hc.fin,
-                      (what & 4u) ? ha.in : (what & 2u) ? ha.act : ha.fin,
-                      ((u64)(u32)hc.best0 << 32) | (u32)ha.best0,
-                      dx ? (((u64)(u32)w_readlane(hvc.vx, l) << 32) | (u32)w_readlane(hva.vx, l)) | 0ull
-                         : (((u64)hc.cells0 << 32) | ha.cells0),
-                      (PAIR ? 1 : 0) | (l << 8) | ((int)(h.split & 0xff) << 16));
+        const u64 v[8] = {hc.act, ha.act, hc.in, ha.in, dx, h.act, hc.fin, ha.fin};
+        a2_shadow_log2(what, it_in, hc.it, ha.it, v, (u32)w_readlane(hvc.vx, l), (u32)w_readlane(hva.vx, l),
+                       (PAIR ? 1u : 0u) | (head ? 2u : 0u) | ((u32)l << 8) | ((u32)(h.split & 0xff) << 16),
+                       hc.cells0, ha.cells0);
     }
     if (a2_shadow_adopt()) {  // (FALCON_AMD_A2_SHADOW=2: go on with the stream's state, as the product does)
         h = ha; hv = hva; rc_k0 = k0a; rc_k1 = k1a;
