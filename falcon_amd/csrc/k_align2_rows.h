@@ -363,7 +363,13 @@ W_FN void a2_rows_asm(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, c
         row0 = PAIR ? (w_popc(h.act & ~h.zone1) == 1 || w_popc(h.act & h.zone1) == 1) : w_popc(h.act) == 1;
     vi x;
     a2_rows_stream<PAIR>(h, hv, rc_k0, rc_k1, rv, words, cells, recs, ring, band, row0 ? h.it + 1u : it_end, x);
-    if (row0) {  // (the caller's loop goes on from here)
+    // The other case the stream gets wrong: two bands laid out with no lane to spare are neighbours,
+    // and when both reach the boundary between the tracks their filter masks merge into one run --
+    // two runs in all, which the stream takes for one hull per track, holes and all.  Both lanes
+    // around the boundary are forbidden to a hull, so such a row always ends its stretch, and
+    // its hulls are made again here.
+    const u64 fence = PAIR ? (3ull << ((h.split - 1) & 63)) : 0ull;
+    if (row0 || (PAIR && (h.in & fence) == fence)) {  // (after a row 0 the caller's loop goes on from here)
         const bool even = ((h.it - 1u) & 1u) == 0u;
         const u64 in = h.in & h.act_row;
         u64 hull;
