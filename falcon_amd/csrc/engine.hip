@@ -711,7 +711,9 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
     static const bool device_pack = getenv("FALCON_AMD_DEVICE_PACK") != nullptr;
     int rc = 0;
     if (device_pack) rc |= b->d_ascii_off.alloc(g);
-    rc |= b->d_words.alloc(b->n_words + 8);
+    // (k_align2 fills its LDS windows with 256 words from wherever a band stands: room behind the
+    // last sequence for a window that begins at its last word)
+    rc |= b->d_words.alloc(b->n_words + 8 + 320);
     rc |= b->d_seq.alloc(g);
     rc |= b->d_pile.alloc(n_pile);
     rc |= b->d_order.alloc(g);

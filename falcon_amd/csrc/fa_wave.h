@@ -86,6 +86,21 @@ W_FN vu w_prefix_add(vu v) {
     return t;
 }
 
+// the minimum over all lanes (signed), wave-uniform: the same six steps, lanes without a source
+// keep their value
+W_FN int w_reduce_min(vi v) {
+    vi t = v;
+    asm volatile("s_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(t));
+    return __builtin_amdgcn_readlane(t, 63);
+}
+
 // The tail of a band row as ONE instruction stream: the inclusive prefix maximum of `key`
 // (as w_prefix_max) with the row's other work in the wait states of its DPP steps, where
 // s_nop would sit otherwise -- a VGPR written by a VALU instruction may be read through DPP

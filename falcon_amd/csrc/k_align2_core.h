@@ -50,7 +50,12 @@
 #define A2_TOP 0x20000000u
 #define A2_CONT 0x80000001u     // ... or: cells 64.. of the row the iteration before began (wide rows)
 #define A2_WIDE_RING 256        // LDS ring of a wide row's V values, per row parity (<= 191 live diagonals)
-#define A2_LDS_WORDS (256 + 2 * A2_WIDE_RING)  // (256 spare words) + the two rings
+// LDS words of a wavefront: four windows of 256 words on the two sequences of the two tracks
+// (k_align2_rows.h), the word bases of the windows behind them -- and, while a track computes
+// its wide rows, the two rings of a2_wide in words 256.. (the windows are filled again then)
+#define A2W_HDR 1024
+#define A2W_INVALID 0xffffffffu
+#define A2_LDS_WORDS (A2W_HDR + 8)
 // Placement policy, measured on the bench workload [MI355X] (scripts/r03_variants.sh +
 // r03_sweep.sh, profiles/r03_policy_sweep.txt; taken while parking and joining still went
 // through the event loop, ~800 instructions a trip -- now ~100 and a call): leaving the pair
@@ -339,6 +344,18 @@ W_FN void a2_result(const A2Args &A, int g, int err, int aligned, int dist, int 
     r.accept = (aligned && r.size > 500 && (double)r.dist / (double)r.size < A.max_diff) ? 1 : 0;  // falcon.c:629
     r.n_ins = n_ins; r.aligned = aligned; r.err = err; r.cells = cells;
     w_store_aln(A.aln + g, r);
+}
+
+// A track's LDS windows (k_align2_rows.h) no longer hold what its rows will read: a new
+// alignment in the track, or the LDS was lent to the wide rows.  (The rows' statement, which
+// the lane emulator runs, reads global memory: nothing to do there.)
+W_FN void a2_win_invalidate(int ti) {
+#if defined(W_ROWS_ASM) && !defined(A2_ROWS_C)
+    u32 *l = w_lds();
+    W_WHERE(3ull) { w_lds_store(l, (vu)(A2W_HDR + 2 * ti) + (vu)w_lane(), (vu)A2W_INVALID); }
+#else
+    (void)ti;
+#endif
 }
 
 // The next alignment of the work queue into `t` (state A2_RUN, no row computed yet); false
@@ -946,6 +963,8 @@ W_FN void a2_rows_c(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, const u32 *words
 struct A2RowsV { vi tdn, tup; vu vcnt; };
 template <bool PAIR>
 W_FN void a2_fold_cells(A2Hot &, vu &) {}
+W_FN void a2_rows_begin(A2RowsV &rv) { rv.tdn = A2_NEG; rv.tup = A2_NEG; rv.vcnt = 0u; }
+W_FN void a2_rows_done(A2RowsV &) {}
 #endif
 
 #if defined(A2_SHADOW)
@@ -968,7 +987,7 @@ W_FN void a2_rows_shadow(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
     rva.vcnt = 0u;
     a2_rows_asm<PAIR>(ha, hva, k0a, k1a, rva, words, cells, recs, ring, band, it_end, head);
     // (a track's row 0 comes back alone: the caller's loop would go on from there)
-    if (head && !ha.ev && ha.it != it_end)
+    while (!ha.ev && ha.it != it_end)  // (... or the rows stopped to have a window filled again)
         a2_rows_asm<PAIR>(ha, hva, k0a, k1a, rva, words, cells, recs, ring, band, it_end, false);
     a2_fold_cells<PAIR>(ha, rva.vcnt);
     u32 what = 0;
@@ -998,7 +1017,8 @@ W_FN void a2_rows_shadow(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
     } else {
         h = hc; hv = hvc; rc_k0 = k0c; rc_k1 = k1c;
     }
-    rv.tdn = rva.tdn; rv.tup = rva.tup;
+    rv = rva;
+    rv.vcnt = 0u;
 }
 #endif
 
@@ -1055,7 +1075,7 @@ W_NOINLINE A2Regs a2_fast(A2Regs r) {
     // with a neighbour parked, every A2_LOOK_EVERY iterations: when the running band has
     // become narrow enough (<= join_at lanes) the loop leaves, for the neighbour to join)
     A2RowsV rv;
-    rv.tdn = A2_NEG; rv.tup = A2_NEG; rv.vcnt = 0u;
+    a2_rows_begin(rv);
     bool head = true;
 #pragma clang loop unroll(disable)
     for (;;) {
@@ -1071,6 +1091,7 @@ W_NOINLINE A2Regs a2_fast(A2Regs r) {
         }
     }
     a2_fold_cells<PAIR>(h, rv.vcnt);
+    a2_rows_done(rv);
     const vi lane = w_lane();
     if (h.big) {
         // the last row had snakes of >= 255 bases: their lengths to the escape list, 255 into
@@ -1423,8 +1444,8 @@ W_FN void a2_wave(const A2Args &A, int slot) {
     w.st_bail_tape = w.st_bail_wide = w.st_bail_esc = 0;
     for (;;) {
         // ---- fill the free tracks
-        if (w.T0.state == A2_IDLE && w.more) { w.more = a2_fetch(A, w.T0); if (w.more) w.st_tracks++; }
-        if (w.T1.state == A2_IDLE && w.more) { w.more = a2_fetch(A, w.T1); if (w.more) w.st_tracks++; }
+        if (w.T0.state == A2_IDLE && w.more) { w.more = a2_fetch(A, w.T0); if (w.more) { w.st_tracks++; a2_win_invalidate(0); } }
+        if (w.T1.state == A2_IDLE && w.more) { w.more = a2_fetch(A, w.T1); if (w.more) { w.st_tracks++; a2_win_invalidate(1); } }
         if (w.T0.state == A2_IDLE && w.T1.state == A2_IDLE) break;
         // (escape entries of tracks long gone: start over when nobody can refer to them, and
         // drop the ones older than every track in flight when the list is half full -- they
@@ -1483,6 +1504,8 @@ W_FN void a2_wave(const A2Args &A, int slot) {
 #endif
             w.st_wide++;
             w.pair = 0;
+            a2_win_invalidate(0);
+            a2_win_invalidate(1);
             if (w.n_esc > A.esc_cap) {
                 if (w.T0.state != A2_IDLE) { a2_hand_back(A, w, w.T0); w.st_bail_esc++; }
                 if (w.T1.state != A2_IDLE) { a2_hand_back(A, w, w.T1); w.st_bail_esc++; }

@@ -38,29 +38,43 @@
 
 // ---- the first 16 bases of a snake: x in %[x], leaves min(matching bases, bases left, 16) in DST
 // TA: the instruction that forms the target address, LIM: the register with L of this row parity
-#define A2R_SNAKE16(TA, LIM, MID)                                  \
-    "v_add_u32 %[qa], %[x], %[cq]\n\t"                             \
+// QA / TA: the instructions that form the query / target address (bases: LDS window or global),
+// LQ / LT: the two loads, W1 / W0: the waits for the first / both, LIM: the register with L of this
+// row parity, MID: what runs in the shadow of the loads
+#define A2R_SNAKE16(...) A2R_SNAKE16_(__VA_ARGS__)
+#define A2R_SNAKE16_(QA, TA, LQ, LT, W1, W0, LIM, MID)             \
+    QA                                                             \
     TA                                                             \
     "v_lshrrev_b32 %[t1], 2, %[qa]\n\t"                            \
     "v_lshrrev_b32 %[t2], 2, %[ta]\n\t"                            \
     "v_and_b32 %[t1], -4, %[t1]\n\t"                               \
     "v_and_b32 %[t2], -4, %[t2]\n\t"                               \
-    "global_load_dwordx2 v[52:53], %[t1], %[words]\n\t"            \
-    "global_load_dwordx2 v[54:55], %[t2], %[words]\n\t"            \
+    LQ                                                             \
+    LT                                                             \
     MID                                                            \
     "v_lshlrev_b32 %[qa], 1, %[qa]\n\t"                            \
     "v_lshlrev_b32 %[ta], 1, %[ta]\n\t"                            \
     "v_sub_u32 %[t1], " LIM ", %[x]\n\t"                           \
-    "s_waitcnt vmcnt(1)\n\t"                                       \
+    W1                                                             \
     "v_alignbit_b32 v52, v53, v52, %[qa]\n\t"                      \
-    "s_waitcnt vmcnt(0)\n\t"                                       \
+    W0                                                             \
     "v_alignbit_b32 v54, v55, v54, %[ta]\n\t"                      \
     "v_xor_b32 v52, v52, v54\n\t"                                  \
     "v_ffbl_b32 v52, v52\n\t"                                      \
     "v_lshrrev_b32 v52, 1, v52\n\t"
 
+// the rows read the two sequences out of the wavefront's LDS windows (a2_win_fill) ...
+#define A2R_QA_LDS "v_add_u32 %[qa], %[x], %[cq]\n\t"
 #define A2R_TA_EVEN "v_add_u32 %[ta], %[x], %[ct]\n\t"
 #define A2R_TA_ODD "v_add3_u32 %[ta], %[x], %[ct], -1\n\t"
+#define A2R_LDS_LOADS "ds_read2_b32 v[52:53], %[t1] offset1:1\n\t", "ds_read2_b32 v[54:55], %[t2] offset1:1\n\t", \
+                      "s_waitcnt lgkmcnt(1)\n\t", "s_waitcnt lgkmcnt(0)\n\t"
+// ... a snake beyond its first 16 bases goes on in global memory (it may leave any window)
+#define A2R_QA_GLB "v_add_u32 %[qa], %[x], %[cqg]\n\t"
+#define A2R_TA_EVEN_GLB "v_add_u32 %[ta], %[x], %[ctg]\n\t"
+#define A2R_TA_ODD_GLB "v_add3_u32 %[ta], %[x], %[ctg], -1\n\t"
+#define A2R_GLB_LOADS "global_load_dwordx2 v[52:53], %[t1], %[words]\n\t", "global_load_dwordx2 v[54:55], %[t2], %[words]\n\t", \
+                      "s_waitcnt vmcnt(1)\n\t", "s_waitcnt vmcnt(0)\n\t"
 
 // ---- best_m and the lanes that pass the band filter, into %[in]
 #define A2R_BEST_PAIR                                              \
@@ -107,7 +121,7 @@
 //   FORB:  the lanes the hull may not reach in this row      SEL: the v_perm selector of byte J
 //   F1 / F2: what fills the wait states of the second and third DPP step (two each)
 //   BEST / HULL / NRUN: pair or single
-#define A2R_ROW(J, DPP, A1, FA, MX, TA, LIM, CK, RD, WR, SH, FORB, SEL, F1, F2, BEST, HULL, NRUN)         \
+#define A2R_ROW(J, DPP, A1, FA, MX, TA, LIM, LW, CK, RD, WR, SH, FORB, SEL, F1, F2, BEST, HULL, NRUN)     \
     ".La2r_r" J "_%=:\n\t"                                                                               \
     DPP                                                                                                  \
     A1                                                                                                   \
@@ -115,7 +129,7 @@
     MX                                                                                                   \
     "s_mov_b64 exec, " RD "\n\t"                                                                         \
     "v_add_u32 %[cnt], 1, %[cnt]\n\t"                                                                    \
-    A2R_SNAKE16(TA, LIM,                                                                                 \
+    A2R_SNAKE16(A2R_QA_LDS, TA, A2R_LDS_LOADS, LIM,                                                      \
                 "v_writelane_b32 %[mlo], vcc_lo, m0\n\t"                                                 \
                 "v_writelane_b32 %[mhi], vcc_hi, m0\n\t")                                                \
     "v_min3_u32 %[vm], v52, %[t1], 16\n\t"                                                               \
@@ -129,7 +143,7 @@
     "s_add_u32 m0, m0, 1\n\t"                                                                            \
     "v_max_i32_dpp %[pm], %[key], %[key] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"          \
     "v_add_u32 %[k2], %[band], %[key]\n\t"                                                               \
-    "v_cmp_ge_i32 %[fin], %[x], " LIM "\n\t"                                                             \
+    "v_cmp_ge_i32 %[fin], %[x], " LW "\n\t"                                                              \
     "v_max_i32_dpp %[pm], %[pm], %[pm] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                         \
     F1                                                                                                   \
     "v_max_i32_dpp %[pm], %[pm], %[pm] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                         \
@@ -157,12 +171,12 @@
 
 // ---- what a row keeps out of line: the snake beyond 16 bases (then: snakes of >= 255 bases end
 // the stretch with this row), the hull of a filter mask with holes
-#define A2R_ROW_FAR(J, TA, LIM, RD, WR, SH, HULL)                                                        \
+#define A2R_ROW_FAR(J, TAG, LIM, RD, WR, SH, HULL)                                                       \
     ".La2r_x" J "_%=:\n\t"                                                                               \
     "s_mov_b64 %[t], vcc\n"                                                                              \
     ".La2r_xl" J "_%=:\n\t"                                                                              \
     "s_mov_b64 exec, %[t]\n\t"                                                                           \
-    A2R_SNAKE16(TA, LIM, "")                                                                             \
+    A2R_SNAKE16(A2R_QA_GLB, TAG, A2R_GLB_LOADS, LIM, "")                                                 \
     "v_min3_u32 v52, v52, %[t1], 16\n\t"                                                                 \
     "v_add_u32 %[x], %[x], v52\n\t"                                                                      \
     "v_add_u32 %[vm], %[vm], v52\n\t"                                                                    \
@@ -188,15 +202,15 @@
             "v_add_u32 %[x], 1, %[tdn]\n\t",                                                             \
             "v_cmp_lt_i32 vcc, %[tdn], %[vx]\n\t",                                                       \
             "v_max_i32 %[x], %[x], %[vx]\n\t",                                                           \
-            A2R_TA_EVEN, "%[le]", "%[cke]", "%[sa]", "%[sb]", "s_lshr_b64", "%[f1]", SEL, F1, F2, BEST, HULL, NRUN)
+            A2R_TA_EVEN, "%[le]", "%[lwe]", "%[cke]", "%[sa]", "%[sb]", "s_lshr_b64", "%[f1]", SEL, F1, F2, BEST, HULL, NRUN)
 #define A2R_ODD(J, SEL, F1, F2, BEST, HULL, NRUN)                                                        \
     A2R_ROW(J, "v_mov_b32_dpp %[tup], %[vx] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t",                  \
             "v_add_u32 %[x], 1, %[vx]\n\t",                                                              \
             "v_cmp_lt_i32 vcc, %[vx], %[tup]\n\t",                                                       \
             "v_max_i32 %[x], %[x], %[tup]\n\t",                                                          \
-            A2R_TA_ODD, "%[lo]", "%[cko]", "%[sb]", "%[sa]", "s_lshl_b64", "%[f0]", SEL, F1, F2, BEST, HULL, NRUN)
-#define A2R_EVEN_FAR(J, HULL) A2R_ROW_FAR(J, A2R_TA_EVEN, "%[le]", "%[sa]", "%[sb]", "s_lshr_b64", HULL)
-#define A2R_ODD_FAR(J, HULL) A2R_ROW_FAR(J, A2R_TA_ODD, "%[lo]", "%[sb]", "%[sa]", "s_lshl_b64", HULL)
+            A2R_TA_ODD, "%[lo]", "%[lwo]", "%[cko]", "%[sb]", "%[sa]", "s_lshl_b64", "%[f0]", SEL, F1, F2, BEST, HULL, NRUN)
+#define A2R_EVEN_FAR(J, HULL) A2R_ROW_FAR(J, A2R_TA_EVEN_GLB, "%[le]", "%[sa]", "%[sb]", "s_lshr_b64", HULL)
+#define A2R_ODD_FAR(J, HULL) A2R_ROW_FAR(J, A2R_TA_ODD_GLB, "%[lo]", "%[sb]", "%[sa]", "s_lshl_b64", HULL)
 
 #define A2R_NOP2 "s_nop 1\n\t"
 // the fourth row of a group: its two fillers send the lanes' cell words to the tape and look
@@ -228,7 +242,7 @@
     "s_branch .La2r_recb_%=\n"
 
 #define A2R_BODY(BEST, HULL, NRUN)                                                                       \
-    "s_nop 1\n\t"                                                                                        \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                           \
     "s_and_b32 m0, %[it], 63\n\t"                                                                        \
     "s_andn2_b32 %[itb], %[it], 63\n\t"                                                                  \
     "s_mov_b64 %[sb], %[sa]\n\t"                                                                         \
@@ -269,11 +283,67 @@ W_FN void a2_fold_cells(A2Hot &h, vu &vcnt) {
     vcnt = 0u;
 }
 
+// ---------------------------------------------------------------------------------------
+// The LDS windows.  A row reads 16 bases of the query and 16 of the target per cell, at
+// positions that creep forward by a base or two per row -- 2 x 64-lane gathers per iteration,
+// and with 32 wavefronts per CU the vector-memory path was what a wavefront waited for (52 % of
+// its cycles parked at the rows' s_waitcnt, profiles/r05_*).  So the stretch of either sequence
+// a track is walking sits in the LDS: per track a window of 4096 query and 4096 target bases
+// (256 words each, A2W_*), filled with one 16-byte read per lane, read by the rows with
+// ds_read2_b32.  A window only ever moves forward (the smallest x and y of a band never
+// decrease).  The rows leave when a cell comes within A2W_MARGIN bases of a window's end -- the
+// same compare that sees a cell reach the end of its sequence, against min(L, the window's
+// limit) -- and the window is filled again from where the band stands.  What may read anywhere
+// -- a snake beyond its first 16 bases, the wide rows -- keeps reading global memory.
+// Word bases of the four windows live in LDS words A2W_HDR.. between two calls of a2_fast (the
+// event loop marks a track's windows invalid when it fetches a new alignment or lets the wide
+// rows use the LDS: a2_win_invalidate).
+// ---------------------------------------------------------------------------------------
+#define A2W_WORDS 256
+#define A2W_MARGIN 128
+static_assert(A2W_HDR >= 4 * A2W_WORDS && A2_LDS_WORDS >= A2W_HDR + 4, "windows, then their header");
+
 // State of the stream that outlives a stretch
 struct A2RowsV {
     vi tdn, tup;   // the previous row shifted one lane up / down; lane 0 / lane 63 hold A2_NEG for good
     vu vcnt;       // cells per lane since the last a2_fold_cells
+    u32 wq0, wt0, wq1, wt1;  // first word (index into words[]) of the windows of track 0 / 1, or A2W_INVALID
 };
+
+W_FN void a2_win_load(A2RowsV &rv) {
+    const u32 *l = w_lds();
+    rv.wq0 = w_uniu(w_lds_bcast(l, A2W_HDR + 0)); rv.wt0 = w_uniu(w_lds_bcast(l, A2W_HDR + 1));
+    rv.wq1 = w_uniu(w_lds_bcast(l, A2W_HDR + 2)); rv.wt1 = w_uniu(w_lds_bcast(l, A2W_HDR + 3));
+}
+W_FN void a2_win_store(const A2RowsV &rv) {
+    u32 *l = w_lds();
+    const vi lane = w_lane();
+    const vu v = w_selu(1ull, w_selu(2ull, w_selu(4ull, (vu)rv.wt1, (vu)rv.wq1), (vu)rv.wt0), (vu)rv.wq0);
+    W_WHERE(0xfull) { w_lds_store(l, (vu)(A2W_HDR + lane), v); }
+}
+
+// Fill the two windows of track TI (its lanes: `zone`) from where its band stands: the smallest
+// x and y of its last row (a track without rows: 0).  `src`: a lane of the zone (its per-lane
+// constants are the track's).
+template <int TI>
+W_FN void a2_win_fill(const u32 *words, const A2HotV &hv, u64 zone, int src, u32 &wq, u32 &wt) {
+    const u64 hull = w_ballot(hv.vx >= 0) & zone;
+    const int xmin = hull ? max(0, w_reduce_min(w_sel(hull, 0x7fffffff, hv.vx))) : 0;
+    // (an odd row has y = x + vnegk - 1, an even one y = x + vnegk: the smaller)
+    const int ymin = hull ? max(0, w_reduce_min(w_sel(hull, 0x7fffffff, hv.vx + hv.vnegk - 1))) : 0;
+    wq = (w_readlaneu(hv.vqb, src) + (u32)xmin) >> 4;
+    wt = (w_readlaneu(hv.vtb, src) + (u32)ymin) >> 4;
+    u32 *l = w_lds();
+    const vu lane4 = (vu)w_lane() << 2;
+    vu a0 = w_load32(words, wq + lane4), a1 = w_load32(words, wq + lane4 + 1u);
+    vu a2 = w_load32(words, wq + lane4 + 2u), a3 = w_load32(words, wq + lane4 + 3u);
+    vu b0 = w_load32(words, wt + lane4), b1 = w_load32(words, wt + lane4 + 1u);
+    vu b2 = w_load32(words, wt + lane4 + 2u), b3 = w_load32(words, wt + lane4 + 3u);
+    const vu at = (vu)(TI * 2 * A2W_WORDS) + lane4;
+    w_lds_store(l, at, a0); w_lds_store(l, at + 1u, a1); w_lds_store(l, at + 2u, a2); w_lds_store(l, at + 3u, a3);
+    w_lds_store(l, at + A2W_WORDS, b0); w_lds_store(l, at + (A2W_WORDS + 1u), b1);
+    w_lds_store(l, at + (A2W_WORDS + 2u), b2); w_lds_store(l, at + (A2W_WORDS + 3u), b3);
+}
 
 // One stretch of rows through the stream: from h.it until a row raises an event or `it_end`.
 // `xrow`: x of every lane after the last row (what hv.vx holds of it inside the hull).
@@ -281,11 +351,33 @@ template <bool PAIR>
 W_FN void a2_rows_stream(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, const u32 *words, u32 *cells,
                          u32 *recs, u32 ring, int band, u32 it_end, vi &xrow) {
     const vi lane = w_lane();
-    // the per-lane constants of the rows (even rows: y = x + vnegk, odd ones: y = x + vnegk - 1)
-    const vu cq = hv.vqb;
-    const vu ct = hv.vtb + (vu)hv.vnegk;
+    // the per-lane constants of the rows (even rows: y = x + vnegk, odd ones: y = x + vnegk - 1):
+    // in global memory the query base of a cell is x + cqg, the target base x + ctg (- 1) ...
+    const vu cqg = hv.vqb;
+    const vu ctg = hv.vtb + (vu)hv.vnegk;
+    // ... in the LDS (as a base index: 16 per word, window w of track t from word (2 t + w) 256 on)
+    // x + cq and x + ct (- 1); xq / xt: the x from which on a window's end is nearer than the margin
+    const bool t0 = PAIR || h.kb0 != A2_INVALID;   // (a track running alone plays track 0, whichever it is)
+    const u32 aq0 = 16u * (0u * A2W_WORDS - rv.wq0), at0 = 16u * (1u * A2W_WORDS - rv.wt0);
+    const u32 aq1 = 16u * (2u * A2W_WORDS - rv.wq1), at1 = 16u * (3u * A2W_WORDS - rv.wt1);
+    vu cq, ct;
+    vi xq, xt;
+    const int room = 16 * A2W_WORDS - A2W_MARGIN;
+    if (PAIR) {
+        cq = cqg + w_selu(h.zone1, aq0, aq1);
+        ct = ctg + w_selu(h.zone1, at0, at1);
+        xq = (vi)w_selu(h.zone1, (u32)room, (u32)(room + 32 * A2W_WORDS)) - (vi)cq;
+        xt = (vi)w_selu(h.zone1, (u32)(room + 16 * A2W_WORDS), (u32)(room + 48 * A2W_WORDS)) - (vi)ct;
+    } else {
+        cq = cqg + (t0 ? aq0 : aq1);
+        ct = ctg + (t0 ? at0 : at1);
+        xq = (t0 ? room : room + 32 * A2W_WORDS) - (vi)cq;
+        xt = (t0 ? room + 16 * A2W_WORDS : room + 48 * A2W_WORDS) - (vi)ct;
+    }
     const vi tn = hv.vtlen - hv.vnegk;
     const vi le = w_min(hv.vqlen, tn), lo = w_min(hv.vqlen, tn + 1);
+    const vi xw = w_min(xq, xt);
+    const vi lwe = w_min(le, xw), lwo = w_min(lo, xw);
     const vu cke = (vu)hv.vnegk + hv.vtop, cko = cke - 1u;
     const vu l4 = (vu)lane << 2;
     const vi neg = A2_NEG;
@@ -307,8 +399,8 @@ W_FN void a2_rows_stream(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
                        [coff] "+s"(coff), [roff] "+s"(roff),
                        [sb] "=&s"(sb), [in] "=&s"(in), [fin] "=&s"(fin), [big] "=&s"(big), [t] "=&s"(t),
                        [c1] "=&s"(c1), [u] "=&s"(u), [p0] "=&s"(p0), [p1] "=&s"(p1), [itb] "=&s"(itb)
-                     : [cq] "v"(cq), [ct] "v"(ct), [le] "v"(le), [lo] "v"(lo), [cke] "v"(cke), [cko] "v"(cko),
-                       [l4] "v"(l4), [neg] "v"(neg),
+                     : [cq] "v"(cq), [ct] "v"(ct), [cqg] "v"(cqg), [ctg] "v"(ctg), [le] "v"(le), [lo] "v"(lo),
+                       [lwe] "v"(lwe), [lwo] "v"(lwo), [cke] "v"(cke), [cko] "v"(cko), [l4] "v"(l4), [neg] "v"(neg),
                        [z1] "s"(h.zone1), [f0] "s"(h.forbid_to0), [f1] "s"(h.forbid_to1), [band] "s"(band),
                        [ln0] "s"(ln0), [words] "s"(words), [cells] "s"(cells), [recs] "s"(recs),
                        [cmaskb] "s"(cmaskb), [rmaskb] "s"(rmaskb), [kb0] "s"(h.kb0), [kb1] "s"(h.kb1),
@@ -325,8 +417,8 @@ W_FN void a2_rows_stream(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
                        [coff] "+s"(coff), [roff] "+s"(roff),
                        [sb] "=&s"(sb), [in] "=&s"(in), [fin] "=&s"(fin), [big] "=&s"(big), [t] "=&s"(t),
                        [c1] "=&s"(c1), [p0] "=&s"(p0), [p1] "=&s"(p1), [itb] "=&s"(itb)
-                     : [cq] "v"(cq), [ct] "v"(ct), [le] "v"(le), [lo] "v"(lo), [cke] "v"(cke), [cko] "v"(cko),
-                       [l4] "v"(l4), [neg] "v"(neg),
+                     : [cq] "v"(cq), [ct] "v"(ct), [cqg] "v"(cqg), [ctg] "v"(ctg), [le] "v"(le), [lo] "v"(lo),
+                       [lwe] "v"(lwe), [lwo] "v"(lwo), [cke] "v"(cke), [cko] "v"(cko), [l4] "v"(l4), [neg] "v"(neg),
                        [f0] "s"(h.forbid_to0), [f1] "s"(h.forbid_to1), [band] "s"(band),
                        [words] "s"(words), [cells] "s"(cells), [recs] "s"(recs),
                        [cmaskb] "s"(cmaskb), [rmaskb] "s"(rmaskb), [kb0] "s"(h.kb0), [kb1] "s"(h.kb1),
@@ -341,10 +433,25 @@ W_FN void a2_rows_stream(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
     h.it = it;
     h.act = last_even ? sb : sa;
     h.act_row = last_even ? sa : sb;
-    h.in = in; h.fin = fin; h.big = big;
+    h.in = in; h.big = big;
     h.best0 = (int)b0;
     if (PAIR) h.best1 = (int)b1;
-    h.ev = fin | big | (in & (last_even ? h.forbid_to1 : h.forbid_to0));
+    // `fin`: the cells at x >= min(L, a window's limit).  The ones at x >= L reached an end of a
+    // sequence; a track with any of the others has its windows filled again before its next row.
+    const u64 ended = w_ballot((vi)x >= (last_even ? le : lo)) & fin;
+    const u64 moved = fin & ~ended;
+    if (moved) {
+        if (PAIR) {
+            if (moved & ~h.zone1) rv.wq0 = A2W_INVALID;
+            if (moved & h.zone1) rv.wq1 = A2W_INVALID;
+        } else if (t0) {
+            rv.wq0 = A2W_INVALID;
+        } else {
+            rv.wq1 = A2W_INVALID;
+        }
+    }
+    h.fin = ended;
+    h.ev = ended | big | (in & (last_even ? h.forbid_to1 : h.forbid_to0));
     hv.vm = vm;
     xrow = (vi)x;
 }
@@ -359,8 +466,18 @@ template <bool PAIR>
 W_FN void a2_rows_asm(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, const u32 *words, u32 *cells,
                       u32 *recs, u32 ring, int band, u32 it_end, bool head) {
     bool row0 = false;
-    if (head)
+    if (head) {
         row0 = PAIR ? (w_popc(h.act & ~h.zone1) == 1 || w_popc(h.act & h.zone1) == 1) : w_popc(h.act) == 1;
+    }
+    // the windows of the tracks that run
+    if (PAIR) {
+        if (rv.wq0 == A2W_INVALID) a2_win_fill<0>(words, hv, ~h.zone1, 0, rv.wq0, rv.wt0);
+        if (rv.wq1 == A2W_INVALID) a2_win_fill<1>(words, hv, h.zone1, 63, rv.wq1, rv.wt1);
+    } else if (h.kb0 != A2_INVALID) {
+        if (rv.wq0 == A2W_INVALID) a2_win_fill<0>(words, hv, ~0ull, 0, rv.wq0, rv.wt0);
+    } else {
+        if (rv.wq1 == A2W_INVALID) a2_win_fill<1>(words, hv, ~0ull, 0, rv.wq1, rv.wt1);
+    }
     vi x;
     a2_rows_stream<PAIR>(h, hv, rc_k0, rc_k1, rv, words, cells, recs, ring, band, row0 ? h.it + 1u : it_end, x);
     // The other case the stream gets wrong: two bands laid out with no lane to spare are neighbours,
@@ -386,3 +503,10 @@ W_FN void a2_rows_asm(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, c
         h.ev = h.fin | h.big | (in & (even ? h.forbid_to1 : h.forbid_to0));
     }
 }
+
+// the beginning and the end of a call of a2_fast: the windows' word bases from and back to the LDS
+W_FN void a2_rows_begin(A2RowsV &rv) {
+    rv.tdn = A2_NEG; rv.tup = A2_NEG; rv.vcnt = 0u;
+    a2_win_load(rv);
+}
+W_FN void a2_rows_done(A2RowsV &rv) { a2_win_store(rv); }

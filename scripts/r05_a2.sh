@@ -8,7 +8,7 @@ TAG=${1:-r05a}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
-( FALCON_AMD_A2_SHADOW=1 timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -s -k "align_golden_one_launch or synthetic_piles_vs_oracle" 2>&1 | grep -v "^$" | tail -60 ) > $O/shadow.txt; cat $O/shadow.txt
+for m in 1 2; do ( FALCON_AMD_A2_SHADOW=$m timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -s -k "align_golden_one_launch or synthetic_piles_vs_oracle or piles_golden_one_batch or ecoli_scale or every_hand_back" 2>&1 | grep -v "^$" | tail -40 ) > $O/shadow$m.txt; cat $O/shadow$m.txt; done
 if [ "$2" = "full" ]; then
   ( timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 ) > $O/pytest_gpu.txt
 else
