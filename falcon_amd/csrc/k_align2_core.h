@@ -707,6 +707,9 @@ W_FN void a2_bounds(A2Hot &h) {
 template <bool PAIR>
 W_FN bool a2_replace(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, const A2TrackConst &tc) {
     if (h.fin | h.big) return false;
+#ifdef A2_HOOK_REPLACE
+    A2_HOOK_REPLACE(PAIR, h);
+#endif
     const vi lane = w_lane();
     const u64 ahead = ~0ull << (h.it & 63u);  // the tape from this iteration on
     const int down = (int)(h.it & 1u);        // the next row is an odd one: its band starts a lane below the hull

@@ -121,7 +121,7 @@
 //   FORB:  the lanes the hull may not reach in this row      SEL: the v_perm selector of byte J
 //   F1 / F2: what fills the wait states of the second and third DPP step (two each)
 //   BEST / HULL / NRUN: pair or single
-#define A2R_ROW(J, DPP, A1, FA, MX, TA, LIM, LW, CK, RD, WR, SH, FORB, SEL, F1, F2, BEST, HULL, NRUN)     \
+#define A2R_ROW(J, DPP, A1, FA, MX, TA, LIM, LW, CK, RD, WR, SH, FORB, OUT, SEL, F1, F2, BEST, HULL, NRUN) \
     ".La2r_r" J "_%=:\n\t"                                                                               \
     DPP                                                                                                  \
     A1                                                                                                   \
@@ -165,9 +165,9 @@
     ".La2r_h" J "_%=:\n\t"                                                                               \
     "s_and_b64 %[t], %[in], " FORB "\n\t"                                                                \
     "s_or_b64 %[t], %[t], %[fin]\n\t"                                                                    \
-    "s_cbranch_scc1 .La2r_out_%=\n\t"                                                                    \
+    "s_cbranch_scc1 " OUT "\n\t"                                                                         \
     "s_sub_u32 %[rem], %[rem], 1\n\t"                                                                    \
-    "s_cbranch_scc1 .La2r_out_%=\n\t"
+    "s_cbranch_scc1 " OUT "\n\t"
 
 // ---- what a row keeps out of line: the snake beyond 16 bases (then: snakes of >= 255 bases end
 // the stretch with this row), the hull of a filter mask with holes
@@ -202,13 +202,13 @@
             "v_add_u32 %[x], 1, %[tdn]\n\t",                                                             \
             "v_cmp_lt_i32 vcc, %[tdn], %[vx]\n\t",                                                       \
             "v_max_i32 %[x], %[x], %[vx]\n\t",                                                           \
-            A2R_TA_EVEN, "%[le]", "%[lwe]", "%[cke]", "%[sa]", "%[sb]", "s_lshr_b64", "%[f1]", SEL, F1, F2, BEST, HULL, NRUN)
+            A2R_TA_EVEN, "%[le]", "%[lwe]", "%[cke]", "%[sa]", "%[sb]", "s_lshr_b64", "%[f1]", ".La2r_oute_%=", SEL, F1, F2, BEST, HULL, NRUN)
 #define A2R_ODD(J, SEL, F1, F2, BEST, HULL, NRUN)                                                        \
     A2R_ROW(J, "v_mov_b32_dpp %[tup], %[vx] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t",                  \
             "v_add_u32 %[x], 1, %[vx]\n\t",                                                              \
             "v_cmp_lt_i32 vcc, %[vx], %[tup]\n\t",                                                       \
             "v_max_i32 %[x], %[x], %[tup]\n\t",                                                          \
-            A2R_TA_ODD, "%[lo]", "%[lwo]", "%[cko]", "%[sb]", "%[sa]", "s_lshl_b64", "%[f0]", SEL, F1, F2, BEST, HULL, NRUN)
+            A2R_TA_ODD, "%[lo]", "%[lwo]", "%[cko]", "%[sb]", "%[sa]", "s_lshl_b64", "%[f0]", ".La2r_outo_%=", SEL, F1, F2, BEST, HULL, NRUN)
 #define A2R_EVEN_FAR(J, HULL) A2R_ROW_FAR(J, A2R_TA_EVEN_GLB, "%[le]", "%[sa]", "%[sb]", "s_lshr_b64", HULL)
 #define A2R_ODD_FAR(J, HULL) A2R_ROW_FAR(J, A2R_TA_ODD_GLB, "%[lo]", "%[sb]", "%[sa]", "s_lshl_b64", HULL)
 
@@ -264,6 +264,12 @@
     A2R_EVEN_FAR("2", HULL)                                                                              \
     A2R_ODD_FAR("3", HULL)                                                                               \
     A2R_REC                                                                                              \
+    ".La2r_oute_%=:\n\t"                                                                                 \
+    "s_mov_b64 %[orow], %[sa]\n\t"                                                                       \
+    "s_mov_b64 %[sa], %[sb]\n\t"                                                                         \
+    "s_branch .La2r_out_%=\n"                                                                            \
+    ".La2r_outo_%=:\n\t"                                                                                 \
+    "s_mov_b64 %[orow], %[sb]\n"                                                                         \
     ".La2r_out_%=:\n\t"                                                                                  \
     "s_add_u32 %[it], %[itb], m0\n\t"
 
@@ -381,7 +387,7 @@ W_FN void a2_rows_stream(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
     const vu cke = (vu)hv.vnegk + hv.vtop, cko = cke - 1u;
     const vu l4 = (vu)lane << 2;
     const vi neg = A2_NEG;
-    u64 sa = h.act, sb, in, fin, big, t, c1, u;
+    u64 sa = h.act, sb, in, fin, big, t, c1, u, orow;
     u32 b0 = (u32)h.best0, b1 = (u32)h.best1;
     u32 rem = it_end - h.it - 1u, it = h.it, itb, p0, p1;
     u32 coff = ((it >> 2) & ((ring >> 2) - 1u)) << 8;            // byte offset of the current group of 4's cell words
@@ -398,7 +404,7 @@ W_FN void a2_rows_stream(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
                        [sa] "+s"(sa), [b0] "+s"(b0), [b1] "+s"(b1), [rem] "+s"(rem), [it] "+s"(it),
                        [coff] "+s"(coff), [roff] "+s"(roff),
                        [sb] "=&s"(sb), [in] "=&s"(in), [fin] "=&s"(fin), [big] "=&s"(big), [t] "=&s"(t),
-                       [c1] "=&s"(c1), [u] "=&s"(u), [p0] "=&s"(p0), [p1] "=&s"(p1), [itb] "=&s"(itb)
+                       [c1] "=&s"(c1), [u] "=&s"(u), [p0] "=&s"(p0), [p1] "=&s"(p1), [itb] "=&s"(itb), [orow] "=&s"(orow)
                      : [cq] "v"(cq), [ct] "v"(ct), [cqg] "v"(cqg), [ctg] "v"(ctg), [le] "v"(le), [lo] "v"(lo),
                        [lwe] "v"(lwe), [lwo] "v"(lwo), [cke] "v"(cke), [cko] "v"(cko), [l4] "v"(l4), [neg] "v"(neg),
                        [z1] "s"(h.zone1), [f0] "s"(h.forbid_to0), [f1] "s"(h.forbid_to1), [band] "s"(band),
@@ -416,7 +422,7 @@ W_FN void a2_rows_stream(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
                        [sa] "+s"(sa), [b0] "+s"(b0), [rem] "+s"(rem), [it] "+s"(it),
                        [coff] "+s"(coff), [roff] "+s"(roff),
                        [sb] "=&s"(sb), [in] "=&s"(in), [fin] "=&s"(fin), [big] "=&s"(big), [t] "=&s"(t),
-                       [c1] "=&s"(c1), [p0] "=&s"(p0), [p1] "=&s"(p1), [itb] "=&s"(itb)
+                       [c1] "=&s"(c1), [p0] "=&s"(p0), [p1] "=&s"(p1), [itb] "=&s"(itb), [orow] "=&s"(orow)
                      : [cq] "v"(cq), [ct] "v"(ct), [cqg] "v"(cqg), [ctg] "v"(ctg), [le] "v"(le), [lo] "v"(lo),
                        [lwe] "v"(lwe), [lwo] "v"(lwo), [cke] "v"(cke), [cko] "v"(cko), [l4] "v"(l4), [neg] "v"(neg),
                        [f0] "s"(h.forbid_to0), [f1] "s"(h.forbid_to1), [band] "s"(band),
@@ -427,31 +433,37 @@ W_FN void a2_rows_stream(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
                      : "vcc", "scc", "memory", "v52", "v53", "v54", "v55");
         (void)u; (void)b1; (void)ln0;
     }
-    // what the stream hands back: the last row was an even one (it read `sa`, wrote `sb`) or an
-    // odd one (the other way round)
-    const bool last_even = ((it - 1u) & 1u) == 0u;
+    // What the stream hands back: `sa` the lanes of the next row, `orow` those of the last one
+    // (the exits put them there, whichever way the two mask registers stood); `t`: the band hull
+    // on a forbidden lane, or a cell at x >= min(L, a window's limit).
     h.it = it;
-    h.act = last_even ? sb : sa;
-    h.act_row = last_even ? sa : sb;
+    h.act = sa;
+    h.act_row = orow;
     h.in = in; h.big = big;
     h.best0 = (int)b0;
     if (PAIR) h.best1 = (int)b1;
-    // `fin`: the cells at x >= min(L, a window's limit).  The ones at x >= L reached an end of a
-    // sequence; a track with any of the others has its windows filled again before its next row.
-    const u64 ended = w_ballot((vi)x >= (last_even ? le : lo)) & fin;
-    const u64 moved = fin & ~ended;
-    if (moved) {
-        if (PAIR) {
-            if (moved & ~h.zone1) rv.wq0 = A2W_INVALID;
-            if (moved & h.zone1) rv.wq1 = A2W_INVALID;
-        } else if (t0) {
-            rv.wq0 = A2W_INVALID;
-        } else {
-            rv.wq1 = A2W_INVALID;
+    if (fin == 0ull) {
+        h.fin = 0ull;
+        h.ev = t | big;
+    } else {
+        // The cells at x >= L reached an end of a sequence; a track with any of the others has
+        // its windows filled again before its next row.
+        const bool last_even = ((it - 1u) & 1u) == 0u;
+        const u64 ended = w_ballot((vi)x >= (last_even ? le : lo)) & fin;
+        const u64 moved = fin & ~ended;
+        if (moved) {
+            if (PAIR) {
+                if (moved & ~h.zone1) rv.wq0 = A2W_INVALID;
+                if (moved & h.zone1) rv.wq1 = A2W_INVALID;
+            } else if (t0) {
+                rv.wq0 = A2W_INVALID;
+            } else {
+                rv.wq1 = A2W_INVALID;
+            }
         }
+        h.fin = ended;
+        h.ev = ended | big | (in & (last_even ? h.forbid_to1 : h.forbid_to0));
     }
-    h.fin = ended;
-    h.ev = ended | big | (in & (last_even ? h.forbid_to1 : h.forbid_to0));
     hv.vm = vm;
     xrow = (vi)x;
 }
