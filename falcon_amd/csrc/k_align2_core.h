@@ -988,11 +988,10 @@ W_FN void a2_rows_shadow(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
     vu k0a = rc_k0, k1a = rc_k1;
     A2RowsV rva = rv;
     rva.vcnt = 0u;
-    // (the stream with its own re-centring of the bands switched off: the statement has none)
-    a2_rows_asm<PAIR>(ha, hva, k0a, k1a, rva, words, cells, recs, ring, band, it_end, head, false);
+    a2_rows_asm<PAIR>(ha, hva, k0a, k1a, rva, words, cells, recs, ring, band, it_end, head);
     // (a track's row 0 comes back alone: the caller's loop would go on from there)
     while (!ha.ev && ha.it != it_end)  // (... or the rows stopped to have a window filled again)
-        a2_rows_asm<PAIR>(ha, hva, k0a, k1a, rva, words, cells, recs, ring, band, it_end, false, false);
+        a2_rows_asm<PAIR>(ha, hva, k0a, k1a, rva, words, cells, recs, ring, band, it_end, false);
     a2_fold_cells<PAIR>(ha, rva.vcnt);
     u32 what = 0;
     if (ha.it != hc.it) what |= 1u;

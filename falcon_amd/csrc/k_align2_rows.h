@@ -165,14 +165,13 @@
     ".La2r_h" J "_%=:\n\t"                                                                               \
     "s_and_b64 %[t], %[in], " FORB "\n\t"                                                                \
     "s_or_b64 %[t], %[t], %[fin]\n\t"                                                                    \
-    "s_cbranch_scc1 .La2r_e" J "_%=\n"                                                                   \
-    ".La2r_n" J "_%=:\n\t"                                                                               \
+    "s_cbranch_scc1 " OUT "\n\t"                                                                         \
     "s_sub_u32 %[rem], %[rem], 1\n\t"                                                                    \
     "s_cbranch_scc1 " OUT "\n\t"
 
 // ---- what a row keeps out of line: the snake beyond 16 bases (then: snakes of >= 255 bases end
 // the stretch with this row), the hull of a filter mask with holes
-#define A2R_ROW_FAR(J, TAG, LIM, RD, WR, SH, HULL, RECENTRE)                                             \
+#define A2R_ROW_FAR(J, TAG, LIM, RD, WR, SH, HULL)                                                       \
     ".La2r_x" J "_%=:\n\t"                                                                               \
     "s_mov_b64 %[t], vcc\n"                                                                              \
     ".La2r_xl" J "_%=:\n\t"                                                                              \
@@ -196,8 +195,7 @@
     "v_cndmask_b32 %[vx], %[neg], %[x], %[c1]\n\t"                                                       \
     SH " %[t], %[c1], 1\n\t"                                                                             \
     "s_or_b64 " WR ", %[c1], %[t]\n\t"                                                                   \
-    "s_branch .La2r_h" J "_%=\n"                                                                         \
-    RECENTRE
+    "s_branch .La2r_h" J "_%=\n"
 
 #define A2R_EVEN(J, SEL, F1, F2, BEST, HULL, NRUN)                                                       \
     A2R_ROW(J, "v_mov_b32_dpp %[tdn], %[vx] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t",                  \
@@ -211,141 +209,8 @@
             "v_cmp_lt_i32 vcc, %[vx], %[tup]\n\t",                                                       \
             "v_max_i32 %[x], %[x], %[tup]\n\t",                                                          \
             A2R_TA_ODD, "%[lo]", "%[lwo]", "%[cko]", "%[sb]", "%[sa]", "s_lshl_b64", "%[f0]", ".La2r_outo_%=", SEL, F1, F2, BEST, HULL, NRUN)
-#define A2R_EVEN_FAR(J, HULL, RC) A2R_ROW_FAR(J, A2R_TA_EVEN_GLB, "%[le]", "%[sa]", "%[sb]", "s_lshr_b64", HULL, \
-                                             RC(J, "1", "s_sub_i32 %[sh0], %[sh0], 1\n\t", "s_sub_i32 %[sh1], %[sh1], 1\n\t", "%[sb]", ".La2r_oute_%="))
-#define A2R_ODD_FAR(J, HULL, RC) A2R_ROW_FAR(J, A2R_TA_ODD_GLB, "%[lo]", "%[sb]", "%[sa]", "s_lshl_b64", HULL, \
-                                            RC(J, "0", "", "", "%[sa]", ".La2r_outo_%="))
-
-// ---- A band hull on a forbidden lane, nothing else the matter: the bands are moved back to the
-// middle of their tracks' lanes without leaving the stream (a2_replace lays BOTH out afresh and
-// moves the boundary between them: that is the caller's, when a band no longer fits its share).
-// DOWN: the next row is an odd one (its band begins a lane below the hull); D0 / D1: the
-// instructions that take DOWN off the two shifts; WR: the mask register of the next row's lanes.
-// Out: the rows and every per-lane constant that depends on a lane's diagonal in their new lanes,
-// `in` = the hulls there, the K fields of the tape from this iteration on, the shifts added to
-// cs0 / cs1 for the caller's own copy of the lanes' diagonals.
-#define A2R_SHIFT_CONSTS                                                                                 \
-    "v_lshlrev_b32 %[t1], 1, %[t1]\n\t"                                                                  \
-    "v_sub_u32 %[ct], %[ct], %[t1]\n\t"                                                                  \
-    "v_sub_u32 %[ctg], %[ctg], %[t1]\n\t"                                                                \
-    "v_sub_u32 %[cke], %[cke], %[t1]\n\t"                                                                \
-    "v_sub_u32 %[cko], %[cko], %[t1]\n\t"                                                                \
-    "v_add_u32 %[tn], %[tn], %[t1]\n\t"                                                                  \
-    "v_add_u32 %[xt], %[xt], %[t1]\n\t"                                                                  \
-    "v_add_u32 %[qa], 1, %[tn]\n\t"                                                                      \
-    "v_min_i32 %[ta], %[xq], %[xt]\n\t"                                                                  \
-    "v_min_i32 %[le], %[vqlen], %[tn]\n\t"                                                               \
-    "v_min_i32 %[lo], %[vqlen], %[qa]\n\t"                                                               \
-    "v_min3_i32 %[lwe], %[vqlen], %[tn], %[ta]\n\t"                                                      \
-    "v_min3_i32 %[lwo], %[vqlen], %[qa], %[ta]\n\t"
-#define A2R_RECENTRE_PAIR(J, DOWN, D0, D1, WR, OUT)                                                      \
-    ".La2r_e" J "_%=:\n\t"                                                                               \
-    "s_cmp_lg_u64 %[fin], 0\n\t"                                                                         \
-    "s_cbranch_scc1 " OUT "\n\t"                                                                         \
-    "s_cmp_eq_u32 %[rcok], 0\n\t"                                                                        \
-    "s_cbranch_scc1 " OUT "\n\t"                                                                         \
-    "s_and_b64 %[c1], %[in], %[fn]\n\t"                                                                  \
-    "s_cmp_eq_u64 %[c1], %[fn]\n\t"                                                                      \
-    "s_cbranch_scc1 " OUT "\n\t"                                                                         \
-    "s_andn2_b64 %[c1], %[in], %[z1]\n\t"                                                                \
-    "s_ff1_i32_b64 %[p0], %[c1]\n\t"                                                                     \
-    "s_flbit_i32_b64 %[p1], %[c1]\n\t"                                                                   \
-    "s_add_i32 %[p1], %[p1], %[p0]\n\t"                                                                  \
-    "s_sub_i32 %[n0], 65, %[p1]\n\t"                                                                     \
-    "s_sub_i32 %[nl0], %[split], %[n0]\n\t"                                                              \
-    "s_cmp_lt_i32 %[nl0], 2\n\t"                                                                         \
-    "s_cbranch_scc1 " OUT "\n\t"                                                                         \
-    "s_lshr_b32 %[nl0], %[nl0], 1\n\t"                                                                   \
-    "s_sub_i32 %[sh0], %[p0], %[nl0]\n\t"                                                                \
-    D0                                                                                                   \
-    "s_and_b64 %[c1], %[in], %[z1]\n\t"                                                                  \
-    "s_ff1_i32_b64 %[p0], %[c1]\n\t"                                                                     \
-    "s_flbit_i32_b64 %[p1], %[c1]\n\t"                                                                   \
-    "s_add_i32 %[p1], %[p1], %[p0]\n\t"                                                                  \
-    "s_sub_i32 %[n1], 65, %[p1]\n\t"                                                                     \
-    "s_sub_i32 %[nl1], %[s64], %[n1]\n\t"                                                                \
-    "s_cmp_lt_i32 %[nl1], 2\n\t"                                                                         \
-    "s_cbranch_scc1 " OUT "\n\t"                                                                         \
-    "s_lshr_b32 %[nl1], %[nl1], 1\n\t"                                                                   \
-    "s_add_i32 %[nl1], %[nl1], %[split]\n\t"                                                             \
-    "s_sub_i32 %[sh1], %[p0], %[nl1]\n\t"                                                                \
-    D1                                                                                                   \
-    "s_sub_i32 %[p0], %[n0], 1\n\t"                                                                      \
-    "s_add_i32 %[p1], %[nl0], " DOWN "\n\t"                                                              \
-    "s_bfm_b64 %[in], %[p0], %[p1]\n\t"                                                                  \
-    "s_sub_i32 %[p0], %[n1], 1\n\t"                                                                      \
-    "s_add_i32 %[p1], %[nl1], " DOWN "\n\t"                                                              \
-    "s_bfm_b64 %[c1], %[p0], %[p1]\n\t"                                                                  \
-    "s_or_b64 %[in], %[in], %[c1]\n\t"                                                                   \
-    "s_bfm_b64 %[t], %[n0], %[nl0]\n\t"                                                                  \
-    "s_bfm_b64 %[c1], %[n1], %[nl1]\n\t"                                                                 \
-    "s_or_b64 " WR ", %[t], %[c1]\n\t"                                                                   \
-    "v_mov_b32 %[t1], %[sh0]\n\t"                                                                        \
-    "v_mov_b32 %[t2], %[sh1]\n\t"                                                                        \
-    "v_cndmask_b32 %[t1], %[t1], %[t2], %[z1]\n\t"                                                       \
-    "v_lshl_add_u32 %[t2], %[t1], 2, %[l4]\n\t"                                                          \
-    "v_and_b32 %[t2], 0xfc, %[t2]\n\t"                                                                   \
-    "ds_bpermute_b32 %[x], %[t2], %[vx]\n\t"                                                             \
-    A2R_SHIFT_CONSTS                                                                                     \
-    "s_lshl1_add_u32 %[kb0], %[sh0], %[kb0]\n\t"                                                         \
-    "s_lshl1_add_u32 %[kb1], %[sh1], %[kb1]\n\t"                                                         \
-    "s_lshl_b64 %[c1], -1, m0\n\t"                                                                       \
-    "v_mov_b32 %[t2], %[kb0]\n\t"                                                                        \
-    "v_cndmask_b32 %[k0], %[k0], %[t2], %[c1]\n\t"                                                       \
-    "v_mov_b32 %[t2], %[kb1]\n\t"                                                                        \
-    "v_cndmask_b32 %[k1], %[k1], %[t2], %[c1]\n\t"                                                       \
-    "s_add_i32 %[cs0], %[cs0], %[sh0]\n\t"                                                               \
-    "s_add_i32 %[cs1], %[cs1], %[sh1]\n\t"                                                               \
-    "s_add_u32 %[nrep], %[nrep], 1\n\t"                                                                  \
-    "s_mov_b64 %[t], 0\n\t"                                                                              \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                           \
-    "v_cndmask_b32 %[vx], %[neg], %[x], %[in]\n\t"                                                       \
-    "s_branch .La2r_n" J "_%=\n"
-// (one track alone: back to the middle of the wave, as a2_replace<false> does; its K field is the
-// one that holds a diagonal)
-#define A2R_RECENTRE_SINGLE(J, DOWN, D0, D1, WR, OUT)                                                    \
-    ".La2r_e" J "_%=:\n\t"                                                                               \
-    "s_cmp_lg_u64 %[fin], 0\n\t"                                                                         \
-    "s_cbranch_scc1 " OUT "\n\t"                                                                         \
-    "s_cmp_eq_u32 %[rcok], 0\n\t"                                                                        \
-    "s_cbranch_scc1 " OUT "\n\t"                                                                         \
-    "s_ff1_i32_b64 %[p0], %[in]\n\t"                                                                     \
-    "s_flbit_i32_b64 %[p1], %[in]\n\t"                                                                   \
-    "s_add_i32 %[p1], %[p1], %[p0]\n\t"                                                                  \
-    "s_sub_i32 %[n0], 65, %[p1]\n\t"                                                                     \
-    "s_cmp_gt_i32 %[n0], 60\n\t"                                                                         \
-    "s_cbranch_scc1 " OUT "\n\t"                                                                         \
-    "s_sub_i32 %[nl0], 64, %[n0]\n\t"                                                                    \
-    "s_lshr_b32 %[nl0], %[nl0], 1\n\t"                                                                   \
-    "s_sub_i32 %[sh0], %[p0], %[nl0]\n\t"                                                                \
-    D0                                                                                                   \
-    "s_sub_i32 %[p0], %[n0], 1\n\t"                                                                      \
-    "s_add_i32 %[p1], %[nl0], " DOWN "\n\t"                                                              \
-    "s_bfm_b64 %[in], %[p0], %[p1]\n\t"                                                                  \
-    "s_bfm_b64 " WR ", %[n0], %[nl0]\n\t"                                                                \
-    "v_mov_b32 %[t1], %[sh0]\n\t"                                                                        \
-    "v_lshl_add_u32 %[t2], %[t1], 2, %[l4]\n\t"                                                          \
-    "v_and_b32 %[t2], 0xfc, %[t2]\n\t"                                                                   \
-    "ds_bpermute_b32 %[x], %[t2], %[vx]\n\t"                                                             \
-    A2R_SHIFT_CONSTS                                                                                     \
-    "s_lshl_b64 %[c1], -1, m0\n\t"                                                                       \
-    "s_cmp_eq_u32 %[kb0], 0x80000000\n\t"                                                                \
-    "s_cbranch_scc1 .La2r_ek" J "_%=\n\t"                                                                \
-    "s_lshl1_add_u32 %[kb0], %[sh0], %[kb0]\n\t"                                                         \
-    "v_mov_b32 %[t2], %[kb0]\n\t"                                                                        \
-    "v_cndmask_b32 %[k0], %[k0], %[t2], %[c1]\n\t"                                                       \
-    "s_branch .La2r_ej" J "_%=\n"                                                                        \
-    ".La2r_ek" J "_%=:\n\t"                                                                              \
-    "s_lshl1_add_u32 %[kb1], %[sh0], %[kb1]\n\t"                                                         \
-    "v_mov_b32 %[t2], %[kb1]\n\t"                                                                        \
-    "v_cndmask_b32 %[k1], %[k1], %[t2], %[c1]\n"                                                         \
-    ".La2r_ej" J "_%=:\n\t"                                                                              \
-    "s_add_i32 %[cs0], %[cs0], %[sh0]\n\t"                                                               \
-    "s_add_u32 %[nrep], %[nrep], 1\n\t"                                                                  \
-    "s_mov_b64 %[t], 0\n\t"                                                                              \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                           \
-    "v_cndmask_b32 %[vx], %[neg], %[x], %[in]\n\t"                                                       \
-    "s_branch .La2r_n" J "_%=\n"
+#define A2R_EVEN_FAR(J, HULL) A2R_ROW_FAR(J, A2R_TA_EVEN_GLB, "%[le]", "%[sa]", "%[sb]", "s_lshr_b64", HULL)
+#define A2R_ODD_FAR(J, HULL) A2R_ROW_FAR(J, A2R_TA_ODD_GLB, "%[lo]", "%[sb]", "%[sa]", "s_lshl_b64", HULL)
 
 #define A2R_NOP2 "s_nop 1\n\t"
 // the fourth row of a group: its two fillers send the lanes' cell words to the tape and look
@@ -376,7 +241,7 @@
     "v_mov_b32 %[k1], %[kb1]\n\t"                                                                        \
     "s_branch .La2r_recb_%=\n"
 
-#define A2R_BODY(BEST, HULL, NRUN, RC)                                                                   \
+#define A2R_BODY(BEST, HULL, NRUN)                                                                       \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                           \
     "s_and_b32 m0, %[it], 63\n\t"                                                                        \
     "s_andn2_b32 %[itb], %[it], 63\n\t"                                                                  \
@@ -394,10 +259,10 @@
     A2R_EVEN("2", "%[sel2]", A2R_NOP2, A2R_NOP2, BEST, HULL, NRUN)                                       \
     A2R_ODD("3", "%[sel3]", A2R_F1_STORE, A2R_F2_STORE, BEST, HULL, NRUN)                                \
     "s_branch .La2r_r0_%=\n"                                                                             \
-    A2R_EVEN_FAR("0", HULL, RC)                                                                          \
-    A2R_ODD_FAR("1", HULL, RC)                                                                           \
-    A2R_EVEN_FAR("2", HULL, RC)                                                                          \
-    A2R_ODD_FAR("3", HULL, RC)                                                                           \
+    A2R_EVEN_FAR("0", HULL)                                                                              \
+    A2R_ODD_FAR("1", HULL)                                                                               \
+    A2R_EVEN_FAR("2", HULL)                                                                              \
+    A2R_ODD_FAR("3", HULL)                                                                               \
     A2R_REC                                                                                              \
     ".La2r_oute_%=:\n\t"                                                                                 \
     "s_mov_b64 %[orow], %[sa]\n\t"                                                                       \
@@ -490,7 +355,7 @@ W_FN void a2_win_fill(const u32 *words, const A2HotV &hv, u64 zone, int src, u32
 // `xrow`: x of every lane after the last row (what hv.vx holds of it inside the hull).
 template <bool PAIR>
 W_FN void a2_rows_stream(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, const u32 *words, u32 *cells,
-                         u32 *recs, u32 ring, int band, u32 it_end, vi &xrow, bool recentre) {
+                         u32 *recs, u32 ring, int band, u32 it_end, vi &xrow) {
     const vi lane = w_lane();
     // the per-lane constants of the rows (even rows: y = x + vnegk, odd ones: y = x + vnegk - 1):
     // in global memory the query base of a cell is x + cqg, the target base x + ctg (- 1) ...
@@ -515,73 +380,58 @@ W_FN void a2_rows_stream(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
         xq = (t0 ? room : room + 32 * A2W_WORDS) - (vi)cq;
         xt = (t0 ? room + 16 * A2W_WORDS : room + 48 * A2W_WORDS) - (vi)ct;
     }
-    vi tn = hv.vtlen - hv.vnegk;
-    vi le = w_min(hv.vqlen, tn), lo = w_min(hv.vqlen, tn + 1);
+    const vi tn = hv.vtlen - hv.vnegk;
+    const vi le = w_min(hv.vqlen, tn), lo = w_min(hv.vqlen, tn + 1);
     const vi xw = w_min(xq, xt);
-    vi lwe = w_min(le, xw), lwo = w_min(lo, xw);
-    vu ctg_ = ctg;
-    vu cke = (vu)hv.vnegk + hv.vtop, cko = cke - 1u;
+    const vi lwe = w_min(le, xw), lwo = w_min(lo, xw);
+    const vu cke = (vu)hv.vnegk + hv.vtop, cko = cke - 1u;
     const vu l4 = (vu)lane << 2;
     const vi neg = A2_NEG;
     u64 sa = h.act, sb, in, fin, big, t, c1, u, orow;
     u32 b0 = (u32)h.best0, b1 = (u32)h.best1;
     u32 rem = it_end - h.it - 1u, it = h.it, itb, p0, p1;
-    // (the compiler keeps some of the caller's wave-uniform state on the vector unit)
-    u32 kb0 = w_uniu(h.kb0), kb1 = w_uniu(h.kb1), cs0 = 0u, cs1 = 0u, nrep = 0u, n0, n1, nl0, nl1, sh0, sh1;
-    const u32 rcok = recentre ? 1u : 0u;
-    const u32 sp = w_uniu((u32)h.split);
-    const u64 fn = PAIR ? (3ull << ((sp - 1u) & 63u)) : 0ull;
-    const u32 ln0 = (sp - 1u) & 63u;
     u32 coff = ((it >> 2) & ((ring >> 2) - 1u)) << 8;            // byte offset of the current group of 4's cell words
     u32 roff = ((it & ~63u) & (ring - 1u)) << 4;                 // ... of the current block of 64's records
     const u32 cmaskb = ((ring >> 2) << 8) - 1u, rmaskb = (ring << 4) - 1u;
-
+    const u32 ln0 = w_uniu((u32)(h.split - 1) & 63u);  // (the compiler keeps `split` on the vector unit)
     vu vm, x, qa, ta, t1, t2, key, pm, k2;
     if (PAIR) {
-        asm volatile(A2R_BODY(A2R_BEST_PAIR, A2R_HULL_PAIR, "2", A2R_RECENTRE_PAIR)
+        asm volatile(A2R_BODY(A2R_BEST_PAIR, A2R_HULL_PAIR, "2")
                      : [vx] "+v"(hv.vx), [acc] "+v"(hv.vacc), [mlo] "+v"(hv.rc_mlo), [mhi] "+v"(hv.rc_mhi),
                        [k0] "+v"(rc_k0), [k1] "+v"(rc_k1), [cnt] "+v"(rv.vcnt), [tdn] "+v"(rv.tdn), [tup] "+v"(rv.tup),
-                       [ct] "+v"(ct), [ctg] "+v"(ctg_), [cke] "+v"(cke), [cko] "+v"(cko), [le] "+v"(le), [lo] "+v"(lo),
-                       [lwe] "+v"(lwe), [lwo] "+v"(lwo), [tn] "+v"(tn), [xt] "+v"(xt),
                        [vm] "=&v"(vm), [x] "=&v"(x), [qa] "=&v"(qa), [ta] "=&v"(ta), [t1] "=&v"(t1), [t2] "=&v"(t2),
                        [key] "=&v"(key), [pm] "=&v"(pm), [k2] "=&v"(k2),
                        [sa] "+s"(sa), [b0] "+s"(b0), [b1] "+s"(b1), [rem] "+s"(rem), [it] "+s"(it),
-                       [coff] "+s"(coff), [roff] "+s"(roff), [kb0] "+s"(kb0), [kb1] "+s"(kb1), [cs0] "+s"(cs0),
-                       [cs1] "+s"(cs1), [nrep] "+s"(nrep),
+                       [coff] "+s"(coff), [roff] "+s"(roff),
                        [sb] "=&s"(sb), [in] "=&s"(in), [fin] "=&s"(fin), [big] "=&s"(big), [t] "=&s"(t),
-                       [c1] "=&s"(c1), [u] "=&s"(u), [p0] "=&s"(p0), [p1] "=&s"(p1), [itb] "=&s"(itb), [orow] "=&s"(orow),
-                       [n0] "=&s"(n0), [n1] "=&s"(n1), [nl0] "=&s"(nl0), [nl1] "=&s"(nl1), [sh0] "=&s"(sh0),
-                       [sh1] "=&s"(sh1)
-                     : [cq] "v"(cq), [cqg] "v"(cqg), [vqlen] "v"(hv.vqlen), [xq] "v"(xq), [l4] "v"(l4), [neg] "v"(neg),
+                       [c1] "=&s"(c1), [u] "=&s"(u), [p0] "=&s"(p0), [p1] "=&s"(p1), [itb] "=&s"(itb), [orow] "=&s"(orow)
+                     : [cq] "v"(cq), [ct] "v"(ct), [cqg] "v"(cqg), [ctg] "v"(ctg), [le] "v"(le), [lo] "v"(lo),
+                       [lwe] "v"(lwe), [lwo] "v"(lwo), [cke] "v"(cke), [cko] "v"(cko), [l4] "v"(l4), [neg] "v"(neg),
                        [z1] "s"(h.zone1), [f0] "s"(h.forbid_to0), [f1] "s"(h.forbid_to1), [band] "s"(band),
                        [ln0] "s"(ln0), [words] "s"(words), [cells] "s"(cells), [recs] "s"(recs),
-                       [cmaskb] "s"(cmaskb), [rmaskb] "s"(rmaskb),
+                       [cmaskb] "s"(cmaskb), [rmaskb] "s"(rmaskb), [kb0] "s"(h.kb0), [kb1] "s"(h.kb1),
                        [sel0] "s"(0x03020104u), [sel1] "s"(0x03020400u), [sel2] "s"(0x03040100u),
-                       [sel3] "s"(0x04020100u), [split] "s"(sp), [s64] "s"(64u - sp),
-                       [fn] "s"(fn), [rcok] "s"(rcok)
+                       [sel3] "s"(0x04020100u)
                      : "vcc", "scc", "memory", "v52", "v53", "v54", "v55");
     } else {
-        asm volatile(A2R_BODY(A2R_BEST_SINGLE, A2R_HULL_SINGLE, "1", A2R_RECENTRE_SINGLE)
+        asm volatile(A2R_BODY(A2R_BEST_SINGLE, A2R_HULL_SINGLE, "1")
                      : [vx] "+v"(hv.vx), [acc] "+v"(hv.vacc), [mlo] "+v"(hv.rc_mlo), [mhi] "+v"(hv.rc_mhi),
                        [k0] "+v"(rc_k0), [k1] "+v"(rc_k1), [cnt] "+v"(rv.vcnt), [tdn] "+v"(rv.tdn), [tup] "+v"(rv.tup),
-                       [ct] "+v"(ct), [ctg] "+v"(ctg_), [cke] "+v"(cke), [cko] "+v"(cko), [le] "+v"(le), [lo] "+v"(lo),
-                       [lwe] "+v"(lwe), [lwo] "+v"(lwo), [tn] "+v"(tn), [xt] "+v"(xt),
                        [vm] "=&v"(vm), [x] "=&v"(x), [qa] "=&v"(qa), [ta] "=&v"(ta), [t1] "=&v"(t1), [t2] "=&v"(t2),
                        [key] "=&v"(key), [pm] "=&v"(pm), [k2] "=&v"(k2),
                        [sa] "+s"(sa), [b0] "+s"(b0), [rem] "+s"(rem), [it] "+s"(it),
-                       [coff] "+s"(coff), [roff] "+s"(roff), [kb0] "+s"(kb0), [kb1] "+s"(kb1), [cs0] "+s"(cs0),
-                       [nrep] "+s"(nrep),
+                       [coff] "+s"(coff), [roff] "+s"(roff),
                        [sb] "=&s"(sb), [in] "=&s"(in), [fin] "=&s"(fin), [big] "=&s"(big), [t] "=&s"(t),
-                       [c1] "=&s"(c1), [p0] "=&s"(p0), [p1] "=&s"(p1), [itb] "=&s"(itb), [orow] "=&s"(orow),
-                       [n0] "=&s"(n0), [nl0] "=&s"(nl0), [sh0] "=&s"(sh0)
-                     : [cq] "v"(cq), [cqg] "v"(cqg), [vqlen] "v"(hv.vqlen), [xq] "v"(xq), [l4] "v"(l4), [neg] "v"(neg),
+                       [c1] "=&s"(c1), [p0] "=&s"(p0), [p1] "=&s"(p1), [itb] "=&s"(itb), [orow] "=&s"(orow)
+                     : [cq] "v"(cq), [ct] "v"(ct), [cqg] "v"(cqg), [ctg] "v"(ctg), [le] "v"(le), [lo] "v"(lo),
+                       [lwe] "v"(lwe), [lwo] "v"(lwo), [cke] "v"(cke), [cko] "v"(cko), [l4] "v"(l4), [neg] "v"(neg),
                        [f0] "s"(h.forbid_to0), [f1] "s"(h.forbid_to1), [band] "s"(band),
                        [words] "s"(words), [cells] "s"(cells), [recs] "s"(recs),
-                       [cmaskb] "s"(cmaskb), [rmaskb] "s"(rmaskb),
+                       [cmaskb] "s"(cmaskb), [rmaskb] "s"(rmaskb), [kb0] "s"(h.kb0), [kb1] "s"(h.kb1),
                        [sel0] "s"(0x03020104u), [sel1] "s"(0x03020400u), [sel2] "s"(0x03040100u),
-                       [sel3] "s"(0x04020100u), [rcok] "s"(rcok)
+                       [sel3] "s"(0x04020100u)
                      : "vcc", "scc", "memory", "v52", "v53", "v54", "v55");
-        (void)u; (void)b1; (void)ln0; (void)cs1; (void)n1; (void)nl1; (void)sh1; (void)fn;
+        (void)u; (void)b1; (void)ln0;
     }
     // What the stream hands back: `sa` the lanes of the next row, `orow` those of the last one
     // (the exits put them there, whichever way the two mask registers stood); `t`: the band hull
@@ -589,11 +439,6 @@ W_FN void a2_rows_stream(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
     h.it = it;
     h.act = sa;
     h.act_row = orow;
-    if (nrep) {  // the bands were moved inside the stream: the caller's copy of the lanes' diagonals
-        hv.vnegk = hv.vnegk - 2 * (PAIR ? w_sel(h.zone1, (int)cs0, (int)cs1) : (vi)(int)cs0);
-        h.kb0 = kb0; h.kb1 = kb1;
-        h.n_replace += nrep;
-    }
     h.in = in; h.big = big;
     h.best0 = (int)b0;
     if (PAIR) h.best1 = (int)b1;
@@ -631,7 +476,7 @@ W_FN void a2_rows_stream(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
 // row 0 runs alone and what it hands back is cut to the row's lanes here.
 template <bool PAIR>
 W_FN void a2_rows_asm(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, const u32 *words, u32 *cells,
-                      u32 *recs, u32 ring, int band, u32 it_end, bool head, bool recentre = true) {
+                      u32 *recs, u32 ring, int band, u32 it_end, bool head) {
     bool row0 = false;
     if (head) {
         row0 = PAIR ? (w_popc(h.act & ~h.zone1) == 1 || w_popc(h.act & h.zone1) == 1) : w_popc(h.act) == 1;
@@ -646,8 +491,7 @@ W_FN void a2_rows_asm(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, c
         if (rv.wq1 == A2W_INVALID) a2_win_fill<1>(words, hv, ~0ull, 0, rv.wq1, rv.wt1);
     }
     vi x;
-    a2_rows_stream<PAIR>(h, hv, rc_k0, rc_k1, rv, words, cells, recs, ring, band, row0 ? h.it + 1u : it_end, x,
-                         recentre);
+    a2_rows_stream<PAIR>(h, hv, rc_k0, rc_k1, rv, words, cells, recs, ring, band, row0 ? h.it + 1u : it_end, x);
     // The other case the stream gets wrong: two bands laid out with no lane to spare are neighbours,
     // and when both reach the boundary between the tracks their filter masks merge into one run --
     // two runs in all, which the stream takes for one hull per track, holes and all.  Both lanes
