@@ -101,6 +101,36 @@ W_FN int w_reduce_min(vi v) {
     return __builtin_amdgcn_readlane(t, 63);
 }
 
+// The trace-back's chain over the rows in lanes base .. 63 (k_align2_core.h, a2_trace): row l of
+// the path sits on lane j of its iteration, the row before it on lane j + step[l] + (bit j of row
+// l's from_above mask).  Returns where the chain ends; lane l of `my` := the j of row l.  One
+// unrolled stream of 64 steps of 40 bytes -- three records read by v_readlane, the lane kept by
+// v_writelane, s_bitcmp1_b64 + s_addc_u32 -- entered at step `base` by a computed jump.
+W_FN int w_chain(vu ra, vu rb, vi step, int j, int base, vi &my) {
+    u32 sj = (u32)fa_uni(j), st;
+    const u32 off = (u32)fa_uni(base) * 40u;
+    asm volatile("s_getpc_b64 vcc\n"
+                 ".Lwch_a_%=:\n\t"
+                 "s_add_u32 vcc_lo, vcc_lo, %[off]\n\t"
+                 "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+                 "s_add_u32 vcc_lo, vcc_lo, .Lwch_0_%=-.Lwch_a_%=\n\t"
+                 "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+                 "s_setpc_b64 vcc\n"
+                 ".Lwch_0_%=:\n\t"
+                 ".irp l,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63\n\t"
+                 "v_readlane_b32 vcc_lo, %[ra], \\l\n\t"
+                 "v_readlane_b32 vcc_hi, %[rb], \\l\n\t"
+                 "v_readlane_b32 %[st], %[step], \\l\n\t"
+                 "v_writelane_b32 %[my], %[j], \\l\n\t"
+                 "s_bitcmp1_b64 vcc, %[j]\n\t"
+                 "s_addc_u32 %[j], %[j], %[st]\n\t"
+                 ".endr"
+                 : [my] "+v"(my), [j] "+s"(sj), [st] "=&s"(st)
+                 : [ra] "v"(ra), [rb] "v"(rb), [step] "v"(step), [off] "s"(off)
+                 : "vcc", "scc");
+    return (int)sj;
+}
+
 // The tail of a band row as ONE instruction stream: the inclusive prefix maximum of `key`
 // (as w_prefix_max) with the row's other work in the wait states of its DPP steps, where
 // s_nop would sit otherwise -- a VGPR written by a VALU instruction may be read through DPP

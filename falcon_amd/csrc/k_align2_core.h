@@ -563,10 +563,12 @@ W_FN int a2_trace(const A2Args &A, A2Wave &w, A2Lanes &wl, const A2Track &t, u32
         A2_HOOK_TRACE(t, ih, have, valid, n_rows, r_top, kv, kb);
 #endif
         if (n_rows > 0) {
-            if (valid != (n_rows >= 64 ? ~0ull : ((1ull << n_rows) - 1ull))) {
-                // iterations the track took no part in (parked; continuation records of wide
-                // rows): its rows move up to lanes 0 .. n_rows - 1
-                const vi to = w_sel(valid, 63, w_rank_in(valid));
+            // The block's rows go to the TOP lanes, newest first: lanes base .. 63 (the chain below
+            // is one unrolled instruction stream entered at lane `base`).  Iterations the track
+            // took no part in (parked; continuation records of wide rows) drop out on the way.
+            const int base = 64 - n_rows;
+            if (base > 0) {
+                const vi to = w_sel(valid, 0, base + w_rank_in(valid));  // (lane 0 holds no row when base > 0)
                 kc = w_push_lanes(kc, to);
                 ra = (vu)w_push_lanes((vi)ra, to);
                 rb = (vu)w_push_lanes((vi)rb, to);
@@ -578,30 +580,23 @@ W_FN int a2_trace(const A2Args &A, A2Wave &w, A2Lanes &wl, const A2Track &t, u32
             // per-row constants.  The chain itself is scalar work: one bit test and one add
             // per row, the records read lane by lane.
             // (dK + 1) / 2 if the path came from above, (dK - 1) / 2 if not: the second plus the bit.
+            // (The oldest row, lane 63, has no row below it in this block: its step is 0, so what
+            // the chain ends on is that row's lane plus its bit.)
             const vi dk = kc - w_from_above(kc);
-            const vi step_dn = (dk - 1) >> 1;
-            // (The chain runs on the VECTOR unit, every lane computing the same numbers: the
-            // kernel as a whole is bound by instruction issue, and a step is eight vector
-            // instructions this way -- three records read by v_readlane, a 64-bit shift, an and,
-            // one three-operand add, and the lane that keeps the position.)
+            const vi step_dn = w_sel(1ull << 63, (dk - 1) >> 1, 0);
             vi my_lane = 0;
-            const int j_top = (kv - w_readlane(kc, 0)) >> 1;
-            vi vj = j_top;
+            const int j_top = (kv - w_readlane(kc, base)) >> 1;
             // no wide row in the block: no continuation record in it, and the newest row (whose
             // continuation records would lie in the block done before this one) is not one
-            const bool plain = (valid == have) && j_top < 64;
+            const bool plain = (w_ballot(kb == A2_CONT) & have) == 0ull && j_top < 64;
             if (plain && !(A.debug & 2)) {
-                const int last = n_rows - 1;
-                for (int l = 0; l < last; l++) {
-                    w_setlane(my_lane, w_readlane(vj, 0), l);
-                    const u64 mask = ((u64)w_readlaneu(rb, l) << 32) | w_readlaneu(ra, l);
-                    vj = vj + (w_readlane(step_dn, l) + w_bit_at(mask, vj));
-                }
-                w_setlane(my_lane, w_readlane(vj, 0), last);
-                const u64 mask = ((u64)w_readlaneu(rb, last) << 32) | w_readlaneu(ra, last);
-                kv = w_uni(w_readlane(kc, last) + 2 * w_readlane(vj, 0) + 2 * w_readlane(w_bit_at(mask, vj), 0) - 1);
+                // six instructions a row (w_chain): three records read by v_readlane, the lane kept
+                // by v_writelane, s_bitcmp1_b64 + s_addc_u32
+                const int j_end = w_chain(ra, rb, step_dn, j_top, base, my_lane);
+                kv = w_uni(w_readlane(kc, 63) + 2 * j_end - 1);
             } else {
-                for (int l = 0; l < ((A.debug & 2) ? 0 : n_rows); l++) {
+                vi vj = j_top;
+                for (int l = base; l < ((A.debug & 2) ? 0 : 64); l++) {
                     my_lane = w_sel(1ull << l, my_lane, vj);
                     vu lo = (vu)w_readlaneu(ra, l), hi = (vu)w_readlaneu(rb, l);
                     if (w_ballot(vj >= 64)) {
@@ -612,7 +607,7 @@ W_FN int a2_trace(const A2Args &A, A2Wave &w, A2Lanes &wl, const A2Track &t, u32
                     }
                     const vu word = w_selu(w_ballot((vj & 32) != 0), lo, hi);
                     const vi bit = (vi)((word >> ((vu)vj & 31u)) & 1u);
-                    if (l == n_rows - 1) {
+                    if (l == 63) {
                         kv = w_uni(w_readlane(kc, l) + 2 * w_readlane(vj, 0) + 2 * w_readlane(bit, 0) - 1);
                     } else {
                         vj = vj + (w_readlane(step_dn, l) + bit);
@@ -620,8 +615,8 @@ W_FN int a2_trace(const A2Args &A, A2Wave &w, A2Lanes &wl, const A2Track &t, u32
                 }
             }
             // every row's own bit, cell and script word, all rows at once
-            const u64 rows = n_rows >= 64 ? ~0ull : ((1ull << n_rows) - 1ull);
-            const vi r = r_top - lane;
+            const u64 rows = ~0ull << base;
+            const vi r = r_top - (lane - base);
             vi my_dir = 0;
             W_WHERE((A.debug & 4) ? 0ull : rows) {
                 vu word = w_selu(w_ballot((my_lane & 32) != 0), ra, rb);

@@ -110,6 +110,16 @@ W_FN vu w_prefix_add(const vu &v) {
     for (int l = 0; l < 64; l++) { m += v.v[l]; r.v[l] = m; }
     return r;
 }
+// the trace-back's chain over the rows in lanes base .. 63: row l of the path sits on lane j of
+// its iteration, the next on j + step[l] + bit j of the row's from_above mask
+W_FN int w_chain(const vu &ra, const vu &rb, const vi &step, int j, int base, vi &my) {
+    for (int l = base & 63; l < 64; l++) {
+        my.v[l] = j;
+        const u64 mask = ((u64)rb.v[l] << 32) | ra.v[l];
+        j += step.v[l] + (int)((mask >> (j & 63)) & 1ull);
+    }
+    return j;
+}
 W_FN vu w_row_tail(const vu &key, const vi &x, const vi &qlen, const vi &y, const vi &tlen, const vu &m, u64 act,
                    u32 band, u64 fa, int slot, vu &rc_lo, vu &rc_hi, u64 &fin, u64 &big, vu &keyb) {
     fin = 0; big = 0;
