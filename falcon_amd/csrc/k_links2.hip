@@ -344,7 +344,10 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
         }
         out += (u32)__builtin_amdgcn_readlane((int)gsum, 63);
     }
-    {   // what the pile's scores are bounded by
+    {   // what the pile's scores are bounded by.  (A segment that overflows this instance's tables
+        // is walked again by the one behind it and adds its share a second time: the bound only
+        // decides whether k_score2's 32-bit scores are safe, so too large a bound sends a pile to
+        // k_score1 a little early and changes no answer.)
         unsigned long long b = bound;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {

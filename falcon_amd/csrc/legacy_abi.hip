@@ -58,10 +58,14 @@ extern "C" consensus_data *generate_consensus(char **input_seq, unsigned int n_s
     if (fa_batch_result(b, 0, &s, &len, &e)) die("generate_consensus(result)");
     char why[256];
     if (fa_batch_pile_error(b, 0, why, (int)sizeof(why)) > 0) {
-        // this ABI has no error channel and the reference no such limit: loud, like its own
-        // failed allocations (DW_banded.c:100-113)
-        fprintf(stderr, "CRITICAL ERROR: falcon_amd generate_consensus: %s\n", why);
-        abort();
+        // A pile this library cannot process (a byte outside ACGT, more than 65 534 reads): this
+        // ABI has no error channel, and the reference has no such limit -- but it aborts only
+        // when an allocation fails (DW_banded.c:100-113), and a ctypes caller
+        // (falcon_kit/mains/consensus.py:102-120, graph_to_contig.py:58-104) must keep its
+        // interpreter.  So: one loud line on stderr and the EMPTY consensus, which every caller
+        // of the reference already handles (falcon.c:651-656; consensus.py:286 drops it).
+        fprintf(stderr, "ERROR: falcon_amd generate_consensus: %s -- empty consensus returned\n", why);
+        len = 0;
     }
     consensus_data *r = (consensus_data *)calloc(1, sizeof(consensus_data));
     r->sequence = (char *)calloc((size_t)len + 1, 1);

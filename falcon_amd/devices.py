@@ -43,28 +43,38 @@ class DevicePool:
         self._lock = threading.Condition()
         self._next = 0
         self._grow = grow
+        self._growing = False
 
     def take(self) -> Device:
         """The device with the least work queued (round robin among equals); waits while
-        every device has MAX_QUEUED batches waiting."""
-        with self._lock:
-            while True:
-                n = len(self.devices)
-                order = [self.devices[(self._next + i) % n] for i in range(n)]
-                dev = min(order, key=lambda d: d.queued)
-                if dev.queued < self.MAX_QUEUED:
-                    break
-                if self._grow is not None:
-                    engine = self._grow()
-                    if engine is not None:
-                        self.devices.append(Device(engine, n))
-                        continue
+        every device has MAX_QUEUED batches waiting.  A further device is opened OUTSIDE the
+        pool's lock (a HIP context, 104 MB of pinned memory, the code objects: a few hundred
+        milliseconds during which the runners must be able to give their devices back)."""
+        while True:
+            grow = None
+            with self._lock:
+                while True:
+                    n = len(self.devices)
+                    order = [self.devices[(self._next + i) % n] for i in range(n)]
+                    dev = min(order, key=lambda d: d.queued)
+                    if dev.queued < self.MAX_QUEUED:
+                        self._next = (dev.index + 1) % len(self.devices)
+                        dev.queued += 1
+                        dev.batches += 1
+                        return dev
+                    if self._grow is not None and not self._growing:
+                        self._growing = True
+                        grow = self._grow
+                        break
+                    self._lock.wait()
+            engine = grow()
+            with self._lock:
+                self._growing = False
+                if engine is not None:
+                    self.devices.append(Device(engine, len(self.devices)))
+                else:
                     self._grow = None  # (nothing left to take: do not ask again at every batch)
-                self._lock.wait()
-            self._next = (dev.index + 1) % len(self.devices)
-            dev.queued += 1
-            dev.batches += 1
-            return dev
+                self._lock.notify_all()
 
     def give_back(self, dev: Device):
         with self._lock:
@@ -91,33 +101,64 @@ _held_locks = []
 
 
 def _lock_dir():
+    """Where the slot files live: one directory for every user of the node (01777, files 0666: the
+    second user's job must be able to open the first user's slot files), or None when it cannot be
+    had -- advisory locking must never be what fails a job."""
     d = os.environ.get("FALCON_AMD_LOCK_DIR") or os.path.join(os.environ.get("TMPDIR", "/tmp"), "falcon_amd.locks")
-    os.makedirs(d, exist_ok=True)
+    try:
+        if not os.path.isdir(d):
+            old = os.umask(0)
+            try:
+                os.makedirs(d, mode=0o1777, exist_ok=True)
+            finally:
+                os.umask(old)
+    except OSError:
+        return None
     return d
 
 
 def _try_lock(dev, slot):
+    """True: this process holds slot `slot` of device `dev` from now on.  False: somebody else does.
+    None: the slot cannot be locked at all (no directory, a file of another user's that is not
+    ours to open, a file system without flock) -- the caller falls back on pid mod n."""
     import fcntl
-    fd = os.open(os.path.join(_lock_dir(), "falcon_amd.dev%d.slot%d" % (dev, slot)), os.O_CREAT | os.O_RDWR, 0o666)
+    d = _lock_dir()
+    if d is None:
+        return None
+    path = os.path.join(d, "falcon_amd.dev%d.slot%d" % (dev, slot))
+    old = os.umask(0)
+    try:
+        fd = os.open(path, os.O_CREAT | os.O_RDWR, 0o666)
+    except OSError:
+        return None
+    finally:
+        os.umask(old)
     try:
         fcntl.flock(fd, fcntl.LOCK_EX | fcntl.LOCK_NB)
-    except OSError:
+    except BlockingIOError:
         os.close(fd)
         return False
+    except OSError:
+        os.close(fd)
+        return None
     _held_locks.append(fd)
     return True
 
 
 def choose_device(devices, max_slots=64, idle_only=False, skip=()):
     """One of `devices` (device ids): the first whose slot is free, slots in the order above.
-    idle_only: only a device nobody holds (slot 0) -- None if there is none."""
+    idle_only: only a device nobody holds (slot 0) -- None if there is none.  When the slots
+    cannot be locked at all (_try_lock: None) the jobs spread by pid alone."""
     n = len(devices)
     first = os.getpid() % n
     order = [devices[(first + i) % n] for i in range(n) if devices[(first + i) % n] not in skip]
     for slot in range(1 if idle_only else max_slots):
         for d in order:
-            if _try_lock(d, slot):
+            got = _try_lock(d, slot)
+            if got:
                 return d
+            if got is None:
+                return None if idle_only or not order else order[0]
     return None if idle_only or not order else order[0]
 
 

@@ -627,6 +627,11 @@ def run(args, stdin=None, stdout=None, consensus_map=None, leave_open=False):
     stdin = sys.stdin if stdin is None else stdin
     stdout = sys.stdout if stdout is None else stdout
     logging.basicConfig(level=int(round(10 * args.verbose_level)))
+    if args.max_n_read > 1024:
+        # (beyond 1024 alignments over one stretch of a seed a pile is
+        # corrected on a best-effort basis and fails ALONE, exit status 3, when it cannot be)
+        LOG.warning("--max-n-read %d: piles are guaranteed to be corrected up to 1024 overlapping reads; "
+                    "deeper ones that cannot be are reported and skipped", args.max_n_read)
     # the reference refuses more workers than cores (consensus.py:258); callers
     # (consensus_task.py:44-54) clamp --n-core accordingly, so keep the contract
     assert args.n_core <= multiprocessing.cpu_count(), \

@@ -107,3 +107,24 @@ def test_named_devices_and_the_multi_stream_worker(stand_in, monkeypatch):
     assert [e.device for e in D.open_engines()] == [2, 5]
     monkeypatch.setenv("FALCON_AMD_DEVICES", "all")
     assert len(D.open_engines()) == 8
+
+
+def test_slots_that_cannot_be_locked_do_not_fail_the_job(tmp_path, monkeypatch):
+    """another user's lock directory (or none at all) must not end a consensus job before it
+    starts -- the device is then chosen by pid alone, without an exception."""
+    import os
+    from falcon_amd import devices
+    not_a_dir = tmp_path / "a_file"
+    not_a_dir.write_text("x")
+    monkeypatch.setenv("FALCON_AMD_LOCK_DIR", str(not_a_dir / "locks"))   # makedirs fails: ENOTDIR
+    assert devices._lock_dir() is None
+    assert devices._try_lock(0, 0) is None
+    got = devices.choose_device([0, 1, 2, 3])
+    assert got == [0, 1, 2, 3][os.getpid() % 4]
+    assert devices.choose_device([0, 1, 2, 3], idle_only=True) is None
+    # a directory that is there is used as it is, and its slot files are open to every user
+    d = tmp_path / "locks"
+    monkeypatch.setenv("FALCON_AMD_LOCK_DIR", str(d))
+    assert devices._try_lock(7, 0) is True
+    assert (os.stat(d).st_mode & 0o1777) == 0o1777
+    assert (os.stat(d / "falcon_amd.dev7.slot0").st_mode & 0o666) == 0o666
