@@ -43,7 +43,8 @@ if ROOT not in sys.path:
 # HBM traffic on file; the names stay importable from here)
 from benchlib.cpu_baseline import cpu_baseline, host_cores  # noqa: E402,F401
 from benchlib.e2e import E2E_REPEATS, end_to_end, end_to_end_multi, end_to_end_workers  # noqa: E402,F401
-from benchlib.traffic import _code_only, kernel_source_sha, measured_stream_rate, measured_traffic  # noqa: E402,F401
+from benchlib.traffic import (KERNEL_NAME, _code_only, kernel_source_sha, measured_issue,  # noqa: E402,F401
+                              measured_stream_rate, measured_traffic)
 from benchlib.workloads import (HBM_PEAK_GBS, K, MAX_N_READ, MIN_COV, MIN_IDT, WORKLOADS, _gen_pile,  # noqa: E402,F401
                                 gen_piles, write_la4falcon)
 
@@ -84,6 +85,8 @@ def relaunch_under_torchrun(args, argv):
     driver would have started them.  Fails loudly when the box has fewer devices."""
     from falcon_amd.lib import load
     n_dev = load().fa_device_count()
+    if os.environ.get("FALCON_BENCH_ONE_DEVICE"):
+        n_dev = max(n_dev, args.gpus) if n_dev > 0 else 0   # (tests: every rank on device 0, see Plumbing)
     if n_dev < args.gpus:
         sys.exit("bench.py: --gpus %d asked for, %d HIP device(s) visible -- refusing to run "
                  "fewer ranks than asked for" % (args.gpus, n_dev))
@@ -99,16 +102,23 @@ def relaunch_under_torchrun(args, argv):
 
 class Plumbing:
     """Device/rendezvous plumbing of a rank: torch.distributed over RCCL ("nccl") on the GPU
-    box; the CPU tests run the same rank logic over gloo with a stand-in engine."""
+    box; the CPU tests run the same rank logic over gloo with a stand-in engine.
+    FALCON_BENCH_BACKEND=gloo + FALCON_BENCH_ONE_DEVICE=1 (tests/test_gpu_cli.py): the REAL engine
+    under world > 1 on a box with one GPU -- every rank on device 0 (RCCL refuses two ranks on
+    one device, gloo does not care), the ranks lined up and the measurement reduced on host
+    tensors.  What stays RCCL-only is the transport of those three numbers."""
 
     def __init__(self, rank, local_rank, world, backend="nccl"):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
+        backend = os.environ.get("FALCON_BENCH_BACKEND") or backend
         self.rank, self.local_rank, self.world, self.backend = rank, local_rank, world, backend
-        self.cuda = backend == "nccl"
-        if self.cuda:
-            torch.cuda.set_device(local_rank)
+        self.cuda = backend == "nccl"                       # collectives on device tensors
+        self.device = 0 if os.environ.get("FALCON_BENCH_ONE_DEVICE") else local_rank
+        self.gpu = self.cuda or bool(os.environ.get("FALCON_BENCH_ONE_DEVICE"))   # a HIP device behind the engine
+        if self.gpu:
+            torch.cuda.set_device(self.device)
         if world > 1:
             kw = {"device_id": torch.device("cuda", local_rank)} if self.cuda else {}
             dist.init_process_group(backend, rank=rank, world_size=world, **kw)
@@ -116,7 +126,7 @@ class Plumbing:
                 raise RuntimeError("rendezvous saw %d ranks, %d expected" % (dist.get_world_size(), world))
 
     def sync(self):
-        if self.cuda:
+        if self.gpu:
             self.torch.cuda.synchronize()
         if self.world > 1:
             self.dist.barrier()
@@ -133,7 +143,7 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
     wl = WORKLOADS[args.workload]
     out = sys.stdout if out is None else out
 
-    eng = make_engine(plumb.local_rank)
+    eng = make_engine(getattr(plumb, "device", plumb.local_rank))
     t_up = time.perf_counter()
     batch = eng.batch(piles)  # ASCII -> 2 bits/base on the host -> HBM
     t_up = time.perf_counter() - t_up
@@ -189,7 +199,7 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
     plumb.sync()
     elapsed = time.perf_counter() - t0
 
-    stream_gbs = measured_stream_rate(plumb.torch) if plumb.cuda else None
+    stream_gbs = measured_stream_rate(plumb.torch) if getattr(plumb, "gpu", plumb.cuda) else None
 
     # the dominant kernel with the device to itself (outside the timed region): in the
     # pipelined steps its launches share the CUs with the previous step's consensus stage
@@ -253,6 +263,11 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
         traffic, traffic_src = measured_traffic(domk, args.piles, args.workload)
         if domk == "k_align" and os.environ.get("FALCON_AMD_ALIGN1"):
             traffic, traffic_src = None, "the PMC measurement on file is of k_align2, this run used k_align"
+        dom_name = KERNEL_NAME.get(domk, domk)
+        if ((domk == "k_align" and os.environ.get("FALCON_AMD_ALIGN1")) or
+                (domk == "k_links" and os.environ.get("FALCON_AMD_LINKS1")) or
+                (domk == "k_score" and os.environ.get("FALCON_AMD_SCORE1"))):
+            dom_name = domk + " (the kernel behind the default one)"
         res = {
             "metric": "consensus_bases_per_sec",
             "value": round(bases_all * args.steps / elapsed, 1),
@@ -276,7 +291,8 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
                           "k_align_ms": round(r[2], 3)} for i, r in enumerate(per_rank)],
             "piles_per_sec": round(piles_all * args.steps / elapsed, 2),
             "roofline": {
-                "bound": "hbm", "kernel": domk,
+                # (`kernel`: the name a rocprofv3 trace shows; `stage`: the key of kernel_ms / stage_ms)
+                "bound": "hbm", "kernel": dom_name, "stage": domk,
                 "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5),
                 # the peak a plain device copy reaches on this box, and the
@@ -294,6 +310,10 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
                           if alone_ms.get(domk) else None),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                # what actually binds this kernel: wave-instructions per launch (SQ_INSTS_* passes on
+                # file) over this run's launch time, against what the chip issues at most
+                "issue": measured_issue(domk, args.piles, args.workload,
+                                        alone_ms.get(domk) or kernel_ms[domk]),
             },
             "stage_ms": {s: round(v, 4) for s, v in stage_ms.items()},
             "kernel_ms": {n: round(v, 4) for n, v in kernel_ms.items()},
@@ -419,7 +439,13 @@ def main(argv=None):
                  % (args.gpus, world))
     wl = WORKLOADS[args.workload]
     # synthetic input first (forks worker processes; no GPU state exists yet)
+    # (worker processes: what this rank's share of the container's CPU quota carries -- 8 ranks forking
+    # 32 generators each on a 16-core quota would be 256 runnable processes)
+    from benchlib.cpu_baseline import _cgroup_cpu
     ncpu = os.cpu_count() or 1
+    quota = _cgroup_cpu()[0]
+    if quota:
+        ncpu = max(1, min(ncpu, int(quota)))
     procs = max(1, min(32, ncpu // max(1, world)))
     seeds = [1000003 * (rank + 1) + i for i in range(args.piles)]
     t0 = time.perf_counter()

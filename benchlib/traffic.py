@@ -30,7 +30,7 @@ def measured_stream_rate(torch, mib=1024, reps=5):
         return None
 
 
-KERNEL_SOURCE = {"k_align": ("k_align2.hip", "k_align2_core.h", "fa_wave.h", "k_align.hip"),
+KERNEL_SOURCE = {"k_align": ("k_align2.hip", "k_align2_core.h", "k_align2_rows.h", "fa_wave.h", "k_align.hip"),
                  "k_score": ("k_score2.hip", "k_score1.hip", "k_msa.h"), "k_links": ("k_links2.hip", "k_msa.hip", "k_msa.h"),
                  "k_tags": ("k_msa.hip", "k_msa.h"), "k_backtrace": ("k_msa.hip", "k_msa.h"), "k_chain": "k_chain.hip",
                  "k_seed_index": "k_seed_index.hip"}
@@ -78,3 +78,41 @@ def measured_traffic(kernel, piles, workload):
         return int(rec["hbm_bytes_per_launch"]), rec.get("what", "")
     except Exception as e:
         return None, "profiles/pmc_traffic.json unreadable: %r" % (e,)
+
+
+# what the stages' kernels are called in a rocprofv3 trace (bench.py's keys are the path's stages; the
+# kernels behind them -- FALCON_AMD_ALIGN1 / _LINKS1 / _SCORE1 -- keep the stage's name)
+KERNEL_NAME = {"k_align": "k_align2", "k_links": "k_links2", "k_score": "k_score2"}
+
+# what a CU of this chip issues at most, vector + scalar instructions of co-resident wavefronts added up
+# (profiles/r02_ubench_issue_rates.txt, scripts/ubench/issue_rates.hip: 1058 G/s vector alone, 610 G/s
+# scalar alone, 1192 G/s of both together)
+ISSUE_CEILING_G_PER_S = {"valu": 1058.0, "salu": 610.0, "valu+salu": 1192.0}
+
+
+def measured_issue(kernel, piles, workload, launch_ms):
+    """The instruction-issue side of the dominant kernel, from the SQ_INSTS_* passes on file
+    (profiles/pmc_issue.json, scripts/pmc_issue_record.py): wave-instructions per launch by class,
+    and -- with THIS run's launch time -- the rate against the measured ceiling.  None unless the
+    passes were taken on the kernel's current source at this batch size and workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_issue.json")) as f:
+            rec = json.load(f).get(kernel)
+        if not rec:
+            return None
+        if int(rec["piles_per_launch"]) != int(piles) or rec.get("workload", "ecoli") != workload:
+            return None
+        if rec.get("source_sha") != kernel_source_sha(kernel):
+            return None
+        v, sc = float(rec["valu"]), float(rec["salu"])
+        rate = (v + sc) / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        return {"valu": int(v), "salu": int(sc), "lds": int(rec.get("lds", 0)), "vmem": int(rec.get("vmem", 0)),
+                "unit": "wave-instructions per launch",
+                "wave_instr_per_s_G": round(rate, 1),
+                "ceiling_measured_G": ISSUE_CEILING_G_PER_S["valu+salu"],
+                "frac": round(rate / ISSUE_CEILING_G_PER_S["valu+salu"], 4),
+                "valu_frac": round(v / (launch_ms * 1e-3) / 1e9 / ISSUE_CEILING_G_PER_S["valu"], 4),
+                "salu_frac": round(sc / (launch_ms * 1e-3) / 1e9 / ISSUE_CEILING_G_PER_S["salu"], 4),
+                "source": rec.get("what", ""), "taken_on": rec.get("taken_on")}
+    except Exception:
+        return None

@@ -228,3 +228,28 @@ def test_random_queue_orders_over_random_tape_contents(port, monkeypatch):
         order = rng.permutation(2 * len(pairs)).astype(np.int32)
         res, _ = align_pairs(pairs, order=order)
         _check(port, pairs, res, allow_handback=True)
+
+
+def test_the_two_primitive_layers_name_the_same_primitives():
+    """k_align2_core.h is written against falcon_amd/csrc/fa_wave.h (registers and single instructions) and
+    runs here against tests/emu/fa_wave.h (64-element arrays): a primitive added to one and not to the
+    other would only show as a compile error of whichever build comes second -- or, for one the core does
+    not use yet, not at all.  The lists must agree, but for what only the device-side code beside the
+    core uses (the hand-scheduled row loop's wrapper, k_align.hip)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def names(path):
+        return set(re.findall(r"\bW_FN\s+[\w:<>\s\*&]+?\b(w_\w+)\s*\(", open(path).read()))
+
+    device = names(os.path.join(root, "falcon_amd", "csrc", "fa_wave.h"))
+    emu = names(os.path.join(root, "tests", "emu", "fa_wave.h"))
+    device_only = {"w_load8", "w_twice_plus",   # (k_align.hip's, not the core's)
+                   "w_reduce_min"}               # (k_align2_rows.h: where a band stands when its LDS windows are filled)
+    assert emu - device == set(), "the emulator implements primitives the device layer does not have"
+    assert device - emu == device_only, sorted(device - emu)
+    # ... and the core uses nothing outside the common list
+    core = open(os.path.join(root, "falcon_amd", "csrc", "k_align2_core.h")).read()
+    used = set(re.findall(r"\b(w_[a-z0-9_]+)\s*(?:<[^>]*>)?\s*\(", core))
+    assert used <= (device & emu) | {"w_lds"}, sorted(used - (device & emu))

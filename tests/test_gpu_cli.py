@@ -222,3 +222,29 @@ def test_two_jobs_started_together_share_what_there_is():
     assert out["distinct_devices"] == min(2, torch.cuda.device_count()), out
     for w in out["workers"]:
         assert w["devices"] is not None and w["wall_s"] > 0, out
+
+
+@pytest.mark.gpu
+def test_the_real_engine_under_world_size_2_on_one_gpu():
+    """`bench.py --gpus N` is one process per GPU, the ranks lined up and the measurement
+    reduced through torch.distributed.  A box with one GPU cannot run RCCL with two ranks (it refuses two
+    ranks on one device), but it can run everything else of that code path on the real engine:
+    FALCON_BENCH_BACKEND=gloo + FALCON_BENCH_ONE_DEVICE=1 put both ranks on device 0.  The line must
+    say two ranks, carry both ranks' own clocks, and start two single-stream workers in its
+    end-to-end leg."""
+    import json
+    env = dict(os.environ, FALCON_BENCH_BACKEND="gloo", FALCON_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--piles", "96", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert len(d["per_rank"]) == 2 and all(r["bases_per_sec"] > 0 for r in d["per_rank"])
+    # whole-job value = the units of both ranks over the slower rank's time
+    assert d["value"] <= sum(r["bases_per_sec"] for r in d["per_rank"]) * 1.001
+    assert d["value"] >= 2 * min(r["bases_per_sec"] for r in d["per_rank"]) * 0.999
+    if "end_to_end_workers" in d and d["end_to_end_workers"]:
+        assert len(d["end_to_end_workers"]["workers"]) == 2
