@@ -57,7 +57,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="ecoli")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["trim", "align1500", "utg"], default="ecoli",
+                    help="ecoli / dmel / arab: BASELINE.json's configs of the falcon_sense path; trim / align1500 / utg: "
+                         "the SURVEY.md 8(f) paths beside it (benchlib/secondary.py), one GPU, their own metrics")
     ap.add_argument("--piles", type=int, default=int(os.environ.get("FALCON_BENCH_PILES", "0")),
                     help="piles per step per GPU (default: 3072 ecoli, 1024 dmel, 1536 arab)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -75,7 +77,8 @@ def parse_args(argv=None):
                     help="one resident batch, every step drained before the next (A/B of the "
                          "two-batch pipelining)")
     args = ap.parse_args(argv)
-    if args.piles <= 0:
+    args.piles_given = args.piles > 0
+    if args.piles <= 0 and args.workload in WORKLOADS:
         args.piles = WORKLOADS[args.workload]["piles"]
     return args
 
@@ -429,6 +432,12 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    if args.workload not in WORKLOADS:
+        if args.gpus != 1:
+            sys.exit("bench.py --workload %s: one GPU (the 8(f) paths have no multi-GPU story of their own)" % args.workload)
+        from benchlib import secondary
+        secondary.run(args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args, argv)  # does not return
     rank = int(os.environ.get("RANK", "0"))
