@@ -25,8 +25,7 @@ SO = os.path.join(ROOT, "falcon_amd", "libfalcon_amd.so")
 
 
 def _sync():
-    import torch
-    torch.cuda.synchronize()
+    """(every call timed here returns with its results on the host: nothing is left in flight)"""
 
 
 def _timed(step, warmup, steps):
@@ -189,7 +188,7 @@ def _utg(args):
     from falcon_amd.synth import codes_to_str, noisy
     from oracle.pyoracle import LegacyABI   # (only its ctypes prototypes: drives the PRODUCT library)
     rng = np.random.default_rng(707)
-    U = 200000 if not args.piles_given else max(5000, args.piles)
+    U = 90000 if not args.piles_given else max(5000, min(99000, args.piles))   # (targets < 100 000 bases: falcon.c:343)
     utg = rng.integers(0, 4, U).astype(np.uint8)
     seqs, offs = [codes_to_str(utg)], [0]
     cover, read_len = 30, 12000
