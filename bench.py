@@ -42,7 +42,8 @@ if ROOT not in sys.path:
 # (the parts of this file live in benchlib/: the input, the CPU baseline, the end-to-end legs, the
 # HBM traffic on file; the names stay importable from here)
 from benchlib.cpu_baseline import cpu_baseline, host_cores  # noqa: E402,F401
-from benchlib.e2e import E2E_REPEATS, end_to_end, end_to_end_multi, end_to_end_workers  # noqa: E402,F401
+from benchlib.e2e import (E2E_REPEATS, end_to_end, end_to_end_multi, end_to_end_served,  # noqa: E402,F401
+                          end_to_end_workers)
 from benchlib.traffic import (KERNEL_NAME, _code_only, kernel_source_sha, measured_issue,  # noqa: E402,F401
                               measured_stream_rate, measured_traffic)
 from benchlib.workloads import (HBM_PEAK_GBS, K, MAX_N_READ, MIN_COV, MIN_IDT, WORKLOADS, _gen_pile,  # noqa: E402,F401
@@ -386,6 +387,10 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
                 res["end_to_end"] = end_to_end(piles, expect=gpu_cns)
             except Exception as e:  # informative; never lose the GPU line
                 res["end_to_end"] = {"piles_per_sec": None, "what": "failed: %r" % (e,)}
+            try:  # ... and with a worker that stays on the node (consensus_server)
+                res["end_to_end_served"] = end_to_end_served(piles, expect=gpu_cns)
+            except Exception as e:
+                res["end_to_end_served"] = {"piles_per_sec": None, "what": "failed: %r" % (e,)}
         if world > 1 and not args.no_end_to_end:
             # N streams through the multi-stream worker over the N GPUs (the other ranks are
             # done and idle; their resident batches only hold memory)

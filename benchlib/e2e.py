@@ -194,3 +194,60 @@ def end_to_end_workers(piles, n_workers, repeats=E2E_REPEATS, worker_cmd=None):
                     "cache) -> %d FASTA files; every worker is a process of its own that takes a GPU through the "
                     "lock slots (falcon_amd/devices.py), process start and HIP initialisation included; the "
                     "aggregate counts the slowest worker" % (n_workers, repeats * len(piles), size / 1e6, n_workers)}
+
+
+def end_to_end_served(piles, expect=None, repeats=E2E_REPEATS, jobs=3):
+    """The same stream as end_to_end(), but through a worker that STAYS (falcon_amd.mains.consensus_server): the
+    server is started first and is not on the clock -- a node starts it once -- and then `jobs` job processes
+    (`python -m falcon_amd.mains.consensus` with FALCON_AMD_SERVER set: interpreter start, connect, hand over stdin /
+    stdout, wait) run back to back, each on the whole stream.  What a .las block costs when process start, HIP
+    context, arena and the driver's VRAM wipe are paid once per node instead of once per block."""
+    import shutil
+    import signal
+    with tempfile.TemporaryDirectory() as tmp:
+        src, dst, sock = os.path.join(tmp, "piles.txt"), os.path.join(tmp, "cns.fasta"), os.path.join(tmp, "srv.sock")
+        per_repeat = sum(sum(len(x) + 10 for x in p) for p in piles) + 1
+        repeats = max(1, min(repeats, int(shutil.disk_usage(tmp).free * 0.6 // per_repeat)))
+        with open(src, "wb") as f:
+            write_la4falcon(piles, f, repeats)
+        size = os.path.getsize(src)
+        env = {k: v for k, v in os.environ.items()
+               if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTRACER", "HSA_TOOLS"))}
+        t_up = time.perf_counter()
+        srv = subprocess.Popen([sys.executable, "-m", "falcon_amd.mains.consensus_server", "--socket", sock], cwd=ROOT,
+                               env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        try:
+            line = srv.stdout.readline()
+            if "ready" not in line:
+                raise RuntimeError("the consensus server did not come up: %s %s" % (line, srv.stderr.read()[-400:]))
+            t_up = time.perf_counter() - t_up
+            cmd = [sys.executable, "-m", "falcon_amd.mains.consensus", "--output-multi", "--min-idt", "0.70", "--min-cov",
+                   "4", "--max-n-read", "200", "--n-core", "1"]
+            walls = []
+            for _ in range(jobs):
+                t0 = time.perf_counter()
+                with open(src) as fin, open(dst, "w") as fout:
+                    subprocess.run(cmd, stdin=fin, stdout=fout, check=True, cwd=ROOT, timeout=600,
+                                   env=dict(env, FALCON_AMD_SERVER=sock))
+                walls.append(time.perf_counter() - t0)
+            with open(dst) as f:
+                text = f.read()
+        finally:
+            srv.send_signal(signal.SIGTERM)
+            try:
+                srv.wait(timeout=60)
+            except subprocess.TimeoutExpired:
+                srv.kill()
+    n = repeats * len(piles)
+    wall = sorted(walls)[len(walls) // 2]
+    out = {"piles_per_sec": round(n / wall, 1), "text_MB_per_sec": round(size / 1e6 / wall, 1), "wall_s": round(wall, 2),
+           "runs_wall_s": [round(w, 2) for w in walls], "server_start_s": round(t_up, 2),
+           "what": "%d piles (%.0f MB of text) -> FASTA per job, %d job processes back to back handing their stdin / "
+                   "stdout to one consensus server on the node (started before, %.2f s, not on the clock); the median "
+                   "job counts, its own process start included" % (n, size / 1e6, jobs, t_up)}
+    if expect is not None:
+        from falcon_amd.mains.consensus import fasta_records
+        want = "".join(fasta_records("%09d" % (rep * len(piles) + i), c, False, True)
+                       for rep in range(repeats) for i, c in enumerate(expect))
+        out["fasta_identical_to_resident_batch"] = (want == text)
+    return out

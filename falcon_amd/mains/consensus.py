@@ -711,6 +711,14 @@ def main(argv=None, own_process=False):
 def console_main(argv=None):
     """``python -m falcon_amd.mains.consensus``, ``bin/fc_consensus``, the drop-in's
     ``python -m falcon_kit.mains.consensus``: main() in a process of its own."""
+    if os.environ.get("FALCON_AMD_SERVER"):
+        # a long-lived worker on this node (falcon_amd/mains/consensus_server.py) takes the stream: this
+        # process hands over its descriptors and waits -- or goes on by itself when nobody is there
+        from falcon_amd.mains._serve_client import try_server
+        code = try_server(sys.argv if argv is None else argv)
+        if code is not None:
+            sys.stdout.flush()
+            os._exit(code)
     main(argv, own_process=True)
 
 

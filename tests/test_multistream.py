@@ -378,3 +378,59 @@ def test_four_devices_are_fed_by_four_streams(tmp_path, monkeypatch):
     assert out1 == out4 and n1 == n4 and n1 >= 40
     assert wall1 >= n1 * 0.020            # one engine: its throughput stages in a row
     assert wall4 <= wall1 / 3.0, (wall1, wall4, n1)
+
+
+def test_jobs_hand_their_descriptors_to_a_server(tmp_path, monkeypatch):
+    """falcon_amd/mains/consensus_server.py with stand-in devices: several job PROCESSES (the console
+    command with FALCON_AMD_SERVER set) hand their stdin / stdout to one server over SCM_RIGHTS, some at
+    the same time; each gets the bytes the stand-alone worker prints for its stream and status 0; a
+    --trim job is declined and runs by itself (here: fails for want of a GPU, which proves it did);
+    without a server behind the socket a job also runs by itself."""
+    import subprocess
+    import sys
+    from falcon_amd.mains import consensus_server as server
+    monkeypatch.setenv("FALCON_AMD_BATCH_BASES", "900")
+    rng = random.Random(33)
+    texts = [_rand_stream(rng, rng.randint(15, 40), with_noise=i % 2 == 1) for i in range(4)]
+    sock = str(tmp_path / "srv.sock")
+    backend = FakeBackend()
+    pool = multi.DevicePool([FakeEngine(), FakeEngine()])
+    stop = threading.Event()
+    th = threading.Thread(target=server.serve, args=(sock,), kwargs=dict(pool=pool, make_backend=lambda a: backend, stop=stop))
+    th.start()
+    try:
+        for _ in range(200):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.01)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, FALCON_AMD_SERVER=sock, PYTHONPATH=root)
+        procs = []
+        for i, text in enumerate(texts):
+            (tmp_path / ("in_%d.txt" % i)).write_text(text)
+            fin, fout = open(tmp_path / ("in_%d.txt" % i)), open(tmp_path / ("out_%d.fa" % i), "w")
+            procs.append((subprocess.Popen([sys.executable, "-m", "falcon_amd.mains.consensus"] + OPTS, stdin=fin, stdout=fout,
+                                           stderr=subprocess.PIPE, env=env, cwd=root), fin, fout))
+        args = single.parse_args(["prog"] + OPTS)
+        for i, (p, fin, fout) in enumerate(procs):
+            _, err = p.communicate(timeout=120)
+            fin.close(); fout.close()
+            assert p.returncode == 0, err.decode()
+            assert (tmp_path / ("out_%d.fa" % i)).read_text() == _single_stream_output(texts[i], args), i
+        assert backend.staged == backend.finished > len(texts)
+        # a job the server declines runs in its own process: no GPU here, so it fails -- by itself
+        with open(tmp_path / "in_0.txt") as fin:
+            p = subprocess.run([sys.executable, "-m", "falcon_amd.mains.consensus", "--trim", "--n-core", "1"] + OPTS, stdin=fin,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=root, timeout=120)
+        assert p.returncode != 0 and b"HIP" in p.stderr + p.stdout
+    finally:
+        stop.set()
+        th.join(timeout=30)
+    assert not os.path.exists(sock)
+    # nobody behind the variable: the job goes on by itself (and, here, fails for want of a GPU)
+    with open(tmp_path / "in_0.txt") as fin:
+        p = subprocess.run([sys.executable, "-m", "falcon_amd.mains.consensus", "--n-core", "1"] + OPTS, stdin=fin,
+                           stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, env=dict(os.environ, FALCON_AMD_SERVER=sock, PYTHONPATH=root),
+                           cwd=root, timeout=120)
+    assert p.returncode != 0 and b"HIP" in p.stderr + p.stdout
