@@ -248,3 +248,42 @@ def test_the_real_engine_under_world_size_2_on_one_gpu():
     assert d["value"] >= 2 * min(r["bases_per_sec"] for r in d["per_rank"]) * 0.999
     if "end_to_end_workers" in d and d["end_to_end_workers"]:
         assert len(d["end_to_end_workers"]["workers"]) == 2
+
+
+@pytest.mark.gpu
+def test_a_job_served_by_the_node_s_server_prints_the_same_bytes():
+    """falcon_amd.mains.consensus_server on the real engine: two jobs one after the other and two at the same
+    time hand their stdin / stdout to it; each FASTA equals what the stand-alone worker prints for the stream."""
+    import signal
+    import tempfile
+    sys.path.insert(0, ROOT)
+    from benchlib.workloads import gen_piles, write_la4falcon
+    piles = gen_piles(range(60, 68), 1, dict(S=4000, coverage=20.0, het=0.0))
+    with tempfile.TemporaryDirectory() as tmp:
+        src, sock = os.path.join(tmp, "piles.txt"), os.path.join(tmp, "srv.sock")
+        with open(src, "wb") as f:
+            write_la4falcon(piles, f, 2)
+        cmd = [sys.executable, "-m", "falcon_amd.mains.consensus", "--output-multi", "--min-idt", "0.70", "--min-cov", "4",
+               "--max-n-read", "200", "--n-core", "1"]
+        with open(src) as fin:
+            want = subprocess.run(cmd, stdin=fin, stdout=subprocess.PIPE, check=True, cwd=ROOT, timeout=600).stdout
+        assert want.count(b">") >= 8
+        srv = subprocess.Popen([sys.executable, "-m", "falcon_amd.mains.consensus_server", "--socket", sock], cwd=ROOT,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        try:
+            assert "ready" in srv.stdout.readline()
+            env = dict(os.environ, FALCON_AMD_SERVER=sock)
+            for _ in range(2):
+                with open(src) as fin:
+                    got = subprocess.run(cmd, stdin=fin, stdout=subprocess.PIPE, check=True, cwd=ROOT, timeout=600, env=env).stdout
+                assert got == want
+            ps = []
+            for j in range(2):
+                ps.append((subprocess.Popen(cmd, stdin=open(src), stdout=open(os.path.join(tmp, "o%d" % j), "wb"), cwd=ROOT, env=env), j))
+            for p, j in ps:
+                assert p.wait(timeout=600) == 0
+                assert open(os.path.join(tmp, "o%d" % j), "rb").read() == want
+        finally:
+            srv.send_signal(signal.SIGTERM)
+            srv.wait(timeout=60)
+        assert not os.path.exists(sock)
