@@ -67,7 +67,8 @@ def measured_traffic(kernel, piles, workload):
     (profiles/pmc_traffic.json, written by scripts/pmc_traffic_record.py)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            rec = json.load(f).get(kernel)
+            doc = json.load(f)
+        rec = doc.get("%s:%s" % (kernel, workload)) or doc.get(kernel)
         if not rec:
             return None, "no PMC measurement of this kernel under profiles/"
         if int(rec["piles_per_launch"]) != int(piles) or rec.get("workload", "ecoli") != workload:

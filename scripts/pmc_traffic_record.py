@@ -88,7 +88,8 @@ def main():
         doc = json.load(open(path))
     except Exception:
         doc = {}
-    doc[kernel] = rec
+    # (the E. coli-like workload under the kernel's name, as ever; the others under "<kernel>:<workload>")
+    doc[kernel if workload == "ecoli" else "%s:%s" % (kernel, workload)] = rec
     json.dump(doc, open(path, "w"), indent=1)
     print(json.dumps(rec, indent=1))
 
