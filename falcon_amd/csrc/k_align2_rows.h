@@ -225,14 +225,19 @@
     "s_cbranch_scc1 .La2r_rec_%=\n"                                                                      \
     ".La2r_recb_%=:\n\t"
 
-// the records of a complete block of 64 iterations to the tape; the K fields start over
+// the records of a complete block of 64 iterations to the tape (one 16-byte store per lane through the
+// snake's four registers, free at this point of a row: four dword stores 16 bytes apart cost 12 GB of
+// partial-line writes per launch, profiles/r05_pmc_traffic*); the K fields start over
 #define A2R_REC                                                                                          \
     ".La2r_rec_%=:\n\t"                                                                                  \
     "v_lshl_add_u32 %[t2], %[l4], 2, %[roff]\n\t"                                                        \
-    "global_store_dword %[t2], %[mlo], %[recs]\n\t"                                                      \
-    "global_store_dword %[t2], %[mhi], %[recs] offset:4\n\t"                                             \
-    "global_store_dword %[t2], %[k0], %[recs] offset:8\n\t"                                              \
-    "global_store_dword %[t2], %[k1], %[recs] offset:12\n\t"                                             \
+    "v_mov_b32 v52, %[mlo]\n\t"                                                                          \
+    "v_mov_b32 v53, %[mhi]\n\t"                                                                          \
+    "v_mov_b32 v54, %[k0]\n\t"                                                                           \
+    "v_mov_b32 v55, %[k1]\n\t"                                                                           \
+    "s_nop 0\n\t"                                                                                        \
+    "global_store_dwordx4 %[t2], v[52:55], %[recs]\n\t"                                                  \
+    "s_nop 1\n\t"                                                                                        \
     "s_add_u32 %[roff], %[roff], 0x400\n\t"                                                              \
     "s_and_b32 %[roff], %[roff], %[rmaskb]\n\t"                                                          \
     "s_add_u32 %[itb], %[itb], 64\n\t"                                                                   \
