@@ -740,7 +740,7 @@ __device__ __forceinline__ void links_segment(const MsaArgs &A, int sidx) {
 // then happens for the round's 64 nodes at once, lanes = nodes (round 3 did it per step on
 // the scalar unit: 7.2 ms per 3072 piles, five times the chase).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_backtrace(MsaArgs A) {
+__global__ __launch_bounds__(64, 8) void k_backtrace(MsaArgs A) {
     // A window of BT_WIN levels (5 node records each) and, per node of it, the node 1, 2, 4, .. 32
     // steps down the path that starts there (a local index, BT_OUT once the path has left the
     // window or ended)
