@@ -53,9 +53,12 @@
 // LDS words of a wavefront: four windows of 256 words on the two sequences of the two tracks
 // (k_align2_rows.h), the word bases of the windows behind them -- and, while a track computes
 // its wide rows, the two rings of a2_wide in words 256.. (the windows are filled again then)
-#define A2W_HDR 1024
+// (4096 bytes in all: the word bases sit in the last four words of the last window, which ends four
+// words early for them -- with 4 KB a wavefront, 32 of them leave a CU 32 KB of LDS for the kernels
+// of the batch before, which run beside this one)
+#define A2W_HDR 1020
 #define A2W_INVALID 0xffffffffu
-#define A2_LDS_WORDS (A2W_HDR + 8)
+#define A2_LDS_WORDS 1024
 // Placement policy, measured on the bench workload [MI355X] (scripts/r03_variants.sh +
 // r03_sweep.sh, profiles/r03_policy_sweep.txt; taken while parking and joining still went
 // through the event loop, ~800 instructions a trip -- now ~100 and a call): leaving the pair

@@ -312,7 +312,8 @@ W_FN void a2_fold_cells(A2Hot &h, vu &vcnt) {
 // ---------------------------------------------------------------------------------------
 #define A2W_WORDS 256
 #define A2W_MARGIN 128
-static_assert(A2W_HDR >= 4 * A2W_WORDS && A2_LDS_WORDS >= A2W_HDR + 4, "windows, then their header");
+#define A2W_USABLE 252   // words of a window the rows may count on (the last window ends at A2W_HDR)
+static_assert(A2W_HDR == 3 * A2W_WORDS + A2W_USABLE && A2_LDS_WORDS >= A2W_HDR + 4, "windows, the last one four words short for their header");
 
 // State of the stream that outlives a stretch
 struct A2RowsV {
@@ -352,8 +353,11 @@ W_FN void a2_win_fill(const u32 *words, const A2HotV &hv, u64 zone, int src, u32
     vu b2 = w_load32(words, wt + lane4 + 2u), b3 = w_load32(words, wt + lane4 + 3u);
     const vu at = (vu)(TI * 2 * A2W_WORDS) + lane4;
     w_lds_store(l, at, a0); w_lds_store(l, at + 1u, a1); w_lds_store(l, at + 2u, a2); w_lds_store(l, at + 3u, a3);
-    w_lds_store(l, at + A2W_WORDS, b0); w_lds_store(l, at + (A2W_WORDS + 1u), b1);
-    w_lds_store(l, at + (A2W_WORDS + 2u), b2); w_lds_store(l, at + (A2W_WORDS + 3u), b3);
+    // (the target window of track 1 is the LDS's last: its last four words are the header's)
+    W_WHERE(TI == 1 ? ~(1ull << 63) : ~0ull) {
+        w_lds_store(l, at + A2W_WORDS, b0); w_lds_store(l, at + (A2W_WORDS + 1u), b1);
+        w_lds_store(l, at + (A2W_WORDS + 2u), b2); w_lds_store(l, at + (A2W_WORDS + 3u), b3);
+    }
 }
 
 // One stretch of rows through the stream: from h.it until a row raises an event or `it_end`.
@@ -373,7 +377,7 @@ W_FN void a2_rows_stream(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
     const u32 aq1 = 16u * (2u * A2W_WORDS - rv.wq1), at1 = 16u * (3u * A2W_WORDS - rv.wt1);
     vu cq, ct;
     vi xq, xt;
-    const int room = 16 * A2W_WORDS - A2W_MARGIN;
+    const int room = 16 * A2W_USABLE - A2W_MARGIN;
     if (PAIR) {
         cq = cqg + w_selu(h.zone1, aq0, aq1);
         ct = ctg + w_selu(h.zone1, at0, at1);
