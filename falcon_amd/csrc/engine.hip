@@ -130,17 +130,6 @@ struct fa_ctx {
     // repeat launches of alignments k_align2 handed back share arena2, from whichever stream
     std::mutex redo_mu;
     hipEvent_t ev_redo = nullptr;  // the last repeat launch (redo_mu)
-    // The gate (FALCON_AMD_GATE=<wavefront slots per CU left free>, 0: off): batch n + 1's k_align2 -- a
-    // persistent grid that owns whatever wavefront slots it is given until its queue is empty -- is held
-    // back on the front stream until batch n's k_tags and k_links2 (throughput kernels: they want the
-    // whole chip) are through, and is then launched on fewer slots than the chip has, so that batch n's
-    // k_score2 and k_backtrace (one or two wavefronts per pile walking a chain of dependent steps: they
-    // want latency hidden, not slots) run BESIDE it instead of after it.  `d_gate`: the number of the
-    // last batch whose links are done (k_gate_open on the back stream), which k_gate_wait on the front
-    // stream waits for -- with a timeout, so that nothing can hang on it.
-    int gate_room = 0;
-    unsigned *d_gate = nullptr;
-    unsigned submit_seq = 0;       // (front_mu)
     char *h_dl = nullptr;    // pinned landing buffer of the downloads (grow only; fetch_mu)
     size_t h_dl_cap = 0;
     // alignment work-slot arena (grow only)
@@ -358,8 +347,6 @@ struct fa_batch {
     // unitig runs, also ones that failed half-way): fa_batch_free waits for that stream
     // before the batch's blocks go back to the cache, where another thread may take them
     bool front_launched = false;
-    unsigned gate_seq = 0;       // its number at the context's gate (0: not gated), and whether its
-    bool gate_opened = false;    // k_gate_open has been queued (fa_ctx::d_gate)
     // The MSA stage (plan on the host, then k_tags .. k_backtrace on a back stream) is the
     // second half of a run, done by whichever thread gets to it first -- the next submit on
     // the context, or this batch's own wait: 0 not begun, 1 some thread is at it, 2 queued
@@ -416,21 +403,6 @@ extern "C" int fa_device_count(void) {
 
 static void planner_main(fa_ctx *c);
 
-// the gate of fa_ctx::d_gate (see there)
-__global__ void k_gate_wait(const unsigned *flag, unsigned want, unsigned long long max_ticks) {
-    if (threadIdx.x != 0) return;
-    const unsigned long long t0 = wall_clock64();   // (100 MHz)
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        __builtin_amdgcn_s_sleep(64);
-        if (wall_clock64() - t0 > max_ticks) break;   // (never hang: a late k_align2 only costs time)
-    }
-}
-__global__ void k_gate_open(unsigned *flag, unsigned seq) {
-    if (threadIdx.x == 0) atomicMax(flag, seq);
-}
-
-
-
 extern "C" fa_ctx *fa_create(int device) {
     PhaseTimer pt("fa_create");
     int n = fa_device_count();
@@ -478,9 +450,6 @@ extern "C" fa_ctx *fa_create(int device) {
     HIP_OK_P(hipMalloc((void **)&c->a2.stats, 12 * sizeof(unsigned long long)));
     HIP_OK_P(hipMemset(c->a2.stats, 0, 12 * sizeof(unsigned long long)));
     c->a2.counter = c->arena.counter;  // (the front stream runs one alignment launch at a time)
-    if (const char *e = getenv("FALCON_AMD_GATE")) c->gate_room = std::max(0, std::min(16, atoi(e)));
-    HIP_OK_P(hipMalloc((void **)&c->d_gate, sizeof(unsigned)));
-    HIP_OK_P(hipMemset(c->d_gate, 0, sizeof(unsigned)));
     c->planner = std::thread(planner_main, c);
     pt.mark("small-buffers");
     return c;
@@ -533,7 +502,6 @@ extern "C" void fa_destroy(fa_ctx *c) {
     if (c->arena2.rowx) (void)hipFree(c->arena2.rowx);
     if (c->a2.mem) (void)hipFree(c->a2.mem);
     if (c->a2.stats) (void)hipFree(c->a2.stats);
-    if (c->d_gate) (void)hipFree(c->d_gate);
     if (c->d_first_bad) (void)hipFree(c->d_first_bad);
     if (c->d_counter2) (void)hipFree(c->d_counter2);
     if (c->ev_redo) (void)hipEventDestroy(c->ev_redo);
@@ -1103,7 +1071,6 @@ static int ensure_arena_a2(fa_ctx *c, const fa_batch *b) {
     int per_cu = std::max(1, std::min(fa_align2_blocks_per_cu(), 32));
     int n_slot = c->n_cu * per_cu;
     n_slot = std::max(1, std::min(n_slot, (b->n_seq + 1) / 2));
-    if (c->gate_room > 0) n_slot = std::min(n_slot, c->n_cu * std::max(4, per_cu - c->gate_room));
     if (const char *e = getenv("FALCON_AMD_SLOTS")) n_slot = std::max(1, std::min(n_slot, atoi(e)));
     const u64 slot_words = fa_align2_slot_words(ring);
     size_t free_b = 0, total_b = 0;
@@ -1270,13 +1237,6 @@ extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double
         if (b->h_range.resize(b->n_seq)) return -1;
         HIP_OK(hipMemcpyAsync(b->h_range.data(), b->d_range.p, (size_t)b->n_seq * sizeof(FaRange),
                               hipMemcpyDeviceToHost, s));
-        b->gate_seq = 0;
-        b->gate_opened = false;
-        if (c->gate_room > 0 && two_per_wave) {
-            b->gate_seq = ++c->submit_seq;
-            if (b->gate_seq > 1)   // (at most 0.2 s: then the alignments go ahead whatever the batch before is doing)
-                hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, s, c->d_gate, b->gate_seq - 1, 20000000ull);
-        }
         if (start_align(b, min_cov, max_diff, FA_BAND, -1, two_per_wave)) return -1;
         pt.mark("launch-front");
         // its second half is the planner's (a failure there is reported by fa_batch_wait)
@@ -1538,10 +1498,6 @@ static int msa_stage(fa_batch *b) {
     HIP_OK(hipEventRecord(b->ev[4], sb));
     fa_launch_msa_front(d, md, min_cov, sb, b->ev[8], b->ev[9]);  // k_tags + k_tscan | k_links
     HIP_OK(hipEventRecord(b->ev[5], sb));
-    if (b->gate_seq) {
-        hipLaunchKernelGGL(k_gate_open, dim3(1), dim3(64), 0, sb, c->d_gate, b->gate_seq);
-        b->gate_opened = true;
-    }
     trace_stage(sb, "links");
     HIP_OK(hipEventRecord(b->ev[7], sb));
     fa_launch_msa_back(d, md, min_cov, sb, b->ev[10], b->ev[11]);  // k_score | k_backtrace
@@ -1583,10 +1539,6 @@ static int msa_stage(fa_batch *b) {
 static void begin_back(fa_batch *p) {
     const std::string mine = g_err;  // (another batch's failure is not this call's)
     const int rc = msa_stage(p);
-    if (p->gate_seq && !p->gate_opened) {  // (a stage that failed before its links: the batch behind it must not wait)
-        hipLaunchKernelGGL(k_gate_open, dim3(1), dim3(64), 0, p->ctx->back_stream[0], p->ctx->d_gate, p->gate_seq);
-        p->gate_opened = true;
-    }
     if (rc) {
         p->back_err = g_err;
         p->back_rc = rc;
