@@ -15,11 +15,8 @@
 // requested one level ahead; position records and link counts are handed out of
 // registers; node records leave with one coalesced store per position.
 // ---------------------------------------------------------------------------
-#define SC_LINKS 640      // link words staged per block (LDS per wavefront: what the kernels running beside this one keep)
-#define SC_LEVELS 64      // levels per block (their link counts sit in one VGPR: one readlane per level)
 #define SC_REG 12         // insertion levels whose scores live in registers
 #define SC_ZERO 63        // lane of the score registers that always holds 0 (start links)
-#define SC_BIAS 2048      // makes every link score positive (score >= -2 - coverage, coverage <= 1023)
 
 struct ScoreAcc { int h, p, k, n; };
 
@@ -156,7 +153,6 @@ __device__ __noinline__ void score_level_slow(int *s_io_v, int prev_h, u32 w_fir
 }
 
 __global__ __launch_bounds__(64) void k_score1(MsaArgs A) {
-    __shared__ u32 s_links[SC_LINKS + 64];
     __shared__ int s_io[SC_IO_WORDS];  // score_level_slow's state (and the deep levels' best nodes)
     const int lane = fa_lane();
     const int p = blockIdx.x;
@@ -213,33 +209,14 @@ __global__ __launch_bounds__(64) void k_score1(MsaArgs A) {
         if (tl < T) { x_lvl = tiw[3 * tl]; x_link = tiw[3 * tl + 1]; x_cn = tiw[3 * tl + 2]; }
         const u32 lvl0 = (u32)__builtin_amdgcn_readfirstlane((int)x_lvl);
         const u32 lnk0 = (u32)__builtin_amdgcn_readfirstlane((int)x_link);
-        const u32 end_l = (tl < T) ? x_lvl : (u32)so.n_levels;
-        const u32 end_k = (tl < T) ? x_link : (u32)so.n_links;
-        // (a block stays inside one k_links segment, whose links are contiguous; the link slots
-        // -- sized by the tags -- bound the links from above)
-        const int seg_end = (t0 / TSEG + 1) * TSEG;
-        const bool fits = lane >= 1 && tl <= T && tl <= seg_end && (end_l - lvl0) <= SC_LEVELS &&
-                          (end_k - lnk0) <= SC_LINKS;
-        // (one position at a time, its link words read straight from HBM: the position records
-        // no longer carry a link slot per position -- only the segment's -- from which a block's
-        // extent in the link words could be bounded; this is the kernel behind k_score2, for
-        // the handful of piles that one hands on)
-        (void)fits;
-        const bool bulk = false;
-        int nb = 1;
-        int nlk0 = 0;
+        // (ONE position at a time, its link words read straight from HBM: the position records
+        // carry a link slot per SEGMENT only, so a block of positions cannot be bounded in the
+        // link words and staged -- rounds 1-3 did that; this is the kernel behind k_score2, for
+        // the handful of piles that one hands on and for the unitig call)
+        (void)lvl0;
+        const int nb = 1;
         if ((t0 & (TSEG - 1)) == 0) lk_run = lnk0;
         lk_run = fa_uni(lk_run);
-        const u32 lb = lk_run;  // the block's first link
-        __syncthreads();
-        if (bulk) {
-            const u32 n_l = (u32)__builtin_amdgcn_readlane((int)end_l, nb) - lvl0;
-            const u32 n_k = (u32)__builtin_amdgcn_readlane((int)end_k, nb) - lnk0;
-            for (u32 i = lane; i < n_k; i += 64) s_links[i] = links[lb + i];
-            if ((u32)lane < n_l) nlk0 = (int)nlk[lvl0 + (u32)lane];
-        }
-        __syncthreads();
-        nlk0 = (int)fa_settled((u32)nlk0);
         x_lvl = fa_settled(x_lvl);
         x_link = fa_settled(x_link);
         x_cn = fa_settled(x_cn);
@@ -251,14 +228,7 @@ __global__ __launch_bounds__(64) void k_score1(MsaArgs A) {
         prev_lvl = fa_uni(prev_lvl);
         prev_nlev = fa_uni(prev_nlev);
         curbuf = fa_uni(curbuf);
-        // the block's positions; two instances of the code so that the oversized-position
-        // case (links read straight from HBM) costs the normal one no branches
-        auto run_block = [&](auto bulk_c) {
-        constexpr bool BULK = decltype(bulk_c)::value;
-        // link words of the level about to be scored, requested while the level before it
-        // is being scored (bulk blocks; a position's first level continues where the
-        // capacity of the position before it ends, uncovered positions have none)
-        u32 w_nx = BULK ? s_links[lane] : 0u;
+        {
         // (covered positions only: a `continue` for the others is a second way to the loop
         // latch and costs every position a round of register copies)
         for (u64 todo = fa_ballot((x_cn & 0xffffu) != 0u) & ((1ull << nb) - 1ull); todo; todo &= todo - 1) {
@@ -282,24 +252,12 @@ __global__ __launch_bounds__(64) void k_score1(MsaArgs A) {
             u32 lk = lk_run;
             for (int dl = 0; dl < nlev; dl++) {
                 const u32 slot = y_lvl + (u32)dl;
-                int n_link;
-                if constexpr (BULK) {
-                    n_link = __builtin_amdgcn_readlane(nlk0, (int)(slot - lvl0));
-                } else {
-                    n_link = __builtin_amdgcn_readfirstlane((int)nlk[slot]);
-                }
+                const int n_link = __builtin_amdgcn_readfirstlane((int)nlk[slot]);
                 const u32 plvl5 = (dl == 0 ? prev_lvl : y_lvl) * 5u;  // node id = plvl5 + pidx
                 // first 64 links of the level, lanes = links
                 u32 w = 0;
-                if constexpr (BULK) {
-                    w = w_nx;
-                    // request the next level's words (the next position's after the last level)
-                    const u32 rel2 = lk - lb + (u32)n_link;
-                    w_nx = s_links[min(rel2, (u32)SC_LINKS) + (u32)lane];
-                } else {
-                    if (lane < n_link) w = links[lk + (u32)lane];
-                    w = fa_settled(w);
-                }
+                if (lane < n_link) w = links[lk + (u32)lane];
+                w = fa_settled(w);
                 {
                     s_io[lane] = cur.h; s_io[64 + lane] = cur.p; s_io[128 + lane] = cur.k;
                     // (scalar -> vector here and nowhere else: the "s" operands keep the
@@ -310,8 +268,7 @@ __global__ __launch_bounds__(64) void k_score1(MsaArgs A) {
                                  : "=&v"(plvl5_v), "=&v"(adj_v), "=&v"(curbuf_v), "=&v"(upper_v), "=&v"(cov_v)
                                  : "s"(plvl5), "s"(adjacent_i), "s"(curbuf), "s"(upper), "s"(cov));
                     s_io[216] = plvl5_v; s_io[217] = adj_v;
-                    const u32 *staged = nullptr;
-                    if constexpr (BULK) staged = s_links + (lk - lb);
+                    const u32 *staged = nullptr;  // (no staged copy of the links: see above)
                     score_level_slow(s_io, prev_h, w, dl, n_link, lk, slot, cov_v, upper_v,
                                      curbuf_v, links, staged, s_deep, (sc_u32x2 *)nodes);
                     cur.h = s_io[lane]; cur.p = s_io[64 + lane]; cur.k = s_io[128 + lane];
@@ -338,8 +295,7 @@ __global__ __launch_bounds__(64) void k_score1(MsaArgs A) {
             prev_nlev = nlev;
             lk_run = lk;
         }
-        };
-        if (bulk) run_block(std::true_type{}); else run_block(std::false_type{});
+        }
         t0 += nb;
     }
     // global best = first strict maximum in (t, delta, base) order (falcon.c:464-469):
