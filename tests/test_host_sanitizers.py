@@ -23,3 +23,20 @@ def test_host_side_under_a_sanitizer(kind):
     out = p.stdout.decode(errors="replace")
     assert p.returncode == 0 and "no difference" in out, out[-4000:]
     assert "Sanitizer" not in out, out[-4000:]
+
+
+def test_the_batch_engine_s_host_logic_under_threadsanitizer():
+    """csrc/engine.hip is pure host code -- staging, the front half under the context's lock, the planner thread,
+    the back half, fetch, results, freeing, the block cache.  ThreadSanitizer cannot load the HIP runtime, so the
+    engine is compiled against stand-ins for the runtime and for the kernel launchers (tests/san/stub,
+    engine_stub_kernels.cpp: no alignment is ever accepted) and driven like the worker drives it: three runner
+    threads on one context, two on another, up to three batches per thread between submit and wait, batches
+    freed while in flight, batches run again (tests/san/engine_san.cpp)."""
+    b = subprocess.run(["make", "-s", "-C", CSRC, "tsan_engine"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert b.returncode == 0, b.stdout.decode(errors="replace")[-3000:]
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
+    p = subprocess.run([os.path.join(ROOT, "tests", "san", "engine_tsan"), "80"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=900)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0 and "nothing failed" in out, out[-4000:]
+    assert "Sanitizer" not in out, out[-4000:]
