@@ -1544,11 +1544,15 @@ static void begin_back(fa_batch *p) {
         p->back_rc = rc;
         g_err = mine;
     }
+    // (once the state is published the batch is its waiter's again, who may free it at once -- a
+    // spurious or another batch's wake-up is enough: nothing of `p` is touched after the store.
+    // Found by the ThreadSanitizer build of this file, tests/san/engine_san.cpp.)
+    fa_ctx *c = p->ctx;
     {
-        std::lock_guard<std::mutex> hold(p->ctx->plan_mu);
+        std::lock_guard<std::mutex> hold(c->plan_mu);
         p->back_state.store(rc ? -1 : 2, std::memory_order_release);
     }
-    p->ctx->done_cv.notify_all();
+    c->done_cv.notify_all();
 }
 
 // The planner thread of a context: the second halves of the submitted runs, in submit order.
