@@ -100,10 +100,14 @@ def test_no_asm_block_names_vcc():
             inside = False
             for n, line in enumerate(open(out), 1):
                 if "#ASMSTART" in line:
-                    inside = True
+                    inside, by_hand = True, False
                 elif "#ASMEND" in line:
                     inside = False
-                elif inside and "vcc" in line:
+                elif inside and (".La2r_" in line or ".Lwch_" in line):
+                    # the hand-scheduled streams (k_align2_rows.h, w_chain), known by their
+                    # labels: VCC named in the text and in the clobber list (checked below).
+                    by_hand = True
+                elif inside and "vcc" in line and not by_hand:
                     # The hazard is a VALU instruction reading VCC as an ordinary SGPR operand
                     # right behind an implicit write.  Two uses are sound and deliberate
                     # (w_row_tail names VCC itself and declares it clobbered, so no operand of
@@ -117,6 +121,12 @@ def test_no_asm_block_names_vcc():
                         continue
                     bad.append("%s:%d: %s" % (os.path.basename(out), n, text))
     assert not bad, bad
+    by_hand = []
+    for name in ("k_align2_rows.h", "fa_wave.h"):
+        text = open(os.path.join(src_dir, name)).read()
+        by_hand += [st for st in re.findall(r"asm volatile\(.*?\);", text, re.S)
+                    if ".Lwch_" in st or st.startswith("asm volatile(A2R_BODY")]
+    assert len(by_hand) >= 3 and all('"vcc"' in st.rsplit(":", 1)[1] for st in by_hand)
 
 
 def test_legacy_window_functions_vs_reference_random(lib, ref):
