@@ -107,7 +107,7 @@ def measured_issue(kernel, piles, workload, launch_ms):
             return None
         v, sc = float(rec["valu"]), float(rec["salu"])
         rate = (v + sc) / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-        return {"valu": int(v), "salu": int(sc), "lds": int(rec.get("lds", 0)), "vmem": int(rec.get("vmem", 0)),
+        return {"valu": int(v), "salu": int(sc), "lds": None if rec.get("lds") is None else int(rec["lds"]), "vmem": int(rec.get("vmem", 0)),
                 "unit": "wave-instructions per launch",
                 "wave_instr_per_s_G": round(rate, 1),
                 "ceiling_measured_G": ISSUE_CEILING_G_PER_S["valu+salu"],

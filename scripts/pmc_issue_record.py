@@ -47,7 +47,7 @@ def main():
         sys.exit("passes with %s of %s are needed" % (" and ".join(need), kname))
     rec = {
         "kernel": kname, "piles_per_launch": line["config"]["piles_per_step_per_gpu"], "workload": workload,
-        "valu": mean("SQ_INSTS_VALU"), "salu": mean("SQ_INSTS_SALU"), "lds": mean("SQ_INSTS_LDS") or 0,
+        "valu": mean("SQ_INSTS_VALU"), "salu": mean("SQ_INSTS_SALU"), "lds": mean("SQ_INSTS_LDS"),  # (None: that pass is not among these)
         "vmem": (mean("SQ_INSTS_VMEM_RD") or 0) + (mean("SQ_INSTS_VMEM_WR") or 0),
         "branch": mean("SQ_INSTS_BRANCH"),
         "wave_cycles": mean("SQ_WAVE_CYCLES"), "wait_any": mean("SQ_WAIT_ANY"), "wait_inst_any": mean("SQ_WAIT_INST_ANY"),
