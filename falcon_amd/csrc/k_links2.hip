@@ -41,6 +41,16 @@
 #define L2_POOL_BIG 4096  // ... of the second instance, which takes the segments the first cannot hold (piles of
                           // a thousand reads list a few dozen groups at every position)
 
+// does any lane hold p?  (The mask is pinned to a scalar register pair: a comparison of
+// ballot(p) with 0 is otherwise rebuilt as a vector compare of a 0/1 select -- three vector
+// instructions where s_cmp_lg_u64 does.)
+__device__ __forceinline__ bool l2_any(bool p) {
+    u64 m = fa_ballot(p);
+#ifndef FA_EMU
+    asm volatile("" : "+s"(m));
+#endif
+    return m != 0ull;
+}
 // base `d` (1-based) of a tag's insertion run
 __device__ __forceinline__ u32 l2_ins_base(const MsaArgs &A, u32 ins_off, u32 w, int d) {
     if (tag_nins(w) <= INL) return (w >> (2 * (d - 1))) & 3u;
@@ -116,6 +126,18 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
             for (u32 e = head; e != L2_NIL; e = pnx[e]) r += ((pk[e] >> 16) & 255u) == (u32)dl ? 1u : 0u;
             return r;
         };
+        // a listed group: found in my list, or a new entry of the pool at its head
+        auto list_add = [&](u32 dl, u32 key) {
+            const u32 k = (dl << 16) | key;
+            for (u32 e = head; e != L2_NIL; e = pnx[e])
+                if (pk[e] == k) { pc[e] += 1u; return; }
+            const u32 e = dl > 255u ? (u32)POOL : atomicAdd(&pool_n, 1u);
+            if (e >= (u32)POOL) { overflow = true; return; }
+            pc[e] = 1u | (new_rank((int)dl) << 16);
+            pk[e] = k;
+            pnx[e] = (pnx_t)head;
+            head = e;
+        };
         auto add_group = [&](int dl, u32 key, int slot) {
             if (slot >= 0) {
                 const u32 c = dcnt[slot * 64 + lane];
@@ -123,42 +145,21 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
                 if (c == 0u) drnk[slot * 64 + lane] = (uint8_t)new_rank(dl);
                 return;
             }
-            const u32 k = ((u32)dl << 16) | key;
-            for (u32 e = head; e != L2_NIL; e = pnx[e])
-                if (pk[e] == k) { pc[e] += 1u; return; }
-            const u32 e = dl > 255 ? (u32)POOL : atomicAdd(&pool_n, 1u);
-            if (e >= (u32)POOL) { overflow = true; return; }
-            pc[e] = 1u | (new_rank(dl) << 16);
-            pk[e] = k;
-            pnx[e] = (pnx_t)head;
-            head = e;
+            list_add((u32)dl, key);
         };
-        // what a column of an alignment adds to my position: its tag word w, the tag word wp of
-        // the column before it (falcon.c:126-160)
-        auto add_column = [&](int u, int ld, u32 insoff, u32 w, u32 wp, bool groups) {
+        // what an alignment's FIRST column adds to my position (falcon.c:126-160): its tag word w;
+        // `ld`: the alignment opens with an insertion run, which sits at the position before its
+        // first column and comes without a delta-0 tag
+        auto add_column_first = [&](int ld, u32 insoff, u32 w) {
             const int nins = tag_nins(w);
             const u32 base0 = (w & TAG_DEL) ? 4u : sb;
-            const bool nocol = ld != 0 && u == 0;  // only the leading insertion run, no delta-0 column
-            maxn = max(maxn, nins);
-            if (!nocol) cov++;  // (coverage counts delta-0 tags, falcon.c:357-360)
-            if (!groups) return;
+            const bool nocol = ld != 0;
             if (!nocol) {
-                if (u == 0) {
-                    // the alignment's first column: no previous node (p_t_pos == -1, falcon.c:434);
-                    // in the unitig mode a read placed at t > 0 links to (t - 1, delta 0) with the
-                    // '.' base, which the scorer reads as '-' (:140, :431)
-                    if (t == 0 || !unitig) add_group(0, base0 | (5u << 3) | (1u << 14), -1);
-                    else add_group(0, base0 | (4u << 3) | (1u << 15), -1);
-                } else {
-                    // the column before it: its last inserted base, or its base / '-'
-                    const u32 pn = (u32)tag_nins(wp);
-                    const u32 pb = pn > 0 ? l2_ins_base(A, insoff, wp, (int)pn) : ((wp & TAG_DEL) ? 4u : sbp);
-                    const int del = base0 == 4u ? 1 : 0;
-                    int slot = -1;
-                    if (pn == 0) slot = del * 2 + (pb == 4u ? 1 : 0);
-                    else if (pn == 1) slot = 4 + del * 4 + (int)pb;
-                    add_group(0, base0 | (pb << 3) | (pn << 6), slot);
-                }
+                // no previous node (p_t_pos == -1, falcon.c:434); in the unitig mode a read placed at
+                // t > 0 links to (t - 1, delta 0) with the '.' base, which the scorer reads as '-'
+                // (:140, :431)
+                if (t == 0 || !unitig) add_group(0, base0 | (5u << 3) | (1u << 14), -1);
+                else add_group(0, base0 | (4u << 3) | (1u << 15), -1);
             }
             for (int dl = 1; dl <= nins; dl++) {
                 const u32 b = l2_ins_base(A, insoff, w, dl);
@@ -195,7 +196,7 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
             // the overlapping alignments four at a time: the tag words of the next four are
             // under way while these four are worked in (one alignment ahead was not enough: a
             // round of ~150 instructions is shorter than a trip to HBM)
-            struct Col4 { int u[4], ld[4]; u32 insoff[4], w[4], wp[4]; bool on[4], valid[4]; };
+            struct Col4 { int u[4], j[4]; u32 w[4], wp[4]; bool on[4], valid[4]; };  // (j: the alignment's lane)
             int j_last = 0;
             auto request4 = [&](u64 &m) -> Col4 {
                 Col4 c;
@@ -207,8 +208,7 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
                     const int j = j_last;
                     const int s2 = __builtin_amdgcn_readlane(v_s2, j);
                     const int tc = __builtin_amdgcn_readlane(v_tc, j);
-                    c.ld[q] = __builtin_amdgcn_readlane(v_ld, j);
-                    c.insoff[q] = (u32)__builtin_amdgcn_readlane((int)v_ins, j);
+                    c.j[q] = j;
                     const u64 doff = ((u64)(u32)__builtin_amdgcn_readlane((int)v_dhi, j) << 32) |
                                      (u64)(u32)__builtin_amdgcn_readlane((int)v_dlo, j);
                     const u32 *dptr = A.desc + doff;
@@ -231,56 +231,93 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
                 const Col4 nxt = request4(m);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    // Every column but an alignment's first one (its start link, or the unitig mode's
-                    // leading run: add_column) takes this path: the group of its delta-0 tag has a
-                    // slot of its own unless the column before it carried two or more inserted bases,
-                    // the group of its first inserted base has one too; only the deeper levels --
-                    // and that one delta-0 case -- go to the list.  (The general add_column for every
-                    // column that was not "plain" cost 7.5 of the kernel's 12.7 ms: a few lanes per
-                    // alignment take it, so the wavefront did, nearly every time.)
+                    // One stream for every lane, nothing divergent on it: the delta-0 group of a column
+                    // behind a column with at most one inserted base and the group of a column's first
+                    // inserted base have slots of their own -- two reads, two writes, the lanes the case
+                    // does not apply to adding 0 to a slot they are not in.  A slot's first alignment
+                    // (its rank) and everything that goes to the list leave the stream through ONE
+                    // wavefront-wide test each.  (Round 4 wrote this as nested per-lane branches: 125
+                    // branch instructions per column in the code, ~200 instructions issued per alignment
+                    // and 64 positions, more than half of them scalar bookkeeping of EXEC.)
                     const u32 w = cur.w[q], wp = cur.wp[q];
+                    const int u = cur.u[q];
+                    const bool on = cur.on[q], in = on && u > 0;
                     const u32 nins = (w >> TAG_NINS_SHIFT) & 0xffu, pn = (wp >> TAG_NINS_SHIFT) & 0xffu;
-                    if (cur.on[q] && cur.u[q] > 0) {
-                        const u32 del = w >> 31, base0 = del ? 4u : sb;
-                        cov++;
-                        maxn = max(maxn, (int)nins);
-                        if (!any_overflow) {
-                            // the column before it: its last inserted base, or its base / '-'
-                            const u32 pb = pn == 0u ? ((wp >> 31) ? 4u : sbp)
-                                                    : (pn == 1u ? (wp & 3u) : l2_ins_base(A, cur.insoff[q], wp, (int)pn));
-                            if (pn <= 1u) {
-                                const u32 slot0 = pn ? 4u + del * 4u + pb : del * 2u + (pb >> 2);
-                                const u32 c = dcnt[slot0 * 64u + (u32)lane];
-                                const bool fresh = c == 0u;
-                                const u32 r = lvln & 255u;
-                                overflow = overflow || (fresh && r == 255u);
-                                dcnt[slot0 * 64u + (u32)lane] = (u16)(c + 1u);
-                                if (fresh) drnk[slot0 * 64u + (u32)lane] = (uint8_t)r;
-                                lvln += fresh ? 1u : 0u;
-                            } else {
-                                add_group(0, base0 | (pb << 3) | (pn << 6), -1);
-                            }
-                            if (nins) {
-                                const u32 b1 = nins <= (u32)INL ? (w & 3u) : l2_ins_base(A, cur.insoff[q], w, 1);
-                                const u32 slot1 = 12u + del * 4u + b1;
-                                const u32 c = dcnt[slot1 * 64u + (u32)lane];
-                                const bool fresh = c == 0u;
-                                const u32 r = (lvln >> 8) & 255u;
-                                overflow = overflow || (fresh && r == 255u);
-                                dcnt[slot1 * 64u + (u32)lane] = (u16)(c + 1u);
-                                if (fresh) drnk[slot1 * 64u + (u32)lane] = (uint8_t)r;
-                                lvln += fresh ? 256u : 0u;
-                                u32 pbb = b1;
-                                for (int dl = 2; dl <= (int)nins; dl++) {
-                                    const u32 b = l2_ins_base(A, cur.insoff[q], w, dl);
-                                    add_group(dl, b | (pbb << 3) | ((u32)(dl - 1) << 6), -1);
-                                    pbb = b;
+                    const u32 del = w >> 31;
+                    // (coverage counts delta-0 tags, falcon.c:357-360: an alignment that opens with an
+                    // insertion run has none at its first position and takes this back below)
+                    cov += on ? 1 : 0;
+                    maxn = max(maxn, on ? (int)nins : 0);
+                    if (any_overflow) {
+                        const int ld = __builtin_amdgcn_readlane(v_ld, cur.j[q]);
+                        cov -= (on && u == 0 && ld != 0) ? 1 : 0;
+                        continue;
+                    }
+                    const u32 pb1 = wp & 3u;  // the column before it carried one inserted base: this one
+                    const bool f0 = in && pn <= 1u, f1 = in && nins >= 1u && nins <= (u32)INL;
+                    const u32 slot0 = pn ? 4u + del * 4u + pb1 : del * 2u + (wp >> 31);  // (after a plain column: was it a '-'?)
+                    const u32 slot1 = 12u + del * 4u + (w & 3u);
+                    const u32 i0 = (f0 ? slot0 : 0u) * 64u + (u32)lane, i1 = (f1 ? slot1 : 12u) * 64u + (u32)lane;
+                    const u32 c0 = dcnt[i0], c1 = dcnt[i1];
+                    dcnt[i0] = (u16)(c0 + (f0 ? 1u : 0u));
+                    dcnt[i1] = (u16)(c1 + (f1 ? 1u : 0u));
+                    // (0 where a slot meets its first alignment)
+                    const u32 z = min(f0 ? c0 : 1u, f1 ? c1 : 1u);
+                    if (l2_any(z == 0u)) {
+                        const bool fresh0 = f0 && c0 == 0u, fresh1 = f1 && c1 == 0u;
+                        const u32 r0 = lvln & 255u, r1 = (lvln >> 8) & 255u;
+                        overflow = overflow || (fresh0 && r0 == 255u) || (fresh1 && r1 == 255u);
+                        if (fresh0) drnk[i0] = (uint8_t)r0;
+                        if (fresh1) drnk[i1] = (uint8_t)r1;
+                        lvln += (fresh0 ? 1u : 0u) + (fresh1 ? 256u : 0u);
+                    }
+                    // ---- the rest, ~1 % of the columns each and a lane or two of every other
+                    // wavefront: a column behind two or more inserted bases (its delta-0 group is a
+                    // listed one), the second and later inserted bases of this column; and, far
+                    // rarer, a run too long for the tag word or an alignment's first column
+                    const u32 deepest = max(pn, nins);
+                    const u32 rest = on ? (u > 0 ? deepest : 255u) : 0u;  // (255: the first column)
+                    if (!l2_any(rest >= 2u)) continue;
+                    // items of a lane: 0 = the delta-0 group behind pn >= 2 inserted bases; k >= 1 = the
+                    // group of inserted base k + 1
+                    const bool deep0 = in && pn >= 2u, deepn = in && nins >= 2u;
+                    const u32 it_end = deepn ? nins : (deep0 ? 1u : 0u);
+                    auto items = [&](auto general, bool mine, u32 insoff) {
+                        u32 it = mine ? (deep0 ? 0u : 1u) : it_end;
+                        while (l2_any(it < it_end)) {
+                            if (it < it_end) {
+                                // (node base, base before it, depth before it): the last inserted base of the
+                                // column before and this column's base -- or two neighbours of this column's run
+                                const u32 src = it ? w : wp, d = it ? it : pn;  // `d`: 1-based index of the base before
+                                u32 pbase, nb;
+                                if (decltype(general)::value) {
+                                    pbase = l2_ins_base(A, insoff, src, (int)d);
+                                    nb = it ? l2_ins_base(A, insoff, w, (int)it + 1) : (del ? 4u : sb);
+                                } else {  // (both runs inline in their tag words)
+                                    pbase = (src >> (2u * d - 2u)) & 3u;
+                                    nb = it ? (w >> (2u * it)) & 3u : (del ? 4u : sb);
                                 }
+                                list_add(it ? it + 1u : 0u, nb | (pbase << 3) | (d << 6));
+                                it++;
                             }
                         }
-                    } else if (cur.on[q]) {
-                        add_column(cur.u[q], cur.ld[q], cur.insoff[q], w, wp, !any_overflow);
+                    };
+                    if (l2_any(rest > (u32)INL)) {
+                        // (what only these cases read of the alignment comes from its lane when they do)
+                        const int ld = __builtin_amdgcn_readlane(v_ld, cur.j[q]);
+                        const u32 insoff = (u32)__builtin_amdgcn_readlane((int)v_ins, cur.j[q]);
+                        const bool first = on && u == 0;
+                        if (first) {
+                            cov -= ld != 0 ? 1 : 0;
+                            add_column_first(ld, insoff, w);
+                        }
+                        if (in && nins > (u32)INL) {
+                            const u32 b1 = l2_ins_base(A, insoff, w, 1);
+                            add_group(1, b1 | ((del ? 4u : sb) << 3), (int)(12u + del * 4u + b1));
+                        }
+                        items(std::true_type(), in && deepest > (u32)INL, insoff);
                     }
+                    items(std::false_type(), in && deepest <= (u32)INL, 0u);
                 }
                 if (!more) break;
                 cur = nxt;
@@ -367,7 +404,7 @@ __device__ __forceinline__ void links2_segment(const MsaArgs &A, int sidx) {
 }
 
 // one wavefront per segment
-__global__ __launch_bounds__(64) void k_links2(MsaArgs A) {
+__global__ __launch_bounds__(64, 8) void k_links2(MsaArgs A) {
     if ((int)blockIdx.x < A.n_seg) links2_segment<L2_POOL>(A, (int)blockIdx.x);
 }
 // a fixed grid looping over the first instance's to-do list (usually empty)
