@@ -110,7 +110,7 @@ struct fa_reader {
     // with a pread() of its own piece at its own offset.  Pieces are handed out and taken in
     // in stream order, always behind `filled`; the buffer only grows or changes hands while
     // no request is in flight.
-    static constexpr int kSlots = 4;
+    static constexpr int kSlots = 8;  // at most; n_slots of them are used
     struct Ahead {
         std::thread th[kSlots];
         std::mutex mu;
@@ -122,11 +122,26 @@ struct fa_reader {
             long long off = -1;  // file offset (pread), -1: read() at the descriptor's position
             ssize_t n = 0;       // the result, -1 with `err` = errno
             int err = 0;
+            // where the piece holds a byte <= 0x20 (offsets from dst, ascending): the helper looks
+            // for them while the piece is in its cache, the scanner only walks the list.  `ev_ok`
+            // false: no list (too many events to be LA4Falcon text) -- the scanner reads the bytes.
+            std::vector<uint32_t> ev;
+            bool ev_ok = false;
         } slot[kSlots];
         bool quit = false;
     } ahead;
     bool wide_scan = false;  // 64-byte compares (the host has AVX-512BW)
-    int n_slots = 1;         // 1: a pipe; kSlots: a regular file (file_off = where the next piece starts)
+    bool scan_ahead = true;  // the helpers list the events of their pieces (FALCON_AMD_READER_SCAN_INLINE: no)
+    int n_slots = 1;         // 1: a pipe; several: a regular file (file_off = where the next piece starts)
+    // pieces taken in whose events are listed and which the scanner has not passed yet, in stream
+    // order: [start, start + len) of `text` (start moves with the text when a batch's tail does)
+    struct Piece {
+        long long start = 0;
+        size_t len = 0, next = 0;  // next: the first event not looked at yet
+        std::vector<uint32_t> ev;
+    };
+    std::vector<Piece> pieces;      // (a handful: a vector used as a queue)
+    std::vector<std::vector<uint32_t>> ev_spare;  // lists given back, for the slots to fill again
     long long file_off = -1;
     int in_flight = 0;       // requests out, slots (issue_at - in_flight .. issue_at - 1) mod n_slots
     int issue_at = 0;
@@ -165,6 +180,36 @@ __attribute__((target("avx512f,avx512bw"))) static size_t scan64(const char *t, 
         i += 64;
     }
     return i;
+}
+
+// the same compares on a helper thread: where [t, t + n) holds a byte <= 0x20, as offsets.
+// false (and no list) beyond kMaxEvents: text of one event per few bytes is not worth listing.
+constexpr size_t kMaxEvents = 1u << 20;
+__attribute__((target("avx512f,avx512bw"))) static size_t list64(const char *t, size_t n, std::vector<uint32_t> &out) {
+    const __m512i lim = _mm512_set1_epi8(0x20);
+    size_t i = 0;
+    for (; i + 64 <= n && out.size() < kMaxEvents; i += 64) {
+        unsigned long long m = _mm512_cmple_epu8_mask(_mm512_loadu_si512((const void *)(t + i)), lim);
+        for (; m; m &= m - 1) out.push_back((uint32_t)(i + (size_t)__builtin_ctzll(m)));
+    }
+    return i;
+}
+static bool list_events(const char *t, size_t n, bool wide, std::vector<uint32_t> &out) {
+    out.clear();
+    size_t i = wide ? list64(t, n, out) : 0;
+    const __m128i lim = _mm_set1_epi8(0x20);
+    for (; i + 16 <= n && out.size() < kMaxEvents; i += 16) {
+        const __m128i v = _mm_loadu_si128((const __m128i *)(t + i));
+        unsigned m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_min_epu8(v, lim), v));
+        for (; m; m &= m - 1) out.push_back((uint32_t)(i + (size_t)__builtin_ctz(m)));
+    }
+    for (; i < n && out.size() < kMaxEvents; i++)
+        if ((unsigned char)t[i] <= 0x20) out.push_back((uint32_t)i);
+    if (out.size() >= kMaxEvents) {
+        out.clear();
+        return false;
+    }
+    return true;
 }
 
 static char *map_text(char *old, size_t old_cap, size_t cap) {
@@ -222,6 +267,8 @@ static void ahead_main(fa_reader *r, int k) {
             err = errno;
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (n < 0 && (err == EINTR || err == EAGAIN)) continue;
+            // (the slot's list is this thread's until the state says DONE)
+            sl.ev_ok = n > 0 && r->scan_ahead && list_events(dst, (size_t)n, r->wide_scan, sl.ev);
             lk.lock();
             r->read_s += dt;
             break;
@@ -257,6 +304,10 @@ static bool request_ahead(fa_reader *r) {
             std::lock_guard<std::mutex> g(a.mu);
             fa_reader::Ahead::Slot &sl = a.slot[k];
             sl.dst = r->text + r->filled + r->pending;
+            if (sl.ev.capacity() == 0 && !r->ev_spare.empty()) {
+                sl.ev.swap(r->ev_spare.back());
+                r->ev_spare.pop_back();
+            }
             sl.want = want;
             sl.off = r->file_off;
             sl.state = fa_reader::Ahead::Slot::REQUESTED;
@@ -289,6 +340,14 @@ static bool settle_ahead(fa_reader *r) {
         n = sl.n;
         err = sl.err;
         want = sl.want;
+        if (n > 0 && !r->eof && sl.ev_ok) {
+            r->pieces.emplace_back();
+            fa_reader::Piece &pc = r->pieces.back();
+            pc.start = (long long)r->filled;
+            pc.len = (size_t)n;
+            pc.ev.swap(sl.ev);
+        }
+        sl.ev_ok = false;
         sl.state = fa_reader::Ahead::Slot::IDLE;
     }
     r->pending -= want;
@@ -430,6 +489,7 @@ extern "C" fa_reader *fa_reader_open(int fd, int min_n_read, int min_len_aln, in
     (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);
 #endif
     r->wide_scan = __builtin_cpu_supports("avx512bw") && !getenv("FALCON_AMD_READER_SSE2");
+    r->scan_ahead = !getenv("FALCON_AMD_READER_SCAN_INLINE");
     // a regular file (a block's LA4Falcon output kept on disk, the benchmarks): several
     // pread()s at a time from where the descriptor stands
     struct stat st;
@@ -437,7 +497,9 @@ extern "C" fa_reader *fa_reader_open(int fd, int min_n_read, int min_len_aln, in
         const off_t at = lseek(fd, 0, SEEK_CUR);
         if (at >= 0) {
             r->file_off = (long long)at;
-            r->n_slots = fa_reader::kSlots;
+            // (a helper copies its piece out of the page cache and lists its events: ~8 GB/s each)
+            const char *want = getenv("FALCON_AMD_READER_THREADS");
+            r->n_slots = std::max(1, std::min((int)fa_reader::kSlots, want ? atoi(want) : 6));
         }
     }
     return r;
@@ -516,6 +578,7 @@ extern "C" int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, 
             r->parsed -= keep_from;
             r->scanned -= keep_from;
             r->line_first_low -= std::min(r->line_first_low, keep_from);
+            for (fa_reader::Piece &pc : r->pieces) pc.start -= (long long)keep_from;
             for (Tok &t : r->pile) t.off -= keep_from;
             if (!r->pile.empty()) r->seed_name.off -= keep_from;
         }
@@ -571,6 +634,33 @@ extern "C" int fa_reader_next(fa_reader *r, int max_piles, long long max_bases, 
         const char *t = r->text;
         size_t i = r->scanned;
         bool go = true;
+        // pieces the scanner is past give their lists back
+        while (!r->pieces.empty() && r->pieces.front().start + (long long)r->pieces.front().len <= (long long)i) {
+            r->ev_spare.emplace_back();
+            r->ev_spare.back().swap(r->pieces.front().ev);
+            r->pieces.erase(r->pieces.begin());
+        }
+        if (!r->pieces.empty()) {
+            fa_reader::Piece &pc = r->pieces.front();
+            if (pc.start == (long long)i || (pc.start < (long long)i && pc.next > 0)) {
+                // the piece's events one by one (`next`: where an earlier visit stopped -- a '\r' at
+                // the end of what had been read by then)
+                const size_t base = (size_t)pc.start, stop = std::min(end, base + pc.len);
+                size_t k = pc.next;
+                for (; go && k < pc.ev.size(); k++) {
+                    const size_t at = base + pc.ev[k];
+                    if (at >= stop) break;
+                    if (!event(at)) go = false;
+                }
+                pc.next = k;  // (the event that closed the batch is behind it: the loop stepped past it)
+                if (go) r->scanned = stop;
+                r->scan_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
+                continue;
+            }
+            // (in the middle of a piece whose list was never begun -- the tail a closed batch left --
+            // or in front of it: byte by byte as far as its end / its start)
+            end = std::min(end, pc.start <= (long long)i ? (size_t)pc.start + pc.len : (size_t)pc.start);
+        }
         if (r->wide_scan) i = scan64(t, i, end, event, go);
         while (go && i + 16 <= end) {
             const __m128i v = _mm_loadu_si128((const __m128i *)(t + i));

@@ -3,7 +3,7 @@
 N distinct E. coli-like piles written R times (new seed ids), so that start-up (process, HIP,
 first buffers) is amortised the way a real .las block amortises it.
 
-    python scripts/exp_e2e.py 3072 3 [ENV=VALUE ...]     # one run per ENV setting, plus the default
+    python scripts/exp_e2e.py 3072 3 [ENV=VALUE[,ENV=VALUE] ...]     # one run per setting, plus the default
 """
 import hashlib
 import multiprocessing as mp
@@ -19,7 +19,7 @@ from falcon_amd.synth import make_pile, pile_to_la4falcon  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-SETTINGS = [{}] + [dict([kv.split("=", 1)]) for kv in sys.argv[3:]]
+SETTINGS = [{}] + [dict(kv.split("=", 1) for kv in arg.split(",")) for arg in sys.argv[3:]]  # (A=1,B=2: one setting)
 
 
 def one(job):
@@ -51,6 +51,12 @@ for env in SETTINGS:
     ref_sha = ref_sha or sha
     runs = [float(ln.split("GPU stages + download ")[1].split()[0]) for ln in open(path + ".err") if "GPU stages + download" in ln]
     print("%-44s %d piles, %.0f MB in %.2f s: %.0f piles/s, %.0f MB/s; %d batches, GPU stages + download "
-          "%.0f ms mean; FASTA %s %s" % (env or "default", N * R, size / 1e6, dt, N * R / dt, size / 1e6 / dt,
+          "%.0f ms mean; FASTA %s %s" % (",".join("%s=%s" % kv for kv in env.items()) or "default", N * R, size / 1e6, dt, N * R / dt, size / 1e6 / dt,
                                         len(runs), 1e3 * sum(runs) / max(1, len(runs)), sha,
                                         "(same)" if sha == ref_sha else "(DIFFERENT)"), flush=True)
+    for ln in open(path + ".err"):
+        if "steady state" in ln or "FALCON_AMD_TIMING" in ln:
+            print("    " + ln.strip()[:300], flush=True)
+if os.environ.get("EXP_E2E_KEEP_LOG"):
+    import shutil
+    shutil.copy(path + ".err", os.environ["EXP_E2E_KEEP_LOG"])

@@ -163,8 +163,10 @@ int main(int argc, char **argv) {
     int variant = 0;
     for (int pipe_mode = 0; pipe_mode < 2; pipe_mode++)
         for (int keep : {2, 8})
-            for (int one_slot = 0; one_slot < 2; one_slot++, variant++) {
-                if (one_slot) setenv("FALCON_AMD_READER_SLOTS1", "1", 1); else unsetenv("FALCON_AMD_READER_SLOTS1");
+            for (int one_slot = 0; one_slot < 3; one_slot++, variant++) {
+                // (2: several helpers again, the scanner reading the bytes itself instead of walking their lists)
+                if (one_slot == 1) setenv("FALCON_AMD_READER_SLOTS1", "1", 1); else unsetenv("FALCON_AMD_READER_SLOTS1");
+                if (one_slot == 2) setenv("FALCON_AMD_READER_SCAN_INLINE", "1", 1); else unsetenv("FALCON_AMD_READER_SCAN_INLINE");
                 int fd;
                 std::thread writer;
                 if (pipe_mode) {

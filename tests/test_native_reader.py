@@ -458,6 +458,15 @@ def test_a_long_file_through_every_reading_mode(monkeypatch):
     monkeypatch.delenv("FALCON_AMD_READER_SLOTS1")
     assert _native(text, 1, 1, 0, 500, 0, max_piles=7)[0] == ref
     monkeypatch.delenv("FALCON_AMD_READER_SSE2")
+    # (the helpers list the white space of their pieces; the scanner reading every byte itself, as it did
+    # through round 4, and other numbers of helpers)
+    monkeypatch.setenv("FALCON_AMD_READER_SCAN_INLINE", "1")
+    assert _native(text, 1, 1, 0, 500, 0, max_piles=7)[0] == ref
+    monkeypatch.delenv("FALCON_AMD_READER_SCAN_INLINE")
+    for n in ("2", "8"):
+        monkeypatch.setenv("FALCON_AMD_READER_THREADS", n)
+        assert _native(text, 1, 1, 0, 500, 0, max_bases=30_000_000)[0] == ref
+    monkeypatch.delenv("FALCON_AMD_READER_THREADS")
     rd, wr = os.pipe()
 
     def feed():
@@ -477,3 +486,38 @@ def test_a_long_file_through_every_reading_mode(monkeypatch):
     th.join()
     os.close(rd)
     assert got == ref
+
+
+
+@pytest.mark.parametrize("ending", ["\r", "\r\n"])
+def test_a_carriage_return_where_a_piece_of_the_file_ends(ending, monkeypatch):
+    """The file is read in pieces of 4 MB whose white space the helper threads list: a line that ends in a
+    lone '\\r' -- or whose '\\r\\n' is cut in two -- exactly where a piece ends is the one place where the
+    scanner has to wait for the next piece (universal newlines: is the next byte a line feed?)."""
+    rng = random.Random(5)
+    piece = 4 << 20
+    lines, size = [], 0
+    p = 0
+    while size < 3 * piece + 100000:
+        n_read = 6
+        pile = ["%08d %s" % (100 * p + i, _rand_seq(rng, rng.randint(3000, 5000))) for i in range(n_read)] + ["+ +"]
+        for ln in pile:
+            # the line that would cross the end of a piece is cut so that its '\r' is the piece's last byte
+            nxt = (size // piece + 1) * piece
+            if size + len(ln) + 1 > nxt and nxt - size > 40 and " " in ln and nxt - size < len(ln):
+                ln = ln[:nxt - size - 1]
+                lines.append(ln + ending)
+                size += len(ln) + len(ending)
+            else:
+                lines.append(ln + "\n")
+                size += len(ln) + 1
+        p += 1
+    lines.append("- -\n")
+    text = "".join(lines)
+    assert text[piece - 1] == "\r" and text[2 * piece - 1] == "\r"
+    want = _python(text, 1, 1, 0, 500, 0)
+    for limits in ((0, 0), (5, 0), (0, 200000)):
+        got, _ = _native(text, 1, 1, 0, 500, 0, max_piles=limits[0], max_bases=limits[1])
+        assert got == want
+    monkeypatch.setenv("FALCON_AMD_READER_SCAN_INLINE", "1")
+    assert _native(text, 1, 1, 0, 500, 0, max_piles=5)[0] == want
