@@ -457,11 +457,26 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None,
         finally:
             raw.put(END)
 
+    stagers_left = [0]  # (set when the threads are made; the last stager to leave ends the runners' queue)
+    stagers_lock = threading.Lock()
+    staged_seqs, next_back = set(), [0]
+
+    def give_back(seq):
+        # The reader's promise counts CALLS (a batch lives through the next `ahead` - 1 of them), so its
+        # buffers go back in stream order: a batch staged before an earlier one waits for that one.
+        with stagers_lock:
+            staged_seqs.add(seq)
+            while next_back[0] in staged_seqs:
+                staged_seqs.remove(next_back[0])
+                next_back[0] += 1
+                lease.release()
+
     def stager():
         try:
             while True:
                 item = raw.get()
                 if item is END:
+                    raw.put(END)  # the other stagers see it too
                     return
                 seq, ps = item
                 try:
@@ -472,14 +487,22 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None,
                     LOG.debug("t=%.3f stager: batch %d staged in %.3f s", _clock(), seq,
                               time.perf_counter() - t0)
                 finally:
-                    lease.release()
+                    give_back(seq)
                 staged.put(out)
         except Exception as exc:
             fail(exc)
-            while raw.get() is not END:  # (the reader never blocks on a full queue)
-                lease.release()
+            while True:  # (the reader never blocks on a full queue)
+                item = raw.get()
+                if item is END:
+                    raw.put(END)
+                    break
+                give_back(item[0])
         finally:
-            staged.put(END)
+            with stagers_lock:
+                stagers_left[0] -= 1
+                last = stagers_left[0] == 0
+            if last:
+                staged.put(END)
 
     def runner():
         try:
@@ -577,10 +600,14 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None,
 
     staged = queue.Queue(maxsize=n_run)
     done = queue.Queue(maxsize=2 * n_run + 2)
-    t_stage = threading.Thread(target=stager, daemon=True)
+    # two staging threads: a batch's layout and device buffers beside the packing and upload of the one before
+    # (those two hold the context's one pinned staging buffer); the printer puts the batches back in order
+    n_stage = max(1, min(4, int(os.environ.get("FALCON_AMD_STAGERS", "2"))))
+    stagers_left[0] = n_stage
+    t_stage = [threading.Thread(target=stager, daemon=True) for _ in range(n_stage)]
     t_run = [threading.Thread(target=runner, daemon=True) for _ in range(n_run)]
     t_out = threading.Thread(target=printer, daemon=True)
-    for t in [t_stage, t_out] + t_run:
+    for t in t_stage + [t_out] + t_run:
         t.start()
     try:
         for t in t_run:
@@ -596,7 +623,7 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None,
         LOG.debug("t=%.3f printer done", _clock())
         # the reader may only be closed once the ingest and staging threads have left it;
         # what they had staged meanwhile is released
-        while t_in.is_alive() or t_stage.is_alive():
+        while t_in.is_alive() or any(t.is_alive() for t in t_stage):
             try:
                 item = staged.get(timeout=0.05)
             except queue.Empty:
