@@ -600,9 +600,10 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None,
 
     staged = queue.Queue(maxsize=n_run)
     done = queue.Queue(maxsize=2 * n_run + 2)
-    # two staging threads: a batch's layout and device buffers beside the packing and upload of the one before
-    # (those two hold the context's one pinned staging buffer); the printer puts the batches back in order
-    n_stage = max(1, min(4, int(os.environ.get("FALCON_AMD_STAGERS", "2"))))
+    # (FALCON_AMD_STAGERS=2: a batch's layout and device buffers beside the packing and upload of the one before
+    # -- those two hold the context's one pinned staging buffer; the printer puts the batches back in order.
+    # Measured: nothing, profiles/r05_e2e_stagers.txt -- the stream waits for the GPU's batches, not for staging)
+    n_stage = max(1, min(4, int(os.environ.get("FALCON_AMD_STAGERS", "1"))))
     stagers_left[0] = n_stage
     t_stage = [threading.Thread(target=stager, daemon=True) for _ in range(n_stage)]
     t_run = [threading.Thread(target=runner, daemon=True) for _ in range(n_run)]
