@@ -87,6 +87,48 @@ def _single_stream_output(text, args):
     return out.getvalue()
 
 
+@pytest.mark.parametrize("stagers", ["2", "4"])
+def test_several_staging_threads_keep_the_order_and_the_readers_buffers(stagers, monkeypatch):
+    """FALCON_AMD_STAGERS > 1: batches are staged side by side and may finish out of order -- the records
+    still leave in stream order, and a batch's text is still there while it is being staged however far
+    the threads beside it have got (the reader's buffers go back in stream order; it keeps two here, so a
+    buffer given back early would be overwritten by the next call)."""
+    monkeypatch.setenv("FALCON_AMD_READ_AHEAD", "2")
+    rng = random.Random(33)
+    text = _rand_stream(rng, 150, with_noise=True)
+    args = single.parse_args(["prog"] + OPTS)
+    want = _single_stream_output(text, args)
+    assert want.count(">") > 80
+    monkeypatch.setenv("FALCON_AMD_STAGERS", stagers)
+    order = []
+
+    class Gpu:
+        engines = [None]
+        parallel = 3
+
+        def stage(self, ps):
+            # every third batch takes its time BEFORE it looks at its piles
+            n = len(order)
+            order.append(n)
+            if n % 3 == 0:
+                time.sleep(0.02)
+            return ps.piles()
+
+        def finish(self, piles):
+            return [(p[0] * 20)[:600] for p in piles]
+
+    rd, wr = os.pipe()
+    t = threading.Thread(target=lambda: (os.write(wr, text.encode()), os.close(wr)))
+    t.start()
+    out = io.StringIO()
+    try:
+        single._run_native(args, single.settings_from(args), rd, Gpu(), out, batch_bases=900)
+    finally:
+        os.close(rd)
+        t.join()
+    assert len(order) > 20 and out.getvalue() == want
+
+
 def test_jobs_share_devices_and_print_what_the_single_worker_prints(tmp_path, monkeypatch):
     monkeypatch.setenv("FALCON_AMD_BATCH_BASES", "900")
     rng = random.Random(9)
