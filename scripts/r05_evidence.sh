@@ -68,4 +68,4 @@ find $O -name "*.csv" -size +2M -delete
 unset FALCON_AMD_DEVICE_PACK
 cd $R
 # the default line again, now that the traffic and issue records of THIS build are on file
-[ -z "$FINAL" ] && timeout 400 python bench.py --no-cpu-baseline --no-end-to-end > $O/bench_ecoli_with_records.json.txt 2> /dev/null; cut -c1-200 $O/bench_ecoli_with_records.json.txt
+if [ -z "$FINAL" ]; then timeout 400 python bench.py --no-cpu-baseline --no-end-to-end > $O/bench_ecoli_with_records.json.txt 2> /dev/null; cut -c1-200 $O/bench_ecoli_with_records.json.txt; fi
