@@ -1217,6 +1217,13 @@ extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double
         const double max_diff = 1.0 - min_idt;  // falcon.c:580
         // (decided once per run: the arena sized here is the one start_align launches on)
         const bool two_per_wave = use_align2(b, FA_BAND);
+        if (!two_per_wave && b->n_words >= (1ull << 28)) {
+            // (not an error -- the answers are the same -- but four times the alignment time, and nobody asked for it)
+            static std::atomic<bool> said{false};
+            if (!said.exchange(true))
+                fprintf(stderr, "falcon_amd: a batch of %llu packed words (>= 2^28, 4.29 G bases) is aligned by k_align, "
+                                "not k_align2: smaller batches are faster\n", (unsigned long long)b->n_words);
+        }
         if (two_per_wave) {
             if (ensure_arena_a2(c, b)) return -1;
         } else {
