@@ -13,12 +13,12 @@
 //     inserted base -- the same keys k_links builds (falcon.c:126-160);
 //   * the groups of a position live in lane-private LDS words.  The keys that make up nearly
 //     all links have a slot of their own -- delta 0 after a plain column (4 keys), delta 0 after
-//     a one-base insertion (8), delta 1 (8): a read-modify-write, no search, reached without the
-//     general column code for every column but an alignment's first; the others (deeper
-//     insertions, alignment starts, the unitig mode's first columns) go to a short linked list
-//     (entries from a pool the 64 positions share: a seed that lost two bases sees a dozen
-//     different two-base insertions at one position and none at its neighbours), searched
-//     linearly;
+//     a one-base insertion (8), delta 1 (8): a read-modify-write, no search -- for all 64 lanes
+//     as ONE predicated stream per column (a lane the case does not apply to adds 0 to a slot it
+//     is not in; round 5); the others (deeper insertions, alignment starts, the unitig mode's
+//     first columns) go to a short linked list (entries from a pool the 64 positions share: a
+//     seed that lost two bases sees a dozen different two-base insertions at one position and
+//     none at its neighbours), searched linearly, behind one wavefront-wide test per column;
 //   * a group's rank among the links of its LEVEL is taken when it is created -- alignments
 //     come in read order, so that is the reference's first-insertion order (Q5) -- and with the
 //     groups per level of every lane known, a prefix sum over the lanes places every link word:
@@ -30,7 +30,8 @@
 // behind that to k_links -- so the tables stay small whatever the input: 4996 bytes of LDS per
 // wavefront (three bytes per slot: u16 count + u8 rank; 128 pool entries with byte links), which is
 // eight wavefronts per SIMD -- the kernel spent 41 % of its wave cycles parked at an s_waitcnt with
-// the five that 7.7 KB allowed (10.65 -> 9.34 ms per 3072 piles, tests/test_kernel_resources.py).
+// the five that 7.7 KB allowed (10.65 -> 9.34 ms per 3072 piles, tests/test_kernel_resources.py;
+// 7.4 ms with the predicated column, at 0.93 of the chip's instruction-issue ceiling).
 #include <type_traits>
 
 #include "k_msa.h"
