@@ -29,9 +29,8 @@ static thread_local std::string g_err;
 
 // FALCON_AMD_TRACE=1: synchronise and report after every stage (debugging aid)
 static bool trace_on() {
-    static int v = -1;
-    if (v < 0) v = getenv("FALCON_AMD_TRACE") ? 1 : 0;
-    return v == 1;
+    static const bool v = getenv("FALCON_AMD_TRACE") != nullptr;  // (one thread-safe initialisation: several threads ask)
+    return v;
 }
 static void trace_stage(hipStream_t s, const char *name) {
     if (!trace_on()) return;
@@ -43,9 +42,8 @@ static void trace_stage(hipStream_t s, const char *name) {
 // FALCON_AMD_TIMING=1: host-side wall time of the phases of fa_batch_create / fa_batch_submit
 // on stderr (where do a worker's stalls come from?)
 static bool timing_on() {
-    static int v = -1;
-    if (v < 0) v = getenv("FALCON_AMD_TIMING") ? 1 : 0;
-    return v == 1;
+    static const bool v = getenv("FALCON_AMD_TIMING") != nullptr;  // (one thread-safe initialisation: several threads ask)
+    return v;
 }
 struct PhaseTimer {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();

@@ -577,9 +577,8 @@ __global__ __launch_bounds__(64, (SEQ_LDS ? 3 : 8)) void k_align(AlignArgs A) {
 }
 
 static bool seq_in_lds() {
-    static int v = -1;
-    if (v < 0) v = getenv("FALCON_AMD_ALIGN_LDS") ? 1 : 0;  // A/B switch; default: L1 path
-    return v == 1;
+    static const bool v = getenv("FALCON_AMD_ALIGN_LDS") != nullptr;  // A/B switch; default: L1 path  // (one thread-safe initialisation: several threads ask)
+    return v;
 }
 
 size_t fa_align_lds_bytes(int max_q_len, int max_t_len) {
