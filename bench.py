@@ -326,6 +326,12 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
             # the co-running alignment kernel frees, so the spans add up to more than a step;
             # `roofline.alone` and the unpipelined profile under profiles/ hold the kernels' own times)
             "kernel_ms_are": "queue-inclusive event spans" if pipelined else "kernel times (one batch at a time)",
+            # the kernels' own times: two unpipelined passes after the timed region (one batch at a time, nothing
+            # beside it) -- and what running the steps as a pipeline of `batches_in_flight` batches buys:
+            # the sum of those times minus the pipelined step
+            "kernel_ms_alone": ({n: round(v, 4) for n, v in alone_ms.items()} if alone_ms else None),
+            "pipeline_gain_ms": (round(sum(alone_ms.values()) - elapsed / max(1, args.steps) * 1e3, 3)
+                                 if alone_ms else None),
             "host_plan_gap_ms": round(host_gap, 3),
             # what a call of fa_batch_submit costs the calling thread (it queues the front
             # kernels and hands the batch to the context's planner thread): mean and worst
@@ -355,6 +361,9 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
                 st.b_alg() * world * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world), 5),
             "setup_s": {"generate": round(t_gen, 2), "stage_to_hbm_incl_pcie": round(t_up, 2),
                         "stage_to_hbm_incl_pcie_again": None},
+            # the pile generators every rank forked before it touched the GPU: its share of the container's CPU quota
+            "generators": {"processes_per_rank": getattr(args, "gen_procs", None), "ranks": world,
+                           "cpu_quota_cores": getattr(args, "cpu_quota", None)},
         }
         gpu_cns = None
         if world == 1 and not (args.no_end_to_end and args.no_cpu_baseline):
@@ -461,6 +470,7 @@ def main(argv=None):
     if quota:
         ncpu = max(1, min(ncpu, int(quota)))
     procs = max(1, min(32, ncpu // max(1, world)))
+    args.gen_procs, args.cpu_quota = procs, (float(quota) if quota else None)
     seeds = [1000003 * (rank + 1) + i for i in range(args.piles)]
     t0 = time.perf_counter()
     piles = gen_piles(seeds, procs, wl)

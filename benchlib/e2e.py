@@ -178,9 +178,11 @@ def end_to_end_workers(piles, n_workers, repeats=E2E_REPEATS, worker_cmd=None):
             if p.returncode != 0:
                 raise RuntimeError("end_to_end_workers: worker %d exited %d: %s" % (j, p.returncode, log[-400:]))
             dev = re.search(r"device\(s\) ([0-9,]+)", log)
+            slot = re.search(r"lock slot\(s\) ([0-9.,]+)", log)
             steady = re.search(r"steady state ([0-9.]+) piles/s", log)
             texts.append(open(os.path.join(tmp, "cns_%d.fasta" % j)).read())
-            workers.append({"worker": j, "devices": dev.group(1) if dev else None, "wall_s": round(wall[j], 2),
+            workers.append({"worker": j, "devices": dev.group(1) if dev else None,
+                            "lock_slots": slot.group(1) if slot else None, "wall_s": round(wall[j], 2),
                             "piles_per_sec": round(repeats * len(piles) / wall[j], 1),
                             "text_GB_per_sec": round(size / 1e9 / wall[j], 2),
                             "steady_state_piles_per_sec": float(steady.group(1)) if steady else None})
@@ -189,6 +191,7 @@ def end_to_end_workers(piles, n_workers, repeats=E2E_REPEATS, worker_cmd=None):
     return {"piles_per_sec": round(n / slowest, 1), "text_MB_per_sec": round(size * n_workers / 1e6 / slowest, 1),
             "wall_s": round(slowest, 2), "workers": workers,
             "distinct_devices": len({w["devices"] for w in workers}),
+            "distinct_lock_slots": len({w["lock_slots"] for w in workers if w["lock_slots"]}),
             "every_fasta_identical": all(t == texts[0] for t in texts) and len(texts[0]) > 0,
             "what": "%d single-stream workers started together, %d piles each (%.0f MB of text each, from the page "
                     "cache) -> %d FASTA files; every worker is a process of its own that takes a GPU through the "

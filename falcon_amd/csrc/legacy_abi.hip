@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -42,6 +43,10 @@ static void die(const char *what) {
     abort();
 }
 
+// piles generate_consensus answered with the empty consensus because this library could not process them
+static std::atomic<long> g_failed_piles{0};
+extern "C" long fa_legacy_failed_piles(void) { return g_failed_piles.load(); }
+
 // ---- falcon.c:562-666 ------------------------------------------------------
 extern "C" consensus_data *generate_consensus(char **input_seq, unsigned int n_seq,
                                               unsigned min_cov, unsigned K, double min_idt) {
@@ -64,14 +69,23 @@ extern "C" consensus_data *generate_consensus(char **input_seq, unsigned int n_s
         // (falcon_kit/mains/consensus.py:102-120, graph_to_contig.py:58-104) must keep its
         // interpreter.  So: one loud line on stderr and the EMPTY consensus, which every caller
         // of the reference already handles (falcon.c:651-656; consensus.py:286 drops it).
+        // (FALCON_AMD_LEGACY_ABORT=1: a caller that would rather stop than lose a read silently gets the
+        // abort of rounds 1-4 back; fa_legacy_failed_piles() counts the piles answered this way)
+        g_failed_piles++;
+        if (getenv("FALCON_AMD_LEGACY_ABORT")) {
+            fprintf(stderr, "CRITICAL ERROR: falcon_amd generate_consensus: %s\n", why);
+            abort();
+        }
         fprintf(stderr, "ERROR: falcon_amd generate_consensus: %s -- empty consensus returned\n", why);
         len = 0;
     }
     consensus_data *r = (consensus_data *)calloc(1, sizeof(consensus_data));
     r->sequence = (char *)calloc((size_t)len + 1, 1);
     r->eqv = (int *)calloc((size_t)len + 1, sizeof(int));
-    memcpy(r->sequence, s, (size_t)len);
-    memcpy(r->eqv, e, (size_t)len * sizeof(int));
+    if (len > 0) {
+        memcpy(r->sequence, s, (size_t)len);
+        memcpy(r->eqv, e, (size_t)len * sizeof(int));
+    }
     fa_batch_free(b);
     return r;
 }
@@ -94,8 +108,10 @@ extern "C" consensus_data *generate_utg_consensus(char **input_seq, seq_coor_t *
     consensus_data *r = (consensus_data *)calloc(1, sizeof(consensus_data));
     r->sequence = (char *)calloc((size_t)len + 1, 1);
     r->eqv = (int *)calloc((size_t)len + 1, sizeof(int));
-    memcpy(r->sequence, s, (size_t)len);
-    memcpy(r->eqv, e, (size_t)len * sizeof(int));
+    if (len > 0) {
+        memcpy(r->sequence, s, (size_t)len);
+        memcpy(r->eqv, e, (size_t)len * sizeof(int));
+    }
     fa_batch_free(b);
     return r;
 }

@@ -67,14 +67,20 @@ class DevicePool:
                         grow = self._grow
                         break
                     self._lock.wait()
-            engine = grow()
-            with self._lock:
-                self._growing = False
-                if engine is not None:
-                    self.devices.append(Device(engine, len(self.devices)))
-                else:
-                    self._grow = None  # (nothing left to take: do not ask again at every batch)
-                self._lock.notify_all()
+            engine, asked = None, False
+            try:
+                engine = grow()
+                asked = True
+            finally:
+                # (a grow() that raised -- no memory for another arena -- must not leave the pool waiting
+                # for a device that never comes: the flag goes back and the waiters look again)
+                with self._lock:
+                    self._growing = False
+                    if engine is not None:
+                        self.devices.append(Device(engine, len(self.devices)))
+                    elif asked:
+                        self._grow = None  # (nothing left to take: do not ask again at every batch)
+                    self._lock.notify_all()
 
     def give_back(self, dev: Device):
         with self._lock:
@@ -98,6 +104,7 @@ class DevicePool:
 # Eight jobs on eight GPUs hold eight different slot-0 locks; the ninth gets slot 1 somewhere.
 # The lock lives as long as the process (flock: the kernel drops it with the descriptor).
 _held_locks = []
+held_slots = []   # (device, slot) of every lock this process holds: what the worker's log line says
 
 
 def _lock_dir():
@@ -142,6 +149,7 @@ def _try_lock(dev, slot):
         os.close(fd)
         return None
     _held_locks.append(fd)
+    held_slots.append((dev, slot))
     return True
 
 

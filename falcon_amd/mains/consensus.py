@@ -671,8 +671,10 @@ def run(args, stdin=None, stdout=None, consensus_map=None, leave_open=False):
 
     def open_gpu():
         opened.append(GpuConsensus(args.min_cov, args.min_idt))
-        LOG.info("falcon_amd consensus on %d engine(s), device(s) %s (t=%.3f)", len(opened[0].engines),
-                 ",".join(str(getattr(e, "device", "?")) for e in opened[0].engines), _clock())
+        from falcon_amd.devices import held_slots
+        LOG.info("falcon_amd consensus on %d engine(s), device(s) %s, lock slot(s) %s (t=%.3f)", len(opened[0].engines),
+                 ",".join(str(getattr(e, "device", "?")) for e in opened[0].engines),
+                 ",".join("%d.%d" % ds for ds in held_slots) or "none", _clock())
         return opened[0]
 
     fd = _stream_fd(stdin)

@@ -112,6 +112,12 @@ consensus_data *generate_utg_consensus(char **input_seq, seq_coor_t *offset, uns
 consensus_data *generate_consensus(char **input_seq, unsigned int n_seq, unsigned min_cov,
                                    unsigned K, double min_idt);
 void free_consensus_data(consensus_data *c);
+/* Additive: generate_consensus has no error channel (falcon.c:562-566 returns a pointer, nothing else), so a
+ * pile this library cannot process (a byte outside ACGT, more than 65 534 reads) comes back as the EMPTY
+ * consensus -- which the reference's callers drop without a word (consensus.py:286) -- with one line on stderr.
+ * This counts those piles for a caller that wants to know; FALCON_AMD_LEGACY_ABORT=1 in the environment makes
+ * generate_consensus abort() there instead, like the reference does on its own fatal errors (DW_banded.c:100-113). */
+long fa_legacy_failed_piles(void);
 
 /* ------------------------------------------------------------------------- */
 /* (2) Batch ABI -- replaces the multiprocessing.Pool.imap over piles of       */

@@ -172,3 +172,49 @@ sys.stderr.write("INFO:falcon_amd.consensus:falcon_amd consensus: 6 piles in 3 b
         assert w["wall_s"] >= 0.4 and w["piles_per_sec"] > 0 and w["steady_state_piles_per_sec"] == 1234.0
     out5 = end_to_end_workers(piles, 5, repeats=1, worker_cmd=stand_in)
     assert out5["distinct_devices"] == 4 and len(out5["workers"]) == 5
+
+
+def test_plumbing_under_nccl_binds_every_rank_to_its_own_device(monkeypatch):
+    """What stays RCCL-only on the GPU box, checked here against a recording stand-in for torch.distributed
+    and torch.cuda: for ranks 0..7 of an 8-rank node Plumbing("nccl") selects cuda:local_rank, hands
+    device_id=cuda:local_rank to init_process_group (RCCL binds its communicator to that device: no lazy
+    init on device 0 by every rank), verifies the world size, and bench_rank opens Engine(local_rank)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import bench
+    calls = []
+    monkeypatch.delenv("FALCON_BENCH_BACKEND", raising=False)
+    monkeypatch.delenv("FALCON_BENCH_ONE_DEVICE", raising=False)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: calls.append(("set_device", d)))
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: calls.append(("synchronize",)))
+    monkeypatch.setattr(dist, "init_process_group", lambda backend, **kw: calls.append(("init", backend, kw)))
+    monkeypatch.setattr(dist, "get_world_size", lambda *a: 8)
+    monkeypatch.setattr(dist, "barrier", lambda *a, **k: calls.append(("barrier",)))
+    monkeypatch.setattr(dist, "destroy_process_group", lambda *a: calls.append(("destroy",)))
+    for local_rank in range(8):
+        del calls[:]
+        pl = bench.Plumbing(local_rank, local_rank, 8, "nccl")
+        assert pl.cuda and pl.gpu and pl.device == local_rank
+        assert calls[0] == ("set_device", local_rank)
+        kind, backend, kw = calls[1]
+        assert (kind, backend) == ("init", "nccl") and kw["rank"] == local_rank and kw["world_size"] == 8
+        assert kw["device_id"] == torch.device("cuda", local_rank)
+        pl.sync()
+        assert calls[-2:] == [("synchronize",), ("barrier",)]
+        pl.close()
+        assert calls[-1] == ("destroy",)
+        # the engine of the rank is opened on the same device
+        opened = []
+
+        class _E(StandInEngine):
+            def __init__(self, device):
+                opened.append(device)
+                raise RuntimeError("stop here")
+        with pytest.raises(RuntimeError, match="stop here"):
+            bench.bench_rank(bench.parse_args(["--gpus", "8", "--piles", "2"]), pl, _E, [[b"ACGT"] * 3] * 2)
+        assert opened == [local_rank]
+    # a rendezvous that saw another number of ranks is refused
+    monkeypatch.setattr(dist, "get_world_size", lambda *a: 7)
+    with pytest.raises(RuntimeError, match="rendezvous saw 7 ranks"):
+        bench.Plumbing(0, 0, 8, "nccl")

@@ -251,6 +251,39 @@ def test_the_real_engine_under_world_size_2_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_the_real_engine_under_world_size_8_on_one_gpu():
+    """The shape of the 8-GPU run nobody could launch here (the reference's fan-out:
+    consensus.py:264-274, consensus_split.py:55-85), on the one GPU of the box: eight ranks rendezvous over
+    127.0.0.1, each with the real Engine, its resident batches and its share of the pile generators (the
+    container's CPU quota divided by eight), lined up by barriers, the measurement reduced over
+    torch.distributed; then eight single-stream workers started together, each a process of its own that
+    takes a lock slot (all eight on device 0 here: eight different slots of it).  Eight arenas of 6.8 GB fit
+    the 288 GB of one MI355X."""
+    import json
+    env = dict(os.environ, FALCON_BENCH_BACKEND="gloo", FALCON_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--piles", "48", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak"
+    assert len(d["per_rank"]) == 8 and all(r["bases_per_sec"] > 0 for r in d["per_rank"])
+    assert d["value"] <= sum(r["bases_per_sec"] for r in d["per_rank"]) * 1.001
+    assert d["value"] >= 8 * min(r["bases_per_sec"] for r in d["per_rank"]) * 0.999
+    # the generators of all ranks together stay inside the CPU quota (8 ranks forked 32 each once)
+    g = d["generators"]
+    assert g["ranks"] == 8 and g["processes_per_rank"] >= 1
+    assert g["processes_per_rank"] * 8 <= max(8, int(g["cpu_quota_cores"] or os.cpu_count()))
+    w = d["end_to_end_workers"]
+    assert len(w["workers"]) == 8 and w["every_fasta_identical"], w
+    assert all(x["devices"] == "0" for x in w["workers"]), w            # one GPU on this box ...
+    assert w["distinct_lock_slots"] == 8, w                             # ... eight different slots of it
+    assert d["end_to_end"]["piles_per_sec"], d["end_to_end"]            # eight streams through the multi-stream worker
+
+
+@pytest.mark.gpu
 def test_a_job_served_by_the_node_s_server_prints_the_same_bytes():
     """falcon_amd.mains.consensus_server on the real engine: two jobs one after the other and two at the same
     time hand their stdin / stdout to it; each FASTA equals what the stand-alone worker prints for the stream."""
