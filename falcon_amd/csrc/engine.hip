@@ -292,6 +292,10 @@ struct fa_batch {
     std::vector<FaSeq> seq;
     std::vector<FaPile> pile;
     std::vector<int> order, chain_order;
+    // k_align2's base indices are 32 bits: stretches of whole piles of < 2^28 packed words each, one launch per
+    // stretch (one stretch for every batch a worker builds); empty when a single pile is larger than that
+    struct A2Group { u32 word_base; int order_begin, order_count; };
+    std::vector<A2Group> a2_groups;
     std::vector<u64> ascii_off, script_off, probe_off;
     u64 n_words = 0, ascii_bytes = 0, script_words = 0, probe_words = 0;
     int max_read_len = 0, max_seed_len = 0, max_rows = 0, max_bins = 4;
@@ -677,13 +681,38 @@ static fa_batch *batch_build(fa_ctx *ctx, int n_pile, const int *pile_n_seq,
     b->max_rows = max_rows;
     // longest reads first: the lanes of a k_chain wave and the tail of the
     // k_align work queue then see similar work
+    // (... inside a stretch of piles k_align2 takes in one launch: one stretch, unless the batch holds 2^28
+    // packed words = 4.29 G bases or more -- FALCON_AMD_A2_MAX_WORDS: tests force the cut)
+    std::vector<int> group_of(n_pile, 0);
+    {
+        u64 lim = (1ull << 28) - 64;
+        if (const char *e = getenv("FALCON_AMD_A2_MAX_WORDS")) lim = std::max<u64>(64, strtoull(e, nullptr, 10));
+        std::vector<u64> base;  // first packed word of every stretch
+        bool ok = true;
+        for (int p = 0; p < n_pile; p++) {
+            const u64 first = b->seq[b->pile[p].first].woff;
+            const u64 end = p + 1 < n_pile ? (u64)b->seq[b->pile[p + 1].first].woff : woff;
+            if (base.empty() || end - base.back() > lim) base.push_back(first);
+            if (end - base.back() > (1ull << 28) - 64) ok = false;   // one pile alone is too large: k_align takes the batch
+            group_of[p] = (int)base.size() - 1;
+        }
+        b->a2_groups.clear();
+        if (ok)
+            for (u64 w : base) b->a2_groups.push_back({(u32)w, 0, 0});
+    }
     b->order.resize(g);
     std::iota(b->order.begin(), b->order.end(), 0);
     std::stable_sort(b->order.begin(), b->order.end(), [&](int x, int y) {
+        const int gx = group_of[b->seq[x].pile], gy = group_of[b->seq[y].pile];
+        if (gx != gy) return gx < gy;
         int lx = b->seq[x].idx == 0 ? -1 : b->seq[x].len;
         int ly = b->seq[y].idx == 0 ? -1 : b->seq[y].len;
         return lx > ly;
     });
+    for (int i = 0; i < g && !b->a2_groups.empty(); i++) {
+        auto &gr = b->a2_groups[group_of[b->seq[b->order[i]].pile]];
+        if (gr.order_count++ == 0) gr.order_begin = i;
+    }
     // k_chain gathers from its pile's k-mer tables (262 KB + 4 B per seed base): its
     // work list is pile-major so that a pile's reads run together, and dealt into 8
     // interleaved streams (pile p -> stream p mod 8, workgroup b takes entry b / 8 of
@@ -1054,7 +1083,7 @@ static int ensure_arena2(fa_ctx *c, const fa_batch *b, int n) {
 // per wavefront kernel for everything (A/B and tests).
 static bool use_align2(const fa_batch *b, int band) {
     const bool off = getenv("FALCON_AMD_ALIGN1") != nullptr;  // (read every time: tests switch it)
-    return !off && band >= 64 && band + 1 <= 64 * FA_ALIGN_MAXCH - 1 && b->n_words < (1ull << 28);
+    return !off && band >= 64 && band + 1 <= 64 * FA_ALIGN_MAXCH - 1 && !b->a2_groups.empty();
 }
 
 // The tape arena of k_align2: one ring per resident wavefront, sized for the batch's
@@ -1215,12 +1244,12 @@ extern "C" int fa_batch_submit(fa_batch *b, unsigned min_cov, unsigned K, double
         const double max_diff = 1.0 - min_idt;  // falcon.c:580
         // (decided once per run: the arena sized here is the one start_align launches on)
         const bool two_per_wave = use_align2(b, FA_BAND);
-        if (!two_per_wave && b->n_words >= (1ull << 28)) {
+        if (!two_per_wave && b->n_seq > 0 && b->a2_groups.empty()) {
             // (not an error -- the answers are the same -- but four times the alignment time, and nobody asked for it)
             static std::atomic<bool> said{false};
             if (!said.exchange(true))
-                fprintf(stderr, "falcon_amd: a batch of %llu packed words (>= 2^28, 4.29 G bases) is aligned by k_align, "
-                                "not k_align2: smaller batches are faster\n", (unsigned long long)b->n_words);
+                fprintf(stderr, "falcon_amd: a pile of 2^28 packed words (4.29 G bases) or more: its batch is aligned by "
+                                "k_align, not k_align2\n");
         }
         if (two_per_wave) {
             if (ensure_arena_a2(c, b)) return -1;
@@ -1286,7 +1315,8 @@ static int start_align(fa_batch *b, unsigned min_cov, double max_diff, int band,
     if (b->h_aln.resize(b->n_seq) || b->h_a2_stats.resize(12)) return -1;
     if (two_per_wave) {
         (void)hipMemsetAsync(c->a2.stats, 0, 12 * sizeof(unsigned long long), s);
-        fa_launch_align2(d, c->a2, max_diff, band, b->order_dev(), b->n_seq, s);
+        for (const auto &gr : b->a2_groups)   // (one launch, unless the batch is cut: base indices are 32 bits)
+            fa_launch_align2(d, c->a2, max_diff, band, b->order_dev() + gr.order_begin, gr.order_count, gr.word_base, s);
     } else if (band + 1 > 64 * FA_ALIGN_MAXCH - 1) {
         fa_launch_align_wide(d, c->arena, max_diff, band, s);
     } else {
@@ -2050,7 +2080,8 @@ extern "C" int fa_align_pairs(fa_ctx *ctx, int n, const char *const *q, const in
     b->stats.align_relaunched = 0;
     if (use_align2(b, band_tolerance)) {
         if (ensure_arena_a2(c, b)) return fail(-1);
-        fa_launch_align2(d, c->a2, 2.0, band_tolerance, b->d_order.p, b->n_seq, s);
+        for (const auto &gr : b->a2_groups)
+            fa_launch_align2(d, c->a2, 2.0, band_tolerance, b->d_order.p + gr.order_begin, gr.order_count, gr.word_base, s);
     } else {
         if (ensure_arena(c, b, lds, true)) return fail(-1);
         if (wide) fa_launch_align_wide(d, c->arena, 2.0, band_tolerance, s);

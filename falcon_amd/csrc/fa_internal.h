@@ -127,8 +127,9 @@ size_t fa_align2_lds_bytes();
 int fa_align2_blocks_per_cu();
 // alignments whose band tolerance is >= 64 and whose packed words fit 2^32 bases; what it
 // cannot hold on its tape comes back with FaAln.err = 2 (repeat with fa_launch_align_list)
+// (`order` / `n_work`: the stretch of the work list to align; `word_base`: the first packed word of its piles)
 void fa_launch_align2(const FaBatchDev &b, const FaAlign2Arena &a, double max_diff, int band,
-                      const int *order, int n_work, hipStream_t s);
+                      const int *order, int n_work, u32 word_base, hipStream_t s);
 
 // first_bad: device int, preset to INT_MAX; receives the lowest sequence index holding a byte
 // other than upper-case A, C, G, T.  bad_pile (optional, n_pile ints, zeroed): 1 for every

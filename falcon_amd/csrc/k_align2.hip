@@ -45,10 +45,10 @@ u32 fa_align2_ring_for(int max_rows) {
 }
 
 void fa_launch_align2(const FaBatchDev &b, const FaAlign2Arena &a, double max_diff, int band,
-                      const int *order, int n_work, hipStream_t s) {
+                      const int *order, int n_work, u32 word_base, hipStream_t s) {
     if (n_work == 0) return;
     A2Args A;
-    A.words = b.words; A.seq = b.seq; A.pile = b.pile; A.range = b.range;
+    A.words = b.words + word_base; A.word_base = word_base; A.seq = b.seq; A.pile = b.pile; A.range = b.range;
     A.order = order; A.n_work = n_work; A.counter = a.counter;
     A.cells = a.mem; A.recs = nullptr; A.esc = nullptr;
     A.slot_words = a.slot_words;

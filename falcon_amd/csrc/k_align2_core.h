@@ -89,6 +89,8 @@ struct A2Args {
     const FaRange *range;
     const int *order;
     int n_work;
+    u32 word_base;     // `words` points at packed word `word_base` of the batch (base indices are 32 bits: a batch of
+                       // 2^28 words or more is aligned in several launches, each on a stretch of whole piles)
     int *counter;
     u32 *cells;        // per slot: ring x 64 bytes, as words: ((it >> 2) & (ring/4 - 1)) * 64 + lane
     u32 *recs;         // per slot: ring x 16 bytes {mask lo, mask hi, K track 0, K track 1}
@@ -370,7 +372,7 @@ W_FN bool a2_fetch(const A2Args &A, A2Track &t) {
         if (wi >= A.n_work) return false;
         const int g = w_uni(A.order[wi]);
         const int q_idx = w_uni(A.seq[g].idx);
-        const u32 q_woff = w_uniu(A.seq[g].woff);
+        const u32 q_woff = w_uniu(A.seq[g].woff) - A.word_base;
         const int pile_id = w_uni(A.seq[g].pile);
         const int s1 = w_uni(A.range[g].s1), e1 = w_uni(A.range[g].e1);
         const int s2 = w_uni(A.range[g].s2), e2 = w_uni(A.range[g].e2);
@@ -380,7 +382,7 @@ W_FN bool a2_fetch(const A2Args &A, A2Track &t) {
             continue;
         }
         const int seed_g = w_uni(A.pile[pile_id].first);
-        const u32 t_woff = w_uniu(A.seq[seed_g].woff);
+        const u32 t_woff = w_uniu(A.seq[seed_g].woff) - A.word_base;
         const int q_len = e1 - s1, t_len = e2 - s2;  // falcon.c:626-627
         const int max_d = w_uni((int)(0.3 * (double)(q_len + t_len)));  // DW_banded.c:149
         if (max_d <= 0) {  // no row is ever computed (:183)

@@ -107,7 +107,7 @@ extern "C" int emu_align2(const u32 *words, u64 n_words, const FaSeq *seq, int n
     emu::reg(aln, (size_t)n_seq * sizeof(FaAln), true);
     (void)n_pile;
     A2Args A;
-    A.words = words; A.seq = seq; A.pile = pile; A.range = range; A.order = order;
+    A.words = words; A.word_base = 0; A.seq = seq; A.pile = pile; A.range = range; A.order = order;
     A.n_work = n_work; A.counter = &counter;
     A.cells = arena.data(); A.recs = nullptr; A.esc = nullptr;
     A.slot_words = slot_words_for(ring);

@@ -16,7 +16,7 @@ void fa_launch_pack(const FaBatchDev &, int *, int *, hipStream_t) {}
 void fa_launch_index(const FaBatchDev &, int, hipStream_t) {}
 void fa_launch_chain(const FaBatchDev &b, int, hipStream_t) { memset(b.range, 0, (size_t)b.n_seq * sizeof(FaRange)); }
 static void no_alignment(const FaBatchDev &b) { memset(b.aln, 0, (size_t)b.n_seq * sizeof(FaAln)); }
-void fa_launch_align2(const FaBatchDev &b, const FaAlign2Arena &, double, int, const int *, int, hipStream_t) { no_alignment(b); }
+void fa_launch_align2(const FaBatchDev &b, const FaAlign2Arena &, double, int, const int *, int, u32, hipStream_t) { no_alignment(b); }
 void fa_launch_align_wide(const FaBatchDev &b, const FaAlignArena &, double, int, hipStream_t) { no_alignment(b); }
 void fa_launch_align(const FaBatchDev &b, const FaAlignArena &, int, int, double, hipStream_t) { no_alignment(b); }
 void fa_launch_align_band(const FaBatchDev &b, const FaAlignArena &, int, int, double, int, hipStream_t) { no_alignment(b); }

@@ -483,6 +483,26 @@ def test_batch_is_order_preserving_and_rerunnable(engine):
     bt.free()
 
 
+def test_a_batch_beyond_32_bit_base_indices_is_cut_into_launches_of_k_align2(engine, monkeypatch):
+    """k_align2 indexes bases with 32 bits: a batch of 2^28 packed words (4.29 G bases) or more is aligned in
+    several launches, each on a stretch of whole piles, not handed to the slower k_align (rounds 1-5).
+    FALCON_AMD_A2_MAX_WORDS forces the cut on a small batch: same strings, same eqv, the two-per-wavefront
+    kernel's iteration counters show it ran, and nothing was handed back."""
+    piles = [_synthetic(160 + i, S=2500 + 300 * (i % 3), coverage=12, min_read=500, mean_read=1500, sd_read=400)
+             for i in range(9)]
+    want = engine.consensus(piles, 4, 8, 0.70, want_eqv=True)
+    for lim in ("3000", "9000", "64"):   # (64: every pile a launch of its own)
+        monkeypatch.setenv("FALCON_AMD_A2_MAX_WORDS", lim)
+        bt = engine.batch(piles)
+        bt.run(4, 8, 0.70).fetch(True)
+        got = [bt.result(i) for i in range(len(piles))]
+        st = bt.stats()
+        bt.free()
+        assert got == want, lim
+        assert st.align_pair_iterations + st.align_single_iterations > 0 and st.align_handed_back == 0, lim
+    monkeypatch.delenv("FALCON_AMD_A2_MAX_WORDS")
+
+
 def test_deep_piles_and_failures_stay_with_their_pile(engine, port):
     """The reference loops over any n_seq (falcon.c:597-647); its driver's default
     --max-n-read is 500.  Piles of ~700 and ~1000 usable reads (more than 64, 128, 256 and 512
