@@ -177,7 +177,7 @@ def end_to_end_workers(piles, n_workers, repeats=E2E_REPEATS, worker_cmd=None):
             ferr.close()
             if p.returncode != 0:
                 raise RuntimeError("end_to_end_workers: worker %d exited %d: %s" % (j, p.returncode, log[-400:]))
-            dev = re.search(r"device\(s\) ([0-9,]+)", log)
+            dev = re.search(r"device\(s\) ([0-9]+(?:,[0-9]+)*)", log)
             slot = re.search(r"lock slot\(s\) ([0-9.,]+)", log)
             steady = re.search(r"steady state ([0-9.]+) piles/s", log)
             texts.append(open(os.path.join(tmp, "cns_%d.fasta" % j)).read())

@@ -131,6 +131,47 @@ W_FN int w_chain(vu ra, vu rb, vi step, int j, int base, vi &my) {
     return (int)sj;
 }
 
+// The same chain in a frame of its own (round 6): index i = lane + shift[l], the shifts chosen by the caller so
+// that the path moves by (bit i of row l's SHIFTED mask) + c_l with c_l = -(l & 1) -- a constant of the unrolled
+// stream, so no step is read: two v_readlane, v_writelane, s_bitcmp1_b64, s_addc_u32, 32 bytes a row.  Lane l of
+// `my` := the i of row l.  From i = 31 the path stays inside 0 .. 63 whatever the 64 rows do (it gains a lane on
+// even rows only, loses one on odd rows only).
+#define W_CH2(L, C)                                   \
+    "v_readlane_b32 vcc_lo, %[ra], " #L "\n\t"        \
+    "v_readlane_b32 vcc_hi, %[rb], " #L "\n\t"        \
+    "v_writelane_b32 %[my], %[i], " #L "\n\t"         \
+    "s_bitcmp1_b64 vcc, %[i]\n\t"                     \
+    "s_addc_u32 %[i], %[i], " #C "\n\t"
+#define W_CH2_8(A, B, C, D, E, F, G, H) W_CH2(A, 0) W_CH2(B, -1) W_CH2(C, 0) W_CH2(D, -1) W_CH2(E, 0) W_CH2(F, -1) W_CH2(G, 0) W_CH2(H, -1)
+W_FN int w_chain2(vu ra, vu rb, int i, int base, vi &my) {
+    u32 si = (u32)fa_uni(i);
+    const u32 off = (u32)fa_uni(base) * 32u;
+    asm volatile("s_getpc_b64 vcc\n"
+                 ".Lwc2_a_%=:\n\t"
+                 "s_add_u32 vcc_lo, vcc_lo, %[off]\n\t"
+                 "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+                 "s_add_u32 vcc_lo, vcc_lo, .Lwc2_0_%=-.Lwc2_a_%=\n\t"
+                 "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+                 "s_setpc_b64 vcc\n"
+                 ".Lwc2_0_%=:\n\t"
+                 W_CH2_8(0, 1, 2, 3, 4, 5, 6, 7) W_CH2_8(8, 9, 10, 11, 12, 13, 14, 15)
+                 W_CH2_8(16, 17, 18, 19, 20, 21, 22, 23) W_CH2_8(24, 25, 26, 27, 28, 29, 30, 31)
+                 W_CH2_8(32, 33, 34, 35, 36, 37, 38, 39) W_CH2_8(40, 41, 42, 43, 44, 45, 46, 47)
+                 W_CH2_8(48, 49, 50, 51, 52, 53, 54, 55) W_CH2_8(56, 57, 58, 59, 60, 61, 62, 63)
+                 ".Lwc2_e_%=:\n\t"
+                 ".if .Lwc2_e_%= - .Lwc2_0_%= != 2048\n\t.error \"w_chain2: a step is not 32 bytes\"\n\t.endif"
+                 : [my] "+v"(my), [i] "+s"(si)
+                 : [ra] "v"(ra), [rb] "v"(rb), [off] "s"(off)
+                 : "vcc", "scc");
+    return (int)si;
+}
+// (hi:lo) of every lane shifted by the lane's s: left for s >= 0, right for s < 0 (|s| < 64)
+W_FN void w_shift64(vu lo, vu hi, vi s, vu &olo, vu &ohi) {
+    const u64 m = ((u64)hi << 32) | lo;
+    const u64 r = s >= 0 ? (m << (s & 63)) : (m >> ((-s) & 63));
+    olo = (u32)r; ohi = (u32)(r >> 32);
+}
+
 // The tail of a band row as ONE instruction stream: the inclusive prefix maximum of `key`
 // (as w_prefix_max) with the row's other work in the wait states of its DPP steps, where
 // s_nop would sit otherwise -- a VGPR written by a VALU instruction may be read through DPP

@@ -597,7 +597,19 @@ W_FN int a2_trace(const A2Args &A, A2Wave &w, A2Lanes &wl, const A2Track &t, u32
             if (plain && !(A.debug & 2)) {
                 // six instructions a row (w_chain): three records read by v_readlane, the lane kept
                 // by v_writelane, s_bitcmp1_b64 + s_addc_u32
-                const int j_end = w_chain(ra, rb, step_dn, j_top, base, my_lane);
+                // (round 6: in a frame that moves with the rows -- index i = lane + s, s chosen so that the
+                // path's move is the mask's bit plus the constant c = -(l & 1) of the unrolled stream: no
+                // step to read, five instructions a row.  s[l + 1] = s[l] + c[l] - step[l], s[base] puts the
+                // path on index 31, from where it cannot leave 0 .. 63 in 64 rows.)
+                const u64 rows_m = ~0ull << base;
+                const vi ds = w_sel(rows_m, 0, -(lane & 1) - step_dn);
+                const vi s_sh = ((vi)w_prefix_add((vu)ds) - ds) + (31 - j_top);
+                vu sa, sb;
+                w_shift64(ra, rb, s_sh, sa, sb);
+                const int i_end = w_chain2(sa, sb, 31, base, my_lane);
+                my_lane = w_sel(rows_m, 0, my_lane - s_sh);
+                // (the oldest row, lane 63: what the chain ends on is its lane plus its bit, c[63] = -1)
+                const int j_end = i_end + 1 - w_readlane(s_sh, 63);
                 kv = w_uni(w_readlane(kc, 63) + 2 * j_end - 1);
             } else {
                 vi vj = j_top;
@@ -689,6 +701,10 @@ struct A2TrackConst {  // what the lanes of a track hold of it
     int q_len0, t_len0, q_len1, t_len1;
     u32 qb0, tb0, qb1, tb1;
 };
+struct A2Regs;
+// (taken out of a2_fast's packed state where it is needed: kept in registers across the row stream, the eight
+// values cost the function vector registers it does not have)
+W_FN A2TrackConst a2_tc(vu sc);
 // the lanes no band hull may reach (PAIR: `split` = first lane of track 1's share; the two
 // lanes around the boundary stay free, so the two bands are never neighbours)
 template <bool PAIR>
@@ -783,8 +799,19 @@ enum { A2_SC_ACT_LO = 0, A2_SC_ACT_HI, A2_SC_IN_LO, A2_SC_IN_HI, A2_SC_BEST0, A2
        A2_SC_ITS,                   // the iteration the current stretch began at
        A2_SC_AGAIN,                 // 1: the tracks were laid out anew -- call the function of MODE again
        A2_SC_MODE,                  // 1: both tracks run, 0: one
-       A2_SC_IT_PAIR, A2_SC_IT_SINGLE, A2_SC_NPARK, A2_SC_NJOIN };
-static_assert(A2_SC_NJOIN < 64, "the wave-uniform state must fit the lanes of one register");
+       A2_SC_IT_PAIR, A2_SC_IT_SINGLE, A2_SC_NPARK, A2_SC_NJOIN,
+       // where the LDS windows of the two tracks stand (the row stream's own: k_align2_rows.h A2R_CONST_PAIR)
+       A2_SC_CQ0, A2_SC_CT0, A2_SC_CQ1, A2_SC_CT1 };
+static_assert(A2_SC_CT1 < 64, "the wave-uniform state must fit the lanes of one register");
+
+W_FN A2TrackConst a2_tc(vu sc) {
+    A2TrackConst tc;
+    tc.q_len0 = (int)w_pack_get<A2_SC_QLEN0>(sc); tc.t_len0 = (int)w_pack_get<A2_SC_TLEN0>(sc);
+    tc.q_len1 = (int)w_pack_get<A2_SC_QLEN1>(sc); tc.t_len1 = (int)w_pack_get<A2_SC_TLEN1>(sc);
+    tc.qb0 = w_pack_get<A2_SC_QB0>(sc); tc.tb0 = w_pack_get<A2_SC_TB0>(sc);
+    tc.qb1 = w_pack_get<A2_SC_QB1>(sc); tc.tb1 = w_pack_get<A2_SC_TB1>(sc);
+    return tc;
+}
 
 // ---------------------------------------------------------------------------------------
 // Leaving and re-forming the pair WITHOUT going back to the wavefront's event loop (a trip
@@ -977,21 +1004,34 @@ W_FN void a2_shadow_log2(u32 what, u32 it_in, u32 it_c, u32 it_a, const u64 *v, 
 W_FN bool a2_shadow_adopt();
 template <bool PAIR>
 W_FN void a2_rows_shadow(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, const u32 *words, u64 *esc,
-                         u32 *cells, u32 *recs, u32 ring, int band, u32 it_end, bool head) {
+                         u32 *cells, u32 *recs, u32 ring, int band, u32 it_end, bool head, vu &sc) {
+    const A2TrackConst tc = a2_tc(sc);
+    // Both renderings run what a2_fast's loop runs -- rows, and the bands laid out again whenever a row's event
+    // allows it -- until an event nobody in there resolves, or `it_end`: the stream lays the bands out again
+    // inside the asm statement (round 6), the statement through a2_replace.
     A2Hot hc = h;
     A2HotV hvc = hv;
     vu k0c = rc_k0, k1c = rc_k1;
     const u32 it_in = h.it;
-    a2_rows_c<PAIR>(hc, hvc, k0c, k1c, words, esc, cells, recs, ring, band, it_end);
+    for (;;) {
+        a2_rows_c<PAIR>(hc, hvc, k0c, k1c, words, esc, cells, recs, ring, band, it_end);
+        if (hc.ev && !a2_replace<PAIR>(hc, hvc, k0c, k1c, tc)) break;
+        if (hc.it == it_end) break;
+    }
     A2Hot ha = h;
     A2HotV hva = hv;
     vu k0a = rc_k0, k1a = rc_k1;
     A2RowsV rva = rv;
     rva.vcnt = 0u;
-    a2_rows_asm<PAIR>(ha, hva, k0a, k1a, rva, words, cells, recs, ring, band, it_end, head);
-    // (a track's row 0 comes back alone: the caller's loop would go on from there)
-    while (!ha.ev && ha.it != it_end)  // (... or the rows stopped to have a window filled again)
-        a2_rows_asm<PAIR>(ha, hva, k0a, k1a, rva, words, cells, recs, ring, band, it_end, false);
+    for (bool first = head;; first = false) {
+        // (a track's row 0 comes back alone, and the rows stop to have a window filled again: go on)
+        a2_rows_asm<PAIR>(ha, hva, k0a, k1a, rva, words, cells, recs, ring, band, it_end, first, sc, it_end, 0);
+        if (ha.ev) {
+            if (PAIR) a2_fold_cells<true>(ha, rva.vcnt);
+            if (!a2_replace<PAIR>(ha, hva, k0a, k1a, tc)) break;
+        }
+        if (ha.it == it_end) break;
+    }
     a2_fold_cells<PAIR>(ha, rva.vcnt);
     u32 what = 0;
     if (ha.it != hc.it) what |= 1u;
@@ -1008,6 +1048,8 @@ W_FN void a2_rows_shadow(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
     if (w_ballot(k0a != k0c) | w_ballot(k1a != k1c)) what |= 1024u;
     if (ha.cells0 != hc.cells0 || (PAIR && ha.cells1 != hc.cells1)) what |= 2048u;
     if (hc.big && (w_ballot(hva.vm != hvc.vm) & hc.big)) what |= 4096u;
+    if (ha.split != hc.split || ha.kb0 != hc.kb0 || ha.kb1 != hc.kb1 || ha.zone1 != hc.zone1) what |= 8192u;
+    if (ha.n_replace != hc.n_replace) what |= 16384u;
     if (what) {
         const int l = dx ? w_lowest(dx) : 0;
         const u64 v[8] = {hc.act, ha.act, hc.in, ha.in, dx, h.act, hc.fin, ha.fin};
@@ -1027,14 +1069,16 @@ W_FN void a2_rows_shadow(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
 
 template <bool PAIR>
 W_FN void a2_rows(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, const u32 *words, u64 *esc, u32 *cells,
-                  u32 *recs, u32 ring, int band, u32 it_end, bool head) {
+                  u32 *recs, u32 ring, int band, u32 it_end, bool head, vu &sc, u32 it_last, int join_at) {
 #if defined(A2_SHADOW)
     // (k_align2_shadow.hip, tests only: both renderings of the rows from the same state, every
     // difference logged, the statement's result kept)
-    a2_rows_shadow<PAIR>(h, hv, rc_k0, rc_k1, rv, words, esc, cells, recs, ring, band, it_end, head);
+    a2_rows_shadow<PAIR>(h, hv, rc_k0, rc_k1, rv, words, esc, cells, recs, ring, band, it_end, head, sc);
+    (void)it_last; (void)join_at;
 #elif defined(W_ROWS_ASM) && !defined(A2_ROWS_C)
-    a2_rows_asm<PAIR>(h, hv, rc_k0, rc_k1, rv, words, cells, recs, ring, band, it_end, head);
+    a2_rows_asm<PAIR>(h, hv, rc_k0, rc_k1, rv, words, cells, recs, ring, band, it_end, head, sc, it_last, join_at);
 #else
+    (void)sc; (void)it_last; (void)join_at;
     a2_rows_c<PAIR>(h, hv, rc_k0, rc_k1, words, esc, cells, recs, ring, band, it_end);
 #endif
 }
@@ -1058,11 +1102,6 @@ W_NOINLINE A2Regs a2_fast(A2Regs r) {
     u32 it_end = w_pack_get<A2_SC_IT_END>(r.sc);
     const u32 it_last = w_pack_get<A2_SC_IT_LAST>(r.sc);
     const int join_at = (int)w_pack_get<A2_SC_JOIN_AT>(r.sc);
-    A2TrackConst tc;
-    tc.q_len0 = (int)w_pack_get<A2_SC_QLEN0>(r.sc); tc.t_len0 = (int)w_pack_get<A2_SC_TLEN0>(r.sc);
-    tc.q_len1 = (int)w_pack_get<A2_SC_QLEN1>(r.sc); tc.t_len1 = (int)w_pack_get<A2_SC_TLEN1>(r.sc);
-    tc.qb0 = w_pack_get<A2_SC_QB0>(r.sc); tc.tb0 = w_pack_get<A2_SC_TB0>(r.sc);
-    tc.qb1 = w_pack_get<A2_SC_QB1>(r.sc); tc.tb1 = w_pack_get<A2_SC_TB1>(r.sc);
     h.n_replace = w_pack_get<A2_SC_NREPLACE>(r.sc);
     const u32 *words = (const u32 *)(((u64)w_pack_get<A2_SC_WORDS_HI>(r.sc) << 32) | w_pack_get<A2_SC_WORDS_LO>(r.sc));
     u32 *cells = (u32 *)(((u64)w_pack_get<A2_SC_CELLS_HI>(r.sc) << 32) | w_pack_get<A2_SC_CELLS_LO>(r.sc));
@@ -1082,11 +1121,14 @@ W_NOINLINE A2Regs a2_fast(A2Regs r) {
     bool head = true;
 #pragma clang loop unroll(disable)
     for (;;) {
-        a2_rows<PAIR>(h, hv, rc_k0, rc_k1, rv, words, esc, cells, recs, ring, band, it_end, head);
+        a2_rows<PAIR>(h, hv, rc_k0, rc_k1, rv, words, esc, cells, recs, ring, band, it_end, head, r.sc, it_last, join_at);
         head = false;
+        // (the stream takes the look-ups a band is still too wide at in its stride: `it_end` follows)
+        while (!PAIR && (int)(h.it - it_end) > 0)
+            it_end = ((int)(it_last - it_end) > A2_LOOK_EVERY) ? it_end + A2_LOOK_EVERY : it_last;
         if (h.ev) {
             if (PAIR) a2_fold_cells<true>(h, rv.vcnt);  // (the boundary between the tracks is about to move)
-            if (!a2_replace<PAIR>(h, hv, rc_k0, rc_k1, tc)) break;
+            if (!a2_replace<PAIR>(h, hv, rc_k0, rc_k1, a2_tc(r.sc))) break;
         }
         if (h.it == it_end) {
             if (PAIR || it_end == it_last || w_span(h.in) + 1 <= join_at) break;
@@ -1122,11 +1164,11 @@ W_NOINLINE A2Regs a2_fast(A2Regs r) {
     if (PAIR) {
         // the two bands no longer fit the wave (a2_replace declined): the narrower track waits
         if (h.ev != 0ull && h.fin == 0ull && h.big == 0ull && w_pack_get<A2_SC_PARKED>(r.sc) == 0u)
-            (void)a2_park(h, hv, rc_k0, rc_k1, tc, r);
+            (void)a2_park(h, hv, rc_k0, rc_k1, a2_tc(r.sc), r);
     } else {
         // the look-ahead found the running band narrow enough for the waiting track
         if (h.ev == 0ull && h.fin == 0ull && h.it != it_last && join_at > 0 && w_span(h.in) + 1 <= join_at)
-            (void)a2_join(h, hv, rc_k0, rc_k1, tc, r);
+            (void)a2_join(h, hv, rc_k0, rc_k1, a2_tc(r.sc), r);
     }
     r.vx = hv.vx; r.vnegk = hv.vnegk; r.vqlen = hv.vqlen; r.vtlen = hv.vtlen;
     r.vqb = hv.vqb; r.vtb = hv.vtb; r.vtop = hv.vtop;

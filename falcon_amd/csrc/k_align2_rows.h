@@ -31,6 +31,18 @@
 //   * exits: one label.  Which row left and why is worked out by the caller from what the
 //     stream hands back (the row's masks, the iteration counter).
 //
+// Round 6: (1) the PAIR stream lays its two bands out again ITSELF (.La2r_relay: what a2_replace<true> states --
+// hulls, the free lanes shared out afresh, the new boundary, ds_bpermute of the row, the tape's K fields)
+// and computes the per-lane constants of both tracks from scalars (.La2r_const), so a band hull on a fence
+// lane no longer leaves the asm statement: 38 M such events per launch were a round trip of ~250 instructions
+// each, a quarter of the kernel.  What it declines (a cell at an end of a sequence, a long snake, bands that no
+// longer fit together, a row 0) leaves through the old exits.  (2) The instructions are chosen by what they
+// cost the vector pipe (profiles/r06_ubench_valu_cost.txt: v_add / v_sub / v_and / v_or / v_xor / v_mov /
+// v_lshrrev 2 cycles per SIMD, everything else -- v_lshlrev, v_max, compares, DPP, three-operand forms,
+// ANY instruction with an SGPR operand -- 3.6): x + x for the left shifts, VGPR copies of `band` and of
+// the odd rows' target constant.  (3) cells are counted per lane in two 16-bit halves (track 0 / track 1:
+// the increment is a per-lane constant), so lanes that change hands need no fold.
+//
 // Hazards kept by hand (the assembler does not insert wait states): VALU write -> DPP read of
 // the same VGPR: 2 wait states; VALU write -> v_readlane of it: 1; VALU writes an SGPR -> use
 // as a lane select: none here (selects come from the scalar unit).
@@ -52,8 +64,8 @@
     LQ                                                             \
     LT                                                             \
     MID                                                            \
-    "v_lshlrev_b32 %[qa], 1, %[qa]\n\t"                            \
-    "v_lshlrev_b32 %[ta], 1, %[ta]\n\t"                            \
+    "v_add_u32 %[qa], %[qa], %[qa]\n\t"                            \
+    "v_add_u32 %[ta], %[ta], %[ta]\n\t"                            \
     "v_sub_u32 %[t1], " LIM ", %[x]\n\t"                           \
     W1                                                             \
     "v_alignbit_b32 v52, v53, v52, %[qa]\n\t"                      \
@@ -72,7 +84,7 @@
 // ... a snake beyond its first 16 bases goes on in global memory (it may leave any window)
 #define A2R_QA_GLB "v_add_u32 %[qa], %[x], %[cqg]\n\t"
 #define A2R_TA_EVEN_GLB "v_add_u32 %[ta], %[x], %[ctg]\n\t"
-#define A2R_TA_ODD_GLB "v_add3_u32 %[ta], %[x], %[ctg], -1\n\t"
+#define A2R_TA_ODD_GLB "v_add3_u32 %[ta], %[x], %[ctg], -1\n\t"   /* (the far path: a fifth of the rows) */
 #define A2R_GLB_LOADS "global_load_dwordx2 v[52:53], %[t1], %[words]\n\t", "global_load_dwordx2 v[54:55], %[t2], %[words]\n\t", \
                       "s_waitcnt vmcnt(1)\n\t", "s_waitcnt vmcnt(0)\n\t"
 
@@ -82,14 +94,17 @@
     "v_readlane_b32 %[p1], %[pm], 63\n\t"                          \
     "s_max_i32 %[b0], %[b0], %[p0]\n\t"                            \
     "s_max_i32 %[b1], %[b1], %[p1]\n\t"                            \
-    "v_cmp_le_i32 vcc, %[b0], %[k2]\n\t"                           \
-    "v_cmp_le_i32 %[c1], %[b1], %[k2]\n\t"                         \
+    "s_sub_i32 %[p0], %[b0], %[band]\n\t"                          \
+    "s_sub_i32 %[p1], %[b1], %[band]\n\t"                          \
+    "v_cmp_le_i32 vcc, %[p0], %[key]\n\t"                          \
+    "v_cmp_le_i32 %[c1], %[p1], %[key]\n\t"                        \
     "s_andn2_b64 %[in], vcc, %[z1]\n\t"                            \
     "s_or_b64 %[in], %[in], %[c1]\n\t"
 #define A2R_BEST_SINGLE                                            \
     "v_readlane_b32 %[p1], %[pm], 63\n\t"                          \
     "s_max_i32 %[b0], %[b0], %[p1]\n\t"                            \
-    "v_cmp_le_i32 %[in], %[b0], %[k2]\n\t"
+    "s_sub_i32 %[p1], %[b0], %[band]\n\t"                          \
+    "v_cmp_le_i32 %[in], %[p1], %[key]\n\t"
 
 // ---- the general hull of %[in] into %[c1] (out of line)
 #define A2R_HULL_PAIR                                              \
@@ -121,14 +136,14 @@
 //   FORB:  the lanes the hull may not reach in this row      SEL: the v_perm selector of byte J
 //   F1 / F2: what fills the wait states of the second and third DPP step (two each)
 //   BEST / HULL / NRUN: pair or single
-#define A2R_ROW(J, DPP, A1, FA, MX, TA, LIM, LW, CK, RD, WR, SH, FORB, OUT, SEL, F1, F2, BEST, HULL, NRUN) \
+#define A2R_ROW(J, DPP, A1, FA, MX, TA, LIM, LW, CK, RD, WR, SH, FORB, OUT, EVT, SEL, F1, F2, BEST, HULL, NRUN) \
     ".La2r_r" J "_%=:\n\t"                                                                               \
     DPP                                                                                                  \
     A1                                                                                                   \
     FA                                                                                                   \
     MX                                                                                                   \
     "s_mov_b64 exec, " RD "\n\t"                                                                         \
-    "v_add_u32 %[cnt], 1, %[cnt]\n\t"                                                                    \
+    "v_add_u32 %[cnt], %[cinc], %[cnt]\n\t"                                                              \
     A2R_SNAKE16(A2R_QA_LDS, TA, A2R_LDS_LOADS, LIM,                                                      \
                 "v_writelane_b32 %[mlo], vcc_lo, m0\n\t"                                                 \
                 "v_writelane_b32 %[mhi], vcc_hi, m0\n\t")                                                \
@@ -142,7 +157,6 @@
     "v_perm_b32 %[acc], %[vm], %[acc], " SEL "\n\t"                                                      \
     "s_add_u32 m0, m0, 1\n\t"                                                                            \
     "v_max_i32_dpp %[pm], %[key], %[key] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"          \
-    "v_add_u32 %[k2], %[band], %[key]\n\t"                                                               \
     "v_cmp_ge_i32 %[fin], %[x], " LW "\n\t"                                                              \
     "v_max_i32_dpp %[pm], %[pm], %[pm] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                         \
     F1                                                                                                   \
@@ -165,7 +179,8 @@
     ".La2r_h" J "_%=:\n\t"                                                                               \
     "s_and_b64 %[t], %[in], " FORB "\n\t"                                                                \
     "s_or_b64 %[t], %[t], %[fin]\n\t"                                                                    \
-    "s_cbranch_scc1 " OUT "\n\t"                                                                         \
+    "s_cbranch_scc1 " EVT J "_%=\n"                                                                       \
+    ".La2r_c" J "_%=:\n\t"                                                                               \
     "s_sub_u32 %[rem], %[rem], 1\n\t"                                                                    \
     "s_cbranch_scc1 " OUT "\n\t"
 
@@ -197,18 +212,18 @@
     "s_or_b64 " WR ", %[c1], %[t]\n\t"                                                                   \
     "s_branch .La2r_h" J "_%=\n"
 
-#define A2R_EVEN(J, SEL, F1, F2, BEST, HULL, NRUN)                                                       \
+#define A2R_EVEN(J, EVT, SEL, F1, F2, BEST, HULL, NRUN)                                                  \
     A2R_ROW(J, "v_mov_b32_dpp %[tdn], %[vx] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t",                  \
             "v_add_u32 %[x], 1, %[tdn]\n\t",                                                             \
             "v_cmp_lt_i32 vcc, %[tdn], %[vx]\n\t",                                                       \
             "v_max_i32 %[x], %[x], %[vx]\n\t",                                                           \
-            A2R_TA_EVEN, "%[le]", "%[lwe]", "%[cke]", "%[sa]", "%[sb]", "s_lshr_b64", "%[f1]", ".La2r_oute_%=", SEL, F1, F2, BEST, HULL, NRUN)
-#define A2R_ODD(J, SEL, F1, F2, BEST, HULL, NRUN)                                                        \
+            A2R_TA_EVEN, "%[le]", "%[lwe]", "%[cke]", "%[sa]", "%[sb]", "s_lshr_b64", "%[f1]", ".La2r_lk" J "_%=", EVT, SEL, F1, F2, BEST, HULL, NRUN)
+#define A2R_ODD(J, EVT, SEL, F1, F2, BEST, HULL, NRUN)                                                   \
     A2R_ROW(J, "v_mov_b32_dpp %[tup], %[vx] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t",                  \
             "v_add_u32 %[x], 1, %[vx]\n\t",                                                              \
             "v_cmp_lt_i32 vcc, %[vx], %[tup]\n\t",                                                       \
             "v_max_i32 %[x], %[x], %[tup]\n\t",                                                          \
-            A2R_TA_ODD, "%[lo]", "%[lwo]", "%[cko]", "%[sb]", "%[sa]", "s_lshl_b64", "%[f0]", ".La2r_outo_%=", SEL, F1, F2, BEST, HULL, NRUN)
+            A2R_TA_ODD, "%[lo]", "%[lwo]", "%[cko]", "%[sb]", "%[sa]", "s_lshl_b64", "%[f0]", ".La2r_lk" J "_%=", EVT, SEL, F1, F2, BEST, HULL, NRUN)
 #define A2R_EVEN_FAR(J, HULL) A2R_ROW_FAR(J, A2R_TA_EVEN_GLB, "%[le]", "%[sa]", "%[sb]", "s_lshr_b64", HULL)
 #define A2R_ODD_FAR(J, HULL) A2R_ROW_FAR(J, A2R_TA_ODD_GLB, "%[lo]", "%[sb]", "%[sa]", "s_lshl_b64", HULL)
 
@@ -246,12 +261,250 @@
     "v_mov_b32 %[k1], %[kb1]\n\t"                                                                        \
     "s_branch .La2r_recb_%=\n"
 
-#define A2R_BODY(BEST, HULL, NRUN)                                                                       \
+// ---- PAIR only: the per-lane constants of both tracks from the tracks' scalars.  Lane l of track t holds diagonal
+// kb_t - 1 + 2 l before an even row: vnegk = 1 - kb_t - 2 l; with the track's scalars
+//   cq = CQ_t                 ct = CT_t + vnegk          cqg = QB_t        ctg = TB_t + vnegk
+//   le = min(QL_t, TL_t - vnegk)    lo = min(QL_t, TL_t - vnegk + 1)     (a cell is at an end iff x >= L)
+//   lw* = min(l*, min(ROOMQ_t - cq, ROOMT_t - ct))                       (... or within the margin of a window)
+//   cke = vnegk + top_t       cko = cke - 1              cinc = 1 / 0x10000 (the lane's half of the cell counter)
+// The scalars live in the lanes of `sc` (a2_fast's packed wave-uniform state, A2_SC_QLEN0 .. A2_SC_CT1: sixteen
+// more SGPR operands do not fit the function's budget) and reach all lanes by ds_bpermute with a zero address and
+// the lane's byte offset in the instruction (no LDS access, no vector instruction): twelve at once into registers
+// that are dead at this point -- the row's temporaries and the constants about to be made again -- then one select
+// by zone each and arithmetic on VGPR operands.  A re-layout issues them BEFORE its scalar algebra, so they have
+// landed when it is done.  `ret` says where to go on: 0..3 = behind row J's event test (then the moved row, which
+// ds_bpermute left in `cinc`, goes into vx here), else the stretch's first row.
+#define A2R_STR_(x) #x
+#define A2R_STR(x) A2R_STR_(x)
+#define A2R_BC(DST, IDX) "ds_bpermute_b32 " DST ", %[t1], %[sc] offset:" A2R_STR(IDX) "\n\t"
+#define A2R_BCAST12                                                                                      \
+    "v_mov_b32 %[t1], 0\n\t"                                                                             \
+    A2R_BC("v52", A2R_O_QL0) A2R_BC("v53", A2R_O_TL0) A2R_BC("v54", A2R_O_QB0) A2R_BC("v55", A2R_O_TB0)  \
+    A2R_BC("%[pm]", A2R_O_CQ0) A2R_BC("%[vm]", A2R_O_CT0)                                                \
+    A2R_BC("%[qa]", A2R_O_QL1) A2R_BC("%[ta]", A2R_O_TL1) A2R_BC("%[key]", A2R_O_QB1)                    \
+    A2R_BC("%[lwe]", A2R_O_TB1) A2R_BC("%[lwo]", A2R_O_CQ1) A2R_BC("%[cko]", A2R_O_CT1)
+#define A2R_CONST_PAIR                                                                                   \
+    A2R_BCAST12                                                                                          \
+    "s_waitcnt lgkmcnt(0)\n"                                                                             \
+    ".La2r_const_%=:\n\t"                                                                                \
+    "v_lshrrev_b32 %[t1], 1, %[l4]\n\t"                                                                  \
+    "s_sub_u32 %[p0], 1, %[kb0]\n\t"                                                                     \
+    "s_sub_u32 %[p1], 1, %[kb1]\n\t"                                                                     \
+    "v_sub_u32 %[t2], %[p0], %[t1]\n\t"                                                                  \
+    "s_mov_b64 exec, %[z1]\n\t"                                                                          \
+    "v_sub_u32 %[t2], %[p1], %[t1]\n\t"                                                                  \
+    "s_mov_b64 exec, -1\n\t"                                                                             \
+    "v_cndmask_b32 %[cq], %[pm], %[lwo], %[z1]\n\t"                                                      \
+    "v_cndmask_b32 %[ct], %[vm], %[cko], %[z1]\n\t"                                                      \
+    "v_cndmask_b32 %[cqg], v54, %[key], %[z1]\n\t"                                                       \
+    "v_cndmask_b32 %[ctg], v55, %[lwe], %[z1]\n\t"                                                       \
+    "v_cndmask_b32 v53, v53, %[ta], %[z1]\n\t"                                                           \
+    "v_cndmask_b32 v52, v52, %[qa], %[z1]\n\t"                                                           \
+    "v_add_u32 %[ct], %[ct], %[t2]\n\t"                                                                  \
+    "v_add_u32 %[ctg], %[ctg], %[t2]\n\t"                                                                \
+    "v_sub_u32 %[qa], v53, %[t2]\n\t"                                                                    \
+    "v_min_i32 %[le], v52, %[qa]\n\t"                                                                    \
+    "v_add_u32 %[ta], 1, %[qa]\n\t"                                                                      \
+    "v_min_i32 %[lo], v52, %[ta]\n\t"                                                                    \
+    "v_sub_u32 %[key], " A2R_STR(A2R_ROOMQ0) ", %[cq]\n\t"                                               \
+    "v_sub_u32 %[pm], " A2R_STR(A2R_ROOMT0) ", %[ct]\n\t"                                                \
+    "v_mov_b32 %[cke], %[t2]\n\t"                                                                        \
+    "s_mov_b64 exec, %[z1]\n\t"                                                                          \
+    "v_sub_u32 %[key], " A2R_STR(A2R_ROOMQ1) ", %[cq]\n\t"                                               \
+    "v_sub_u32 %[pm], " A2R_STR(A2R_ROOMT1) ", %[ct]\n\t"                                                \
+    "v_add_u32 %[cke], 0x20000000, %[t2]\n\t"                                                            \
+    "s_mov_b64 exec, -1\n\t"                                                                             \
+    "v_min_i32 %[key], %[key], %[pm]\n\t"                                                                \
+    "v_min_i32 %[lwe], %[le], %[key]\n\t"                                                                \
+    "v_min_i32 %[lwo], %[lo], %[key]\n\t"                                                                \
+    "v_add_u32 %[cko], -1, %[cke]\n\t"                                                                   \
+    "s_cmp_gt_u32 %[ret], 3\n\t"                                                                         \
+    "s_cbranch_scc1 .La2r_cinc_%=\n\t"                                                                   \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                           \
+    "v_cndmask_b32 %[vx], %[neg], %[cinc], %[in]\n"                                                      \
+    ".La2r_cinc_%=:\n\t"                                                                                 \
+    "v_mov_b32 %[cinc], 1\n\t"                                                                           \
+    "s_mov_b64 exec, %[z1]\n\t"                                                                          \
+    "v_mov_b32 %[cinc], 0x10000\n\t"                                                                     \
+    "s_mov_b64 exec, -1\n\t"                                                                             \
+    "s_cmp_eq_u32 %[ret], 0\n\t"                                                                         \
+    "s_cbranch_scc1 .La2r_c0_%=\n\t"                                                                     \
+    "s_cmp_eq_u32 %[ret], 1\n\t"                                                                         \
+    "s_cbranch_scc1 .La2r_c1_%=\n\t"                                                                     \
+    "s_cmp_eq_u32 %[ret], 2\n\t"                                                                         \
+    "s_cbranch_scc1 .La2r_c2_%=\n\t"                                                                     \
+    "s_cmp_eq_u32 %[ret], 3\n\t"                                                                         \
+    "s_cbranch_scc1 .La2r_c3_%=\n\t"
+// the x from which on a window's end is nearer than the margin, as base indices into the four windows
+#define A2R_ROOMQ0 3904
+#define A2R_ROOMT0 8000
+#define A2R_ROOMQ1 12096
+#define A2R_ROOMT1 16192
+
+// byte offsets of the tracks' scalars in `sc` (4 x A2_SC_*: the preprocessor cannot see an enum)
+#define A2R_O_QL0 120
+#define A2R_O_TL0 124
+#define A2R_O_QL1 128
+#define A2R_O_TL1 132
+#define A2R_O_QB0 136
+#define A2R_O_TB0 140
+#define A2R_O_QB1 144
+#define A2R_O_TB1 148
+#define A2R_O_CQ0 236
+#define A2R_O_CT0 240
+#define A2R_O_CQ1 244
+#define A2R_O_CT1 248
+static_assert(A2R_O_QL0 == 4 * A2_SC_QLEN0 && A2R_O_TL0 == 4 * A2_SC_TLEN0 && A2R_O_QL1 == 4 * A2_SC_QLEN1 &&
+              A2R_O_TL1 == 4 * A2_SC_TLEN1 && A2R_O_QB0 == 4 * A2_SC_QB0 && A2R_O_TB0 == 4 * A2_SC_TB0 &&
+              A2R_O_QB1 == 4 * A2_SC_QB1 && A2R_O_TB1 == 4 * A2_SC_TB1 && A2R_O_CQ0 == 4 * A2_SC_CQ0 &&
+              A2R_O_CT0 == 4 * A2_SC_CT0 && A2R_O_CQ1 == 4 * A2_SC_CQ1 && A2R_O_CT1 == 4 * A2_SC_CT1,
+              "A2R_BCAST12 spells the lanes of the packed state out");
+static_assert(A2_TOP == 0x20000000u, "A2R_CONST_PAIR spells A2_TOP out");
+// (values the compiler may keep on the vector unit -- in the shadow kernel the whole state comes back from memory --
+// must not reach an "s" operand as they are: readfirstlane is free for the ones that are in SGPRs already)
+#define A2R_UNI(x) w_uniu(x)
+#define A2R_UNI64(x) (((u64)w_uniu((u32)((x) >> 32)) << 32) | w_uniu((u32)(x)))
+
+// ---- PAIR only: a band hull reached a fence lane or an end of the wave (row J's event test): both bands are
+// laid out again where they stand -- a2_replace<true> (k_align2_core.h) restated on the scalar unit.  The row
+// moves by ds_bpermute (taken from the row's raw x: a hull with holes, or two hulls that met at the boundary,
+// come out whole), the tape's K fields change from this iteration on, the lanes of the next row go to the
+// mask register the row wrote.  Declined -- a cell at an end of a sequence or of a window, a long snake, a
+// stretch that must not (row 0: the top bit of `nrep`), bands that no longer fit: out through the row's exit.
+#define A2R_RELAY_PAIR                                                                                   \
+    ".La2r_ev0_%=:\n\t"                                                                                  \
+    "s_mov_b32 %[ret], 0\n\t"                                                                            \
+    "s_branch .La2r_relay_%=\n"                                                                          \
+    ".La2r_ev1_%=:\n\t"                                                                                  \
+    "s_mov_b32 %[ret], 1\n\t"                                                                            \
+    "s_branch .La2r_relay_%=\n"                                                                          \
+    ".La2r_ev2_%=:\n\t"                                                                                  \
+    "s_mov_b32 %[ret], 2\n\t"                                                                            \
+    "s_branch .La2r_relay_%=\n"                                                                          \
+    ".La2r_ev3_%=:\n\t"                                                                                  \
+    "s_mov_b32 %[ret], 3\n"                                                                              \
+    ".La2r_relay_%=:\n\t"                                                                                \
+    "s_bitcmp1_b32 %[nrep], 31\n\t"                                                                      \
+    "s_cbranch_scc1 .La2r_decl_%=\n\t"                                                                   \
+    "s_or_b64 %[u], %[fin], %[big]\n\t"                                                                  \
+    "s_cbranch_scc1 .La2r_decl_%=\n\t"                                                                   \
+    "s_andn2_b64 %[c1], %[in], %[z1]\n\t"                                                                \
+    "s_and_b64 %[u], %[in], %[z1]\n\t"                                                                   \
+    "s_ff1_i32_b64 %[p0], %[c1]\n\t"                                                                     \
+    "s_flbit_i32_b64 %[p1], %[c1]\n\t"                                                                   \
+    "s_ff1_i32_b64 %[r0], %[u]\n\t"                                                                      \
+    "s_flbit_i32_b64 %[r1], %[u]\n\t"                                                                    \
+    "s_add_u32 %[p1], %[p1], %[p0]\n\t"                                                                  \
+    "s_sub_u32 %[p1], 64, %[p1]\n\t"                                                                     \
+    "s_add_u32 %[r1], %[r1], %[r0]\n\t"                                                                  \
+    "s_sub_u32 %[r1], 64, %[r1]\n\t"                                                                     \
+    "s_add_u32 %[r2], %[p1], %[r1]\n\t"                                                                  \
+    "s_sub_i32 %[r2], 62, %[r2]\n\t"                                                                     \
+    "s_cmp_lt_i32 %[r2], 0\n\t"                                                                          \
+    "s_cbranch_scc1 .La2r_decl_%=\n\t"                                                                   \
+    A2R_BCAST12                                                                                          \
+    "s_lshr_b32 %[r3], %[r2], 2\n\t"                                                                     \
+    "s_lshr_b32 %[r2], %[r2], 1\n\t"                                                                     \
+    "s_add_u32 vcc_lo, %[r3], %[p1]\n\t"                                                                 \
+    "s_add_u32 vcc_lo, vcc_lo, 1\n\t"                                                                    \
+    "s_lshr_b32 vcc_hi, %[r2], 1\n\t"                                                                    \
+    "s_add_u32 vcc_hi, vcc_hi, vcc_lo\n\t"                                                               \
+    "s_add_u32 vcc_lo, vcc_lo, %[r2]\n\t"                                                                \
+    "s_and_b32 %[r2], m0, 1\n\t"                                                                         \
+    "s_sub_u32 %[p0], %[p0], %[r2]\n\t"                                                                  \
+    "s_sub_u32 %[p0], %[p0], %[r3]\n\t"                                                                  \
+    "s_sub_u32 %[r0], %[r0], %[r2]\n\t"                                                                  \
+    "s_sub_u32 %[r0], %[r0], vcc_lo\n\t"                                                                 \
+    "s_lshl_b64 %[z1], -1, vcc_hi\n\t"                                                                   \
+    "s_sub_u32 %[ln0], vcc_hi, 1\n\t"                                                                    \
+    "s_lshl_b64 %[c1], 3, %[ln0]\n\t"                                                                    \
+    "s_or_b64 %[f1], %[c1], 1\n\t"                                                                       \
+    "s_mov_b64 %[f0], %[c1]\n\t"                                                                         \
+    "s_bitset1_b64 %[f0], 63\n\t"                                                                        \
+    "s_add_u32 vcc_hi, %[r3], %[r2]\n\t"                                                                 \
+    "s_bfm_b64 %[in], %[p1], vcc_hi\n\t"                                                                 \
+    "s_add_u32 vcc_hi, vcc_lo, %[r2]\n\t"                                                                \
+    "s_bfm_b64 %[u], %[r1], vcc_hi\n\t"                                                                  \
+    "s_or_b64 %[in], %[in], %[u]\n\t"                                                                    \
+    "s_add_u32 %[p1], %[p1], 1\n\t"                                                                      \
+    "s_bfm_b64 %[c1], %[p1], %[r3]\n\t"                                                                  \
+    "s_add_u32 %[r1], %[r1], 1\n\t"                                                                      \
+    "s_bfm_b64 %[u], %[r1], vcc_lo\n\t"                                                                  \
+    "s_or_b64 %[c1], %[c1], %[u]\n\t"                                                                    \
+    "s_bitcmp1_b32 %[ret], 0\n\t"                                                                        \
+    "s_cselect_b64 %[sa], %[c1], %[sa]\n\t"                                                              \
+    "s_cselect_b64 %[sb], %[sb], %[c1]\n\t"                                                              \
+    "s_lshl_b32 vcc_hi, %[p0], 1\n\t"                                                                    \
+    "s_add_u32 %[kb0], %[kb0], vcc_hi\n\t"                                                               \
+    "s_lshl_b32 vcc_hi, %[r0], 1\n\t"                                                                    \
+    "s_add_u32 %[kb1], %[kb1], vcc_hi\n\t"                                                               \
+    "s_lshl_b32 %[p0], %[p0], 2\n\t"                                                                     \
+    "s_lshl_b32 %[r0], %[r0], 2\n\t"                                                                     \
+    "s_add_u32 %[nrep], %[nrep], 1\n\t"                                                                  \
+    "v_add_u32 %[t2], %[p0], %[l4]\n\t"                                                                  \
+    "s_mov_b64 exec, %[z1]\n\t"                                                                          \
+    "v_add_u32 %[t2], %[r0], %[l4]\n\t"                                                                  \
+    "s_mov_b64 exec, -1\n\t"                                                                             \
+    "ds_bpermute_b32 %[cinc], %[t2], %[x]\n\t"                                                           \
+    "s_lshl_b64 %[u], -1, m0\n\t"                                                                        \
+    "s_mov_b64 exec, %[u]\n\t"                                                                           \
+    "v_mov_b32 %[k0], %[kb0]\n\t"                                                                        \
+    "v_mov_b32 %[k1], %[kb1]\n\t"                                                                        \
+    "s_mov_b64 exec, -1\n\t"                                                                             \
+    "s_mov_b64 %[t], 0\n\t"                                                                              \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                                           \
+    "s_branch .La2r_const_%=\n"                                                                          \
+    ".La2r_decl_%=:\n\t"                                                                                 \
+    "s_bitcmp1_b32 %[ret], 0\n\t"                                                                        \
+    "s_cbranch_scc1 .La2r_outo_%=\n\t"                                                                   \
+    "s_branch .La2r_oute_%=\n"                                                                            \
+    ".La2r_lk0_%=:\n"                                                                                     \
+    ".La2r_lk2_%=:\n\t"                                                                                   \
+    "s_branch .La2r_oute_%=\n"                                                                            \
+    ".La2r_lk1_%=:\n"                                                                                     \
+    ".La2r_lk3_%=:\n\t"                                                                                   \
+    "s_branch .La2r_outo_%=\n"
+
+// ---- SINGLE: the rows asked for are done.  With the neighbour parked that is a look-up (a2_fast: every
+// A2_LOOK_EVERY iterations): has the running band become narrow enough for the neighbour -- lanes from the lowest
+// to the highest of `in`, plus one, <= join_at, i.e. leading + trailing zeros >= 65 - join_at = `thr`?  If not,
+// and the row had no snake of >= 255 bases, the next min(`more`, A2_LOOK_EVERY) rows run without leaving the
+// statement (11.8 M such look-ups per launch were a round trip of ~150 instructions each).
+#define A2R_LOOK(J, OUT)                                                                                 \
+    ".La2r_lk" J "_%=:\n\t"                                                                               \
+    "s_cmp_eq_u32 %[more], 0\n\t"                                                                        \
+    "s_cbranch_scc1 " OUT "\n\t"                                                                         \
+    "s_cmp_lg_u64 %[big], 0\n\t"                                                                         \
+    "s_cbranch_scc1 " OUT "\n\t"                                                                         \
+    "s_ff1_i32_b64 %[p0], %[in]\n\t"                                                                     \
+    "s_flbit_i32_b64 %[p1], %[in]\n\t"                                                                   \
+    "s_add_u32 %[p0], %[p0], %[p1]\n\t"                                                                  \
+    "s_cmp_ge_u32 %[p0], %[thr]\n\t"                                                                     \
+    "s_cbranch_scc1 " OUT "\n\t"                                                                         \
+    "s_min_u32 %[rem], %[more], " A2R_STR(A2_LOOK_EVERY) "\n\t"                                          \
+    "s_sub_u32 %[more], %[more], %[rem]\n\t"                                                             \
+    "s_branch .La2r_c" J "_%=\n"
+
+// ---- SINGLE: a row's event leaves the stream (a2_fast centres the band: 86 times in 7 M iterations)
+#define A2R_RELAY_SINGLE                                                                                 \
+    ".La2r_ev0_%=:\n\t"                                                                                  \
+    "s_branch .La2r_oute_%=\n"                                                                           \
+    ".La2r_ev1_%=:\n\t"                                                                                  \
+    "s_branch .La2r_outo_%=\n"                                                                           \
+    ".La2r_ev2_%=:\n\t"                                                                                  \
+    "s_branch .La2r_oute_%=\n"                                                                           \
+    ".La2r_ev3_%=:\n\t"                                                                                  \
+    "s_branch .La2r_outo_%=\n"                                                                            \
+    A2R_LOOK("0", ".La2r_oute_%=") A2R_LOOK("1", ".La2r_outo_%=") A2R_LOOK("2", ".La2r_oute_%=") A2R_LOOK("3", ".La2r_outo_%=")
+
+#define A2R_BODY(BEST, HULL, NRUN, CONST, RELAY)                                                         \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                           \
+    "s_mov_b32 %[sm0], m0\n\t"                                                                           \
     "s_and_b32 m0, %[it], 63\n\t"                                                                        \
     "s_andn2_b32 %[itb], %[it], 63\n\t"                                                                  \
     "s_mov_b64 %[sb], %[sa]\n\t"                                                                         \
     "s_mov_b64 %[big], 0\n\t"                                                                            \
+    CONST                                                                                                \
     "s_and_b32 %[p0], %[it], 3\n\t"                                                                      \
     "s_cmp_eq_u32 %[p0], 1\n\t"                                                                          \
     "s_cbranch_scc1 .La2r_r1_%=\n\t"                                                                     \
@@ -259,16 +512,17 @@
     "s_cbranch_scc1 .La2r_r2_%=\n\t"                                                                     \
     "s_cmp_eq_u32 %[p0], 3\n\t"                                                                          \
     "s_cbranch_scc1 .La2r_r3_%=\n"                                                                       \
-    A2R_EVEN("0", "%[sel0]", A2R_NOP2, A2R_NOP2, BEST, HULL, NRUN)                                       \
-    A2R_ODD("1", "%[sel1]", A2R_NOP2, A2R_NOP2, BEST, HULL, NRUN)                                        \
-    A2R_EVEN("2", "%[sel2]", A2R_NOP2, A2R_NOP2, BEST, HULL, NRUN)                                       \
-    A2R_ODD("3", "%[sel3]", A2R_F1_STORE, A2R_F2_STORE, BEST, HULL, NRUN)                                \
+    A2R_EVEN("0", ".La2r_ev", "%[sel0]", A2R_NOP2, A2R_NOP2, BEST, HULL, NRUN)                           \
+    A2R_ODD("1", ".La2r_ev", "%[sel1]", A2R_NOP2, A2R_NOP2, BEST, HULL, NRUN)                            \
+    A2R_EVEN("2", ".La2r_ev", "%[sel2]", A2R_NOP2, A2R_NOP2, BEST, HULL, NRUN)                           \
+    A2R_ODD("3", ".La2r_ev", "%[sel3]", A2R_F1_STORE, A2R_F2_STORE, BEST, HULL, NRUN)                    \
     "s_branch .La2r_r0_%=\n"                                                                             \
     A2R_EVEN_FAR("0", HULL)                                                                              \
     A2R_ODD_FAR("1", HULL)                                                                               \
     A2R_EVEN_FAR("2", HULL)                                                                              \
     A2R_ODD_FAR("3", HULL)                                                                               \
     A2R_REC                                                                                              \
+    RELAY                                                                                                \
     ".La2r_oute_%=:\n\t"                                                                                 \
     "s_mov_b64 %[orow], %[sa]\n\t"                                                                       \
     "s_mov_b64 %[sa], %[sb]\n\t"                                                                         \
@@ -276,20 +530,20 @@
     ".La2r_outo_%=:\n\t"                                                                                 \
     "s_mov_b64 %[orow], %[sb]\n"                                                                         \
     ".La2r_out_%=:\n\t"                                                                                  \
-    "s_add_u32 %[it], %[itb], m0\n\t"
+    "s_add_u32 %[it], %[itb], m0\n\t"                                                                    \
+    "s_mov_b32 m0, %[sm0]\n\t"
 
-// the sums of the lanes' cell counters over the two tracks' lanes into h.cells0 / h.cells1; the
-// counters start over.  (Wherever the lanes change hands: a2_replace, the end of a2_fast.)
+// the sums of the lanes' cell counters into h.cells0 / h.cells1; the counters start over (the end of a2_fast).
+// PAIR: a lane's counter holds the cells it computed for track 0 in its low half and those for track 1 in its
+// high half (A2R_CONST_PAIR's `cinc`), so lanes change hands without a fold; a half cannot overflow -- a call
+// of a2_fast runs fewer iterations than the tape ring holds (<= 32768).
 template <bool PAIR>
 W_FN void a2_fold_cells(A2Hot &h, vu &vcnt) {
-    const vu ps = w_prefix_add(vcnt);
-    const u32 all = w_readlaneu(ps, 63);
     if (PAIR) {
-        const u32 low = w_readlaneu(ps, (h.split - 1) & 63);
-        h.cells0 += low;
-        h.cells1 += all - low;
+        h.cells0 += w_readlaneu(w_prefix_add(vcnt & 0xffffu), 63);
+        h.cells1 += w_readlaneu(w_prefix_add(vcnt >> 16), 63);
     } else {
-        h.cells0 += all;
+        h.cells0 += w_readlaneu(w_prefix_add(vcnt), 63);
     }
     vcnt = 0u;
 }
@@ -360,87 +614,122 @@ W_FN void a2_win_fill(const u32 *words, const A2HotV &hv, u64 zone, int src, u32
     }
 }
 
-// One stretch of rows through the stream: from h.it until a row raises an event or `it_end`.
-// `xrow`: x of every lane after the last row (what hv.vx holds of it inside the hull).
+// One stretch of rows through the stream: from h.it until a row raises an event the stream does not
+// resolve itself, or `it_end`.  `xrow`: x of every lane after the last row (what hv.vx holds of it inside the
+// hull).  PAIR: the stream lays the bands out again by itself (h.split / zone1 / forbid_* / kb0 / kb1 / in / act
+// come back as the last layout has them, h.n_replace counts; `relay` = false forbids it: a stretch that begins
+// with a track's row 0) and makes its per-lane constants itself, of the scalars in `sc` (a2_fast's packed state);
+// what the code around the rows keeps per lane of a layout (hv.vnegk .. hv.vtop) is made again here, so none of
+// it stays alive across the stream -- with it the function needed more than its 64 vector registers, and every
+// call of a2_fast paid for the spills.
 template <bool PAIR>
 W_FN void a2_rows_stream(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, const u32 *words, u32 *cells,
-                         u32 *recs, u32 ring, int band, u32 it_end, vi &xrow) {
+                         u32 *recs, u32 ring, int band, u32 it_end, vi &xrow, vu &sc, bool relay, u32 more,
+                         u32 thr) {
     const vi lane = w_lane();
-    // the per-lane constants of the rows (even rows: y = x + vnegk, odd ones: y = x + vnegk - 1):
-    // in global memory the query base of a cell is x + cqg, the target base x + ctg (- 1) ...
-    const vu cqg = hv.vqb;
-    const vu ctg = hv.vtb + (vu)hv.vnegk;
-    // ... in the LDS (as a base index: 16 per word, window w of track t from word (2 t + w) 256 on)
-    // x + cq and x + ct (- 1); xq / xt: the x from which on a window's end is nearer than the margin
+    // In global memory the query base of a cell is x + qb, the target base x + tb + vnegk (- 1 in an odd row:
+    // even rows have y = x + vnegk, odd ones y = x + vnegk - 1); in the LDS (as a base index: 16 per word,
+    // window w of track t from word (2 t + w) 256 on) x + cq and x + ct (- 1); xq / xt: the x from which on a
+    // window's end is nearer than the margin.
     const bool t0 = PAIR || h.kb0 != A2_INVALID;   // (a track running alone plays track 0, whichever it is)
     const u32 aq0 = 16u * (0u * A2W_WORDS - rv.wq0), at0 = 16u * (1u * A2W_WORDS - rv.wt0);
     const u32 aq1 = 16u * (2u * A2W_WORDS - rv.wq1), at1 = 16u * (3u * A2W_WORDS - rv.wt1);
-    vu cq, ct;
-    vi xq, xt;
     const int room = 16 * A2W_USABLE - A2W_MARGIN;
-    if (PAIR) {
-        cq = cqg + w_selu(h.zone1, aq0, aq1);
-        ct = ctg + w_selu(h.zone1, at0, at1);
-        xq = (vi)w_selu(h.zone1, (u32)room, (u32)(room + 32 * A2W_WORDS)) - (vi)cq;
-        xt = (vi)w_selu(h.zone1, (u32)(room + 16 * A2W_WORDS), (u32)(room + 48 * A2W_WORDS)) - (vi)ct;
-    } else {
-        cq = cqg + (t0 ? aq0 : aq1);
-        ct = ctg + (t0 ? at0 : at1);
-        xq = (t0 ? room : room + 32 * A2W_WORDS) - (vi)cq;
-        xt = (t0 ? room + 16 * A2W_WORDS : room + 48 * A2W_WORDS) - (vi)ct;
-    }
-    const vi tn = hv.vtlen - hv.vnegk;
-    const vi le = w_min(hv.vqlen, tn), lo = w_min(hv.vqlen, tn + 1);
-    const vi xw = w_min(xq, xt);
-    const vi lwe = w_min(le, xw), lwo = w_min(lo, xw);
-    const vu cke = (vu)hv.vnegk + hv.vtop, cko = cke - 1u;
+    static_assert(A2R_ROOMQ0 == 16 * A2W_USABLE - A2W_MARGIN && A2R_ROOMT0 == A2R_ROOMQ0 + 16 * A2W_WORDS &&
+                  A2R_ROOMQ1 == A2R_ROOMQ0 + 32 * A2W_WORDS && A2R_ROOMT1 == A2R_ROOMQ0 + 48 * A2W_WORDS,
+                  "A2R_CONST_PAIR spells the windows' limits out");
     const vu l4 = (vu)lane << 2;
     const vi neg = A2_NEG;
     u64 sa = h.act, sb, in, fin, big, t, c1, u, orow;
     u32 b0 = (u32)h.best0, b1 = (u32)h.best1;
-    u32 rem = it_end - h.it - 1u, it = h.it, itb, p0, p1;
+    u32 rem = it_end - h.it - 1u, it = h.it, itb, p0, p1, sm0;
     u32 coff = ((it >> 2) & ((ring >> 2) - 1u)) << 8;            // byte offset of the current group of 4's cell words
     u32 roff = ((it & ~63u) & (ring - 1u)) << 4;                 // ... of the current block of 64's records
     const u32 cmaskb = ((ring >> 2) << 8) - 1u, rmaskb = (ring << 4) - 1u;
-    const u32 ln0 = w_uniu((u32)(h.split - 1) & 63u);  // (the compiler keeps `split` on the vector unit)
-    vu vm, x, qa, ta, t1, t2, key, pm, k2;
+    vu vm, x, qa, ta, t1, t2, key, pm;
+    vi le, lo;
     if (PAIR) {
-        asm volatile(A2R_BODY(A2R_BEST_PAIR, A2R_HULL_PAIR, "2")
+        // where the windows stand, into the packed state beside the tracks' other scalars (A2R_CONST_PAIR)
+        w_pack_put<A2_SC_CQ0>(sc, w_pack_get<A2_SC_QB0>(sc) + aq0);
+        w_pack_put<A2_SC_CT0>(sc, w_pack_get<A2_SC_TB0>(sc) + at0);
+        w_pack_put<A2_SC_CQ1>(sc, w_pack_get<A2_SC_QB1>(sc) + aq1);
+        w_pack_put<A2_SC_CT1>(sc, w_pack_get<A2_SC_TB1>(sc) + at1);
+        u64 z1 = A2R_UNI64(h.zone1), f0 = A2R_UNI64(h.forbid_to0), f1 = A2R_UNI64(h.forbid_to1);
+        // (`nrep`: the re-layouts so far; its top bit set: none allowed in this stretch)
+        u32 kb0 = A2R_UNI(h.kb0), kb1 = A2R_UNI(h.kb1), ret = 4u, r0, r1, r2, r3;
+        u32 nrep = A2R_UNI(h.n_replace | (relay ? 0u : 0x80000000u));
+        u32 ln0 = w_uniu((u32)(h.split - 1) & 63u);  // (the compiler keeps `split` on the vector unit)
+        vu cq, ct, cqg, ctg, lwe, lwo, cke, cko, cinc;
+        asm volatile(A2R_BODY(A2R_BEST_PAIR, A2R_HULL_PAIR, "2", A2R_CONST_PAIR, A2R_RELAY_PAIR)
                      : [vx] "+v"(hv.vx), [acc] "+v"(hv.vacc), [mlo] "+v"(hv.rc_mlo), [mhi] "+v"(hv.rc_mhi),
                        [k0] "+v"(rc_k0), [k1] "+v"(rc_k1), [cnt] "+v"(rv.vcnt), [tdn] "+v"(rv.tdn), [tup] "+v"(rv.tup),
+                       [sc] "+v"(sc),
                        [vm] "=&v"(vm), [x] "=&v"(x), [qa] "=&v"(qa), [ta] "=&v"(ta), [t1] "=&v"(t1), [t2] "=&v"(t2),
-                       [key] "=&v"(key), [pm] "=&v"(pm), [k2] "=&v"(k2),
+                       [key] "=&v"(key), [pm] "=&v"(pm),
+                       [cq] "=&v"(cq), [ct] "=&v"(ct), [cqg] "=&v"(cqg), [ctg] "=&v"(ctg),
+                       [le] "=&v"(le), [lo] "=&v"(lo), [lwe] "=&v"(lwe), [lwo] "=&v"(lwo), [cke] "=&v"(cke),
+                       [cko] "=&v"(cko), [cinc] "=&v"(cinc),
                        [sa] "+s"(sa), [b0] "+s"(b0), [b1] "+s"(b1), [rem] "+s"(rem), [it] "+s"(it),
                        [coff] "+s"(coff), [roff] "+s"(roff),
+                       [z1] "+s"(z1), [f0] "+s"(f0), [f1] "+s"(f1), [kb0] "+s"(kb0), [kb1] "+s"(kb1),
+                       [ln0] "+s"(ln0), [nrep] "+s"(nrep), [ret] "+s"(ret),
                        [sb] "=&s"(sb), [in] "=&s"(in), [fin] "=&s"(fin), [big] "=&s"(big), [t] "=&s"(t),
-                       [c1] "=&s"(c1), [u] "=&s"(u), [p0] "=&s"(p0), [p1] "=&s"(p1), [itb] "=&s"(itb), [orow] "=&s"(orow)
-                     : [cq] "v"(cq), [ct] "v"(ct), [cqg] "v"(cqg), [ctg] "v"(ctg), [le] "v"(le), [lo] "v"(lo),
-                       [lwe] "v"(lwe), [lwo] "v"(lwo), [cke] "v"(cke), [cko] "v"(cko), [l4] "v"(l4), [neg] "v"(neg),
-                       [z1] "s"(h.zone1), [f0] "s"(h.forbid_to0), [f1] "s"(h.forbid_to1), [band] "s"(band),
-                       [ln0] "s"(ln0), [words] "s"(words), [cells] "s"(cells), [recs] "s"(recs),
-                       [cmaskb] "s"(cmaskb), [rmaskb] "s"(rmaskb), [kb0] "s"(h.kb0), [kb1] "s"(h.kb1),
+                       [c1] "=&s"(c1), [u] "=&s"(u), [p0] "=&s"(p0), [p1] "=&s"(p1), [itb] "=&s"(itb), [orow] "=&s"(orow),
+                       [sm0] "=&s"(sm0), [r0] "=&s"(r0), [r1] "=&s"(r1), [r2] "=&s"(r2), [r3] "=&s"(r3)
+                     : [l4] "v"(l4), [neg] "v"(neg), [band] "s"(band),
+                       [words] "s"(words), [cells] "s"(cells), [recs] "s"(recs),
+                       [cmaskb] "s"(cmaskb), [rmaskb] "s"(rmaskb),
                        [sel0] "s"(0x03020104u), [sel1] "s"(0x03020400u), [sel2] "s"(0x03040100u),
                        [sel3] "s"(0x04020100u)
                      : "vcc", "scc", "memory", "v52", "v53", "v54", "v55");
+        // the layout as the stream left it, and what the code around the rows keeps per lane of it (a2_replace's
+        // last lines), from the scalars
+        h.n_replace = nrep & 0x7fffffffu;
+        h.zone1 = z1; h.forbid_to0 = f0; h.forbid_to1 = f1;
+        h.split = (int)ln0 + 1;
+        h.kb0 = kb0; h.kb1 = kb1;
+        hv.vnegk = w_sel(h.zone1, 1 - (int)h.kb0, 1 - (int)h.kb1) - 2 * lane;
+        hv.vqlen = w_sel(h.zone1, (int)w_pack_get<A2_SC_QLEN0>(sc), (int)w_pack_get<A2_SC_QLEN1>(sc));
+        hv.vtlen = w_sel(h.zone1, (int)w_pack_get<A2_SC_TLEN0>(sc), (int)w_pack_get<A2_SC_TLEN1>(sc));
+        hv.vqb = w_selu(h.zone1, w_pack_get<A2_SC_QB0>(sc), w_pack_get<A2_SC_QB1>(sc));
+        hv.vtb = w_selu(h.zone1, w_pack_get<A2_SC_TB0>(sc), w_pack_get<A2_SC_TB1>(sc));
+        hv.vtop = w_selu(h.zone1, 0u, A2_TOP);
     } else {
-        asm volatile(A2R_BODY(A2R_BEST_SINGLE, A2R_HULL_SINGLE, "1")
+        const vu cqg = hv.vqb;
+        const vu ctg = hv.vtb + (vu)hv.vnegk;
+        const vu cq = cqg + (t0 ? aq0 : aq1);
+        const vu ct = ctg + (t0 ? at0 : at1);
+        const vi xq = (t0 ? room : room + 32 * A2W_WORDS) - (vi)cq;
+        const vi xt = (t0 ? room + 16 * A2W_WORDS : room + 48 * A2W_WORDS) - (vi)ct;
+        const vi tn = hv.vtlen - hv.vnegk;
+        le = w_min(hv.vqlen, tn); lo = w_min(hv.vqlen, tn + 1);
+        const vi xw = w_min(xq, xt);
+        const vi lwe = w_min(le, xw), lwo = w_min(lo, xw);
+        const vu cke = (vu)hv.vnegk + hv.vtop, cko = cke - 1u;
+        const vu cinc = 1u;
+        asm volatile(A2R_BODY(A2R_BEST_SINGLE, A2R_HULL_SINGLE, "1", "", A2R_RELAY_SINGLE)
                      : [vx] "+v"(hv.vx), [acc] "+v"(hv.vacc), [mlo] "+v"(hv.rc_mlo), [mhi] "+v"(hv.rc_mhi),
                        [k0] "+v"(rc_k0), [k1] "+v"(rc_k1), [cnt] "+v"(rv.vcnt), [tdn] "+v"(rv.tdn), [tup] "+v"(rv.tup),
                        [vm] "=&v"(vm), [x] "=&v"(x), [qa] "=&v"(qa), [ta] "=&v"(ta), [t1] "=&v"(t1), [t2] "=&v"(t2),
-                       [key] "=&v"(key), [pm] "=&v"(pm), [k2] "=&v"(k2),
+                       [key] "=&v"(key), [pm] "=&v"(pm),
                        [sa] "+s"(sa), [b0] "+s"(b0), [rem] "+s"(rem), [it] "+s"(it),
-                       [coff] "+s"(coff), [roff] "+s"(roff),
+                       [coff] "+s"(coff), [roff] "+s"(roff), [more] "+s"(more),
                        [sb] "=&s"(sb), [in] "=&s"(in), [fin] "=&s"(fin), [big] "=&s"(big), [t] "=&s"(t),
-                       [c1] "=&s"(c1), [p0] "=&s"(p0), [p1] "=&s"(p1), [itb] "=&s"(itb), [orow] "=&s"(orow)
+                       [c1] "=&s"(c1), [p0] "=&s"(p0), [p1] "=&s"(p1), [itb] "=&s"(itb), [orow] "=&s"(orow),
+                       [sm0] "=&s"(sm0)
                      : [cq] "v"(cq), [ct] "v"(ct), [cqg] "v"(cqg), [ctg] "v"(ctg), [le] "v"(le), [lo] "v"(lo),
-                       [lwe] "v"(lwe), [lwo] "v"(lwo), [cke] "v"(cke), [cko] "v"(cko), [l4] "v"(l4), [neg] "v"(neg),
-                       [f0] "s"(h.forbid_to0), [f1] "s"(h.forbid_to1), [band] "s"(band),
+                       [lwe] "v"(lwe), [lwo] "v"(lwo), [cke] "v"(cke), [cko] "v"(cko), [cinc] "v"(cinc), [l4] "v"(l4),
+                       [neg] "v"(neg), [band] "s"(band), [thr] "s"(thr),
+                       [f0] "s"(h.forbid_to0), [f1] "s"(h.forbid_to1),
                        [words] "s"(words), [cells] "s"(cells), [recs] "s"(recs),
                        [cmaskb] "s"(cmaskb), [rmaskb] "s"(rmaskb), [kb0] "s"(h.kb0), [kb1] "s"(h.kb1),
                        [sel0] "s"(0x03020104u), [sel1] "s"(0x03020400u), [sel2] "s"(0x03040100u),
                        [sel3] "s"(0x04020100u)
                      : "vcc", "scc", "memory", "v52", "v53", "v54", "v55");
-        (void)u; (void)b1; (void)ln0;
+        (void)u; (void)b1; (void)sc; (void)relay;
+    }
+    if (PAIR) {
+        (void)more; (void)thr;
     }
     // What the stream hands back: `sa` the lanes of the next row, `orow` those of the last one
     // (the exits put them there, whichever way the two mask registers stood); `t`: the band hull
@@ -485,11 +774,20 @@ W_FN void a2_rows_stream(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
 // row 0 runs alone and what it hands back is cut to the row's lanes here.
 template <bool PAIR>
 W_FN void a2_rows_asm(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, const u32 *words, u32 *cells,
-                      u32 *recs, u32 ring, int band, u32 it_end, bool head) {
+                      u32 *recs, u32 ring, int band, u32 it_end, bool head, vu &sc, u32 it_last, int join_at) {
     bool row0 = false;
     if (head) {
         row0 = PAIR ? (w_popc(h.act & ~h.zone1) == 1 || w_popc(h.act & h.zone1) == 1) : w_popc(h.act) == 1;
     }
+#if defined(A2_DBG_COUNT)
+    // (experiments only: what the `parkings` statistic counts instead -- 1: window fills, 2: calls of the stream)
+#define A2_DBG_TICK(n) w_pack_put<A2_SC_NPARK>(sc, w_pack_get<A2_SC_NPARK>(sc) + (n))
+    if (A2_DBG_COUNT == 2) A2_DBG_TICK(1u);
+    if (A2_DBG_COUNT == 1) {
+        if (PAIR) A2_DBG_TICK((rv.wq0 == A2W_INVALID ? 1u : 0u) + (rv.wq1 == A2W_INVALID ? 1u : 0u));
+        else A2_DBG_TICK(((h.kb0 != A2_INVALID ? rv.wq0 : rv.wq1) == A2W_INVALID) ? 1u : 0u);
+    }
+#endif
     // the windows of the tracks that run
     if (PAIR) {
         if (rv.wq0 == A2W_INVALID) a2_win_fill<0>(words, hv, ~h.zone1, 0, rv.wq0, rv.wt0);
@@ -500,7 +798,15 @@ W_FN void a2_rows_asm(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv, c
         if (rv.wq1 == A2W_INVALID) a2_win_fill<1>(words, hv, ~0ull, 0, rv.wq1, rv.wt1);
     }
     vi x;
-    a2_rows_stream<PAIR>(h, hv, rc_k0, rc_k1, rv, words, cells, recs, ring, band, row0 ? h.it + 1u : it_end, x);
+    // (SINGLE, the neighbour parked: the look-ups behind `it_end` are the stream's own -- A2R_LOOK)
+    const bool looks = !PAIR && !row0 && join_at > 0 && (int)(it_last - it_end) > 0;
+#if defined(A2_DBG_NORELAY)
+    a2_rows_stream<PAIR>(h, hv, rc_k0, rc_k1, rv, words, cells, recs, ring, band, row0 ? h.it + 1u : it_end, x, sc, false,
+                         0u, 0u);
+#else
+    a2_rows_stream<PAIR>(h, hv, rc_k0, rc_k1, rv, words, cells, recs, ring, band, row0 ? h.it + 1u : it_end, x, sc,
+                         !row0, looks ? it_last - it_end : 0u, (u32)(65 - join_at));
+#endif
     // The other case the stream gets wrong: two bands laid out with no lane to spare are neighbours,
     // and when both reach the boundary between the tracks their filter masks merge into one run --
     // two runs in all, which the stream takes for one hull per track, holes and all.  Both lanes

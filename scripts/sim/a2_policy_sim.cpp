@@ -37,6 +37,7 @@ struct Stats {
 };
 
 static int FREE_MIN = 0, FREE_JOIN = 6, LOOK_EVERY = 8, MAX_N = 60;
+static int RIGID_ASYM = 0;
 static int SOFT_ASYM = 1;   // minimal (asymmetric) fences instead of the two-lane fence
 static int RING_MINGAP = 1; // ring: a gap this small (or smaller) while the other has room: rotate; both: park
 static int RING_JOIN_GAP = 3;
@@ -260,7 +261,7 @@ static void step(Wave &w, Stats &s) {
     if (policy == 0 || policy == 1) {
         bool ev;
         const int sp = w.split;
-        if (policy == 0 || !SOFT_ASYM) {
+        if ((policy == 0 && !RIGID_ASYM) || (policy == 1 && !SOFT_ASYM)) {
             // hull on a fence lane (split-1, split) or on the wall of the side the next row grows to
             ev = (T0.h >= sp - 1) || (T1.l <= sp) || (pn == 1 ? (T0.l <= 0) : (T1.h >= 63));
         } else {
@@ -372,6 +373,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "free_join")) FREE_JOIN = v;
         else if (!strcmp(argv[i], "look")) LOOK_EVERY = v;
         else if (!strcmp(argv[i], "asym")) SOFT_ASYM = v;
+        else if (!strcmp(argv[i], "rasym")) RIGID_ASYM = v;
         else if (!strcmp(argv[i], "mingap")) RING_MINGAP = v;
         else if (!strcmp(argv[i], "joingap")) RING_JOIN_GAP = v;
     }

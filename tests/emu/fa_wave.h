@@ -120,6 +120,22 @@ W_FN int w_chain(const vu &ra, const vu &rb, const vi &step, int j, int base, vi
     }
     return j;
 }
+// ... in a frame of its own: i = lane + shift, the path moves by the shifted mask's bit i and -(l & 1)
+W_FN int w_chain2(const vu &ra, const vu &rb, int i, int base, vi &my) {
+    for (int l = base & 63; l < 64; l++) {
+        my.v[l] = i;
+        const u64 mask = ((u64)rb.v[l] << 32) | ra.v[l];
+        i += (int)((mask >> (i & 63)) & 1ull) - (l & 1);
+    }
+    return i;
+}
+W_FN void w_shift64(const vu &lo, const vu &hi, const vi &s, vu &olo, vu &ohi) {
+    for (int l = 0; l < 64; l++) {
+        const u64 m = ((u64)hi.v[l] << 32) | lo.v[l];
+        const u64 r = s.v[l] >= 0 ? (m << (s.v[l] & 63)) : (m >> ((-s.v[l]) & 63));
+        olo.v[l] = (u32)r; ohi.v[l] = (u32)(r >> 32);
+    }
+}
 W_FN vu w_row_tail(const vu &key, const vi &x, const vi &qlen, const vi &y, const vi &tlen, const vu &m, u64 act,
                    u32 band, u64 fa, int slot, vu &rc_lo, vu &rc_hi, u64 &fin, u64 &big, vu &keyb) {
     fin = 0; big = 0;

@@ -14,7 +14,8 @@ import pytest
 
 from conftest import load_golden
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scripts"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
 
 def test_campaign_fixture_vs_restatement(port):
@@ -56,3 +57,43 @@ def test_campaign_pairs_on_the_gpu():
     finally:
         eng.close()
     assert n == 10240 and not stale and not bad, (bad, stale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_the_hand_scheduled_rows_against_their_statement_on_the_device(mode):
+    """k_align2's row loop is one hand-written gfx950 instruction stream (k_align2_rows.h) that since round 6 also
+    lays the two bands out again inside the asm statement; what it computes is stated in portable code beside it
+    (a2_rows_c + a2_replace, k_align2_core.h -- what the lane emulator runs).  k_align2_shadow runs BOTH from the
+    same state, stretch by stretch, and logs every difference in what they hand back: iteration, masks, best_m,
+    every lane's x, the tape's K fields, cell counts, the layout (split, zones, lane-0 diagonals), the number of
+    re-layouts.  FALCON_AMD_A2_SHADOW=1 goes on with the statement's state, =2 with the stream's (as the product
+    does).  Campaign pairs at band 150, bench-like piles and the frozen campaign's pile shapes: every launch must
+    report 0 differing stretches, and the answers are checked against the campaign digests."""
+    import subprocess
+    code = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "scripts")); sys.path.insert(0, os.path.join(%r, "tests"))
+import gpu_differential_campaign as camp
+from conftest import load_golden
+from falcon_amd.engine import Engine
+from benchlib.workloads import WORKLOADS, gen_piles
+eng = Engine(0)
+gold = load_golden("f9_campaign")
+n, bad, stale = camp.run_pairs(eng, 0, 48, gold)
+assert n == 48 * 40 and not bad and not stale, (n, bad, stale)
+n, bad, stale = camp.run_piles(eng, 0, 24, gold)
+assert not bad and not stale, (bad, stale)
+piles = gen_piles(range(700, 716), 1, WORKLOADS["ecoli"])
+out = eng.consensus(piles, 4, 8, 0.70)
+assert all(len(s) > 15000 for s in out)
+eng.close()
+print("shadow run done")
+''' % (ROOT, ROOT, ROOT)
+    env = dict(os.environ, FALCON_AMD_A2_SHADOW=mode)
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode == 0 and b"shadow run done" in p.stdout, err[-3000:]
+    lines = [ln for ln in err.splitlines() if ln.startswith("a2_shadow:")]
+    assert len(lines) >= 3, err[-2000:]                       # (the shadow kernel is what ran)
+    assert all(ln.strip() == "a2_shadow: 0 stretches differ" for ln in lines), "\n".join(err.splitlines()[:60])

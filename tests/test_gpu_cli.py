@@ -278,7 +278,8 @@ def test_the_real_engine_under_world_size_8_on_one_gpu():
     assert g["processes_per_rank"] * 8 <= max(8, int(g["cpu_quota_cores"] or os.cpu_count()))
     w = d["end_to_end_workers"]
     assert len(w["workers"]) == 8 and w["every_fasta_identical"], w
-    assert all(x["devices"] == "0" for x in w["workers"]), w            # one GPU on this box ...
+    # one GPU on this box ...
+    assert {x["devices"] for x in w["workers"]} == {"0"}, [(x["devices"], x["lock_slots"]) for x in w["workers"]]
     assert w["distinct_lock_slots"] == 8, w                             # ... eight different slots of it
     assert d["end_to_end"]["piles_per_sec"], d["end_to_end"]            # eight streams through the multi-stream worker
 
