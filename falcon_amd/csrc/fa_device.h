@@ -159,7 +159,8 @@ __device__ __forceinline__ void fa_writelane2(int &a, int &b, int sa, int sb, in
                  "v_writelane_b32 %0, %3, m0\n\t"
                  "v_writelane_b32 %1, %4, m0"
                  : "+v"(a), "+v"(b)
-                 : "s"(l), "s"(sa), "s"(sb));
+                 : "s"(l), "s"(sa), "s"(sb)
+                 : "m0");
 }
 
 // The lanes of a wavefront run in lockstep: where one lane reads what another lane wrote to

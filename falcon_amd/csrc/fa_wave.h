@@ -39,11 +39,12 @@ W_FN void w_writelane2(vu &a, vu &b, u32 sa, u32 sb, int l) {
                  "v_writelane_b32 %0, %2, m0\n\t"
                  "v_writelane_b32 %1, %3, m0"
                  : "+v"(a), "+v"(b)
-                 : "s"(sa), "s"(sb), "s"(l));
+                 : "s"(sa), "s"(sb), "s"(l)
+                 : "m0");
 }
 // lane l of v := the wave-uniform s (l wave-uniform)
 W_FN void w_setlane(vi &v, int s, int l) {
-    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(fa_uni(s)), "s"(fa_uni(l)));
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(fa_uni(s)), "s"(fa_uni(l)) : "m0");
 }
 // lane dst (per lane, 0..63) receives this lane's v; lanes nobody sends to read 0, of two
 // senders to one lane the higher lane wins
@@ -204,7 +205,7 @@ W_FN vu w_row_tail(vu key, vi x, vi qlen, vi y, vi tlen, vu m, u64 act, u32 band
                  : "=&v"(t), "=&s"(f), "=&s"(b), "=&v"(kb), "+v"(rc_lo), "+v"(rc_hi)
                  : "v"(key), "v"(x), "v"(qlen), "v"(y), "v"(tlen), "v"(m), "s"(act), "s"(band),
                    "s"((u32)fa), "s"((u32)(fa >> 32)), "s"(slot)
-                 : "vcc");
+                 : "vcc", "m0");
     fin = f; big = b; keyb = kb;
     return t;
 }

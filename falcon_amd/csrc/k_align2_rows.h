@@ -681,7 +681,7 @@ W_FN void a2_rows_stream(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
                        [cmaskb] "s"(cmaskb), [rmaskb] "s"(rmaskb),
                        [sel0] "s"(0x03020104u), [sel1] "s"(0x03020400u), [sel2] "s"(0x03040100u),
                        [sel3] "s"(0x04020100u)
-                     : "vcc", "scc", "memory", "v52", "v53", "v54", "v55");
+                     : "vcc", "scc", "memory", "m0", "v52", "v53", "v54", "v55");
         // the layout as the stream left it, and what the code around the rows keeps per lane of it (a2_replace's
         // last lines), from the scalars
         h.n_replace = nrep & 0x7fffffffu;
@@ -725,7 +725,7 @@ W_FN void a2_rows_stream(A2Hot &h, A2HotV &hv, vu &rc_k0, vu &rc_k1, A2RowsV &rv
                        [cmaskb] "s"(cmaskb), [rmaskb] "s"(rmaskb), [kb0] "s"(h.kb0), [kb1] "s"(h.kb1),
                        [sel0] "s"(0x03020104u), [sel1] "s"(0x03020400u), [sel2] "s"(0x03040100u),
                        [sel3] "s"(0x04020100u)
-                     : "vcc", "scc", "memory", "v52", "v53", "v54", "v55");
+                     : "vcc", "scc", "memory", "m0", "v52", "v53", "v54", "v55");
         (void)u; (void)b1; (void)sc; (void)relay;
     }
     if (PAIR) {

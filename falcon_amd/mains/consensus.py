@@ -362,16 +362,30 @@ def fasta_records(seed_id, cns, output_full, output_multi):
 FAILED_PILES = []
 
 
+class FailedPiles(list):
+    """A list of seed ids that also keeps why each pile failed (the server tells the job, whose stderr is not
+    the one the worker's log goes to)."""
+
+    def __init__(self):
+        super().__init__()
+        self.reasons = {}
+
+
+def _note_failed(failed_piles, sid, reason):
+    lst = FAILED_PILES if failed_piles is None else failed_piles
+    lst.append(sid)
+    if hasattr(lst, "reasons"):
+        lst.reasons[sid] = str(reason)
+    LOG.error("seed %s is not corrected: %s", sid, reason)
+
+
 def note_failed_piles(ids, cns_all, failed_piles=None):
     """``failed_piles``: the list the seeds go to (one per stream in the multi-stream worker);
     default: the process-wide one ``main`` looks at."""
-    if failed_piles is None:
-        failed_piles = FAILED_PILES
     for sid, cns in zip(ids, cns_all):
         reason = getattr(cns, "reason", None)
         if reason is not None:
-            failed_piles.append(sid)
-            LOG.error("seed %s is not corrected: %s", sid, reason)
+            _note_failed(failed_piles, sid, reason)
 
 
 def _stream_fd(stream):
@@ -552,8 +566,7 @@ def _run_native(args, cfg, fd, gpu, stdout, batch_bases=None, failed_piles=None,
                     if native_fasta:
                         text, bad = res
                         for p, reason in bad:
-                            (FAILED_PILES if failed_piles is None else failed_piles).append(ids[p])
-                            LOG.error("seed %s is not corrected: %s", ids[p], reason)
+                            _note_failed(failed_piles, ids[p], reason)
                         write_bytes(text)
                         printed.append((time.perf_counter(), len(ids)))
                         LOG.debug("t=%.3f printer: %d piles in %.3f s", _clock(), len(ids),

@@ -55,7 +55,7 @@ def _handle(conn, pool, stats, make_backend=None):
             reply = {"status": "decline", "message": "--trim runs in the job's own process"}
             return
         cfg = single.settings_from(args)
-        failed = []
+        failed = single.FailedPiles()
         t0 = time.perf_counter()
         out = os.fdopen(os.dup(fds[1]), "w")
         try:
@@ -67,7 +67,7 @@ def _handle(conn, pool, stats, make_backend=None):
         if failed:
             with os.fdopen(os.dup(fds[2]), "w") as err:
                 for sid in failed:
-                    err.write("falcon_amd: seed %s is not corrected (reason on the server's stderr)\n" % sid)
+                    err.write("falcon_amd: seed %s is not corrected: %s\n" % (sid, failed.reasons.get(sid, "?")))
                 err.write("falcon_amd: %d pile(s) were not corrected (see above)\n" % len(failed))
             if not req.get("skip_failed"):
                 code = 3
@@ -100,6 +100,20 @@ def serve(path, idle_exit=0.0, ready=None, pool=None, make_backend=None, stop=No
     from falcon_amd.devices import DevicePool, open_engines
     if pool is None:
         pool = DevicePool(open_engines(all_devices=os.environ.get("FALCON_AMD_DEVICES") is None))
+    # a socket file somebody still answers on is a live server: its jobs must not lose it to a second one
+    probe = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    try:
+        probe.settimeout(1.0)
+        probe.connect(path)
+        alive = True
+    except OSError:
+        alive = False
+    finally:
+        probe.close()
+    if alive:
+        if pool is not None and hasattr(pool, "close"):
+            pool.close()
+        raise RuntimeError("falcon_amd: a consensus server is already listening on %s" % path)
     try:
         os.unlink(path)
     except OSError:

@@ -460,6 +460,10 @@ def test_jobs_hand_their_descriptors_to_a_server(tmp_path, monkeypatch):
             assert p.returncode == 0, err.decode()
             assert (tmp_path / ("out_%d.fa" % i)).read_text() == _single_stream_output(texts[i], args), i
         assert backend.staged == backend.finished > len(texts)
+        # a second server on the same path does not take the socket from a live one
+        with pytest.raises(RuntimeError, match="already listening"):
+            server.serve(sock, pool=multi.DevicePool([FakeEngine()]), make_backend=lambda a: backend)
+        assert os.path.exists(sock)
         # a job the server declines runs in its own process: no GPU here, so it fails -- by itself
         with open(tmp_path / "in_0.txt") as fin:
             p = subprocess.run([sys.executable, "-m", "falcon_amd.mains.consensus", "--trim", "--n-core", "1"] + OPTS, stdin=fin,
