@@ -14,7 +14,46 @@ thread_local uint64_t exec = ~0ull;
 thread_local Region regions[16];
 thread_local int n_regions = 0;
 thread_local u32 lds[1024];
+// ---- accounting (scripts/a2_bytes.py): bytes and 32 / 64 / 128-byte units touched per wave-wide access, by what is
+// accessed: 0 packed words, 1 tape cells, 2 tape records, 3 escape list, 4 edit scripts, 5 alignment records
+static bool acct_on = false;
+static int acct_depth = 0;
+static bool acct_write = false;
+static std::vector<std::pair<uintptr_t, size_t>> acct_lanes;
+static double acct_tab[6][2][5];   // [what][read / write][instructions, bytes, 32 B units, 64 B units, 128 B units]
+static const void *acct_arena = nullptr;
+static size_t acct_arena_bytes = 0, acct_slot_words = 0;
+static unsigned acct_ring = 0;
+static int acct_what(uintptr_t a) {
+    for (int i = 0; i < n_regions; i++) {
+        const uintptr_t b = (uintptr_t)regions[i].p;
+        if (a >= b && a < b + regions[i].bytes) {
+            if (regions[i].p != acct_arena) return i == 0 ? 0 : i == 2 ? 4 : 5;
+            const size_t w = ((a - b) / 4) % acct_slot_words;
+            return w < (size_t)acct_ring * 16u ? 1 : w < (size_t)acct_ring * 20u ? 2 : 3;
+        }
+    }
+    return 5;
+}
+Acct::Acct() { if (acct_on && acct_depth++ == 0) acct_lanes.clear(); }
+Acct::~Acct() {
+    if (!acct_on || --acct_depth != 0 || acct_lanes.empty()) return;
+    const int what = acct_what(acct_lanes[0].first), rw = acct_write ? 1 : 0;
+    double *t = acct_tab[what][rw];
+    t[0] += 1;
+    std::vector<uintptr_t> u[3];
+    for (auto &ln : acct_lanes) {
+        t[1] += (double)ln.second;
+        for (int g = 0; g < 3; g++)
+            for (uintptr_t x = ln.first >> (5 + g); x <= (ln.first + ln.second - 1) >> (5 + g); x++) u[g].push_back(x);
+    }
+    for (int g = 0; g < 3; g++) {
+        std::sort(u[g].begin(), u[g].end());
+        t[2 + g] += (double)(std::unique(u[g].begin(), u[g].end()) - u[g].begin());
+    }
+}
 void check(const void *p, size_t bytes, bool write, const char *what) {
+    if (acct_on && acct_depth > 0) { acct_write = write; acct_lanes.emplace_back((uintptr_t)p, bytes); }
     const char *c = (const char *)p;
     for (int i = 0; i < n_regions; i++) {
         const char *b = (const char *)regions[i].p;
@@ -84,6 +123,9 @@ extern "C" void emu_drive_counts(long *out) { out[0] = drive_n[0]; out[1] = driv
 // words per arena slot for a tape of `ring` iterations (must match the engine's sizing)
 static u64 slot_words_for(u32 ring) { return (u64)ring * 16u + (u64)ring * 4u + (u64)A2_ESC_CAP * 2u; }
 
+extern "C" void emu_acct_on(int on) { emu::acct_on = on != 0; if (on) memset(emu::acct_tab, 0, sizeof(emu::acct_tab)); }
+extern "C" void emu_acct_get(double *out) { memcpy(out, emu::acct_tab, sizeof(emu::acct_tab)); }
+
 extern "C" int emu_align2(const u32 *words, u64 n_words, const FaSeq *seq, int n_seq, const FaPile *pile,
                           int n_pile, const FaRange *range, const int *order, int n_work, u32 ring,
                           int n_wave, int band, double max_diff, u32 *script, u64 script_words,
@@ -103,6 +145,8 @@ extern "C" int emu_align2(const u32 *words, u64 n_words, const FaSeq *seq, int n
     emu::n_regions = 0;
     emu::reg(words, n_words * 4, false);
     emu::reg(arena.data(), arena.size() * 4, true);
+    emu::acct_arena = arena.data(); emu::acct_arena_bytes = arena.size() * 4;
+    emu::acct_slot_words = (size_t)slot_words_for(ring); emu::acct_ring = ring;
     emu::reg(script, script_words * 4, true);
     emu::reg(aln, (size_t)n_seq * sizeof(FaAln), true);
     (void)n_pile;

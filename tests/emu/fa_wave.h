@@ -200,8 +200,11 @@ struct Region { const void *p; size_t bytes; bool writable; };
 extern thread_local Region regions[16];
 extern thread_local int n_regions;
 void check(const void *p, size_t bytes, bool write, const char *what);
+// optional accounting (scripts/a2_bytes.py): one object per wave-wide access gathers what its lanes touch
+struct Acct { Acct(); ~Acct(); };
 }
 W_FN void w_load_pair(const u32 *base, const vu &i, vu &lo, vu &hi) {
+    emu::Acct acct_;
     for (int l = 0; l < 64; l++) if (emu::on(l)) {
         emu::check(base + i.v[l], 8, false, "w_load_pair");
         lo.v[l] = base[i.v[l]];
@@ -209,20 +212,24 @@ W_FN void w_load_pair(const u32 *base, const vu &i, vu &lo, vu &hi) {
     }
 }
 W_FN vu w_load32(const u32 *base, const vu &i) {
+    emu::Acct acct_;
     vu r;
     for (int l = 0; l < 64; l++) if (emu::on(l)) { emu::check(base + i.v[l], 4, false, "w_load32"); r.v[l] = base[i.v[l]]; }
     return r;
 }
 W_FN void w_store32(u32 *base, const vu &i, const vu &v) {
+    emu::Acct acct_;
     for (int l = 0; l < 64; l++) if (emu::on(l)) { emu::check(base + i.v[l], 4, true, "w_store32"); base[i.v[l]] = v.v[l]; }
 }
 W_FN void w_store64(u64 *base, const vu &i, const vu &lo, const vu &hi) {
+    emu::Acct acct_;
     for (int l = 0; l < 64; l++) if (emu::on(l)) {
         emu::check(base + i.v[l], 8, true, "w_store64");
         base[i.v[l]] = ((u64)hi.v[l] << 32) | lo.v[l];
     }
 }
 W_FN void w_load64(const u64 *base, const vu &i, vu &lo, vu &hi) {
+    emu::Acct acct_;
     for (int l = 0; l < 64; l++) if (emu::on(l)) {
         emu::check(base + i.v[l], 8, false, "w_load64");
         lo.v[l] = (u32)base[i.v[l]];
@@ -230,6 +237,7 @@ W_FN void w_load64(const u64 *base, const vu &i, vu &lo, vu &hi) {
     }
 }
 W_FN void w_store_x4(u32 *base16, const vu &i, const vu &a, const vu &b, const vu &c, const vu &d) {
+    emu::Acct acct_;
     for (int l = 0; l < 64; l++) if (emu::on(l)) {
         u32 *p = base16 + 4 * (size_t)i.v[l];
         emu::check(p, 16, true, "w_store_x4");
@@ -237,6 +245,7 @@ W_FN void w_store_x4(u32 *base16, const vu &i, const vu &a, const vu &b, const v
     }
 }
 W_FN void w_load_x4(const u32 *base16, const vu &i, vu &a, vu &b, vu &c, vu &d) {
+    emu::Acct acct_;
     for (int l = 0; l < 64; l++) if (emu::on(l)) {
         const u32 *p = base16 + 4 * (size_t)i.v[l];
         emu::check(p, 16, false, "w_load_x4");
