@@ -273,28 +273,42 @@ typedef __attribute__((address_space(1))) uint8_t w_gu8;
 typedef __attribute__((address_space(1))) w_u32x4 w_gu32x4;
 typedef __attribute__((address_space(1))) u64 w_gu64;
 
+// W_AT(T, base, i): element i of the array of T at `base`.  W_ADDR32 (a build switch, off): the byte offset is
+// formed in 32 bits -- every array the kernels index this way is smaller than 4 GB (the packed words of a launch:
+// < 2^28 of them, engine.hip cuts larger batches; a tape slot; a script) -- so that the access is `SGPR base +
+// 32-bit VGPR offset`.  As it is, hipcc widens the index to 64 bits (it cannot know the product fits), keeps a
+// register tuple with a zero high half for that through k_align2's whole event loop, and spills / reloads the
+// tuple around it: 99 of the kernel's 200 scratch instructions, 16 bytes per lane each
+// (profiles/r06_k_align2_bytes_by_site.txt).  Off until it has run on the GPU.
+typedef __attribute__((address_space(1))) char w_gchar;
+#if defined(W_ADDR32)
+#define W_AT(T, base, i) (*(T *)((w_gchar *)(base) + (size_t)(u32)((u32)(i) * (u32)sizeof(T))))
+#define W_AT_C(T, base, i) (*(const T *)((const w_gchar *)(base) + (size_t)(u32)((u32)(i) * (u32)sizeof(T))))
+#else
+#define W_AT(T, base, i) (((T *)(base))[i])
+#define W_AT_C(T, base, i) (((const T *)(base))[i])
+#endif
 // words base[i], base[i + 1] (i per lane)
 W_FN void w_load_pair(const u32 *base, vu i, vu &lo, vu &hi) {
-    const w_gu32 *p = (const w_gu32 *)base;
-    lo = p[i];
-    hi = p[i + 1u];
+    lo = W_AT_C(w_gu32, base, i);
+    hi = W_AT_C(w_gu32, base, i + 1u);
 }
-W_FN vu w_load32(const u32 *base, vu i) { return ((const w_gu32 *)base)[i]; }
-W_FN void w_store32(u32 *base, vu i, vu v) { ((w_gu32 *)base)[i] = v; }
+W_FN vu w_load32(const u32 *base, vu i) { return W_AT_C(w_gu32, base, i); }
+W_FN void w_store32(u32 *base, vu i, vu v) { W_AT(w_gu32, base, i) = v; }
 W_FN vu w_load8(const uint8_t *base, vu i) { return (vu)((const w_gu8 *)base)[i]; }
-W_FN void w_store64(u64 *base, vu i, vu lo, vu hi) { ((w_gu64 *)base)[i] = ((u64)hi << 32) | lo; }
+W_FN void w_store64(u64 *base, vu i, vu lo, vu hi) { W_AT(w_gu64, base, i) = ((u64)hi << 32) | lo; }
 W_FN void w_load64(const u64 *base, vu i, vu &lo, vu &hi) {
-    const u64 v = ((const w_gu64 *)base)[i];
+    const u64 v = W_AT_C(w_gu64, base, i);
     lo = (vu)v;
     hi = (vu)(v >> 32);
 }
 // 16-byte records
 W_FN void w_store_x4(u32 *base16, vu i, vu a, vu b, vu c, vu d) {
     const w_u32x4 r = {a, b, c, d};
-    ((w_gu32x4 *)base16)[i] = r;
+    W_AT(w_gu32x4, base16, i) = r;
 }
 W_FN void w_load_x4(const u32 *base16, vu i, vu &a, vu &b, vu &c, vu &d) {
-    const w_u32x4 r = ((const w_gu32x4 *)base16)[i];
+    const w_u32x4 r = W_AT_C(w_gu32x4, base16, i);
     a = r.x; b = r.y; c = r.z; d = r.w;
 }
 // the same value from every lane (results, counters)
