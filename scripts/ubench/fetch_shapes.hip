@@ -6,7 +6,7 @@
 //   shape_dword_s16  one dword per lane, lanes 16 bytes apart, four such loads per 64 bytes  (the LDS window fill)
 //   shape_dwordx2    8 bytes per lane from a window of a few cache lines per wavefront        (a snake beyond 16 bases)
 //   shape_gather4    one dword per lane at an address of its own (one 64-byte line per lane)  (the trace-back's cell bytes)
-// build: hipcc --offload-arch=gfx950 -O2 fetch_shapes.hip -o fetch_shapes.bin ; run under rocprofv3 (scripts/r05_evidence.sh)
+// build: hipcc --offload-arch=gfx950 -O2 fetch_shapes.hip -o fetch_shapes.bin ; run under rocprofv3 --kernel-trace --pmc FETCH_SIZE (round 5: git show 40b807a:scripts/r05_evidence.sh)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
