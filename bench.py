@@ -58,11 +58,13 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["trim", "align1500", "utg"], default="ecoli",
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["trim", "align1500", "utg", "e2e-long"], default="ecoli",
                     help="ecoli / dmel / arab: BASELINE.json's configs of the falcon_sense path; trim / align1500 / utg: "
                          "the SURVEY.md 8(f) paths beside it (benchlib/secondary.py), one GPU, their own metrics")
     ap.add_argument("--piles", type=int, default=int(os.environ.get("FALCON_BENCH_PILES", "0")),
                     help="piles per step per GPU (default: 3072 ecoli, 1024 dmel, 1536 arab)")
+    ap.add_argument("--jobs", type=int, default=10, help="e2e-long: jobs of the whole text through one server")
+    ap.add_argument("--parallel", type=int, default=3, help="e2e-long: jobs at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-procs", default="",
                     help="worker-process counts of the CPU baseline, comma separated (default: 1,8,16,24,32,64 and "
@@ -446,6 +448,21 @@ def bench_rank(args, plumb, make_engine, piles, t_gen=0.0, out=None):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    if args.workload == "e2e-long":
+        # (SURVEY.md 8d "end-to-end", on a stream long enough that start-up is a few per cent of it: its own line,
+        # never the headline's `value`)
+        from benchlib.e2e import end_to_end_long
+        from benchlib.workloads import gen_piles
+        wl = WORKLOADS["ecoli"]
+        n = args.piles if args.piles > 0 else wl["piles"]
+        piles = gen_piles(range(1000, 1000 + n), max(1, (os.cpu_count() or 2) // 2), wl)
+        res = end_to_end_long(piles, jobs=args.jobs, parallel=args.parallel)
+        best = max((r for r in res["settings"] if r.get("piles_per_sec")), key=lambda r: r["piles_per_sec"])
+        print(json.dumps({"metric": "end-to-end piles/sec, LA4Falcon text -> FASTA through one consensus server, long stream",
+                          "value": best["piles_per_sec"], "unit": "piles/s", "n_gpus": 1, "higher_is_better": True,
+                          "data": "synthetic", "config": {"workload": wl["text"], "jobs": args.jobs, "parallel": args.parallel},
+                          "end_to_end_long": res}))
+        return
     if args.workload not in WORKLOADS:
         if args.gpus != 1:
             sys.exit("bench.py --workload %s: one GPU (the 8(f) paths have no multi-GPU story of their own)" % args.workload)

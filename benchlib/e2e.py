@@ -254,3 +254,93 @@ def end_to_end_served(piles, expect=None, repeats=E2E_REPEATS, jobs=3):
                        for rep in range(repeats) for i, c in enumerate(expect))
         out["fasta_identical_to_resident_batch"] = (want == text)
     return out
+
+
+def end_to_end_long(piles, jobs=10, parallel=3, repeats=E2E_REPEATS, settings=None, server_cmd=None, job_cmd=None):
+    """A stream long enough to call a rate a rate: `jobs` jobs of the whole text (each `repeats` x the step's piles:
+    30 720 of them, 25 GB) through ONE consensus server, `parallel` of them at a time -- the devices' queues never run
+    dry between jobs, so what the server sees is one stream of jobs x 30 720 piles (the file itself cannot be made a
+    hundred times longer: it would not fit the scratch disk, and a pipe delivers a tenth of the rate).  The clock runs
+    from the first job's start to the last job's end; server start is not on it (a node pays it once).
+    `settings`: [(name, {environment of the server})], e.g. the worker's batch size -- one server per setting, one
+    after the other, same text.  Every job's FASTA must be the same bytes."""
+    import hashlib
+    import shutil
+    import signal
+    settings = settings or [("batch 0.4 G bases (the default)", {}),
+                            ("batch 1.3 G bases, 4 text buffers ahead", {"FALCON_AMD_BATCH_BASES": "1300000000",
+                                                                         "FALCON_AMD_READ_AHEAD": "4"})]
+    out = {"settings": []}
+    with tempfile.TemporaryDirectory() as tmp:
+        src, sock = os.path.join(tmp, "piles.txt"), os.path.join(tmp, "srv.sock")
+        per_repeat = sum(sum(len(x) + 10 for x in p) for p in piles) + 1
+        repeats = max(1, min(repeats, int(shutil.disk_usage(tmp).free * 0.4 // per_repeat)))
+        with open(src, "wb") as f:
+            write_la4falcon(piles, f, repeats)
+        size = os.path.getsize(src)
+        env = {k: v for k, v in os.environ.items()
+               if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTRACER", "HSA_TOOLS"))}
+        # (`server_cmd` / `job_cmd`: the CPU tests' stand-ins)
+        cmd = job_cmd or [sys.executable, "-m", "falcon_amd.mains.consensus", "--output-multi", "--min-idt", "0.70",
+                          "--min-cov", "4", "--max-n-read", "200", "--n-core", "1"]
+        n_job = repeats * len(piles)
+        digest0 = None
+        for name, senv in settings:
+            srv = subprocess.Popen((server_cmd or [sys.executable, "-m", "falcon_amd.mains.consensus_server"]) +
+                                   ["--socket", sock], cwd=ROOT, env=dict(env, **senv), stdout=subprocess.PIPE,
+                                   stderr=subprocess.PIPE, text=True)
+            row = {"setting": name}
+            try:
+                line = srv.stdout.readline()
+                if "ready" not in line:
+                    raise RuntimeError("the consensus server did not come up: %s %s" % (line, srv.stderr.read()[-400:]))
+                running, done_at, started, digests = [], [], 0, []
+                t0 = time.perf_counter()
+                while started < jobs or running:
+                    while started < jobs and len(running) < parallel:
+                        dst = os.path.join(tmp, "cns_%d.fasta" % started)
+                        fin, fout = open(src), open(dst, "w")
+                        running.append((subprocess.Popen(cmd, stdin=fin, stdout=fout, cwd=ROOT,
+                                                         env=dict(env, FALCON_AMD_SERVER=sock)), fin, fout, dst,
+                                        time.perf_counter()))
+                        started += 1
+                    for item in list(running):
+                        p, fin, fout, dst, t_job = item
+                        if p.poll() is None:
+                            continue
+                        running.remove(item)
+                        fin.close(); fout.close()
+                        if p.returncode != 0:
+                            raise RuntimeError("end_to_end_long: a job exited %d" % p.returncode)
+                        done_at.append((time.perf_counter() - t0, time.perf_counter() - t_job))
+                        h = hashlib.sha1()
+                        with open(dst, "rb") as f:
+                            for blk in iter(lambda: f.read(1 << 24), b""):
+                                h.update(blk)
+                        digests.append(h.hexdigest()[:16])
+                        os.unlink(dst)
+                    if time.perf_counter() - t0 > 1500:
+                        raise RuntimeError("end_to_end_long: the jobs did not finish")
+                    time.sleep(0.002)
+                wall = max(t for t, _ in done_at)
+                digest0 = digest0 or digests[0]
+                # the rate between the first job's end and the last job's end: start-up and the first jobs' ramp excluded
+                firsts = sorted(t for t, _ in done_at)
+                steady = (len(firsts) - 1) * n_job / (firsts[-1] - firsts[0]) if len(firsts) > 1 and firsts[-1] > firsts[0] else None
+                row.update({"piles": jobs * n_job, "wall_s": round(wall, 2), "piles_per_sec": round(jobs * n_job / wall, 1),
+                            "text_GB_per_sec": round(jobs * size / 1e9 / wall, 2),
+                            "piles_per_sec_between_first_and_last_job_end": round(steady, 1) if steady else None,
+                            "job_wall_s": [round(w, 2) for _, w in done_at],
+                            "every_fasta_identical": len(set(digests)) == 1 and digests[0] == digest0,
+                            "fasta_sha1": digests[0]})
+            finally:
+                srv.send_signal(signal.SIGTERM)
+                try:
+                    srv.wait(timeout=120)
+                except subprocess.TimeoutExpired:
+                    srv.kill()
+            out["settings"].append(row)
+    out["what"] = ("%d jobs of %d piles (%.0f MB of text each, from the page cache), %d at a time, through one consensus "
+                   "server per setting (started before, not on the clock): first job's start to last job's end"
+                   % (jobs, n_job, size / 1e6, parallel))
+    return out

@@ -218,3 +218,25 @@ def test_plumbing_under_nccl_binds_every_rank_to_its_own_device(monkeypatch):
     monkeypatch.setattr(dist, "get_world_size", lambda *a: 7)
     with pytest.raises(RuntimeError, match="rendezvous saw 7 ranks"):
         bench.Plumbing(0, 0, 8, "nccl")
+
+
+def test_the_long_end_to_end_leg_with_stand_ins(tmp_path):
+    """benchlib.e2e.end_to_end_long (bench.py --workload e2e-long): jobs of the whole text through one server per
+    setting, a few at a time, the clock from the first job's start to the last job's end, every FASTA the same
+    bytes.  Stand-ins for the server (prints its ready line, waits for SIGTERM) and for the jobs (copy stdin to
+    stdout): the orchestration is what runs here, the GPU box runs it with the real ones."""
+    import sys
+    from benchlib.e2e import end_to_end_long
+    server = [sys.executable, "-c",
+              "import sys, time, signal\n"
+              "signal.signal(signal.SIGTERM, lambda *a: sys.exit(0))\n"
+              "print('stand-in ready'); sys.stdout.flush()\n"
+              "time.sleep(600)\n"]
+    job = [sys.executable, "-c", "import sys, time; time.sleep(0.05); sys.stdout.write(sys.stdin.read())"]
+    piles = [[b"ACGTACGTAC" * 30, b"ACGTACGTAC" * 30, b"ACGTACGTAC" * 20] for _ in range(5)]
+    res = end_to_end_long(piles, jobs=5, parallel=2, repeats=2, settings=[("a", {}), ("b", {"X": "1"})],
+                          server_cmd=server, job_cmd=job)
+    assert [r["setting"] for r in res["settings"]] == ["a", "b"]
+    for r in res["settings"]:
+        assert r["piles"] == 5 * 2 * 5 and r["every_fasta_identical"] and len(r["job_wall_s"]) == 5
+        assert r["piles_per_sec"] > 0 and r["wall_s"] >= 0.05 * 3   # (five jobs, two at a time: three rounds)
