@@ -142,10 +142,14 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
     u32 cnt_max = 0;  // largest bucket a probe of this read hits
     for (int p0 = 0; p0 < n_probe; p0 += 64 * CH_UA) {
         u32 km[CH_UA], lo[CH_UA], hi[CH_UA], tl[CH_UA], th[CH_UA];
+        // (round 6: NO branch around the read -- `(p < n_probe) ? fa_kmer8(..) : 0` put each of the five reads into a
+        // block of its own that ends with an s_waitcnt vmcnt(0) where the lanes join: five latencies in a row
+        // where the comment above promises one.  A probe beyond the last reads the last one's bases; its
+        // bucket is emptied below.)
 #pragma unroll
         for (int u = 0; u < CH_UA; u++) {
             const int p = p0 + 64 * u + lane;
-            km[u] = (p < n_probe) ? fa_kmer8(w, 4 * p) : 0u;
+            km[u] = fa_kmer8(w, 4 * min(p, n_probe - 1));
         }
 #pragma unroll
         for (int u = 0; u < CH_UA; u++) {
@@ -161,19 +165,16 @@ __global__ __launch_bounds__(64) void k_chain(ChainArgs A) {
             th[u] = P[any ? hi[u] - 1u : 0u];
         }
 #pragma unroll
-        for (int u = 0; u < CH_UA; u++) {
+        for (int u = 0; u < CH_UA; u++) {  // (selects, not branches: only the store is under a lane mask)
             const int p = p0 + 64 * u + lane;
-            if (p < n_probe) {
-                const int i = 4 * p;
-                const u32 cnt = hi[u] - lo[u];
-                pr[p] = cnt == 0 ? 0ull : cnt <= 2 ? CH_REC(cnt, tl[u], th[u]) : CH_REC(3u, lo[u], cnt);
-                if (hi[u] > lo[u]) {
-                    n_hit += (int)(hi[u] - lo[u]);
-                    cnt_max = max(cnt_max, hi[u] - lo[u]);
-                    d_min = min(d_min, i - (int)th[u]);
-                    d_max = max(d_max, i - (int)tl[u]);
-                }
-            }
+            const int i = 4 * p;
+            const u32 cnt = hi[u] - lo[u];  // (0 beyond the last probe)
+            const u64 rec = cnt == 0 ? 0ull : cnt <= 2 ? CH_REC(cnt, tl[u], th[u]) : CH_REC(3u, lo[u], cnt);
+            if (p < n_probe) pr[p] = rec;
+            n_hit += (int)cnt;
+            cnt_max = max(cnt_max, cnt);
+            d_min = min(d_min, cnt ? i - (int)th[u] : 0x7fffffff);
+            d_max = max(d_max, cnt ? i - (int)tl[u] : -0x7fffffff);
         }
     }
     d_min = fa_wave_min(d_min);
