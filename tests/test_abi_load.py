@@ -103,8 +103,8 @@ def test_no_asm_block_names_vcc():
                     inside, by_hand = True, False
                 elif "#ASMEND" in line:
                     inside = False
-                elif inside and (".La2r_" in line or ".Lwch_" in line):
-                    # the hand-scheduled streams (k_align2_rows.h, w_chain), known by their
+                elif inside and (".La2r_" in line or ".Lwch_" in line or ".Lwc2_" in line):
+                    # the hand-scheduled streams (k_align2_rows.h, w_chain, w_chain2), known by their
                     # labels: VCC named in the text and in the clobber list (checked below).
                     by_hand = True
                 elif inside and "vcc" in line and not by_hand:
@@ -125,8 +125,8 @@ def test_no_asm_block_names_vcc():
     for name in ("k_align2_rows.h", "fa_wave.h"):
         text = open(os.path.join(src_dir, name)).read()
         by_hand += [st for st in re.findall(r"asm volatile\(.*?\);", text, re.S)
-                    if ".Lwch_" in st or st.startswith("asm volatile(A2R_BODY")]
-    assert len(by_hand) >= 3 and all('"vcc"' in st.rsplit(":", 1)[1] for st in by_hand)
+                    if ".Lwch_" in st or ".Lwc2_" in st or st.startswith("asm volatile(A2R_BODY")]
+    assert len(by_hand) >= 4 and all('"vcc"' in st.rsplit(":", 1)[1] for st in by_hand)
 
 
 def test_legacy_window_functions_vs_reference_random(lib, ref):
