@@ -10,9 +10,9 @@ D=$R/gpurun_variants/$NAME; mkdir -p $D
 cd $SRC/falcon_amd/csrc
 [ "$SRC" != "$R" ] && make -s -j8 >/dev/null 2>&1
 MINE=""; SKIP=""
-for f in $FILES; do
-  o=${f%.hip}.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -Wno-pass-failed "$@" -c $f -o $D/$o
+for f in $FILES; do   # (a path with a slash: that file instead of the tree's source of the same name, e.g. an older revision)
+  o=$(basename ${f%.hip}.o)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -Wno-pass-failed -I. "$@" -c $f -o $D/$o
   MINE="$MINE $D/$o"; SKIP="$SKIP -e ^$o\$"
 done
 OBJS=$(ls *.o | grep -v $SKIP)
