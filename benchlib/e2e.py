@@ -268,6 +268,8 @@ def end_to_end_long(piles, jobs=10, parallel=3, repeats=E2E_REPEATS, settings=No
     import shutil
     import signal
     settings = settings or [("batch 0.4 G bases (the default)", {}),
+                            ("batches that grow: x 1.5 from the 4th on, up to 1.4 G bases; 4 text buffers ahead",
+                             {"FALCON_AMD_BATCH_GROW": "3:1.5:1400000000", "FALCON_AMD_READ_AHEAD": "4"}),
                             ("batch 1.3 G bases, 4 text buffers ahead", {"FALCON_AMD_BATCH_BASES": "1300000000",
                                                                          "FALCON_AMD_READ_AHEAD": "4"})]
     out = {"settings": []}

@@ -87,6 +87,48 @@ def _single_stream_output(text, args):
     return out.getvalue()
 
 
+def test_batches_that_grow_print_the_same_bytes(monkeypatch):
+    """FALCON_AMD_BATCH_GROW=FROM:FACTOR:MAX: from batch FROM on every batch is FACTOR times the one before, up to
+    MAX bases (for streams that go on: the GPU is faster on large batches).  The records leave in input order and
+    the bytes are those of constant batches; the schedule itself is checked, and what it refuses."""
+    f = single.batch_schedule(900, "2:2:5000")
+    assert [f(n) for n in range(7)] == [900, 900, 1800, 3600, 5000, 5000, 5000]
+    assert [single.batch_schedule(900, None)(n) for n in (0, 5, 500)] == [900] * 3
+    assert single.batch_schedule(400_000_000, "3:1.5:1600000000")(200) == 1_600_000_000
+    for bad in ("2:0.5:5000", "-1:2:5000", "2:2:100"):
+        with pytest.raises(ValueError):
+            single.batch_schedule(900, bad)
+    rng = random.Random(35)
+    text = _rand_stream(rng, 150, with_noise=True)
+    args = single.parse_args(["prog"] + OPTS)
+    want = _single_stream_output(text, args)
+    sizes = []
+
+    class Gpu:
+        engines = [None]
+        parallel = 3
+
+        def stage(self, ps):
+            sizes.append(ps.n_pile)
+            return ps.piles()
+
+        def finish(self, piles):
+            return [(p[0] * 20)[:600] for p in piles]
+
+    monkeypatch.setenv("FALCON_AMD_BATCH_GROW", "3:2:20000")
+    rd, wr = os.pipe()
+    t = threading.Thread(target=lambda: (os.write(wr, text.encode()), os.close(wr)))
+    t.start()
+    out = io.StringIO()
+    try:
+        single._run_native(args, single.settings_from(args), rd, Gpu(), out, batch_bases=900)
+    finally:
+        os.close(rd)
+        t.join()
+    assert out.getvalue() == want and want.count(">") > 80
+    assert max(sizes[5:]) > 4 * max(sizes[:3]), sizes   # (the later batches ARE larger)
+
+
 @pytest.mark.parametrize("stagers", ["2", "4"])
 def test_several_staging_threads_keep_the_order_and_the_readers_buffers(stagers, monkeypatch):
     """FALCON_AMD_STAGERS > 1: batches are staged side by side and may finish out of order -- the records
