@@ -85,6 +85,14 @@ __device__ __forceinline__ void s2_chain(u32 *L, u32 rec_b, int n_l, int nl, int
     // (consumed here, so that the loop head need not wait for it -- a wait there is also a wait
     // for the atomic of the level before, on every level)
     r.x = fa_settled(r.x); r.y = fa_settled(r.y);
+#if defined(S2_SETTLE_NL)
+    // (round 6, a build switch, off until it has run on a GPU: the levels' link counts, which the caller read out of
+    // the LDS a moment ago, consumed here too.  Left pending, their wait lands at the loop's head -- the compiler
+    // cannot tell the first trip from the others -- where from the second trip on it is a wait for the ATOMIC of
+    // the level before: the listing has `s_waitcnt lgkmcnt(0)` twice per level, i.e. the second LDS round trip this
+    // loop was written to avoid.  With this line the one at the head is gone.)
+    nl = (int)fa_settled((u32)nl);
+#endif
     for (int i = 0; i < n_l; i++) {
         const int n_i = __builtin_amdgcn_readlane(nl, i);
         ra += 8u * (u32)n_i;
