@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of library builds under gpurun_variants/<name>/libfalcon_amd.so (and "head" = the tree's own):
 # k_align2's time alone (3 unpipelined steps) and, with "pmc", its instruction / wait counters.
-# usage: scripts/r06_ab.sh <tag> "<variants>" [pmc]
+# usage: scripts/ab_counters.sh <tag> "<variants>" [pmc]
 TAG=${1:-r06ab}; VARS=${2:-head}; PMC=$3
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG; mkdir -p $O

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The kernels' own times (three unpipelined steps) of the tree's library and of builds under gpurun_variants/, then the
-# pipelined line of the tree's.   usage: scripts/r06_quick.sh <tag> ["<variants>"]
+# pipelined line of the tree's.   usage: scripts/ab_times.sh <tag> ["<variants>"]
 TAG=${1:-r06q}; VARS=${2:-head}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG; mkdir -p $O

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round 6, k_align2 on the GPU box: the shadow kernel (both renderings of the rows side by side), the
-# alignment-facing part of the GPU suite (or all of it), a short bench line.   usage: scripts/r06_a2.sh <tag> [full]
+# k_align2 on the GPU box: the shadow kernel (both renderings of the rows side by side), the
+# alignment-facing part of the GPU suite (or all of it), a short bench line.   usage: scripts/check_align2.sh <tag> [full]
 TAG=${1:-r06b}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG; mkdir -p $O
