@@ -58,3 +58,12 @@ def test_the_seed_index_table_fits_one_cu():
     r = resources("k_seed_index.hip")
     (lds, vgpr), = [v for k, v in r.items() if "k_seed_index" in k and "long" not in k]
     assert 128 * 1024 < lds <= LDS_PER_CU and 4 * (-(-vgpr // 8) * 8) <= 512, (lds, vgpr)   # 16 wavefronts of one workgroup
+
+
+def test_the_chaining_kernel_keeps_eight_wavefronts_per_simd():
+    """k_chain hides a string of dependent reads behind its occupancy: more than 64 vector registers would cost it a
+    wavefront per SIMD (512 registers per lane and SIMD).  Round 6's first pass, with its five packed-read loads issued
+    together, needs 60."""
+    r = resources("k_chain.hip")
+    (lds, vgpr), = [v for k, v in r.items() if "k_chain" in k]
+    assert vgpr <= 64, vgpr
