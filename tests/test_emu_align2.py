@@ -253,3 +253,33 @@ def test_the_two_primitive_layers_name_the_same_primitives():
     core = open(os.path.join(root, "falcon_amd", "csrc", "k_align2_core.h")).read()
     used = set(re.findall(r"\b(w_[a-z0-9_]+)\s*(?:<[^>]*>)?\s*\(", core))
     assert used <= (device & emu) | {"w_lds"}, sorted(used - (device & emu))
+
+
+def test_the_emulator_counts_what_the_kernel_touches(port):
+    """scripts/a2_bytes.py's instrument: with emu_acct_on every wave-wide load / store of the kernel's source is
+    counted by what it touches (packed words, tape cells, tape records, escape list, edit scripts, alignment
+    records).  The tape's layout makes three of the sums predictable: a 256-byte row of cell words per 4 iterations,
+    a 16-byte record per iteration, 4 bytes of edit script per band row -- plus, per trace-back, the partial group /
+    block that a2_flush_partial writes ahead of it."""
+    import ctypes as C
+    from emu_driver import lib
+    rng = np.random.default_rng(77)
+    pairs = [_pair(rng, int(n), 0.12) for n in (1500, 2200, 900, 3000, 1800, 2600)]
+    lib().emu_acct_on(1)
+    try:
+        res, stats = align_pairs(pairs)
+        tab = np.zeros((6, 2, 5))
+        lib().emu_acct_get(tab.ctypes.data_as(C.c_void_p))
+    finally:
+        lib().emu_acct_on(0)
+    _check(port, pairs, res)
+    its = int(stats[0]) + int(stats[1])
+    n = len(pairs)
+    rows = sum(r["dist"] + 1 for r in res if r["aligned"])
+    cells_w, recs_w, script_w = tab[1][1][1], tab[2][1][1], tab[4][1][1]
+    assert its // 4 * 256 <= cells_w <= (its // 4 + n + 1) * 256, (its, cells_w)
+    assert its // 64 * 1024 <= recs_w <= its * 16 + n * 1024, (its, recs_w)
+    assert script_w == 4 * rows, (rows, script_w)
+    # the trace-back reads every block of 64 iterations it walks as 16-byte records, and one cell word per row
+    assert tab[2][0][1] >= 16 * rows and tab[1][0][1] == 4 * rows, (rows, tab[2][0], tab[1][0])
+    assert tab[3].sum() == 0   # (no snake of >= 255 bases here: the escape list is not touched)
