@@ -24,6 +24,8 @@ if want "full quick"; then
   timeout 900 python bench.py > $O/bench_ecoli.json.txt 2> $O/bench_ecoli.err; show $O/bench_ecoli.json.txt
   timeout 300 python bench.py --no-pipeline --no-cpu-baseline --no-end-to-end > $O/bench_ecoli_one_batch_at_a_time.json.txt 2> /dev/null; show $O/bench_ecoli_one_batch_at_a_time.json.txt 160
   timeout 300 python bench.py --steps 400 --warmup 5 --no-cpu-baseline --no-end-to-end > $O/bench_ecoli_400_steps.json.txt 2> /dev/null; show $O/bench_ecoli_400_steps.json.txt 160
+  # (two resident batches instead of three: the round-5 review's question whether the third one earns its 6.8 GB)
+  timeout 300 python bench.py --in-flight 2 --no-cpu-baseline --no-end-to-end > $O/bench_ecoli_in_flight_2.json.txt 2> /dev/null; show $O/bench_ecoli_in_flight_2.json.txt 160
   for w in dmel arab; do
     timeout 600 python bench.py --workload $w --no-cpu-baseline --no-end-to-end > $O/bench_$w.json.txt 2> $O/bench_$w.err; show $O/bench_$w.json.txt 160
   done
