@@ -404,5 +404,10 @@ int main(int argc, char **argv) {
     // instruction model: 63 per iteration, 250 per data move, 120 per mask move, 300 per park / join, 800 per place
     const double instr = 63.0 * it + 250.0 * (s.replace + s.rotate) + 120.0 * s.soft + 300.0 * (s.park + s.join) + 800.0 * s.place;
     printf("  instruction model: %.3f G (rows %.1f %%) = %.1f per row\n", instr / 1e9, 100.0 * 63.0 * it / instr, instr / s.rows);
+    // ... and with round 6's costs: a data move inside the stream ~120, a look-up in the single stream's stride 12
+    // per LOOK_EVERY single iterations (it was a round trip of ~150)
+    const double instr6 = 63.0 * it + 120.0 * (s.replace + s.rotate) + 12.0 * s.soft + 12.0 * s.it_single / LOOK_EVERY +
+                          300.0 * (s.park + s.join) + 800.0 * s.place;
+    printf("  round-6 costs: %.3f G = %.1f per row\n", instr6 / 1e9, instr6 / s.rows);
     return 0;
 }
