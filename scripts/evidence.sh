@@ -6,6 +6,7 @@
 #   quick           bench lines and kernel traces only
 #   pmc             the counter passes only
 #   e2e             the long end-to-end stream only
+#   ab              the kernels' own times of the builds under gpurun_variants/ against the tree's
 # Counter passes: ONE kernel per pass (--kernel-include-regex; unrestricted wait / LDS passes hung rocprofv3 on this
 # pool in round 5), three SQ_* sets per kernel, FETCH_SIZE / WRITE_SIZE for the alignment kernel (with k_pack, whose
 # traffic is known exactly: the calibration) and for k_links2, k_tags, k_chain; a pass that times out is repeated once.
@@ -75,6 +76,11 @@ if want "full pmc"; then
   cd $R
   # the default line again, now that the traffic and issue records of THIS build are on file
   timeout 400 python bench.py --no-cpu-baseline --no-end-to-end > $O/bench_ecoli_with_records.json.txt 2> /dev/null; show $O/bench_ecoli_with_records.json.txt
+fi
+if want "full ab"; then
+  # the builds under gpurun_variants/ (scripts/build_variant.sh) against the tree's: the kernels' own times
+  V=$(ls $R/gpurun_variants 2>/dev/null | tr '\n' ' ')
+  if [ -n "$V" ]; then $R/scripts/ab_times.sh $TAG/ab "head $V" > $O/ab_times.txt 2>&1; cat $O/ab_times.txt; fi
 fi
 if want "full e2e"; then
   timeout 1200 python bench.py --workload e2e-long > $O/e2e_long.txt 2> $O/e2e_long.err; cat $O/e2e_long.txt
