@@ -41,6 +41,14 @@ if want "full quick"; then
   python $R/scripts/rocpd_summary.py $(ls $O/kts/*/*.db $O/kts/*.db 2>/dev/null | head -1) > $O/kernel_stats.txt 2>&1; head -12 $O/kernel_stats.txt | cut -c1-140
   cd $R
 fi
+if want "full ab"; then
+  # the builds under gpurun_variants/ (scripts/build_variant.sh) against the tree's: the kernels' own times
+  V=$(ls $R/gpurun_variants 2>/dev/null | tr '\n' ' ')
+  if [ -n "$V" ]; then $R/scripts/ab_times.sh $TAG/ab "head $V" > $O/ab_times.txt 2>&1; cat $O/ab_times.txt; fi
+fi
+if want "full e2e"; then
+  timeout 1200 python bench.py --workload e2e-long > $O/e2e_long.txt 2> $O/e2e_long.err; cat $O/e2e_long.txt
+fi
 if want "full pmc"; then
   cd /tmp && export TMPDIR=/tmp
   export FALCON_AMD_DEVICE_PACK=1   # (the batch staged through k_pack: the calibration kernel of the traffic passes)
@@ -76,13 +84,5 @@ if want "full pmc"; then
   cd $R
   # the default line again, now that the traffic and issue records of THIS build are on file
   timeout 400 python bench.py --no-cpu-baseline --no-end-to-end > $O/bench_ecoli_with_records.json.txt 2> /dev/null; show $O/bench_ecoli_with_records.json.txt
-fi
-if want "full ab"; then
-  # the builds under gpurun_variants/ (scripts/build_variant.sh) against the tree's: the kernels' own times
-  V=$(ls $R/gpurun_variants 2>/dev/null | tr '\n' ' ')
-  if [ -n "$V" ]; then $R/scripts/ab_times.sh $TAG/ab "head $V" > $O/ab_times.txt 2>&1; cat $O/ab_times.txt; fi
-fi
-if want "full e2e"; then
-  timeout 1200 python bench.py --workload e2e-long > $O/e2e_long.txt 2> $O/e2e_long.err; cat $O/e2e_long.txt
 fi
 find $O -name "*.db" -size +5M -delete
