@@ -67,3 +67,32 @@ def test_the_chaining_kernel_keeps_eight_wavefronts_per_simd():
     r = resources("k_chain.hip")
     (lds, vgpr), = [v for k, v in r.items() if "k_chain" in k]
     assert vgpr <= 64, vgpr
+
+
+def _listing(src, *flags):
+    return subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", "-",
+                           *flags, os.path.join(CSRC, src)], capture_output=True, text=True, check=True, cwd=CSRC).stdout
+
+
+def test_what_the_unmeasured_build_switches_change_in_the_listings():
+    """Round 6 left two build switches OFF because the GPU was closed before they could run.
+    What each is there for can be read off the listing without one:
+    W_ADDR32 -- k_align2's event loop keeps a register tuple for 64-bit array indices in scratch (99 of ~200 scratch
+    instructions, 16 bytes per lane each: the 16 GB of writes that were nobody's data); with 32-bit offsets the
+    tuple and most 64-bit address additions are gone.
+    S2_SETTLE_NL -- k_score2's chain loop waits for the LDS twice per level; with the link counts consumed before
+    the loop the wait at the loop's head (for the atomic of the level before) is gone."""
+    base, addr32 = _listing("k_align2.hip"), _listing("k_align2.hip", "-DW_ADDR32")
+    n = lambda text, pat: len(re.findall(pat, text))
+    assert n(base, r"\bscratch_(load|store)") >= 190 and n(addr32, r"\bscratch_(load|store)") <= 140
+    assert n(base, r"v_lshl_add_u64") >= 40 and n(addr32, r"v_lshl_add_u64") <= 6
+
+    def chain_loop(text):   # the loop around the chain's ds_max_u32, from its header to its back edge
+        lines = text.split("\n")
+        at = next(i for i, ln in enumerate(lines) if "ds_max_u32" in ln)
+        head = max(i for i in range(at) if lines[i].startswith(".LBB"))
+        tail = next(i for i in range(at, len(lines)) if "s_cbranch" in lines[i])
+        return lines[head:tail + 1]
+    waits = lambda body: sum(1 for ln in body if "s_waitcnt lgkmcnt(0)" in ln)
+    assert waits(chain_loop(_listing("k_score2.hip"))) == 2
+    assert waits(chain_loop(_listing("k_score2.hip", "-DS2_SETTLE_NL"))) == 1
