@@ -96,3 +96,18 @@ def test_what_the_unmeasured_build_switches_change_in_the_listings():
     waits = lambda body: sum(1 for ln in body if "s_waitcnt lgkmcnt(0)" in ln)
     assert waits(chain_loop(_listing("k_score2.hip"))) == 2
     assert waits(chain_loop(_listing("k_score2.hip", "-DS2_SETTLE_NL"))) == 1
+
+
+def test_the_first_pass_of_k_chain_issues_its_packed_read_loads_together():
+    """Round 6: written `(p < n_probe) ? fa_kmer8(..) : 0`, each of the five loads of a step sat in a block of its own
+    that ended in `s_waitcnt vmcnt(0)` -- five latencies in a row.  With the index clamped instead they are issued
+    back to back: in the listing of the first pass's loop, five loads stand before the first wait."""
+    lines = _listing("k_chain.hip").split("\n")
+    head = next(i for i, ln in enumerate(lines) if "Inner Loop Header: Depth=1" in ln)
+    loads = 0
+    for ln in lines[head:head + 200]:
+        if "global_load" in ln:
+            loads += 1
+        if "s_waitcnt vmcnt" in ln:
+            break
+    assert loads >= 5, loads
