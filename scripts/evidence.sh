@@ -1,8 +1,9 @@
 #!/bin/bash
-# The evidence of HEAD on the GPU box, one gpurun call.     usage: scripts/evidence.sh <tag> [mode]
+# The evidence of HEAD on the GPU box, one gpurun call.     usage: scripts/evidence.sh <tag> ["<mode> ..."]
 #   full (default)  GPU suite; bench lines (default = BASELINE config 2 with CPU baseline and end-to-end legs; one batch
 #                   at a time; 400 steps; dmel; dmel at 2048 piles; arab; the 8(f) paths); rocprofv3 kernel traces
 #                   (pipelined, one batch at a time); the counter passes; the long end-to-end stream
+#   suite           the GPU suite only
 #   quick           bench lines and kernel traces only
 #   pmc             the counter passes only
 #   e2e             the long end-to-end stream only
@@ -15,10 +16,11 @@ TAG=${1:-ev}; MODE=${2:-full}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG; mkdir -p $O/pmc
 cd $R
-want() { case " $1 " in *" $MODE "*) return 0;; esac; return 1; }
+# (MODE may list several steps: "suite quick ab"; `full` is all of them)
+want() { local m; for m in $MODE; do case " $1 " in *" $m "*) return 0;; esac; done; return 1; }
 show() { cut -c1-${2:-200} $1; echo; }
 
-if want "full"; then
+if want "full suite"; then
   ( timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -5 ) > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
 fi
 if want "full quick"; then
